@@ -1,0 +1,110 @@
+"""Deterministic synthetic inputs for the hot path (tests, golden fixtures, bench).
+
+The reference ships no test data for this path, so every workload is
+synthetic.  Everything here is built from numpy's PCG64 stream and the four IEEE
+basic operations only (no exp/sin), so the bytes are identical on every host; each
+generator also returns a sha256 so fixtures can detect drift.
+
+Shapes follow the reference's dump format (scripts/sampling/sd_pipeline_vspw.py:103-120):
+a dumped attention tensor is ``[2F, N, C]`` with the unconditional half first
+(sgm/modules/diffusionmodules/guiders.py:33-42).
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+
+def _rng(seed: int) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def sha256_of(*arrays: np.ndarray) -> str:
+    h = hashlib.sha256()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode())
+        h.update(str(a.shape).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def blob_weights(num_frames: int, h: int, w: int, num_blobs: int, seed: int) -> np.ndarray:
+    """Soft membership of every cell in `num_blobs` drifting blobs + background.
+
+    Returns float64 [F, h*w, num_blobs+1], rows sum to 1.  Rational falloff so that
+    only + - * / are used.
+    """
+    g = _rng(seed)
+    cy = g.uniform(0.15, 0.85, size=num_blobs) * h
+    cx = g.uniform(0.15, 0.85, size=num_blobs) * w
+    vy = g.uniform(-0.25, 0.25, size=num_blobs)
+    vx = g.uniform(-0.25, 0.25, size=num_blobs)
+    rad = g.uniform(0.12, 0.28, size=num_blobs) * min(h, w)
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    out = np.empty((num_frames, h * w, num_blobs + 1), dtype=np.float64)
+    for t in range(num_frames):
+        wts = [np.full(h * w, 0.35)]
+        for b in range(num_blobs):
+            d2 = (yy - (cy[b] + vy[b] * t)) ** 2 + (xx - (cx[b] + vx[b] * t)) ** 2
+            q = d2 / (rad[b] * rad[b])
+            wts.append((1.0 / (1.0 + q * q * q)).reshape(-1))
+        wt = np.stack(wts, axis=-1)
+        out[t] = wt / wt.sum(axis=-1, keepdims=True)
+    return out
+
+
+def attention_q_dumps(
+    num_frames: int,
+    h: int,
+    w: int,
+    channels: int,
+    num_blocks: int = 3,
+    num_blobs: int = 6,
+    seed: int = 1,
+    noise: float = 0.15,
+    scale: float = 3.0,
+):
+    """Synthetic stand-ins for the dumped decoder-block self-attention queries.
+
+    Returns (list of `num_blocks` float16 arrays [2F, h*w, C], sha256).  The
+    conditional half (rows F:) carries cluster + position structure so that
+    K-means, KNN and dense tracking are all non-degenerate; the unconditional
+    half is an independent draw (it must be ignored by the analysis path,
+    feature_extraction.py:550-551).
+    """
+    g = _rng(seed)
+    wts = blob_weights(num_frames, h, w, num_blobs, seed + 1000)          # [F, N, G+1]
+    protos = g.standard_normal((num_blobs + 1, channels))
+    pos_basis = g.standard_normal((3, channels)) * 0.6
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float64) / h, np.arange(w, dtype=np.float64) / w, indexing="ij")
+    pos = np.stack([yy.reshape(-1), xx.reshape(-1), (yy * xx).reshape(-1)], axis=-1) @ pos_basis  # [N, C]
+    base = wts @ protos + pos[None]                                                              # [F, N, C]
+    blocks = []
+    for _ in range(num_blocks):
+        gain = 1.0 + 0.1 * g.standard_normal(channels)
+        cond = (base * gain + noise * g.standard_normal(base.shape)) * scale
+        uncond = g.standard_normal(base.shape) * scale
+        blocks.append(np.concatenate([uncond, cond], axis=0).astype(np.float16))
+    return blocks, sha256_of(*blocks)
+
+
+def latent_clip(num_frames: int, h: int, w: int, seed: int = 1, channels: int = 4) -> np.ndarray:
+    """Seeded smooth latent field with the blob motion, float32 [F, C, h, w] (VAE excluded,
+    SURVEY.md §8(d)): 0.18215-scaled like encode_first_stage output (sd_pipeline_vspw.py:258-260)."""
+    g = _rng(seed)
+    wts = blob_weights(num_frames, h, w, 6, seed + 2000)                   # [F, N, 7]
+    protos = g.standard_normal((7, channels)) * 4.0
+    lat = (wts @ protos).reshape(num_frames, h, w, channels)
+    lat = lat + 0.3 * g.standard_normal(lat.shape)
+    return np.ascontiguousarray((lat * 0.18215 * 4.0).transpose(0, 3, 1, 2)).astype(np.float32)
+
+
+def sd_conditioning(num_frames: int, context_dim: int = 1024, seq: int = 77, seed: int = 1):
+    """`c["crossattn"]` ~ N(0,1) [F, seq, ctx], `uc` zeros (force_uc_zero_embeddings,
+    sd_pipeline_vspw.py:299-305); float32."""
+    g = _rng(seed + 3000)
+    c = g.standard_normal((1, seq, context_dim)).astype(np.float32)
+    c = np.repeat(c, num_frames, axis=0)
+    return c, np.zeros_like(c)
