@@ -1,0 +1,984 @@
+// HIPCC_FLAGS: -ffp-contract=off
+// (bit-faithful arithmetic: no implicit FMA contraction; every fused multiply-add below is an explicit fma())
+// Post-UNet analysis kernels for gfx950: block aggregation, K-means (k-means++ / Lloyd, batched over
+// the n_init restarts), 4-NN label propagation, dense cosine tracking and the trajectory vote.
+//
+// Arithmetic follows the reference bit for bit where it is defined (see include/vidseg_hip.h for the
+// reference file:line each entry point replaces): fp16 roundings happen exactly where torch/numpy round,
+// everything sklearn evaluates in float64 is evaluated in float64 here (v_fma_f64; inputs are fp16-valued
+// so products are exact and sums are order-insensitive far below any decision threshold), reductions that
+// feed later decisions use a fixed order (no floating-point atomics), ties follow the reference's rules.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f16 f64_to_f16_rn(double d) {
+    // correct single rounding double -> half: round-to-odd into f32, then RN to f16
+    float r = __double2float_rz(d);
+    if ((double)r != d) r = __uint_as_float(__float_as_uint(r) | 1u);
+    return (f16)r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a13 + a14 step (2): mean over decoder blocks (fp32 accumulate, one fp16 rounding) and per-token
+// max-abs normalisation (fp16 / fp16 evaluated in fp32, one rounding).  One wave per token row.
+// ---------------------------------------------------------------------------------------------
+struct BlockPtrs { const f16* p[8]; };
+
+__global__ void __launch_bounds__(256) k_mean_normalize(BlockPtrs blocks, int nblk, int64_t row0, int64_t rows, int C,
+                                                        f16* __restrict__ out_mean, f16* __restrict__ out_norm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t off = (row0 + row) * (int64_t)C;
+    const float inv = (float)nblk;
+    float vmax = 0.f;
+    constexpr int MAXCH = 8;                       // chunks of 8 halves per lane: C <= 64*8*8 = 4096
+    f16x8 m[MAXCH];
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+        const int c = lane * 8 + ch * 512;
+        if (c < C) {
+            float acc[8];
+            f16x8 v = *reinterpret_cast<const f16x8*>(blocks.p[0] + off + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = (float)v[j];
+            for (int b = 1; b < nblk; ++b) {
+                v = *reinterpret_cast<const f16x8*>(blocks.p[b] + off + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = acc[j] + (float)v[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f16 h = (f16)(acc[j] / inv);
+                m[ch][j] = h;
+                vmax = fmaxf(vmax, fabsf((float)h));
+            }
+        }
+    }
+    vmax = wave_max_f32(vmax);
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+        const int c = lane * 8 + ch * 512;
+        if (c < C) {
+            if (out_mean) *reinterpret_cast<f16x8*>(out_mean + row * (int64_t)C + c) = m[ch];
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)((float)m[ch][j] / vmax);
+            if (out_norm) *reinterpret_cast<f16x8*>(out_norm + row * (int64_t)C + c) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// float64 64x64 tile product  D[s][j] = sum_c A[s][c] * B[j][c]  (256 threads, 4x4 per thread)
+// ---------------------------------------------------------------------------------------------
+#define TS 64
+#define TJ 64
+#define KC 32
+#define LDP 65
+
+struct RowsF16 {                 // rows of an fp16 matrix, optionally gathered and mean-centred
+    const f16* base;
+    const int32_t* gather;       // nullptr -> identity
+    const double* mean;          // nullptr -> no centring
+    int64_t nrows;               // logical rows (after gather)
+    int C;
+};
+struct RowsF64 {
+    const double* base;
+    int64_t nrows;
+    int C;
+};
+
+__device__ __forceinline__ void load_tile(double (*L)[LDP], const RowsF16& R, int64_t r0, int c0) {
+    const int t = threadIdx.x;
+    const int r = t >> 2, sub = (t & 3) * 8;
+    const int64_t row = r0 + r;
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.0;
+    if (row < R.nrows && c0 + sub < R.C) {
+        const int64_t src = R.gather ? (int64_t)R.gather[row] : row;
+        f16x8 h = *reinterpret_cast<const f16x8*>(R.base + src * (int64_t)R.C + c0 + sub);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (double)h[j];
+        if (R.mean) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] -= R.mean[c0 + sub + j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) L[sub + j][r] = v[j];
+}
+__device__ __forceinline__ void load_tile(double (*L)[LDP], const RowsF64& R, int64_t r0, int c0) {
+    const int t = threadIdx.x;
+    const int r = t >> 2, sub = (t & 3) * 8;
+    const int64_t row = r0 + r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double v = 0.0;
+        if (row < R.nrows && c0 + sub + j < R.C) v = R.base[row * (int64_t)R.C + c0 + sub + j];
+        L[sub + j][r] = v;
+    }
+}
+
+template <class RA, class RB>
+__device__ __forceinline__ void tile_gemm(double (&acc)[4][4], double (*LA)[LDP], double (*LB)[LDP], const RA& A, int64_t a0,
+                                          const RB& B, int64_t b0, int C) {
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int c0 = 0; c0 < C; c0 += KC) {
+        __syncthreads();
+        load_tile(LA, A, a0, c0);
+        load_tile(LB, B, b0, c0);
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < KC; ++k) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = LA[k][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = LB[k][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-means preparation: column mean (numpy axis-0 order: sequential over rows), squared row norms of
+// the centred data, sum of per-feature variances (for sklearn's tol).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_col_mean(const f16* __restrict__ x, int64_t n, int C, double* __restrict__ mean) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) s += (double)x[i * C + c];
+    mean[c] = s / (double)n;
+}
+
+__global__ void __launch_bounds__(256) k_row_sqnorm(const f16* __restrict__ x, const double* __restrict__ mean, int64_t n, int C,
+                                                    double* __restrict__ xsq) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    double s = 0.0;
+    for (int c = lane; c < C; c += 64) {
+        double v = (double)x[row * C + c] - (mean ? mean[c] : 0.0);
+        s = fma(v, v, s);
+    }
+    s = wave_sum_f64(s);
+    if (lane == 0) xsq[row] = s;
+}
+
+// per-column sum of squares of centred data -> var_sum = sum_c mean_i (xc_ic - m2_c)^2
+__global__ void k_col_var(const f16* __restrict__ x, const double* __restrict__ mean, int64_t n, int C, double* __restrict__ colvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, m = mean[c];
+    for (int64_t i = 0; i < n; ++i) s += (double)x[i * C + c] - m;
+    const double m2 = s / (double)n;
+    double q = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        double d = ((double)x[i * C + c] - m) - m2;
+        q = fma(d, d, q);
+    }
+    colvar[c] = q / (double)n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k-means++ (sklearn cluster/_kmeans.py:174-274), all restarts in one launch.
+//   kpp_dist : dcand[r][t][i] = min(closest[r][i], max(0, -2 x_cand.x_i + |x_cand|^2 + |x_i|^2)), per-tile pot partials
+//   kpp_pick : finalise the previous step (first-min over trials), then scan closest[] and draw the next
+//              candidates by searchsorted(cumsum(closest), u * pot)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_kpp_dist(RowsF16 X, const double* __restrict__ xsq, const int32_t* __restrict__ cand, int R,
+                                                  int T, const double* __restrict__ closest, double* __restrict__ dcand,
+                                                  double* __restrict__ part, int ntiles) {
+    __shared__ double LA[KC][LDP];
+    __shared__ double LB[KC][LDP];
+    __shared__ double LD[TS][LDP];
+    const int64_t n = X.nrows;
+    const int J = R * T;
+    const int64_t s0 = (int64_t)blockIdx.x * TS;
+    const int j0 = blockIdx.y * TJ;
+    RowsF16 B = X;
+    B.gather = cand;
+    B.nrows = J;
+    double acc[4][4];
+    tile_gemm(acc, LA, LB, X, s0, B, (int64_t)j0, X.C);
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t s = s0 + ty * 4 + i;
+            const int col = j0 + tx * 4 + j;
+            double v = 0.0;
+            if (s < n && col < J) {
+                const int r = col / T;
+                double d = -2.0 * acc[i][j];
+                d += xsq[cand[col]];
+                d += xsq[s];
+                d = fmax(d, 0.0);
+                v = fmin(closest[(int64_t)r * n + s], d);
+                dcand[(int64_t)col * n + s] = v;
+            }
+            LD[ty * 4 + i][tx * 4 + j] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < TJ && j0 + threadIdx.x < J) {
+        double s = 0.0;
+        for (int i = 0; i < TS; ++i) s += LD[i][threadIdx.x];
+        part[(int64_t)(j0 + threadIdx.x) * ntiles + blockIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_kpp_pick(int64_t n, int R, int K, int c, int Tprev, int Tnext, const double* __restrict__ u,
+                                                   int ustride, double* __restrict__ closest, const double* __restrict__ dcand,
+                                                   const double* __restrict__ part, int ntiles, double* __restrict__ pot,
+                                                   int32_t* __restrict__ cand, int32_t* __restrict__ center_ids, int Tmax) {
+    // one block per restart r.  Finalises centre c-1 from the Tprev trial results, then (if c < K)
+    // draws Tnext candidates for centre c.
+    const int r = blockIdx.x;
+    __shared__ double s_pots[16];
+    __shared__ int s_best;
+    __shared__ double s_seg[1024];
+    __shared__ int s_cnt[16];
+    const int t = threadIdx.x;
+    if (t < Tprev) {
+        double s = 0.0;
+        const double* p = part + (int64_t)(r * Tprev + t) * ntiles;
+        for (int i = 0; i < ntiles; ++i) s += p[i];
+        s_pots[t] = s;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int best = 0;
+        for (int k = 1; k < Tprev; ++k)
+            if (s_pots[k] < s_pots[best]) best = k;
+        s_best = best;
+        pot[r] = s_pots[best];
+        center_ids[r * K + (c - 1)] = cand[r * Tprev + best];
+    }
+    if (t < 16) s_cnt[t] = 0;
+    __syncthreads();
+    const int best = s_best;
+    const double* src = dcand + (int64_t)(r * Tprev + best) * n;
+    double* dst = closest + (int64_t)r * n;
+    const int64_t seg = (n + 1023) / 1024;
+    const int64_t i0 = (int64_t)t * seg, i1 = min(n, i0 + seg);
+    double tot = 0.0;
+    for (int64_t i = i0; i < i1; ++i) {
+        double v = src[i];
+        dst[i] = v;
+        tot += v;
+    }
+    if (c >= K) return;
+    s_seg[t] = tot;
+    __syncthreads();
+    if (t == 0) {                                     // exclusive scan of segment totals, sequential order
+        double run = 0.0;
+        for (int k = 0; k < 1024; ++k) {
+            double v = s_seg[k];
+            s_seg[k] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    const double potr = s_pots[best];
+    double rv[8];
+    int cnt[8];
+    for (int k = 0; k < Tnext; ++k) {
+        rv[k] = u[(int64_t)r * ustride + k] * potr;
+        cnt[k] = 0;
+    }
+    double run = s_seg[t];
+    for (int64_t i = i0; i < i1; ++i) {
+        run += src[i];
+        for (int k = 0; k < Tnext; ++k) cnt[k] += (run < rv[k]) ? 1 : 0;
+    }
+    for (int k = 0; k < Tnext; ++k)
+        if (cnt[k]) atomicAdd(&s_cnt[k], cnt[k]);
+    __syncthreads();
+    if (t < Tnext) cand[r * Tnext + t] = (int32_t)min((int64_t)s_cnt[t], n - 1);
+}
+
+__global__ void k_gather_centers(RowsF16 X, const int32_t* __restrict__ ids, int J, double* __restrict__ centers) {
+    const int j = blockIdx.x;
+    if (j >= J) return;
+    const int64_t src = ids[j];
+    for (int c = threadIdx.x; c < X.C; c += blockDim.x)
+        centers[(int64_t)j * X.C + c] = (double)X.base[src * X.C + c] - (X.mean ? X.mean[c] : 0.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lloyd (sklearn cluster/_k_means_lloyd.pyx), restarts batched, `active` is a bit mask over restarts.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_center_sqnorm(const double* __restrict__ centers, int J, int C, double* __restrict__ cn) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= J) return;
+    double s = 0.0;
+    for (int c = lane; c < C; c += 64) s = fma(centers[(int64_t)j * C + c], centers[(int64_t)j * C + c], s);
+    s = wave_sum_f64(s);
+    if (lane == 0) cn[j] = s;
+}
+
+__global__ void __launch_bounds__(256) k_lloyd_assign(RowsF16 X, const double* __restrict__ centers, const double* __restrict__ cn,
+                                                      int R, int K, int rpt, unsigned active, int32_t* __restrict__ labels,
+                                                      int32_t* __restrict__ changed) {
+    // blockIdx.y selects `rpt` restarts (rpt*K <= 64 columns).  argmin_j (|c_j|^2 - 2 x.c_j), first min wins.
+    __shared__ double LA[KC][LDP];
+    __shared__ double LB[KC][LDP];
+    __shared__ double LD[TS][LDP];
+    const int rbase = blockIdx.y * rpt;
+    unsigned need = 0;
+    for (int q = 0; q < rpt; ++q)
+        if (rbase + q < R && ((active >> (rbase + q)) & 1u)) need = 1;
+    if (!need) return;
+    const int64_t n = X.nrows;
+    const int64_t s0 = (int64_t)blockIdx.x * TS;
+    const int ncol = min(rpt, R - rbase) * K;
+    RowsF64 B{centers + (int64_t)rbase * K * X.C, ncol, X.C};
+    double acc[4][4];
+    tile_gemm(acc, LA, LB, X, s0, B, 0, X.C);
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = tx * 4 + j;
+            double d = 0.0;
+            if (col < ncol) d = cn[rbase * K + col] + (-2.0 * acc[i][j]);
+            LD[ty * 4 + i][col] = d;
+        }
+    __syncthreads();
+    const int s = threadIdx.x & 63, q = threadIdx.x >> 6;      // 4 restarts handled per pass
+    for (int qq = q; qq < rpt; qq += 4) {
+        const int r = rbase + qq;
+        if (r >= R || !((active >> r) & 1u) || s0 + s >= n) continue;
+        const double* row = &LD[s][qq * K];
+        double best = row[0];
+        int lab = 0;
+        for (int j = 1; j < K; ++j)
+            if (row[j] < best) {
+                best = row[j];
+                lab = j;
+            }
+        const int64_t idx = (int64_t)r * n + s0 + s;
+        if (labels[idx] != lab) atomicAdd(&changed[r], 1);
+        labels[idx] = lab;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_lloyd_accum(RowsF16 X, const int32_t* __restrict__ labels, int R, int K, unsigned active,
+                                                     int S, double* __restrict__ psum, int32_t* __restrict__ pcnt, int nblk) {
+    // block (chunk, restart): fixed-order partial sums of the chunk's samples per cluster.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int r = blockIdx.y;
+    if (!((active >> r) & 1u)) return;
+    const int C = X.C;
+    constexpr int CCH = 256;                                     // channels per pass, one per thread
+    double* acc = reinterpret_cast<double*>(smem);               // [K][CCH]
+    int* slab = reinterpret_cast<int*>(acc + (size_t)K * CCH);   // [S]
+    int* scnt = slab + S;                                        // [K]
+    const int64_t n = X.nrows;
+    const int64_t s0 = (int64_t)blockIdx.x * S;
+    const int ns = (int)min((int64_t)S, n - s0);
+    for (int i = threadIdx.x; i < ns; i += 256) slab[i] = labels[(int64_t)r * n + s0 + i];
+    for (int k = threadIdx.x; k < K; k += 256) scnt[k] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int i = 0; i < ns; ++i) scnt[slab[i]]++;
+    double* out = psum + ((int64_t)r * nblk + blockIdx.x) * K * C;
+    for (int c0 = 0; c0 < C; c0 += CCH) {
+        const int c = c0 + threadIdx.x;
+        for (int k = 0; k < K; ++k) acc[k * CCH + threadIdx.x] = 0.0;
+        if (c < C) {
+            const double m = X.mean ? X.mean[c] : 0.0;
+            for (int i = 0; i < ns; ++i) {
+                const double v = (double)X.base[(s0 + i) * C + c] - m;
+                acc[slab[i] * CCH + threadIdx.x] += v;
+            }
+            for (int k = 0; k < K; ++k) out[(int64_t)k * C + c] = acc[k * CCH + threadIdx.x];
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) pcnt[((int64_t)r * nblk + blockIdx.x) * K + k] = scnt[k];
+}
+
+__global__ void __launch_bounds__(256) k_lloyd_update(const double* __restrict__ psum, const int32_t* __restrict__ pcnt, int nblk,
+                                                      int R, int K, int C, unsigned active, double* __restrict__ centers,
+                                                      double* __restrict__ shift2, int32_t* __restrict__ counts) {
+    // block (k, r): new centre = (sum over chunks, ascending) * (1/count); shift2 = |new-old|^2
+    const int k = blockIdx.x, r = blockIdx.y;
+    if (!((active >> r) & 1u)) return;
+    __shared__ double red[256];
+    int cnt = 0;
+    for (int b = 0; b < nblk; ++b) cnt += pcnt[((int64_t)r * nblk + b) * K + k];
+    double sh = 0.0;
+    if (cnt > 0) {
+        const double alpha = 1.0 / (double)cnt;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            double s = 0.0;
+            for (int b = 0; b < nblk; ++b) s += psum[(((int64_t)r * nblk + b) * K + k) * C + c];
+            s *= alpha;
+            const int64_t ci = ((int64_t)r * K + k) * C + c;
+            const double d = s - centers[ci];
+            sh = fma(d, d, sh);
+            centers[ci] = s;
+        }
+    }
+    red[threadIdx.x] = sh;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        shift2[r * K + k] = red[0];
+        counts[r * K + k] = cnt;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_inertia(RowsF16 X, const double* __restrict__ centers, const int32_t* __restrict__ labels,
+                                                 int R, int K, double* __restrict__ part, int nblk) {
+    // block (chunk of 256 samples, restart): wave per sample, fixed-order sum inside the block
+    __shared__ double ws[4];
+    const int r = blockIdx.y, C = X.C;
+    const int64_t n = X.nrows;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double tot = 0.0;
+    for (int i = w; i < 256; i += 4) {
+        const int64_t s = (int64_t)blockIdx.x * 256 + i;
+        if (s >= n) break;
+        const double* cp = centers + ((int64_t)r * K + labels[(int64_t)r * n + s]) * C;
+        double q = 0.0;
+        for (int c = lane; c < C; c += 64) {
+            const double d = ((double)X.base[s * C + c] - (X.mean ? X.mean[c] : 0.0)) - cp[c];
+            q = fma(d, d, q);
+        }
+        tot += wave_sum_f64(q);
+    }
+    if (lane == 0) ws[w] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(int64_t)r * nblk + blockIdx.x] = ((ws[0] + ws[1]) + ws[2]) + ws[3];
+}
+
+__global__ void k_sum_rows(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+    const int r = blockIdx.x;
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += part[(int64_t)r * nblk + b];
+        out[r] = s;
+    }
+}
+
+__global__ void k_add_mean(double* __restrict__ centers, const double* __restrict__ mean, int K, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K * C) centers[i] += mean[i % C];
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4-NN classifier (sklearn neighbors, brute force in float64): d = |q|^2 - 2 q.y + |y|^2 clipped at 0
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_knn(RowsF16 Q, RowsF16 Y, const double* __restrict__ qq, const double* __restrict__ yy,
+                                             const int32_t* __restrict__ ylab, int32_t* __restrict__ out) {
+    __shared__ double LA[KC][LDP];
+    __shared__ double LB[KC][LDP];
+    __shared__ double LD[TS][LDP];
+    const int64_t q0 = (int64_t)blockIdx.x * TS;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double bd[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    int bi[4] = {-1, -1, -1, -1};
+    for (int64_t y0 = 0; y0 < Y.nrows; y0 += TJ) {
+        double acc[4][4];
+        tile_gemm(acc, LA, LB, Q, q0, Y, y0, Q.C);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t qi = q0 + ty * 4 + i, yi = y0 + tx * 4 + j;
+                double d = INFINITY;
+                if (qi < Q.nrows && yi < Y.nrows) {
+                    d = -2.0 * acc[i][j];
+                    d += qq[qi];
+                    d += yy[yi];
+                    d = fmax(d, 0.0);
+                }
+                LD[ty * 4 + i][tx * 4 + j] = d;
+            }
+        __syncthreads();
+        if (threadIdx.x < TS) {
+            const double* row = LD[threadIdx.x];
+            for (int j = 0; j < TJ; ++j) {
+                const double d = row[j];
+                if (d < bd[3]) {
+                    int p = 3;
+                    while (p > 0 && d < bd[p - 1]) {
+                        bd[p] = bd[p - 1];
+                        bi[p] = bi[p - 1];
+                        --p;
+                    }
+                    bd[p] = d;
+                    bi[p] = (int)(y0 + j);
+                }
+            }
+        }
+    }
+    if (threadIdx.x < TS && q0 + threadIdx.x < Q.nrows) {
+        int lab[4], nn = 0;
+        for (int p = 0; p < 4; ++p)
+            if (bi[p] >= 0) lab[nn++] = ylab[bi[p]];
+        int bestc = 0, bestl = 0;
+        for (int p = 0; p < nn; ++p) {
+            int c = 0;
+            for (int q = 0; q < nn; ++q) c += (lab[q] == lab[p]);
+            if (c > bestc || (c == bestc && lab[p] < bestl)) {
+                bestc = c;
+                bestl = lab[p];
+            }
+        }
+        out[q0 + threadIdx.x] = bestl;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense tracking (feature_extraction.py:176-323)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_track_normalize(const f16* __restrict__ x, int64_t rows, int C, int nb, f16* __restrict__ out) {
+    // out[b][row][:] = row normalised b+1 times: n = f16(sqrt(sum x^2)), x = f16(f32(x)/f32(n))
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    constexpr int MAXE = 32;                                     // C <= 2048
+    f16 v[MAXE];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int c = lane + 64 * e;
+        v[e] = (c < C) ? x[row * C + c] : (f16)0.f;
+    }
+    for (int b = 0; b < nb; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) {
+            const double d = (double)v[e];
+            s = fma(d, d, s);
+        }
+        s = wave_sum_f64(s);
+        const float nrm = (float)f64_to_f16_rn(sqrt(s));
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) {
+            const int c = lane + 64 * e;
+            if (c < C) {
+                v[e] = (f16)((float)v[e] / nrm);
+                out[((int64_t)b * rows + row) * C + c] = v[e];
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_track_cos(const f16* __restrict__ normed, int64_t FN, int N, int C, int f, int batch,
+                                                   int tiles_per_batch, const int32_t* __restrict__ cur, int use_aux, f16 w1, f16 w2,
+                                                   f16* __restrict__ blend) {
+    // normed: [nb][F*N][C].  Query tile = 64 queries inside one 500-query batch b; targets = frame f+1
+    // normalised b+1 times; aux = frame 0 normalised b+1 times.  blend[q][col] fp16.
+    __shared__ double LA[KC][LDP];
+    __shared__ double LB[KC][LDP];
+    __shared__ double LD[KC][LDP];
+    const int b = blockIdx.x / tiles_per_batch;
+    const int tq = blockIdx.x % tiles_per_batch;
+    const int q0 = b * batch + tq * TS;
+    const int qend = min(N, (b + 1) * batch);
+    if (q0 >= qend) return;
+    const int t0 = blockIdx.y * TJ;
+    RowsF16 A{normed + (int64_t)f * N * C, cur, nullptr, (int64_t)qend, C};                      // version 0, gathered
+    RowsF16 T{normed + ((int64_t)b * FN + (int64_t)(f + 1) * N) * C, nullptr, nullptr, (int64_t)N, C};
+    RowsF16 X{normed + ((int64_t)b * FN) * C, nullptr, nullptr, (int64_t)N, C};
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double acc[4][4], acx[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = acx[i][j] = 0.0;
+    for (int c0 = 0; c0 < C; c0 += KC) {
+        __syncthreads();
+        load_tile(LA, A, (int64_t)q0, c0);
+        load_tile(LB, T, (int64_t)t0, c0);
+        if (use_aux) load_tile(LD, X, (int64_t)t0, c0);
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < KC; ++k) {
+            double a[4], bb[4], xx[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = LA[k][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bb[j] = LB[k][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], bb[j], acc[i][j]);
+            if (use_aux) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xx[j] = LD[k][tx * 4 + j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acx[i][j] = fma(a[i], xx[j], acx[i][j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + ty * 4 + i, col = t0 + tx * 4 + j;
+            if (q < qend && col < N) {
+                f16 c1 = f64_to_f16_rn(acc[i][j]);
+                if (use_aux) {
+                    const f16 c2 = f64_to_f16_rn(acx[i][j]);
+                    const f16 p1 = (f16)((float)w1 * (float)c1);
+                    const f16 p2 = (f16)((float)w2 * (float)c2);
+                    c1 = (f16)((float)p1 + (float)p2);
+                }
+                blend[(int64_t)q * N + col] = c1;
+            }
+        }
+}
+
+// ---- numpy arg-introselect replay (oracle/npselect.py documents the algorithm) -------------------
+struct SelCtx {
+    const float* v;
+    short* t;
+};
+__device__ __forceinline__ float sv(const SelCtx& s, int i) { return s.v[s.t[i]]; }
+__device__ __forceinline__ void ssw(const SelCtx& s, int a, int b) {
+    short x = s.t[a];
+    s.t[a] = s.t[b];
+    s.t[b] = x;
+}
+__device__ int sel_median5(const SelCtx& s, int o) {
+    if (sv(s, o + 1) < sv(s, o + 0)) ssw(s, o + 1, o + 0);
+    if (sv(s, o + 4) < sv(s, o + 3)) ssw(s, o + 4, o + 3);
+    if (sv(s, o + 3) < sv(s, o + 0)) ssw(s, o + 3, o + 0);
+    if (sv(s, o + 4) < sv(s, o + 1)) ssw(s, o + 4, o + 1);
+    if (sv(s, o + 2) < sv(s, o + 1)) ssw(s, o + 2, o + 1);
+    if (sv(s, o + 3) < sv(s, o + 2)) return (sv(s, o + 3) < sv(s, o + 1)) ? 1 : 3;
+    return 2;
+}
+template <int LVL>
+__device__ void sel_introselect(const SelCtx& s, int off, int num, int kth) {
+    int low = 0, high = num - 1;
+    if (kth - low < 3) {
+        for (int i = 0; i <= kth; ++i) {
+            int minidx = i;
+            float minval = sv(s, off + i);
+            for (int k = i + 1; k < num; ++k)
+                if (sv(s, off + k) < minval) {
+                    minidx = k;
+                    minval = sv(s, off + k);
+                }
+            ssw(s, off + i, off + minidx);
+        }
+        return;
+    }
+    int depth = 0;
+    for (int m = num; m > 1; m >>= 1) ++depth;
+    depth *= 2;
+    while (low + 1 < high) {
+        int ll = low + 1, hh = high;
+        if (depth > 0 || hh - ll < 5 || LVL >= 3) {
+            const int mid = low + (high - low) / 2;
+            if (sv(s, off + high) < sv(s, off + mid)) ssw(s, off + high, off + mid);
+            if (sv(s, off + high) < sv(s, off + low)) ssw(s, off + high, off + low);
+            if (sv(s, off + low) < sv(s, off + mid)) ssw(s, off + low, off + mid);
+            ssw(s, off + mid, off + low + 1);
+        } else {
+            const int n2 = hh - ll, nmed = n2 / 5;
+            int sub = 0;
+            for (int i = 0; i < nmed; ++i, sub += 5) {
+                const int m = sel_median5(s, off + ll + sub);
+                ssw(s, off + ll + sub + m, off + ll + i);
+            }
+            if constexpr (LVL < 3) {
+                if (nmed > 2) sel_introselect<LVL + 1>(s, off + ll, nmed, nmed / 2);
+            }
+            const int mid = ll + nmed / 2;
+            ssw(s, off + mid, off + low);
+            ll--;
+            hh++;
+        }
+        depth--;
+        const float pivot = sv(s, off + low);
+        for (;;) {
+            do { ll++; } while (sv(s, off + ll) < pivot);
+            do { hh--; } while (pivot < sv(s, off + hh));
+            if (hh < ll) break;
+            ssw(s, off + ll, off + hh);
+        }
+        ssw(s, off + low, off + hh);
+        if (hh >= kth) high = hh - 1;
+        if (hh <= kth) low = ll;
+    }
+    if (high == low + 1)
+        if (sv(s, off + high) < sv(s, off + low)) ssw(s, off + high, off + low);
+}
+
+__global__ void __launch_bounds__(64) k_row_select(const f16* __restrict__ blend, int N, int w, int32_t* __restrict__ next,
+                                                   int32_t* __restrict__ tie_rows) {
+    // one wave per query row: unique maximum -> its index; ties -> replay numpy's fp16 arg-introselect.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* v = reinterpret_cast<float*>(smem);
+    short* t = reinterpret_cast<short*>(v + N);
+    const int q = blockIdx.x, lane = threadIdx.x;
+    float mx = -INFINITY;
+    for (int i = lane; i < N; i += 64) {
+        const float x = (float)blend[(int64_t)q * N + i];
+        v[i] = x;
+        t[i] = (short)i;
+        mx = fmaxf(mx, x);
+    }
+    mx = wave_max_f32(mx);
+    int cnt = 0, first = N;
+    for (int i = lane; i < N; i += 64)
+        if (v[i] == mx) {
+            cnt++;
+            first = min(first, i);
+        }
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_xor(cnt, o, 64);
+        first = min(first, __shfl_xor(first, o, 64));
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int res = first;
+        if (cnt > 1) {
+            SelCtx s{v, t};
+            sel_introselect<0>(s, 0, N, N - 1);
+            res = t[N - 1];
+            if (tie_rows) atomicAdd(tie_rows, 1);
+        }
+        next[q] = res;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Trajectory filter + majority vote + write-back (feature_extraction.py:392-421)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_traj_vote(const int32_t* __restrict__ idx, const int32_t* __restrict__ labels, int F, int N, int w,
+                            int spatial_filter, int32_t* __restrict__ common, int32_t* __restrict__ winner) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    bool keep = true;
+    if (spatial_filter) {
+        int ph = idx[p] / w, pw = idx[p] % w;
+        for (int t = 1; t < F; ++t) {
+            const int i = idx[t * N + p];
+            const int h = i / w, ww = i % w;
+            if (h - ph > 1 || ww - pw > 1) {
+                keep = false;
+                break;
+            }
+            ph = h;
+            pw = ww;
+        }
+    }
+    if (!keep) {
+        common[p] = -1;
+        return;
+    }
+    // Counter.most_common(1): highest count, ties -> label met first along the trajectory
+    int best = 0, bestc = 0;
+    for (int t = 0; t < F; ++t) {
+        const int lt = labels[t * N + idx[t * N + p]];
+        bool seen = false;
+        for (int s = 0; s < t; ++s)
+            if (labels[s * N + idx[s * N + p]] == lt) {
+                seen = true;
+                break;
+            }
+        if (seen) continue;
+        int c = 0;
+        for (int s = t; s < F; ++s) c += (labels[s * N + idx[s * N + p]] == lt);
+        if (c > bestc) {
+            bestc = c;
+            best = lt;
+        }
+    }
+    common[p] = best;
+    for (int t = 0; t < F; ++t) atomicMax(&winner[t * N + idx[t * N + p]], p);   // last writer (largest p) wins
+}
+
+__global__ void k_traj_write(const int32_t* __restrict__ labels, const int32_t* __restrict__ common, const int32_t* __restrict__ winner,
+                             int64_t total, int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int wp = winner[i];
+    out[i] = wp >= 0 ? common[wp] : labels[i];
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int vidseg_mean_normalize_f16(const void* const* blocks, int nblk, int64_t row0, int64_t rows, int C, void* out_mean, void* out_norm,
+                              hipStream_t st) {
+    VS_REQUIRE(nblk >= 1 && nblk <= 8, "mean_normalize: nblk=%d out of [1,8]", nblk);
+    VS_REQUIRE(C % 8 == 0 && C >= 8 && C <= 4096, "mean_normalize: C=%d must be a multiple of 8 in [8,4096]", C);
+    if (rows == 0) return VS_OK;
+    BlockPtrs bp;
+    for (int i = 0; i < nblk; ++i) bp.p[i] = static_cast<const f16*>(blocks[i]);
+    k_mean_normalize<<<dim3((unsigned)cdiv64(rows, 4)), 256, 0, st>>>(bp, nblk, row0, rows, C, (f16*)out_mean, (f16*)out_norm);
+    VS_CHECK_LAUNCH("mean_normalize");
+    return VS_OK;
+}
+
+int vidseg_kmeans_prepare(const void* x16, int64_t n, int C, double* mean, double* xsq, double* colvar, hipStream_t st) {
+    VS_REQUIRE(n > 0 && C % 8 == 0, "kmeans_prepare: n=%lld C=%d", (long long)n, C);
+    k_col_mean<<<dim3((C + 63) / 64), 64, 0, st>>>((const f16*)x16, n, C, mean);
+    k_row_sqnorm<<<dim3((unsigned)cdiv64(n, 4)), 256, 0, st>>>((const f16*)x16, mean, n, C, xsq);
+    if (colvar) k_col_var<<<dim3((C + 63) / 64), 64, 0, st>>>((const f16*)x16, mean, n, C, colvar);
+    VS_CHECK_LAUNCH("kmeans_prepare");
+    return VS_OK;
+}
+
+int vidseg_row_sqnorm_f64(const void* x16, int64_t n, int C, double* xsq, hipStream_t st) {
+    if (n == 0) return VS_OK;
+    k_row_sqnorm<<<dim3((unsigned)cdiv64(n, 4)), 256, 0, st>>>((const f16*)x16, nullptr, n, C, xsq);
+    VS_CHECK_LAUNCH("row_sqnorm");
+    return VS_OK;
+}
+
+// One k-means++ round for all R restarts: finalise centre c-1 (Tprev trials), draw Tnext candidates for
+// centre c (if c < K) and evaluate them.  Call with c = 0 after writing cand[r] = first centre ids
+// and closest = +inf (Tprev = 0, Tnext = 1 evaluates the first centre), then c = 1..K.
+int vidseg_kpp_round(const void* x16, const double* mean, const double* xsq, int64_t n, int C, int R, int K, int c, int Tprev,
+                     int Tnext, int Tmax, const double* u /*[R][ustride], this round's uniforms*/, int ustride, double* closest,
+                     double* dcand /*[R*Tmax][n]*/, double* part /*[R*Tmax][ntiles]*/, double* pot, int32_t* cand,
+                     int32_t* center_ids, hipStream_t st) {
+    VS_REQUIRE(R >= 1 && R <= 32 && Tmax <= 8 && K >= 1, "kpp_round: R=%d Tmax=%d K=%d", R, Tmax, K);
+    const int ntiles = (int)cdiv64(n, TS);
+    RowsF16 X{(const f16*)x16, nullptr, mean, n, C};
+    if (c > 0) {
+        k_kpp_pick<<<dim3(R), 1024, 0, st>>>(n, R, K, c, Tprev, Tnext, u, ustride, closest, dcand, part, ntiles, pot, cand, center_ids,
+                                             Tmax);
+        VS_CHECK_LAUNCH("kpp_pick");
+    }
+    if (c < K) {
+        // candidates of restart r live compactly at cand[r*Tnext + t]
+        VS_REQUIRE(Tnext >= 1 && Tnext <= Tmax, "kpp_round: Tnext=%d out of [1,%d]", Tnext, Tmax);
+        k_kpp_dist<<<dim3(ntiles, (R * Tnext + TJ - 1) / TJ), 256, 0, st>>>(X, xsq, cand, R, Tnext, closest, dcand, part, ntiles);
+        VS_CHECK_LAUNCH("kpp_dist");
+    }
+    return VS_OK;
+}
+
+int vidseg_gather_rows_f64(const void* x16, const double* mean, int C, const int32_t* ids, int J, double* out, hipStream_t st) {
+    RowsF16 X{(const f16*)x16, nullptr, mean, 0, C};
+    k_gather_centers<<<dim3(J), 256, 0, st>>>(X, ids, J, out);
+    VS_CHECK_LAUNCH("gather_rows");
+    return VS_OK;
+}
+
+// One Lloyd iteration for the restarts in `active`: E-step (labels updated in place, changed[r] += #changes),
+// M-step (fixed-order partial sums), centres updated in place, shift2[r][k] and counts[r][k] written.
+int vidseg_lloyd_iter(const void* x16, const double* mean, int64_t n, int C, int R, int K, unsigned active, int update_centers,
+                      double* centers, double* cnorm, int32_t* labels, int32_t* changed, double* psum, int32_t* pcnt, int chunk,
+                      double* shift2, int32_t* counts, hipStream_t st) {
+    VS_REQUIRE(K >= 1 && K <= 64 && R >= 1 && R <= 32, "lloyd_iter: K=%d R=%d unsupported", K, R);
+    RowsF16 X{(const f16*)x16, nullptr, mean, n, C};
+    const int rpt = 64 / K;
+    k_center_sqnorm<<<dim3((R * K + 3) / 4), 256, 0, st>>>(centers, R * K, C, cnorm);
+    k_lloyd_assign<<<dim3((unsigned)cdiv64(n, TS), (R + rpt - 1) / rpt), 256, 0, st>>>(X, centers, cnorm, R, K, rpt, active, labels,
+                                                                                    changed);
+    VS_CHECK_LAUNCH("lloyd_assign");
+    if (update_centers) {
+        const int nblk = (int)cdiv64(n, chunk);
+        const size_t lds = (size_t)K * 256 * 8 + (size_t)chunk * 4 + (size_t)K * 4;
+        VS_REQUIRE(lds <= 160 * 1024, "lloyd_iter: LDS %zu too large", lds);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)k_lloyd_accum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        k_lloyd_accum<<<dim3(nblk, R), 256, lds, st>>>(X, labels, R, K, active, chunk, psum, pcnt, nblk);
+        VS_CHECK_LAUNCH("lloyd_accum");
+        k_lloyd_update<<<dim3(K, R), 256, 0, st>>>(psum, pcnt, nblk, R, K, C, active, centers, shift2, counts);
+        VS_CHECK_LAUNCH("lloyd_update");
+    }
+    return VS_OK;
+}
+
+int vidseg_kmeans_inertia(const void* x16, const double* mean, int64_t n, int C, int R, int K, const double* centers,
+                          const int32_t* labels, double* part, double* inertia, hipStream_t st) {
+    RowsF16 X{(const f16*)x16, nullptr, mean, n, C};
+    const int nblk = (int)cdiv64(n, 256);
+    k_inertia<<<dim3(nblk, R), 256, 0, st>>>(X, centers, labels, R, K, part, nblk);
+    k_sum_rows<<<dim3(R), 64, 0, st>>>(part, nblk, inertia);
+    VS_CHECK_LAUNCH("kmeans_inertia");
+    return VS_OK;
+}
+
+int vidseg_add_mean_f64(double* centers, const double* mean, int K, int C, hipStream_t st) {
+    k_add_mean<<<dim3((K * C + 255) / 256), 256, 0, st>>>(centers, mean, K, C);
+    VS_CHECK_LAUNCH("add_mean");
+    return VS_OK;
+}
+
+int vidseg_knn_vote(const void* q16, int64_t nq, const void* ref16, int64_t nref, int C, const double* qq, const double* yy,
+                    const int32_t* ref_labels, int32_t* out, hipStream_t st) {
+    VS_REQUIRE(C % 8 == 0, "knn_vote: C=%d must be a multiple of 8", C);
+    if (nq == 0) return VS_OK;
+    VS_REQUIRE(nref >= 1, "knn_vote: empty reference set");
+    RowsF16 Q{(const f16*)q16, nullptr, nullptr, nq, C};
+    RowsF16 Y{(const f16*)ref16, nullptr, nullptr, nref, C};
+    k_knn<<<dim3((unsigned)cdiv64(nq, TS)), 256, 0, st>>>(Q, Y, qq, yy, ref_labels, out);
+    VS_CHECK_LAUNCH("knn_vote");
+    return VS_OK;
+}
+
+int vidseg_track_normalize(const void* x16, int64_t rows, int C, int nb, void* out, hipStream_t st) {
+    VS_REQUIRE(C <= 2048 && nb >= 1, "track_normalize: C=%d nb=%d", C, nb);
+    if (rows == 0) return VS_OK;
+    k_track_normalize<<<dim3((unsigned)cdiv64(rows, 4)), 256, 0, st>>>((const f16*)x16, rows, C, nb, (f16*)out);
+    VS_CHECK_LAUNCH("track_normalize");
+    return VS_OK;
+}
+
+// One frame pair f -> f+1: blend map then per-row arg-max with numpy's tie rule.
+int vidseg_track_step(const void* normed, int F, int N, int w, int C, int f, int batch, const int32_t* cur, int use_aux, void* blend,
+                      int32_t* next, int32_t* tie_rows, hipStream_t st) {
+    VS_REQUIRE(C % 8 == 0 && N <= 32767 && f >= 0 && f + 1 < F, "track_step: C=%d N=%d f=%d F=%d", C, N, f, F);
+    const int nb = N / batch + 1;
+    const int tpb = (batch + TS - 1) / TS;
+    const f16 w1 = (f16)((double)f / (double)(f + 1)), w2 = (f16)(1.0 / (double)(f + 1));
+    k_track_cos<<<dim3(nb * tpb, (N + TJ - 1) / TJ), 256, 0, st>>>((const f16*)normed, (int64_t)F * N, N, C, f, batch, tpb, cur, use_aux,
+                                                                   w1, w2, (f16*)blend);
+    VS_CHECK_LAUNCH("track_cos");
+    k_row_select<<<dim3(N), 64, (size_t)N * 6, st>>>((const f16*)blend, N, w, next, tie_rows);
+    VS_CHECK_LAUNCH("row_select");
+    return VS_OK;
+}
+
+int vidseg_trajectory_vote(const int32_t* idx, const int32_t* labels, int F, int N, int w, int spatial_filter, int32_t* common,
+                           int32_t* winner, int32_t* out, hipStream_t st) {
+    if (N == 0 || F == 0) return VS_OK;
+    hipError_t e = hipMemsetAsync(winner, 0xFF, sizeof(int32_t) * (size_t)F * N, st);
+    if (e != hipSuccess) VS_FAIL(VS_ERR_HIP, "trajectory_vote memset: %s", hipGetErrorString(e));
+    k_traj_vote<<<dim3((N + 255) / 256), 256, 0, st>>>(idx, labels, F, N, w, spatial_filter, common, winner);
+    k_traj_write<<<dim3((unsigned)cdiv64((int64_t)F * N, 256)), 256, 0, st>>>(labels, common, winner, (int64_t)F * N, out);
+    VS_CHECK_LAUNCH("trajectory_vote");
+    return VS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// Shared host/device helpers for libvidseg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define VS_OK 0
+#define VS_ERR_ARG (-1)
+#define VS_ERR_HIP (-2)
+#define VS_ERR_UNSUPPORTED (-3)
+
+extern thread_local char g_vs_err[512];
+
+#define VS_FAIL(code, ...)                                   \
+    do {                                                     \
+        snprintf(g_vs_err, sizeof(g_vs_err), __VA_ARGS__);   \
+        return (code);                                       \
+    } while (0)
+
+#define VS_REQUIRE(cond, ...)                                \
+    do {                                                     \
+        if (!(cond)) VS_FAIL(VS_ERR_ARG, __VA_ARGS__);       \
+    } while (0)
+
+#define VS_CHECK_LAUNCH(name)                                                        \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) VS_FAIL(VS_ERR_HIP, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned short bf16_t;   // raw bf16 bits
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {       // round-to-nearest-even, NaN-safe enough for finite data
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
