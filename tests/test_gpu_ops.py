@@ -1,0 +1,170 @@
+"""Numerics of each hand-written UNet HIP kernel against a plain PyTorch fp32 reference of the same
+op evaluated on the CPU from the same bf16-rounded inputs.
+
+Tolerance (stated once): kernels accumulate in fp32 and round the result once to bf16, so
+|err| <= 2^-8 * |ref| (output rounding) + 1e-3 * max|ref| (accumulation-order slack).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from vidseg_diffusion_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).bfloat16().float()      # bf16-representable fp32
+
+
+def check(out, ref, what):
+    out = out.float().cpu()
+    tol = (2.0 ** -8) * ref.abs() + 1e-3 * ref.abs().max()
+    bad = (out - ref).abs() > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.numel()} outside tolerance, max err {(out - ref).abs().max():.4g}"
+
+
+@pytest.mark.parametrize("M,K,N", [(256, 64, 128), (300, 128, 320), (28, 320, 1280), (1000, 192, 64), (515, 1024, 640)])
+def test_linear(dev, M, K, N):
+    from vidseg_diffusion_amd import ops
+    a, w, b = rnd((M, K), 1), rnd((N, K), 2, 0.05), rnd((N,), 3)
+    res = rnd((M, N), 4)
+    out = ops.linear(a.bfloat16().to(dev), ops.pack_linear(w, dev), b.to(dev), residual=res.bfloat16().to(dev))
+    check(out, a @ w.T + b + res, "linear+bias+residual")
+    out32 = ops.linear(a.bfloat16().to(dev), ops.pack_linear(w, dev), b.to(dev), act=ops.ACT_SILU, out_f32=True)
+    ref = TF.silu(a @ w.T + b)
+    assert (out32.cpu() - ref).abs().max() <= 1e-3 * ref.abs().max() + 1e-5
+
+
+def test_linear_concat_rowvec_tap(dev):
+    from vidseg_diffusion_amd import ops
+    B, HW, C0, C1, N = 3, 50, 128, 64, 192
+    a0, a1 = rnd((B, HW, C0), 1), rnd((B, HW, C1), 2)
+    w, bias, rv = rnd((N, C0 + C1), 3, 0.05), rnd((N,), 4), rnd((B, N), 5)
+    tap = torch.empty((B, HW, 64), dtype=torch.float16, device=dev)
+    out = ops.linear(a0.bfloat16().to(dev), ops.pack_linear(w, dev), bias.to(dev), a1=a1.bfloat16().to(dev), rowvec=rv.to(dev),
+                     rows_per_sample=HW, tap=tap, tap_cols=64)
+    ref = torch.cat([a0, a1], -1) @ w.T + bias + rv[:, None, :]
+    check(out, ref, "linear concat+rowvec")
+    assert (tap.float().cpu() - ref[..., :64]).abs().max() <= 2.0 ** -10 * ref.abs().max() + 1e-3 * ref.abs().max()
+
+
+@pytest.mark.parametrize("M,K,inner", [(200, 64, 256), (130, 320, 1280)])
+def test_geglu(dev, M, K, inner):
+    from vidseg_diffusion_amd import ops
+    a, w, b = rnd((M, K), 1), rnd((2 * inner, K), 2, 0.08), rnd((2 * inner,), 3, 0.5)
+    wp, bp = ops.pack_geglu(w, b, dev)
+    out = ops.linear(a.bfloat16().to(dev), wp, bp, act=ops.ACT_GEGLU)
+    y = a @ w.T + b
+    ref = y[:, :inner] * TF.gelu(y[:, inner:])
+    check(out, ref, "GEGLU")
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, H=8, W=8, C0=64, C1=0, Cout=64, stride=1, up=1),
+    dict(B=3, H=6, W=10, C0=128, C1=64, Cout=128, stride=1, up=1),
+    dict(B=2, H=8, W=8, C0=64, C1=0, Cout=64, stride=2, up=1),
+    dict(B=2, H=5, W=7, C0=128, C1=0, Cout=128, stride=1, up=2),
+    dict(B=1, H=16, W=16, C0=320, C1=0, Cout=320, stride=1, up=1),
+])
+def test_conv3x3(dev, cfg):
+    from vidseg_diffusion_amd import ops
+    B, H, W, C0, C1, Cout = cfg["B"], cfg["H"], cfg["W"], cfg["C0"], cfg["C1"], cfg["Cout"]
+    x0 = rnd((B, H, W, C0), 1)
+    x1 = rnd((B, H, W, C1), 2) if C1 else None
+    w, b = rnd((Cout, C0 + C1, 3, 3), 3, 0.03), rnd((Cout,), 4)
+    x = torch.cat([x0, x1], -1) if C1 else x0
+    xn = x.permute(0, 3, 1, 2)
+    if cfg["up"] == 2:
+        xn = TF.interpolate(xn, scale_factor=2, mode="nearest")
+    ref = TF.conv2d(xn, w, b, stride=cfg["stride"], padding=1)
+    rv = rnd((B, Cout), 5)
+    res = rnd(tuple(ref.permute(0, 2, 3, 1).shape), 6)
+    ref = (ref + rv[:, :, None, None]).permute(0, 2, 3, 1) + res
+    out = ops.conv3x3(x0.bfloat16().to(dev), ops.pack_conv3x3(w, dev), b.to(dev),
+                      x1=x1.bfloat16().to(dev) if C1 else None, stride=cfg["stride"], up=cfg["up"], rowvec=rv.to(dev),
+                      residual=res.bfloat16().to(dev))
+    check(out, ref, f"conv3x3 {cfg}")
+
+
+def test_conv3x3_direct(dev):
+    from vidseg_diffusion_amd import ops
+    x = rnd((2, 8, 8, 4), 1)
+    w, b = rnd((64, 4, 3, 3), 2, 0.2), rnd((64,), 3)
+    ref = TF.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1).permute(0, 2, 3, 1)
+    out = ops.conv3x3_direct(x.to(dev), ops.pack_conv3x3_direct(w, dev), b.to(dev))
+    check(out, ref, "conv_in direct")
+    x2 = rnd((2, 8, 8, 64), 4)
+    w2, b2 = rnd((4, 64, 3, 3), 5, 0.05), rnd((4,), 6)
+    ref2 = TF.conv2d(x2.permute(0, 3, 1, 2), w2, b2, padding=1)
+    out2 = ops.conv3x3_direct(x2.bfloat16().to(dev), ops.pack_conv3x3_direct(w2, dev), b2.to(dev), out_nchw_f32=True)
+    assert (out2.cpu() - ref2).abs().max() <= 1e-4 * ref2.abs().max() + 1e-5
+
+
+@pytest.mark.parametrize("B,HW,C0,C1,silu,eps", [(2, 64, 64, 0, True, 1e-5), (3, 100, 128, 64, True, 1e-5), (2, 256, 320, 0, False, 1e-6),
+                                                   (2, 30, 1280, 640, True, 1e-5)])
+def test_groupnorm(dev, B, HW, C0, C1, silu, eps):
+    from vidseg_diffusion_amd import ops
+    x0 = (rnd((B, HW, C0), 1, 2.0) + 0.5).bfloat16().float()
+    x1 = rnd((B, HW, C1), 2) if C1 else None
+    C = C0 + C1
+    g, bt = rnd((C,), 3) * 0.2 + 1.0, rnd((C,), 4) * 0.2
+    x = torch.cat([x0, x1], -1) if C1 else x0
+    ref = TF.group_norm(x.permute(0, 2, 1), 32, g, bt, eps).permute(0, 2, 1)
+    if silu:
+        ref = TF.silu(ref)
+    out = ops.groupnorm(x0.bfloat16().to(dev), g.to(dev), bt.to(dev), x1=x1.bfloat16().to(dev) if C1 else None, eps=eps, silu=silu)
+    check(out, ref, "groupnorm")
+
+
+@pytest.mark.parametrize("M,C", [(100, 64), (257, 320), (64, 1280)])
+def test_layernorm(dev, M, C):
+    from vidseg_diffusion_amd import ops
+    x, g, b = (rnd((M, C), 1, 2.0) + 0.3).bfloat16().float(), rnd((C,), 2) * 0.2 + 1.0, rnd((C,), 3) * 0.2
+    out = ops.layernorm(x.bfloat16().to(dev), g.to(dev), b.to(dev))
+    check(out, TF.layer_norm(x, (C,), g, b, 1e-5), "layernorm")
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 1, 64, 64), (2, 2, 256, 256), (3, 5, 100, 77), (1, 4, 16, 16), (2, 2, 4, 4), (1, 5, 1024, 1024)])
+def test_attention(dev, B, H, Nq, Nk):
+    from vidseg_diffusion_amd import ops
+    C = H * 64
+    q, k, v = rnd((B, Nq, C), 1), rnd((B, Nk, C), 2), rnd((B, Nk, C), 3)
+    qh, kh, vh = (t.view(B, -1, H, 64).transpose(1, 2) for t in (q, k, v))
+    ref = TF.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Nq, C)
+    out = ops.attention(q.bfloat16().to(dev), k.bfloat16().to(dev), v.bfloat16().to(dev), H)
+    # P is rounded to bf16 before P.V: allow 2^-8 relative on top
+    out = out.float().cpu()
+    tol = (2.0 ** -7) * ref.abs() + 2e-3 * ref.abs().max()
+    assert ((out - ref).abs() <= tol).all(), f"attention max err {(out - ref).abs().max():.4g}"
+
+
+def test_attention_fused_qkv_strides(dev):
+    from vidseg_diffusion_amd import ops
+    B, H, N = 2, 2, 128
+    C = H * 64
+    qkv = rnd((B, N, 3 * C), 1)
+    d = qkv.bfloat16().to(dev)
+    out = ops.attention(d[..., :C], d[..., C:2 * C], d[..., 2 * C:], H)
+    q, k, v = (qkv[..., i * C:(i + 1) * C].reshape(B, N, H, 64).transpose(1, 2) for i in range(3))
+    ref = TF.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, C)
+    assert ((out.float().cpu() - ref).abs() <= (2.0 ** -7) * ref.abs() + 2e-3 * ref.abs().max()).all()
+
+
+def test_timestep_embedding(dev):
+    from vidseg_diffusion_amd import ops
+    t = torch.tensor([0.0, 1.0, 500.0, 999.0])
+    half = 160
+    freqs = torch.exp(-np.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    args = t[:, None] * freqs[None]
+    ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
+    out = ops.timestep_embedding(t.to(dev), 320).float().cpu()
+    assert (out - ref).abs().max() <= 2.0 ** -8 + 2e-3          # bf16 output; fp32 sin/cos argument error at t~1000

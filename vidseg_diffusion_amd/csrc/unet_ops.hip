@@ -1,0 +1,471 @@
+// Non-GEMM UNet operators for gfx950 on NHWC bf16 activations: GroupNorm(+SiLU) over an optional
+// two-source channel concat, LayerNorm, flash-style attention (head dim 64, MFMA), timestep embedding,
+// and the sampler's small elementwise steps.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm32 (sgm/modules/diffusionmodules/util.py:276-278, fp32 statistics) + optional SiLU.
+// Input: concat of x0 [B][HW][C0] and x1 [B][HW][C1] (bf16).  Output bf16 [B][HW][C0+C1].
+//   pass 1: per (b, row-chunk) per-channel partial sum / sumsq  -> part[b][chunk][2][C]
+//   pass 2: per (b, group) fixed-order reduction -> mean, rstd
+//   pass 3: apply
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ const bf16_t* src_ptr(const bf16_t* x0, const bf16_t* x1, int C0, int C1, long long row, int c) {
+    return (c < C0) ? x0 + row * C0 + c : x1 + row * C1 + (c - C0);
+}
+
+__global__ void __launch_bounds__(256) k_gn_partial(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, int C0, int C1, int HW,
+                                                    int rows_per_chunk, int nchunk, float* __restrict__ part) {
+    // grid (nchunk, B, ceil(C/8/256)); thread owns 8 consecutive channels
+    const int C = C0 + C1;
+    const int c = (blockIdx.z * 256 + threadIdx.x) * 8;
+    if (c >= C) return;
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int r0 = ch * rows_per_chunk, r1 = min(HW, r0 + rows_per_chunk);
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(src_ptr(x0, x1, C0, C1, (long long)b * HW + r, c));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = bf16_to_f32((bf16_t)v[j]);
+            s[j] += f;
+            q[j] = fmaf(f, f, q[j]);
+        }
+    }
+    float* o = part + (((long long)b * nchunk + ch) * 2) * C;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        o[c + j] = s[j];
+        o[C + c + j] = q[j];
+    }
+}
+
+__global__ void __launch_bounds__(64) k_gn_stats(const float* __restrict__ part, int C, int G, int HW, int nchunk, float eps,
+                                                 float* __restrict__ stats) {
+    // grid (G, B), one wave: lanes stride over (chunk, channel-in-group); double accumulation, fixed order
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int cpg = C / G;
+    double s = 0.0, q = 0.0;
+    const int total = nchunk * cpg;
+    for (int i = lane; i < total; i += 64) {
+        const int ch = i / cpg, c = g * cpg + i % cpg;
+        const float* o = part + (((long long)b * nchunk + ch) * 2) * C;
+        s += (double)o[c];
+        q += (double)o[C + c];
+    }
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    if (lane == 0) {
+        const double n = (double)HW * cpg;
+        const double mean = s / n;
+        const double var = fmax(q / n - mean * mean, 0.0);
+        stats[((long long)b * G + g) * 2] = (float)mean;
+        stats[((long long)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gn_apply(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, int C0, int C1, int HW,
+                                                  int G, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int silu, long long total8, bf16_t* __restrict__ out) {
+    const int C = C0 + C1;
+    const int cpg = C / G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
+        const long long e = i * 8;
+        const long long row = e / C;
+        const int c = (int)(e % C);
+        const int b = (int)(row / HW);
+        const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(src_ptr(x0, x1, C0, C1, row, c));
+        bf16x8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (c + j) / cpg;
+            const float mean = stats[((long long)b * G + g) * 2], rstd = stats[((long long)b * G + g) * 2 + 1];
+            float f = (bf16_to_f32((bf16_t)v[j]) - mean) * rstd * gamma[c + j] + beta[c + j];
+            if (silu) f = silu_f(f);
+            o[j] = (short)f32_to_bf16(f);
+        }
+        *reinterpret_cast<bf16x8_t*>(out + e) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (eps 1e-5), one wave per row, fp32 two-pass in registers.  C <= 2048.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_layernorm(const bf16_t* __restrict__ x, long long M, int C, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float eps, bf16_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    constexpr int MAXCH = 4;                                  // 64 lanes * 8 * 4 = 2048 channels
+    float v[MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+        const int c = lane * 8 + ch * 512;
+        if (c < C) {
+            const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(x + row * C + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[ch][j] = bf16_to_f32((bf16_t)t[j]);
+                s += v[ch][j];
+            }
+        }
+    }
+    const float mean = wave_sum_f32(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+        const int c = lane * 8 + ch * 512;
+        if (c < C) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[ch][j] - mean;
+                q = fmaf(d, d, q);
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum_f32(q) / (float)C + eps);
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+        const int c = lane * 8 + ch * 512;
+        if (c < C) {
+            bf16x8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (short)f32_to_bf16((v[ch][j] - mean) * rstd * gamma[c + j] + beta[c + j]);
+            *reinterpret_cast<bf16x8_t*>(out + row * C + c) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Attention, head dim 64 (sgm/modules/attention.py:352-356: softmax(q k^T / sqrt(64)) v per head).
+// q: [B][Nq][*] rows with stride ldq, head h at column h*64; likewise k, v (stride ldk / ldv), out stride ldo.
+// Block = 4 waves x 32 queries.  Per 64-key tile: S^T = K Q^T (keys on MFMA rows, queries on columns, so each
+// lane owns one query column: softmax statistics are lane-local plus one lane<->lane+32 exchange),
+// then O^T += V^T P^T with P kept in registers; the key order inside each 16-key MFMA slice is the
+// accumulator's native order for both operands, so no cross-lane shuffle of P is needed.
+// ---------------------------------------------------------------------------------------------
+#define VT_LD 68   // Vt[d][key] row stride in bf16 (136 B): conflict-free ds_read_b64 across d rows
+
+__global__ void __launch_bounds__(256) k_attention(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                                                   const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo, int Nq,
+                                                   int Nk, int H, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) char sK[64 * 128];              // K tile [key][d], 16-B slot XOR swizzle
+    __shared__ __attribute__((aligned(16))) bf16_t sVt[64 * VT_LD];         // V tile transposed [d][key]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bf16_t* qp = q + (long long)b * Nq * ldq + h * 64;
+    const bf16_t* kp = k + (long long)b * Nk * ldk + h * 64;
+    const bf16_t* vp = v + (long long)b * Nk * ldv + h * 64;
+
+    // Q^T as the MFMA B operand: lane holds query (q0 + l31), d = s*16 + hi*8 .. +8
+    bf16x8_t fq[4];
+    {
+        const int qi = min(q0 + l31, Nq - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fq[s] = *reinterpret_cast<const bf16x8_t*>(qp + (long long)qi * ldq + s * 16 + hi * 8);
+    }
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (Nk + 63) / 64;
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * 64;
+        __syncthreads();
+        // stage K (row-major, swizzled) and V (transposed)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (tid >> 3) + 32 * i, ch = tid & 7;
+            const int key = min(k0 + r, Nk - 1);
+            const u32x4 kv = *reinterpret_cast<const u32x4*>(kp + (long long)key * ldk + ch * 8);
+            *reinterpret_cast<u32x4*>(sK + r * 128 + ((ch ^ (r & 7)) << 4)) = kv;
+            const bf16x8_t vv = *reinterpret_cast<const bf16x8_t*>(vp + (long long)key * ldv + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sVt[(ch * 8 + e) * VT_LD + r] = (bf16_t)vv[e];
+        }
+        __syncthreads();
+        // S^T[j] : rows = keys j*32 + .., cols = queries
+        f32x16 sacc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[j][r] = 0.f;
+            const int r = j * 32 + l31;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int ch = s * 2 + hi;
+                const bf16x8_t fk = *reinterpret_cast<const bf16x8_t*>(sK + r * 128 + ((ch ^ (r & 7)) << 4));
+                sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[s], sacc[j], 0, 0, 0);
+            }
+        }
+        // online softmax for this lane's query; key index of sacc[j][r] = k0 + j*32 + (r&3) + 8*(r>>2) + 4*hi
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float sv = sacc[j][r] * scale_log2e;
+                if (key >= Nk) sv = -INFINITY;
+                sacc[j][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(sacc[j][r] - m_new);
+                sacc[j][r] = pv;
+                psum += pv;
+            }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        // O^T[i] += V^T[d-block i] P^T : k-slices of 16 keys, lane's 8 k-slots = keys base + {0..3, 8..11} + 4*hi
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8_t fp;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fp[e] = (short)f32_to_bf16(sacc[j][s * 8 + e]);
+                const int kb = j * 32 + s * 16 + 4 * hi;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bf16_t* vr = sVt + (i * 32 + l31) * VT_LD + kb;
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(vr);
+                    const u32x2 hi2 = *reinterpret_cast<const u32x2*>(vr + 8);
+                    u32x4 pk = {lo[0], lo[1], hi2[0], hi2[1]};
+                    const bf16x8_t fv = *reinterpret_cast<bf16x8_t*>(&pk);
+                    oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv, fp, oacc[i], 0, 0, 0);
+                }
+            }
+    }
+    // write O: lane owns query q0 + l31; oacc[i][r] is d = i*32 + (r&3) + 8*(r>>2) + 4*hi
+    const int qi = q0 + l31;
+    if (qi < Nq) {
+        const float inv = 1.0f / l_run;
+        bf16_t* op = o + ((long long)b * Nq + qi) * ldo + h * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned w0 = (unsigned)f32_to_bf16(oacc[i][g * 4 + 0] * inv) | ((unsigned)f32_to_bf16(oacc[i][g * 4 + 1] * inv) << 16);
+                unsigned w1 = (unsigned)f32_to_bf16(oacc[i][g * 4 + 2] * inv) | ((unsigned)f32_to_bf16(oacc[i][g * 4 + 3] * inv) << 16);
+                u32x2 pk = {w0, w1};
+                *reinterpret_cast<u32x2*>(op + i * 32 + 8 * g + 4 * hi) = pk;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// timestep_embedding (sgm/modules/diffusionmodules/util.py:209-233): [cos(t f_i) | sin(t f_i)], bf16 out
+// ---------------------------------------------------------------------------------------------
+__global__ void k_timestep_embedding(const float* __restrict__ t, int B, int dim, float max_period, bf16_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= B * half) return;
+    const int b = i / half, j = i % half;
+    const float freq = expf(-logf(max_period) * (float)j / (float)half);
+    const float a = t[b] * freq;
+    out[(long long)b * dim + j] = f32_to_bf16(cosf(a));
+    out[(long long)b * dim + half + j] = f32_to_bf16(sinf(a));
+    if ((dim & 1) && j == 0) out[(long long)b * dim + dim - 1] = 0;
+}
+
+__global__ void k_silu_bf16(const bf16_t* __restrict__ x, long long n, bf16_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f32_to_bf16(silu_f(bf16_to_f32(x[i])));
+}
+
+__global__ void k_f32_to_bf16(const float* __restrict__ x, long long n, bf16_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f32_to_bf16(x[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sampler glue (fp32 latents, NCHW [F][C][h][w]):
+//   prepare : net_in NHWC fp32 [2F][h][w][C+Cc] = cat([x,x]) * c_in, optional `concat` channels appended unscaled
+//             (guiders.py:33-42, denoiser.py:23-46, wrappers.py:23-34)
+//   step    : denoised = net*c_out + x*c_skip for both halves, CFG combine x_u + s*(x_c - x_u) (guiders.py:28-31,
+//             per-frame scale for LinearPredictionGuider :60-100), d = (x - denoised)/sigma, x += d*(sigma_next - sigma)
+//             (sampling_utils.py:34, sampling.py:125-131)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_prepare_net_input(const float* __restrict__ x, const float* __restrict__ cc_u, const float* __restrict__ cc_c, int F,
+                                    int C, int Cc, int HW, float c_in, float* __restrict__ out) {
+    const long long total = (long long)2 * F * HW * (C + Cc);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int Ct = C + Cc;
+    const int c = (int)(i % Ct);
+    const long long pix = i / Ct;
+    const int p = (int)(pix % HW);
+    const int n = (int)(pix / HW);
+    const int f = n % F;
+    float v;
+    if (c < C) v = x[((long long)f * C + c) * HW + p] * c_in;
+    else v = (n < F ? cc_u : cc_c)[((long long)f * Cc + (c - C)) * HW + p];
+    out[i] = v;
+}
+
+__global__ void k_cfg_euler_step(float* __restrict__ x, const float* __restrict__ net, int F, int C, int HW, float c_out, float c_skip,
+                                 const float* __restrict__ scale, float scale_const, float sigma, float sigma_next,
+                                 float* __restrict__ denoised_out) {
+    const long long total = (long long)F * C * HW;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int f = (int)(i / ((long long)C * HW));
+    const float xv = x[i];
+    const float du = net[i] * c_out + xv * c_skip;
+    const float dc = net[total + i] * c_out + xv * c_skip;
+    const float s = scale ? scale[f] : scale_const;
+    const float den = du + s * (dc - du);
+    if (denoised_out) denoised_out[i] = den;
+    const float d = (xv - den) / sigma;
+    x[i] = xv + d * (sigma_next - sigma);
+}
+
+__global__ void k_add_noise(float* __restrict__ x, const float* __restrict__ eps, long long n, float sigma, float inv_scale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = (x[i] + eps[i] * sigma) * inv_scale;
+}
+
+__global__ void k_scale_f32(float* __restrict__ x, long long n, float s) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= s;
+}
+
+// latent blending (sampling.py:229-250): x = x*m + xt*(1-m), m nearest-upsampled from [F][fh][fw] to [h][w]
+__global__ void k_latent_blend(float* __restrict__ x, const float* __restrict__ xt, const float* __restrict__ mask, int F, int C, int h,
+                               int w, int fh, int fw) {
+    const long long total = (long long)F * C * h * w;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int xw = (int)(i % w), xh = (int)((i / w) % h);
+    const int f = (int)(i / ((long long)C * h * w));
+    const int sh = min((int)floorf((float)xh * ((float)fh / (float)h)), fh - 1);
+    const int sw = min((int)floorf((float)xw * ((float)fw / (float)w)), fw - 1);
+    const float m = mask[((long long)f * fh + sh) * fw + sw];
+    x[i] = x[i] * m + xt[i] * (1.0f - m);
+}
+
+extern "C" {
+
+int vidseg_groupnorm_nhwc_bf16(const void* x0, const void* x1, int C0, int C1, int B, int HW, int G, const float* gamma,
+                               const float* beta, float eps, int silu, float* part, int part_floats, float* stats, void* out,
+                               hipStream_t st) {
+    const int C = C0 + (x1 ? C1 : 0);
+    VS_REQUIRE(C % G == 0 && C0 % 8 == 0 && (!x1 || C1 % 8 == 0), "groupnorm: C0=%d C1=%d G=%d", C0, C1, G);
+    int rows_per_chunk = 64;
+    int nchunk = (HW + rows_per_chunk - 1) / rows_per_chunk;
+    VS_REQUIRE((long long)B * nchunk * 2 * C <= part_floats, "groupnorm: partial buffer too small (%lld > %d)",
+               (long long)B * nchunk * 2 * C, part_floats);
+    k_gn_partial<<<dim3(nchunk, B, (C / 8 + 255) / 256), 256, 0, st>>>((const bf16_t*)x0, (const bf16_t*)x1, C0, x1 ? C1 : 0, HW,
+                                                                      rows_per_chunk, nchunk, part);
+    k_gn_stats<<<dim3(G, B), 64, 0, st>>>(part, C, G, HW, nchunk, eps, stats);
+    const long long total8 = (long long)B * HW * C / 8;
+    const unsigned blocks = (unsigned)((total8 + 255) / 256 < 4096 ? (total8 + 255) / 256 : 4096);
+    k_gn_apply<<<dim3(blocks), 256, 0, st>>>((const bf16_t*)x0, (const bf16_t*)x1, C0, x1 ? C1 : 0, HW, G, stats, gamma, beta, silu,
+                                             total8, (bf16_t*)out);
+    VS_CHECK_LAUNCH("groupnorm");
+    return VS_OK;
+}
+
+int vidseg_layernorm_bf16(const void* x, long long M, int C, const float* gamma, const float* beta, float eps, void* out,
+                          hipStream_t st) {
+    VS_REQUIRE(C % 8 == 0 && C <= 2048, "layernorm: C=%d", C);
+    if (M == 0) return VS_OK;
+    k_layernorm<<<dim3((unsigned)((M + 3) / 4)), 256, 0, st>>>((const bf16_t*)x, M, C, gamma, beta, eps, (bf16_t*)out);
+    VS_CHECK_LAUNCH("layernorm");
+    return VS_OK;
+}
+
+int vidseg_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int H,
+                          int Nq, int Nk, int head_dim, hipStream_t st) {
+    VS_REQUIRE(head_dim == 64, "attention: head_dim=%d (only 64 is on the path)", head_dim);
+    VS_REQUIRE(Nq > 0 && Nk > 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attention: bad sizes/strides");
+    const float scale_log2e = 0.125f * 1.44269504088896340736f;           // dim_head ** -0.5 * log2(e)
+    k_attention<<<dim3((Nq + 127) / 128, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
+                                                                (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
+    VS_CHECK_LAUNCH("attention");
+    return VS_OK;
+}
+
+int vidseg_timestep_embedding(const float* t, int B, int dim, float max_period, void* out, hipStream_t st) {
+    const int n = B * (dim / 2);
+    k_timestep_embedding<<<dim3((n + 255) / 256), 256, 0, st>>>(t, B, dim, max_period, (bf16_t*)out);
+    VS_CHECK_LAUNCH("timestep_embedding");
+    return VS_OK;
+}
+
+int vidseg_silu_bf16(const void* x, long long n, void* out, hipStream_t st) {
+    k_silu_bf16<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>((const bf16_t*)x, n, (bf16_t*)out);
+    VS_CHECK_LAUNCH("silu");
+    return VS_OK;
+}
+
+int vidseg_f32_to_bf16(const float* x, long long n, void* out, hipStream_t st) {
+    k_f32_to_bf16<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(x, n, (bf16_t*)out);
+    VS_CHECK_LAUNCH("f32_to_bf16");
+    return VS_OK;
+}
+
+int vidseg_prepare_net_input(const float* x, const float* concat_u, const float* concat_c, int F, int C, int Cc, int HW, float c_in,
+                             float* out_nhwc, hipStream_t st) {
+    const long long total = (long long)2 * F * HW * (C + Cc);
+    k_prepare_net_input<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(x, concat_u, concat_c, F, C, Cc, HW, c_in, out_nhwc);
+    VS_CHECK_LAUNCH("prepare_net_input");
+    return VS_OK;
+}
+
+int vidseg_cfg_euler_step(float* x, const float* net_out, int F, int C, int HW, float c_out, float c_skip, const float* frame_scale,
+                          float scale, float sigma, float sigma_next, float* denoised_out, hipStream_t st) {
+    const long long total = (long long)F * C * HW;
+    k_cfg_euler_step<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(x, net_out, F, C, HW, c_out, c_skip, frame_scale, scale,
+                                                                           sigma, sigma_next, denoised_out);
+    VS_CHECK_LAUNCH("cfg_euler_step");
+    return VS_OK;
+}
+
+int vidseg_add_noise(float* x, const float* eps, long long n, float sigma, float inv_scale, hipStream_t st) {
+    k_add_noise<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(x, eps, n, sigma, inv_scale);
+    VS_CHECK_LAUNCH("add_noise");
+    return VS_OK;
+}
+
+int vidseg_scale_f32(float* x, long long n, float s, hipStream_t st) {
+    k_scale_f32<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(x, n, s);
+    VS_CHECK_LAUNCH("scale_f32");
+    return VS_OK;
+}
+
+int vidseg_latent_blend(float* x, const float* xt, const float* mask, int F, int C, int h, int w, int fh, int fw, hipStream_t st) {
+    const long long total = (long long)F * C * h * w;
+    k_latent_blend<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(x, xt, mask, F, C, h, w, fh, fw);
+    VS_CHECK_LAUNCH("latent_blend");
+    return VS_OK;
+}
+
+}  // extern "C"

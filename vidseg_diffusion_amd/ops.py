@@ -1,0 +1,185 @@
+"""Thin Python wrappers over the UNet operator entry points of libvidseg_hip.so.
+
+Activations are NHWC bf16 device tensors (tokens [B, H*W, C] and images [B, H, W, C] share the
+same memory); weights are packed once by `pack_*`.  Every function launches asynchronously on
+torch's current HIP stream and returns the output tensor it allocated.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+_lib.register({
+    "vidseg_linear_bf16": [_P, _P, _I, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P],
+    "vidseg_conv3x3_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
+    "vidseg_conv3x3_direct": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "vidseg_groupnorm_nhwc_bf16": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _P, _P],
+    "vidseg_layernorm_bf16": [_P, _L, _I, _P, _P, _F, _P, _P],
+    "vidseg_attention_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vidseg_timestep_embedding": [_P, _I, _I, _F, _P, _P],
+    "vidseg_silu_bf16": [_P, _L, _P, _P],
+    "vidseg_f32_to_bf16": [_P, _L, _P, _P],
+    "vidseg_prepare_net_input": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P],
+    "vidseg_cfg_euler_step": [_P, _P, _I, _I, _I, _F, _F, _P, _F, _F, _F, _P, _P],
+    "vidseg_add_noise": [_P, _P, _L, _F, _F, _P],
+    "vidseg_scale_f32": [_P, _L, _F, _P],
+    "vidseg_latent_blend": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+})
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+
+
+# ----------------------------------------------------------------------------- weight packing
+def pack_linear(weight: torch.Tensor, device) -> torch.Tensor:
+    """nn.Linear weight [N, K] -> bf16 [N, K] (already the K-contiguous 'B^T' layout MFMA wants)."""
+    return weight.detach().to(device=device, dtype=BF16).contiguous()
+
+
+def pack_conv3x3(weight: torch.Tensor, device) -> torch.Tensor:
+    """Conv2d weight [Cout, Cin, 3, 3] -> bf16 [Cout, (kh*3+kw)*Cin + c] for the NHWC implicit GEMM."""
+    co, ci, kh, kw = weight.shape
+    return weight.detach().permute(0, 2, 3, 1).reshape(co, kh * kw * ci).to(device=device, dtype=BF16).contiguous()
+
+
+def pack_conv3x3_direct(weight: torch.Tensor, device) -> torch.Tensor:
+    """Conv2d weight [Cout, Cin, 3, 3] -> fp32 [Cout, 3, 3, Cin] for the tiny-channel direct kernel."""
+    return weight.detach().permute(0, 2, 3, 1).to(device=device, dtype=F32).contiguous()
+
+
+def pack_geglu(weight: torch.Tensor, bias: torch.Tensor, device):
+    """GEGLU proj [2*inner, K]: rows [0,inner) = value, [inner, 2*inner) = gate (attention.py:92-96).
+    Interleave in 32-row groups (value group, gate group, ...) so that one MFMA wave tile holds the
+    value and the gate of the same output column in the same lane."""
+    two_inner, K = weight.shape
+    inner = two_inner // 2
+    assert inner % 32 == 0
+    w = weight.detach().view(2, inner // 32, 32, K).permute(1, 0, 2, 3).reshape(two_inner, K)
+    b = bias.detach().view(2, inner // 32, 32).permute(1, 0, 2).reshape(two_inner)
+    return w.to(device=device, dtype=BF16).contiguous(), b.to(device=device, dtype=F32).contiguous()
+
+
+def f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=F32).contiguous()
+
+
+# ----------------------------------------------------------------------------- operators
+def linear(a, w, bias=None, *, a1=None, rowvec=None, rows_per_sample=0, residual=None, act=ACT_NONE, out_f32=False,
+           tap=None, tap_cols=0):
+    """out = act(cat(a, a1) @ w.T + bias + rowvec[sample]) + residual.  a: bf16 [..., K0]."""
+    C0 = a.shape[-1]
+    C1 = a1.shape[-1] if a1 is not None else 0
+    M = a.numel() // C0
+    N = w.shape[0]
+    n_out = N // 2 if act == ACT_GEGLU else N
+    out = torch.empty(a.shape[:-1] + (n_out,), dtype=F32 if out_f32 else BF16, device=a.device)
+    call("vidseg_linear_bf16", ptr(a), ptr(a1), C0, C1, M, ptr(w), N, ptr(bias), ptr(rowvec),
+         rowvec.shape[-1] if rowvec is not None else 0, rows_per_sample, ptr(residual),
+         residual.shape[-1] if residual is not None else 0,
+         None if out_f32 else ptr(out), ptr(out) if out_f32 else None, n_out,
+         ptr(tap), tap_cols, tap.shape[-1] if tap is not None else 0, act, stream())
+    return out
+
+
+def conv3x3(x0, w, bias, *, x1=None, stride=1, up=1, rowvec=None, residual=None):
+    """3x3 conv, padding 1, on NHWC bf16 [B, H, W, C0] (+ channel-concat x1), optional fused nearest-2x
+    upsample of the input (openaimodel.py:149-167) or stride 2 (openaimodel.py:202-217)."""
+    B, H, W, C0 = x0.shape
+    C1 = x1.shape[-1] if x1 is not None else 0
+    Cout = w.shape[0]
+    Ho = (H * up + 2 - 3) // stride + 1
+    Wo = (W * up + 2 - 3) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cout), dtype=BF16, device=x0.device)
+    call("vidseg_conv3x3_bf16", ptr(x0), ptr(x1), C0, C1, B, H, W, stride, up, ptr(w), Cout, ptr(bias), ptr(rowvec),
+         rowvec.shape[-1] if rowvec is not None else 0, ptr(residual), ptr(out), stream())
+    return out
+
+
+def conv3x3_direct(x, w_f32, bias, *, out_nchw_f32=False):
+    """Tiny-channel 3x3 conv (input conv Cin=4/8 from fp32 NHWC; output conv Cout=4 to fp32 NCHW)."""
+    B, H, W, Cin = x.shape
+    Cout = w_f32.shape[0]
+    if out_nchw_f32:
+        out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
+        call("vidseg_conv3x3_direct", ptr(x), int(x.dtype == F32), ptr(w_f32), ptr(bias), B, H, W, Cin, Cout, None, ptr(out),
+             stream())
+    else:
+        out = torch.empty((B, H, W, Cout), dtype=BF16, device=x.device)
+        call("vidseg_conv3x3_direct", ptr(x), int(x.dtype == F32), ptr(w_f32), ptr(bias), B, H, W, Cin, Cout, ptr(out), None,
+             stream())
+    return out
+
+
+class Workspace:
+    """Scratch for GroupNorm partials, sized once per device."""
+
+    def __init__(self, device, floats=1 << 24):
+        self.part = torch.empty(floats, dtype=F32, device=device)
+        self.stats = torch.empty(64 * 32 * 2 * 4, dtype=F32, device=device)
+
+
+_ws = {}
+
+
+def workspace(device) -> Workspace:
+    key = (device.type, device.index)
+    if key not in _ws:
+        _ws[key] = Workspace(device)
+    return _ws[key]
+
+
+def groupnorm(x0, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True):
+    """GroupNorm32 (+SiLU) over NHWC bf16 [B, H, W, C0] (+concat x1) -> bf16 [B, H, W, C0+C1]."""
+    B = x0.shape[0]
+    C0 = x0.shape[-1]
+    C1 = x1.shape[-1] if x1 is not None else 0
+    HW = x0.numel() // (B * C0)
+    ws = workspace(x0.device)
+    out = torch.empty(x0.shape[:-1] + (C0 + C1,), dtype=BF16, device=x0.device)
+    call("vidseg_groupnorm_nhwc_bf16", ptr(x0), ptr(x1), C0, C1, B, HW, groups, ptr(gamma), ptr(beta), eps, int(silu),
+         ptr(ws.part), ws.part.numel(), ptr(ws.stats), ptr(out), stream())
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    call("vidseg_layernorm_bf16", ptr(x), x.numel() // C, C, ptr(gamma), ptr(beta), eps, ptr(out), stream())
+    return out
+
+
+def attention(q, k, v, heads, *, q_ld=None, k_ld=None, v_ld=None, Nq=None, Nk=None, B=None):
+    """softmax(q k^T / 8) v per 64-wide head.  q/k/v may be column slices of wider row-major buffers
+    (pass the data pointers' leading dimensions)."""
+    B = q.shape[0] if B is None else B
+    Nq = q.shape[1] if Nq is None else Nq
+    Nk = k.shape[1] if Nk is None else Nk
+    out = torch.empty((B, Nq, heads * 64), dtype=BF16, device=q.device)
+    call("vidseg_attention_bf16", q.data_ptr(), q_ld or q.stride(1), k.data_ptr(), k_ld or k.stride(1), v.data_ptr(),
+         v_ld or v.stride(1), ptr(out), heads * 64, B, heads, Nq, Nk, 64, stream())
+    return out
+
+
+def timestep_embedding(t, dim, max_period=10000.0):
+    out = torch.empty((t.shape[0], dim), dtype=BF16, device=t.device)
+    call("vidseg_timestep_embedding", ptr(t), t.shape[0], dim, float(max_period), ptr(out), stream())
+    return out
+
+
+def silu(x):
+    out = torch.empty_like(x)
+    call("vidseg_silu_bf16", ptr(x), x.numel(), ptr(out), stream())
+    return out
+
+
+def to_bf16(x):
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    call("vidseg_f32_to_bf16", ptr(x), x.numel(), ptr(out), stream())
+    return out
