@@ -1,0 +1,215 @@
+"""Oracle (CPU restatement, torch fp32) of the SD 2.1 UNet forward with Q/K taps and of the
+sampler/denoiser/guider arithmetic -- test infrastructure only.
+
+The network structure is read off the state-dict keys themselves (upstream SD key names), so this
+file shares no code with vidseg_diffusion_amd/unet.py.  Restates:
+
+  sgm/modules/diffusionmodules/openaimodel.py  UNetModel.forward :831-954, ResBlock._forward :341-369,
+      Upsample :149-167, Downsample :214-217, TimestepEmbedSequential :87-114
+  sgm/modules/attention.py  SpatialTransformer.forward :889-927, BasicTransformerBlock._forward :609-759,
+      CrossAttention.forward :286-364 (q/k capture :330-331), GEGLU :89-96
+  sgm/modules/diffusionmodules/util.py  timestep_embedding :209-233, GroupNorm32 :276-278
+  sgm/modules/diffusionmodules/{sampling,guiders,denoiser,denoiser_scaling,discretizer}.py (see each function)
+
+`round_bf16=True` additionally rounds every matmul/conv operand and every stored activation to
+bf16 exactly where the HIP path does (fp32 accumulation), which isolates accumulation-order
+effects from format effects in the parity tests.
+
+Pinned by tests/golden/unet_*.npz (tools/gen_golden_unet.py runs the reference's UNetModel and
+EulerEDMSampler on a narrow-width instance of the same topology).
+"""
+from __future__ import annotations
+
+import math
+import re
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _bf(x, on):
+    return x.bfloat16().float() if on else x
+
+
+class UNetOracle:
+    def __init__(self, state_dict, num_head_channels=64, round_bf16=False):
+        self.sd = {k: v.float() for k, v in state_dict.items()}
+        self.hc = num_head_channels
+        self.rb = round_bf16
+        self.taps = {}
+        self.n_in = 1 + max(int(m.group(1)) for k in self.sd if (m := re.match(r"input_blocks\.(\d+)\.", k)))
+        self.n_out = 1 + max(int(m.group(1)) for k in self.sd if (m := re.match(r"output_blocks\.(\d+)\.", k)))
+
+    # ---- primitives ---------------------------------------------------------------------------
+    def w(self, name):
+        t = self.sd[name]
+        return _bf(t, self.rb) if (t.dim() >= 2) else t                # matrices/conv kernels are bf16 operands
+
+    def has(self, prefix):
+        return any(k.startswith(prefix) for k in self.sd)
+
+    def lin(self, x, p, bias=True):
+        return F.linear(_bf(x, self.rb), self.w(p + ".weight"), self.sd[p + ".bias"] if bias else None)
+
+    def conv(self, x, p, stride=1, pad=1):
+        return F.conv2d(_bf(x, self.rb), self.w(p + ".weight"), self.sd[p + ".bias"], stride=stride, padding=pad)
+
+    def gn(self, x, p, eps):
+        return F.group_norm(x, 32, self.sd[p + ".weight"], self.sd[p + ".bias"], eps)
+
+    # ---- blocks -------------------------------------------------------------------------------
+    def resblock(self, x, emb_silu, p):
+        h = _bf(F.silu(self.gn(x, p + ".in_layers.0", 1e-5)), self.rb)
+        h = self.conv(h, p + ".in_layers.2") + self.lin(emb_silu, p + ".emb_layers.1")[:, :, None, None]
+        h = _bf(h, self.rb)
+        h = _bf(F.silu(self.gn(h, p + ".out_layers.0", 1e-5)), self.rb)
+        if self.has(p + ".skip_connection."):
+            skip = _bf(self.conv(x, p + ".skip_connection", pad=0), self.rb)
+        else:
+            skip = x
+        return _bf(self.conv(h, p + ".out_layers.3") + skip, self.rb)
+
+    def attention(self, x, ctx, p, tapname):
+        q = self.lin(x, p + ".to_q", bias=False)
+        k = self.lin(ctx, p + ".to_k", bias=False)
+        v = self.lin(ctx, p + ".to_v", bias=False)
+        if tapname is not None:
+            self.taps[tapname + "_q"] = q.half()
+            self.taps[tapname + "_k"] = k.half()
+        B, N, C = q.shape
+        H = C // self.hc
+        qh, kh, vh = (_bf(t, self.rb).view(B, -1, H, self.hc).transpose(1, 2) for t in (q, k, v))
+        a = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, N, C)
+        return self.lin(_bf(a, self.rb), p + ".to_out.0")
+
+    def ln(self, x, p):
+        return _bf(F.layer_norm(x, (x.shape[-1],), self.sd[p + ".weight"], self.sd[p + ".bias"], 1e-5), self.rb)
+
+    def transformer(self, x, context, p, tapname):
+        B, C, H, W = x.shape
+        t = _bf(self.gn(x, p + ".norm", 1e-6), self.rb).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        t = _bf(self.lin(t, p + ".proj_in"), self.rb)
+        d = 0
+        while self.has(f"{p}.transformer_blocks.{d}."):
+            b = f"{p}.transformer_blocks.{d}"
+            tn = tapname if d == 0 else None
+            n1 = self.ln(t, b + ".norm1")
+            t = _bf(self.attention(n1, n1, b + ".attn1", tn and tn + "_spatial_self_attn") + t, self.rb)
+            t = _bf(self.attention(self.ln(t, b + ".norm2"), context, b + ".attn2", tn and tn + "_spatial_cross_attn") + t, self.rb)
+            y = self.lin(self.ln(t, b + ".norm3"), b + ".ff.net.0.proj")
+            val, gate = y.chunk(2, dim=-1)
+            t = _bf(self.lin(_bf(val * F.gelu(gate), self.rb), b + ".ff.net.2") + t, self.rb)
+            d += 1
+        t = self.lin(t, p + ".proj_out")
+        return _bf(t.reshape(B, H, W, C).permute(0, 3, 1, 2) + x, self.rb)
+
+    def block(self, h, emb_silu, context, p, tapname):
+        j = 0
+        while self.has(f"{p}.{j}."):
+            q = f"{p}.{j}"
+            if self.has(q + ".in_layers."):
+                h = self.resblock(h, emb_silu, q)
+            elif self.has(q + ".transformer_blocks."):
+                h = self.transformer(h, context, q, tapname)
+            elif self.has(q + ".op."):
+                h = _bf(self.conv(h, q + ".op", stride=2), self.rb)
+            elif self.has(q + ".conv."):
+                h = _bf(self.conv(F.interpolate(h, scale_factor=2, mode="nearest"), q + ".conv"), self.rb)
+            else:
+                h = _bf(self.conv(h, q), self.rb)                                  # input_blocks.0.0
+            j += 1
+        return h
+
+    def timestep_embedding(self, t, dim):
+        half = dim // 2
+        freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+        args = t[:, None].float() * freqs[None]
+        return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+    def forward(self, x, timesteps, context, y=None):
+        """x [B, Cin, h, w] fp32, context [B, L, ctx]; returns fp32 [B, Cout, h, w]; self.taps filled with
+        fp16 'output_block_{i}_spatial_{self,cross}_attn_{q,k}' like the reference's dump names."""
+        self.taps = {}
+        mc = self.sd["time_embed.0.weight"].shape[1]
+        t_emb = _bf(self.timestep_embedding(timesteps, mc), self.rb)
+        emb = self.lin(_bf(F.silu(self.lin(t_emb, "time_embed.0")), self.rb), "time_embed.2")
+        emb = _bf(emb, self.rb)
+        if y is not None:
+            le = self.lin(_bf(F.silu(self.lin(_bf(y, self.rb), "label_emb.0.0")), self.rb), "label_emb.0.2")
+            emb = _bf(emb + le, self.rb)
+        emb_silu = _bf(F.silu(emb), self.rb)
+        context = _bf(context, self.rb)
+        hs = []
+        h = x if not self.rb else x                                                # input conv reads fp32 latents
+        for i in range(self.n_in):
+            if i == 0:
+                h = _bf(F.conv2d(h, self.sd["input_blocks.0.0.weight"], self.sd["input_blocks.0.0.bias"], padding=1), self.rb)
+            else:
+                h = self.block(h, emb_silu, context, f"input_blocks.{i}", None)
+            hs.append(h)
+        h = self.block(h, emb_silu, context, "middle_block", None)
+        for i in range(self.n_out):
+            h = torch.cat([h, hs.pop()], dim=1)
+            h = self.block(h, emb_silu, context, f"output_blocks.{i}", f"output_block_{i}")
+        h = _bf(F.silu(self.gn(h, "out.0", 1e-5)), self.rb)
+        return F.conv2d(h, self.sd["out.2.weight"], self.sd["out.2.bias"], padding=1)
+
+
+# ---------------------------------------------------------------------------------------------
+# sampler arithmetic
+# ---------------------------------------------------------------------------------------------
+def legacy_ddpm_sigmas(n, linear_start=0.00085, linear_end=0.0120, num_timesteps=1000):
+    """LegacyDDPMDiscretization (discretizer.py:43-70) + append_zero (:18-21): float32 [n+1], descending.
+    make_beta_schedule('linear') = linspace(sqrt(start), sqrt(end), T, float64)**2 (util.py)."""
+    betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, num_timesteps, dtype=torch.float64) ** 2
+    alphas_cumprod = np.cumprod(1.0 - betas.numpy(), axis=0)
+    if n < num_timesteps:
+        ts = np.linspace(num_timesteps - 1, 0, n, endpoint=False).astype(int)[::-1]
+        alphas_cumprod = alphas_cumprod[ts]
+    sig = torch.tensor((1 - alphas_cumprod) / alphas_cumprod, dtype=torch.float32) ** 0.5
+    sig = torch.flip(sig, (0,))
+    return torch.cat([sig, sig.new_zeros([1])])
+
+
+def discrete_sigma_table(num_idx=1000):
+    """DiscreteDenoiser.sigmas (denoiser.py:60-66): discretization(num_idx, do_append_zero=False, flip=True)."""
+    return torch.flip(legacy_ddpm_sigmas(num_idx)[:-1], (0,))
+
+
+def sigma_to_idx(sigma, table):
+    return (sigma - table[:, None]).abs().argmin(dim=0)
+
+
+def euler_sample(unet: UNetOracle, latent, c_cross, uc_cross, num_steps=25, t_start=22, scale=5.0, noise=None,
+                 callback=None):
+    """add_noise (sampling.py:133-144) + EulerEDMSampler.__call__ (:146-262) with VanillaCFG (guiders.py:24-42),
+    DiscreteDenoiser + EpsScaling (denoiser.py:23-82, denoiser_scaling.py:29-37), s_churn = 0.
+    latent [F,4,h,w] fp32; returns the final x and calls callback(x, i, unet.taps) after every step."""
+    sigmas = legacy_ddpm_sigmas(num_steps)
+    table = discrete_sigma_table(1000)
+    x = latent.clone()
+    if noise is not None:
+        x = x + noise * sigmas[t_start]
+        x = x / torch.sqrt(1.0 + sigmas[0] ** 2.0)
+    x = x * torch.sqrt(1.0 + sigmas[0] ** 2.0)                                     # prepare_sampling_loop :54
+    Fn = x.shape[0]
+    for i in range(t_start, num_steps):
+        sigma, nxt = sigmas[i], sigmas[i + 1]
+        s2 = torch.full((2 * Fn,), float(sigma))
+        idx = sigma_to_idx(s2, table)                                              # possibly_quantize_sigma
+        sq = table[idx]
+        c_in = 1 / (sq ** 2 + 1.0) ** 0.5
+        c_out = -sq
+        c_noise = sigma_to_idx(sq, table)                                          # quantized c_noise = index
+        xin = torch.cat([x, x]) * c_in[:, None, None, None]
+        ctx = torch.cat([uc_cross, c_cross])
+        net = unet.forward(xin, c_noise.float(), ctx)
+        den = net * c_out[:, None, None, None] + torch.cat([x, x])
+        xu, xc = den.chunk(2)
+        den = xu + scale * (xc - xu)
+        d = (x - den) / sigma
+        x = x + d * (nxt - sigma)
+        if callback is not None:
+            callback(x, i, unet.taps)
+    return x

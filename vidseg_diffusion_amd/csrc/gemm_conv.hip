@@ -36,6 +36,7 @@ struct GemmParams {
     int ldo;
     float* out_f32;          // [M][ldo] or nullptr
     f16* tap;                // fp16 copy of columns [0, tap_cols) with leading dim tap_ld, or nullptr
+    f16* tap2;               // fp16 copy of columns [tap_cols, 2*tap_cols) (same leading dim), or nullptr
     int tap_cols, tap_ld;
     int act;                 // 0 none, 1 SiLU, 2 GEGLU (32-column interleaved x|gate groups)
 };
@@ -222,6 +223,7 @@ __global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
                     if (p.rowvec) v += p.rowvec[(m / p.rows_per_sample) * p.rv_stride + n];
                     if (p.act == 1) v = silu_f(v);
                     if (p.tap && n < p.tap_cols) p.tap[m * p.tap_ld + n] = (f16)v;
+                    if (p.tap2 && n >= p.tap_cols && n < 2 * p.tap_cols) p.tap2[m * p.tap_ld + (n - p.tap_cols)] = (f16)v;
                     if (p.residual) v += bf16_to_f32(p.residual[m * p.ldr + n]);
                     if (p.out) p.out[m * p.ldo + n] = f32_to_bf16(v);
                     if (p.out_f32) p.out_f32[m * p.ldo + n] = v;
@@ -293,7 +295,7 @@ static int launch_gemm(const GemmParams& p, hipStream_t st) {
 // out[M][N] = A[M][K] @ W[N][K]^T (+bias)(+rowvec)(act)(+residual); A may be the channel concat of two [M][C] tensors.
 int vidseg_linear_bf16(const void* a0, const void* a1, int C0, int C1, long long M, const void* w, int N, const float* bias,
                        const float* rowvec, int rv_stride, int rows_per_sample, const void* residual, int ldr, void* out,
-                       float* out_f32, int ldo, void* tap, int tap_cols, int tap_ld, int act, hipStream_t st) {
+                       float* out_f32, int ldo, void* tap, void* tap2, int tap_cols, int tap_ld, int act, hipStream_t st) {
     GemmParams p{};
     p.x0 = (const bf16_t*)a0;
     p.x1 = (const bf16_t*)a1;
@@ -317,6 +319,7 @@ int vidseg_linear_bf16(const void* a0, const void* a1, int C0, int C1, long long
     p.out_f32 = out_f32;
     p.ldo = ldo;
     p.tap = (f16*)tap;
+    p.tap2 = (f16*)tap2;
     p.tap_cols = tap_cols;
     p.tap_ld = tap_ld;
     p.act = act;

@@ -16,7 +16,7 @@ from ._lib import call, ptr, stream
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
 _lib.register({
-    "vidseg_linear_bf16": [_P, _P, _I, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P],
+    "vidseg_linear_bf16": [_P, _P, _I, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P],
     "vidseg_conv3x3_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
     "vidseg_conv3x3_direct": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "vidseg_groupnorm_nhwc_bf16": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _P, _P],
@@ -30,6 +30,11 @@ _lib.register({
     "vidseg_add_noise": [_P, _P, _L, _F, _F, _P],
     "vidseg_scale_f32": [_P, _L, _F, _P],
     "vidseg_latent_blend": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vidseg_rows_axpby": [_P, _P, _P, _P, _L, _L, _P, _P],
+    "vidseg_cfg_combine": [_P, _L, _L, _P, _I, _F, _P, _P],
+    "vidseg_euler_update": [_P, _P, _P, _P, _L, _L, _P, _P],
+    "vidseg_axpy_f32": [_P, _P, _L, _F, _F, _P, _P],
+    "vidseg_blend_f32": [_P, _P, _P, _L, _P, _P],
 })
 
 BF16 = torch.bfloat16
@@ -72,7 +77,7 @@ def f32(t: torch.Tensor, device) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- operators
 def linear(a, w, bias=None, *, a1=None, rowvec=None, rows_per_sample=0, residual=None, act=ACT_NONE, out_f32=False,
-           tap=None, tap_cols=0):
+           tap=None, tap2=None, tap_cols=0):
     """out = act(cat(a, a1) @ w.T + bias + rowvec[sample]) + residual.  a: bf16 [..., K0]."""
     C0 = a.shape[-1]
     C1 = a1.shape[-1] if a1 is not None else 0
@@ -81,10 +86,10 @@ def linear(a, w, bias=None, *, a1=None, rowvec=None, rows_per_sample=0, residual
     n_out = N // 2 if act == ACT_GEGLU else N
     out = torch.empty(a.shape[:-1] + (n_out,), dtype=F32 if out_f32 else BF16, device=a.device)
     call("vidseg_linear_bf16", ptr(a), ptr(a1), C0, C1, M, ptr(w), N, ptr(bias), ptr(rowvec),
-         rowvec.shape[-1] if rowvec is not None else 0, rows_per_sample, ptr(residual),
+         rowvec.stride(0) if rowvec is not None else 0, rows_per_sample, ptr(residual),
          residual.shape[-1] if residual is not None else 0,
          None if out_f32 else ptr(out), ptr(out) if out_f32 else None, n_out,
-         ptr(tap), tap_cols, tap.shape[-1] if tap is not None else 0, act, stream())
+         ptr(tap), ptr(tap2), tap_cols, tap.shape[-1] if tap is not None else 0, act, stream())
     return out
 
 
@@ -98,7 +103,7 @@ def conv3x3(x0, w, bias, *, x1=None, stride=1, up=1, rowvec=None, residual=None)
     Wo = (W * up + 2 - 3) // stride + 1
     out = torch.empty((B, Ho, Wo, Cout), dtype=BF16, device=x0.device)
     call("vidseg_conv3x3_bf16", ptr(x0), ptr(x1), C0, C1, B, H, W, stride, up, ptr(w), Cout, ptr(bias), ptr(rowvec),
-         rowvec.shape[-1] if rowvec is not None else 0, ptr(residual), ptr(out), stream())
+         rowvec.stride(0) if rowvec is not None else 0, ptr(residual), ptr(out), stream())
     return out
 
 
@@ -182,4 +187,68 @@ def silu(x):
 def to_bf16(x):
     out = torch.empty(x.shape, dtype=BF16, device=x.device)
     call("vidseg_f32_to_bf16", ptr(x), x.numel(), ptr(out), stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- sampler arithmetic (fp32 latents)
+def _rowvec(v, B, device):
+    """per-row scalars as a small fp32 device vector [B] (accepts python floats or CPU/GPU tensors)."""
+    if not torch.is_tensor(v):
+        v = torch.full((B,), float(v), dtype=F32)
+    v = v.reshape(-1).to(dtype=F32)
+    if v.numel() == 1 and B > 1:
+        v = v.expand(B)
+    return v.contiguous().to(device, non_blocking=True)
+
+
+def rows_axpby(a, sa, b=None, sb=None):
+    """a * sa[row] (+ b * sb[row]) with per-batch-row scalars."""
+    B = a.shape[0]
+    a = a.contiguous()
+    out = torch.empty_like(a)
+    dsa = _rowvec(sa, B, a.device)
+    dsb = _rowvec(sb, B, a.device) if b is not None else None
+    call("vidseg_rows_axpby", ptr(a), ptr(dsa), ptr(b.contiguous()) if b is not None else None, ptr(dsb), a.numel(),
+         a.numel() // B, ptr(out), stream())
+    return out
+
+
+def cfg_combine(x, scale, num_frames=0):
+    """x_u + s (x_c - x_u) on a [2F, ...] stack (guiders.py:28-31); `scale` float or per-frame device vector."""
+    x = x.contiguous()
+    half = x.numel() // 2
+    out = torch.empty((x.shape[0] // 2,) + tuple(x.shape[1:]), dtype=F32, device=x.device)
+    fs = scale if torch.is_tensor(scale) else None
+    call("vidseg_cfg_combine", ptr(x), half, x.numel() // x.shape[0], ptr(fs), num_frames,
+         0.0 if fs is not None else float(scale), ptr(out), stream())
+    return out
+
+
+def euler_update(x, denoised, sigma, sigma_next):
+    B = x.shape[0]
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    call("vidseg_euler_update", ptr(x), ptr(denoised.contiguous()), ptr(_rowvec(sigma, B, x.device)),
+         ptr(_rowvec(sigma_next, B, x.device)), x.numel(), x.numel() // B, ptr(out), stream())
+    return out
+
+
+def axpy(x, e, s, post=1.0):
+    """(x + e * s) * post."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    call("vidseg_axpy_f32", ptr(x), ptr(e.contiguous()), x.numel(), float(s), float(post), ptr(out), stream())
+    return out
+
+
+def scale(x, s):
+    out = x.clone()
+    call("vidseg_scale_f32", ptr(out), out.numel(), float(s), stream())
+    return out
+
+
+def blend(x, y, m):
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    call("vidseg_blend_f32", ptr(x), ptr(y.contiguous()), ptr(m.contiguous()), x.numel(), ptr(out), stream())
     return out

@@ -108,3 +108,45 @@ def sd_conditioning(num_frames: int, context_dim: int = 1024, seq: int = 77, see
     c = g.standard_normal((1, seq, context_dim)).astype(np.float32)
     c = np.repeat(c, num_frames, axis=0)
     return c, np.zeros_like(c)
+
+
+def fill_state_dict(shapes: dict, seed: int = 1234, gain: float = 1.0) -> dict:
+    """Deterministic synthetic weights for a state dict given {name: shape}.
+
+    Every tensor gets its own PCG64 stream keyed by (seed, sha256(name)), so the values do not depend
+    on dict order or on which other tensors exist.  Matrices / conv kernels ~ N(0, gain/sqrt(fan_in))
+    -- including the reference's zero-initialised modules (openaimodel.py:306-314, :828;
+    attention.py:880-886), which would otherwise silence every residual branch -- 1-D ".weight"
+    (norm scales) ~ 1 + 0.1 N(0,1), biases ~ 0.05 N(0,1).  Returns float32 numpy arrays.
+    """
+    out = {}
+    for name in sorted(shapes):
+        shape = tuple(int(s) for s in shapes[name])
+        key = int.from_bytes(hashlib.sha256(name.encode()).digest()[:8], "little")
+        g = np.random.Generator(np.random.PCG64([seed, key]))
+        n = g.standard_normal(shape, dtype=np.float32)
+        if len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            n *= np.float32(gain / np.sqrt(fan_in))
+        elif name.endswith("weight"):
+            n = np.float32(1.0) + np.float32(0.1) * n
+        else:
+            n *= np.float32(0.05)
+        out[name] = n
+    return out
+
+
+def state_dict_signature(shapes: dict) -> str:
+    h = hashlib.sha256()
+    for name in sorted(shapes):
+        h.update(name.encode())
+        h.update(str(tuple(int(s) for s in shapes[name])).encode())
+    return h.hexdigest()
+
+
+SD21_NARROW = dict(in_channels=4, out_channels=4, model_channels=64, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+                   channel_mult=[1, 2, 4, 4], num_head_channels=64, use_linear_in_transformer=True, transformer_depth=1,
+                   context_dim=64)
+SD21_FULL = dict(in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+                 channel_mult=[1, 2, 4, 4], num_head_channels=64, use_linear_in_transformer=True, transformer_depth=1,
+                 context_dim=1024)                                     # configs/inference/sd_2_1.yaml:19-30

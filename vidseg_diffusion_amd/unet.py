@@ -1,0 +1,422 @@
+"""MI355X-native UNet behind the reference's network plug-in seam.
+
+`UNetModel` takes the constructor kwargs of configs/inference/sd_2_1.yaml:19-30 (the class the
+YAML's `network_config.target` names, sgm/modules/diffusionmodules/openaimodel.py:487-829), keeps
+the upstream state-dict key names (load_state_dict works on SD 2.1 checkpoints) and the attribute
+protocol the drivers poke (scripts/sampling/sd_pipeline_vspw.py:107-120):
+
+    len(block) > 1 and "SpatialTransformer" in str(type(block[1]))
+    block[1].transformer_blocks[0].attn{1,2}.{q,k}      # tensors valid after each forward
+
+The forward pass is a sequence of hand-written HIP kernels on NHWC bf16 activations (ops.py); the
+torch.nn modules here only hold parameters and names.  Nothing falls back to torch operators.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import VidsegError
+
+F16 = torch.float16
+
+
+def _meta(factory, *a, **k):
+    return factory(*a, device="meta", **k)
+
+
+class GroupNorm32(nn.GroupNorm):
+    """Parameter holder for normalization(channels) (diffusionmodules/util.py:261-278)."""
+
+
+class Upsample(nn.Module):
+    """openaimodel.py:117-167 (dims=2, use_conv=True): nearest x2 fused into the conv's addressing."""
+
+    def __init__(self, channels, out_channels=None):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.conv = _meta(nn.Conv2d, channels, self.out_channels, 3, padding=1)
+
+    def pack(self, dev):
+        self.w = ops.pack_conv3x3(self.conv.weight, dev)
+        self.b = ops.f32(self.conv.bias, dev)
+
+    def run(self, x):
+        return ops.conv3x3(x, self.w, self.b, up=2)
+
+
+class Downsample(nn.Module):
+    """openaimodel.py:170-217 (dims=2, use_conv=True): stride-2 3x3 conv."""
+
+    def __init__(self, channels, out_channels=None):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.op = _meta(nn.Conv2d, channels, self.out_channels, 3, stride=2, padding=1)
+
+    def pack(self, dev):
+        self.w = ops.pack_conv3x3(self.op.weight, dev)
+        self.b = ops.f32(self.op.bias, dev)
+
+    def run(self, x):
+        return ops.conv3x3(x, self.w, self.b, stride=2)
+
+
+class ResBlock(nn.Module):
+    """openaimodel.py:220-369, the configuration SD 2.1 / SVD use (no scale-shift norm, no up/down)."""
+
+    def __init__(self, channels, emb_channels, out_channels=None):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.in_layers = nn.Sequential(_meta(GroupNorm32, 32, channels), nn.SiLU(),
+                                       _meta(nn.Conv2d, channels, self.out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), _meta(nn.Linear, emb_channels, self.out_channels))
+        self.out_layers = nn.Sequential(_meta(GroupNorm32, 32, self.out_channels), nn.SiLU(), nn.Dropout(p=0.0),
+                                        _meta(nn.Conv2d, self.out_channels, self.out_channels, 3, padding=1))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = _meta(nn.Conv2d, channels, self.out_channels, 1)
+        self.emb_offset = None                                     # column offset into the batched emb GEMM
+        self.in_layers_features = None
+        self.out_layers_features = None
+
+    def pack(self, dev):
+        self.g1, self.b1 = ops.f32(self.in_layers[0].weight, dev), ops.f32(self.in_layers[0].bias, dev)
+        self.w1, self.cb1 = ops.pack_conv3x3(self.in_layers[2].weight, dev), ops.f32(self.in_layers[2].bias, dev)
+        self.g2, self.b2 = ops.f32(self.out_layers[0].weight, dev), ops.f32(self.out_layers[0].bias, dev)
+        self.w2, self.cb2 = ops.pack_conv3x3(self.out_layers[3].weight, dev), ops.f32(self.out_layers[3].bias, dev)
+        if not isinstance(self.skip_connection, nn.Identity):
+            self.ws = ops.pack_linear(self.skip_connection.weight.reshape(self.out_channels, self.channels), dev)
+            self.bs = ops.f32(self.skip_connection.bias, dev)
+
+    def run(self, x0, x1, emb_all):
+        """x0 (+ x1: skip tensor to concatenate on channels, openaimodel.py:912) NHWC bf16;
+        emb_all: fp32 [B, sum(Cout)] = every block's emb_layers output from one batched GEMM."""
+        h = ops.groupnorm(x0, self.g1, self.b1, x1=x1, eps=1e-5, silu=True)
+        rv = emb_all[:, self.emb_offset:self.emb_offset + self.out_channels]
+        h = ops.conv3x3(h, self.w1, self.cb1, rowvec=rv)                               # conv + bias + emb_out (OAI:353-365)
+        self.in_layers_features = h
+        h = ops.groupnorm(h, self.g2, self.b2, eps=1e-5, silu=True)
+        if isinstance(self.skip_connection, nn.Identity):
+            if x1 is not None:
+                raise VidsegError("ResBlock: identity skip with a concatenated input")
+            res = x0
+        else:
+            res = ops.linear(x0, self.ws, self.bs, a1=x1)
+        out = ops.conv3x3(h, self.w2, self.cb2, residual=res)                          # OAI:369
+        self.out_layers_features = out
+        return out
+
+
+class CrossAttention(nn.Module):
+    """attention.py:257-364.  q/k hold the fp16 projections before the head split (ATT:330-331)."""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64):
+        super().__init__()
+        if dim_head != 64:
+            raise NotImplementedError("only 64-channel heads are on the path (num_head_channels: 64)")
+        inner = heads * dim_head
+        self.heads = heads
+        self.inner = inner
+        self.is_self = context_dim is None
+        context_dim = context_dim or query_dim
+        self.scale = dim_head ** -0.5
+        self.to_q = _meta(nn.Linear, query_dim, inner, bias=False)
+        self.to_k = _meta(nn.Linear, context_dim, inner, bias=False)
+        self.to_v = _meta(nn.Linear, context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(_meta(nn.Linear, inner, query_dim), nn.Dropout(0.0))
+        self.q = None
+        self.k = None
+
+    def pack(self, dev):
+        if self.is_self:
+            self.w_qkv = ops.pack_linear(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0), dev)
+        else:
+            self.w_q = ops.pack_linear(self.to_q.weight, dev)
+            self.w_kv = ops.pack_linear(torch.cat([self.to_k.weight, self.to_v.weight], 0), dev)
+        self.w_o = ops.pack_linear(self.to_out[0].weight, dev)
+        self.b_o = ops.f32(self.to_out[0].bias, dev)
+
+    def run(self, x, context, residual, tap):
+        """x: normed tokens bf16 [B, N, C]; returns to_out(attn) + residual."""
+        B, N, _ = x.shape
+        C = self.inner
+        dev = x.device
+        if self.is_self:
+            tq = torch.empty((B, N, C), dtype=F16, device=dev) if tap else None
+            tk = torch.empty((B, N, C), dtype=F16, device=dev) if tap else None
+            qkv = ops.linear(x, self.w_qkv, tap=tq, tap2=tk, tap_cols=C)
+            a = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], self.heads)
+        else:
+            L = context.shape[1]
+            tq = torch.empty((B, N, C), dtype=F16, device=dev) if tap else None
+            tk = torch.empty((B, L, C), dtype=F16, device=dev) if tap else None
+            q = ops.linear(x, self.w_q, tap=tq, tap_cols=C)
+            kv = ops.linear(context, self.w_kv, tap=tk, tap_cols=C)
+            a = ops.attention(q, kv[..., :C], kv[..., C:], self.heads)
+        if tap:
+            self.q, self.k = tq, tk
+        return ops.linear(a, self.w_o, self.b_o, residual=residual)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = _meta(nn.Linear, dim_in, dim_out * 2)
+
+
+class FeedForward(nn.Module):
+    """attention.py:98-115 with glu=True."""
+
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.Sequential(GEGLU(dim, dim * mult), nn.Dropout(0.0), _meta(nn.Linear, dim * mult, dim))
+
+    def pack(self, dev):
+        self.w1, self.b1 = ops.pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias, dev)
+        self.w2, self.b2 = ops.pack_linear(self.net[2].weight, dev), ops.f32(self.net[2].bias, dev)
+
+    def run(self, x, residual):
+        g = ops.linear(x, self.w1, self.b1, act=ops.ACT_GEGLU)
+        return ops.linear(g, self.w2, self.b2, residual=residual)
+
+
+class BasicTransformerBlock(nn.Module):
+    """attention.py:504-759 (feature-dump path: no modulation, no injection)."""
+
+    def __init__(self, dim, n_heads, d_head, context_dim=None):
+        super().__init__()
+        self.attn1 = CrossAttention(dim, None, n_heads, d_head)
+        self.ff = FeedForward(dim)
+        self.attn2 = CrossAttention(dim, context_dim, n_heads, d_head)
+        self.norm1 = _meta(nn.LayerNorm, dim)
+        self.norm2 = _meta(nn.LayerNorm, dim)
+        self.norm3 = _meta(nn.LayerNorm, dim)
+
+    def pack(self, dev):
+        for m in (self.attn1, self.attn2, self.ff):
+            m.pack(dev)
+        self.ln = [(ops.f32(n.weight, dev), ops.f32(n.bias, dev)) for n in (self.norm1, self.norm2, self.norm3)]
+
+    def run(self, x, context, tap):
+        x = self.attn1.run(ops.layernorm(x, *self.ln[0]), None, x, tap)               # ATT:636-672
+        x = self.attn2.run(ops.layernorm(x, *self.ln[1]), context, x, tap)            # ATT:689-726
+        return self.ff.run(ops.layernorm(x, *self.ln[2]), x)                          # ATT:728-757
+
+
+class SpatialTransformer(nn.Module):
+    """attention.py:806-927 with use_linear=True."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, context_dim=None):
+        super().__init__()
+        inner = n_heads * d_head
+        self.in_channels = in_channels
+        self.norm = _meta(nn.GroupNorm, 32, in_channels, eps=1e-6)
+        self.proj_in = _meta(nn.Linear, in_channels, inner)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner, n_heads, d_head, context_dim) for _ in range(depth)])
+        self.proj_out = _meta(nn.Linear, inner, in_channels)
+        self.tap = True
+
+    def pack(self, dev):
+        self.g, self.b = ops.f32(self.norm.weight, dev), ops.f32(self.norm.bias, dev)
+        self.w_in, self.b_in = ops.pack_linear(self.proj_in.weight, dev), ops.f32(self.proj_in.bias, dev)
+        self.w_out, self.b_out = ops.pack_linear(self.proj_out.weight, dev), ops.f32(self.proj_out.bias, dev)
+        for blk in self.transformer_blocks:
+            blk.pack(dev)
+
+    def run(self, x, context):
+        B, H, W, C = x.shape
+        t = ops.groupnorm(x, self.g, self.b, eps=1e-6, silu=False).view(B, H * W, C)  # ATT:897-903
+        t = ops.linear(t, self.w_in, self.b_in)
+        for i, blk in enumerate(self.transformer_blocks):
+            t = blk.run(t, context, self.tap and i == 0)
+        out = ops.linear(t, self.w_out, self.b_out, residual=x.view(B, H * W, C))     # ATT:921-927
+        return out.view(B, H, W, C)
+
+
+class TimestepEmbedSequential(nn.Sequential):
+    """openaimodel.py:67-114: children dispatched by type."""
+
+    def run(self, x, x_skip, emb_all, context):
+        for layer in self:
+            if isinstance(layer, ResBlock):
+                x = layer.run(x, x_skip, emb_all)
+                x_skip = None
+            elif isinstance(layer, SpatialTransformer):
+                x = layer.run(x, context)
+            elif isinstance(layer, (Upsample, Downsample)):
+                x = layer.run(x)
+            else:
+                raise VidsegError(f"unexpected layer {type(layer)}")
+        return x
+
+
+class _ConvIn(nn.Conv2d):
+    pass
+
+
+class UNetModel(nn.Module):
+    """sgm/modules/diffusionmodules/openaimodel.py:487-954 for the SD 2.1 configuration."""
+
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, dropout=0.0,
+                 channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False, num_heads=-1,
+                 num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
+                 transformer_depth=1, context_dim=None, disable_self_attentions=None, num_attention_blocks=None,
+                 disable_middle_self_attn=False, disable_middle_transformer=False, use_linear_in_transformer=False,
+                 spatial_transformer_attn_type="softmax", adm_in_channels=None):
+        super().__init__()
+        unsupported = dict(dims=(dims, 2), use_scale_shift_norm=(use_scale_shift_norm, False), resblock_updown=(resblock_updown, False),
+                           conv_resample=(conv_resample, True), disable_self_attentions=(disable_self_attentions, None),
+                           num_attention_blocks=(num_attention_blocks, None), disable_middle_self_attn=(disable_middle_self_attn, False),
+                           disable_middle_transformer=(disable_middle_transformer, False),
+                           use_linear_in_transformer=(use_linear_in_transformer, True))
+        for k, (v, want) in unsupported.items():
+            if v != want:
+                raise NotImplementedError(f"UNetModel({k}={v!r}) is not on the SD 2.1 / SVD path (expects {want!r})")
+        if num_head_channels != 64:
+            raise NotImplementedError("num_head_channels must be 64")
+        if context_dim is None:
+            raise NotImplementedError("context_dim is required (cross-attention UNet)")
+        if model_channels % 64 != 0:
+            raise NotImplementedError("model_channels must be a multiple of 64 (MFMA K tiling)")
+        if isinstance(num_res_blocks, int):
+            num_res_blocks = len(channel_mult) * [num_res_blocks]
+        if isinstance(transformer_depth, int):
+            transformer_depth = len(channel_mult) * [transformer_depth]
+        transformer_depth_middle = transformer_depth[-1]
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.num_res_blocks, self.attention_resolutions = num_res_blocks, list(attention_resolutions)
+        self.channel_mult, self.num_classes, self.context_dim = list(channel_mult), num_classes, context_dim
+        ted = model_channels * 4
+        self.time_embed = nn.Sequential(_meta(nn.Linear, model_channels, ted), nn.SiLU(), _meta(nn.Linear, ted, ted))
+        if num_classes is not None:
+            if num_classes != "sequential":
+                raise NotImplementedError("only num_classes='sequential' (SVD) is supported")
+            self.label_emb = nn.Sequential(nn.Sequential(_meta(nn.Linear, adm_in_channels, ted), nn.SiLU(), _meta(nn.Linear, ted, ted)))
+
+        def attn(ch, depth):
+            return SpatialTransformer(ch, ch // num_head_channels, num_head_channels, depth=depth, context_dim=context_dim)
+
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(_meta(_ConvIn, in_channels, model_channels, 3, padding=1))])
+        chans = [model_channels]
+        ch, ds = model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks[level]):
+                layers = [ResBlock(ch, ted, mult * model_channels)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers.append(attn(ch, transformer_depth[level]))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, ch)))
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = TimestepEmbedSequential(ResBlock(ch, ted, ch), attn(ch, transformer_depth_middle), ResBlock(ch, ted, ch))
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks[level] + 1):
+                ich = chans.pop()
+                layers = [ResBlock(ch + ich, ted, model_channels * mult)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers.append(attn(ch, transformer_depth[level]))
+                if level and i == num_res_blocks[level]:
+                    layers.append(Upsample(ch, ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(_meta(GroupNorm32, 32, ch), nn.SiLU(), _meta(nn.Conv2d, model_channels, out_channels, 3, padding=1))
+        self._packed_on = None
+        self.tap_mode = "output"                                    # "output" (reference dumps), "all", "none"
+
+    # ------------------------------------------------------------------ parameters
+    def load_state_dict(self, state_dict, strict=True, assign=True):
+        r = super().load_state_dict(state_dict, strict=strict, assign=True)
+        self._packed_on = None
+        return r
+
+    def _resblocks(self):
+        return [m for m in self.modules() if isinstance(m, ResBlock)]
+
+    def pack(self, device):
+        """One-time weight packing into the layouts the kernels read (bf16 K-contiguous matrices)."""
+        device = torch.device(device)
+        for p in self.parameters():
+            if p.is_meta:
+                raise VidsegError("UNetModel has no weights: call load_state_dict() first")
+        for m in self.modules():
+            if m is not self and hasattr(m, "pack") and not isinstance(m, (BasicTransformerBlock, CrossAttention, FeedForward)):
+                m.pack(device)
+        te = self.time_embed
+        self.te_w1, self.te_b1 = ops.pack_linear(te[0].weight, device), ops.f32(te[0].bias, device)
+        self.te_w2, self.te_b2 = ops.pack_linear(te[2].weight, device), ops.f32(te[2].bias, device)
+        if self.num_classes is not None:
+            le = self.label_emb[0]
+            self.le_w1, self.le_b1 = ops.pack_linear(le[0].weight, device), ops.f32(le[0].bias, device)
+            self.le_w2, self.le_b2 = ops.pack_linear(le[2].weight, device), ops.f32(le[2].bias, device)
+        rbs = self._resblocks()
+        off = 0
+        for rb in rbs:
+            rb.emb_offset = off
+            off += rb.out_channels
+        self.emb_w = ops.pack_linear(torch.cat([rb.emb_layers[1].weight for rb in rbs], 0), device)
+        self.emb_b = ops.f32(torch.cat([rb.emb_layers[1].bias for rb in rbs], 0), device)
+        cin = self.input_blocks[0][0]
+        self.cin_w, self.cin_b = ops.pack_conv3x3_direct(cin.weight, device), ops.f32(cin.bias, device)
+        self.out_g, self.out_beta = ops.f32(self.out[0].weight, device), ops.f32(self.out[0].bias, device)
+        self.out_w, self.out_b = ops.pack_conv3x3_direct(self.out[2].weight, device), ops.f32(self.out[2].bias, device)
+        self._set_taps()
+        self._packed_on = device
+
+    def _set_taps(self):
+        for name, blocks in (("input", self.input_blocks), ("middle", [self.middle_block]), ("output", self.output_blocks)):
+            for blk in blocks:
+                for layer in blk:
+                    if isinstance(layer, SpatialTransformer):
+                        layer.tap = self.tap_mode == "all" or (self.tap_mode == "output" and name == "output")
+
+    # ------------------------------------------------------------------ forward
+    def embed(self, timesteps, y=None):
+        t_emb = ops.timestep_embedding(timesteps.float(), self.model_channels)                         # DU:209-233
+        emb = ops.linear(ops.linear(t_emb, self.te_w1, self.te_b1, act=ops.ACT_SILU), self.te_w2, self.te_b2)
+        if self.num_classes is not None:
+            yb = y if y.dtype == torch.bfloat16 else ops.to_bf16(y.float().contiguous())
+            emb = ops.linear(ops.linear(yb, self.le_w1, self.le_b1, act=ops.ACT_SILU), self.le_w2, self.le_b2, residual=emb)
+        return emb
+
+    def forward_nhwc(self, x_nhwc_f32, timesteps, context_bf16, y=None):
+        """x: fp32 NHWC [B, h, w, Cin]; context: bf16 [B, L, ctx]; returns fp32 NCHW [B, Cout, h, w]."""
+        if self._packed_on is None:
+            self.pack(x_nhwc_f32.device)
+        emb = self.embed(timesteps, y)
+        emb_all = ops.linear(ops.silu(emb), self.emb_w, self.emb_b, out_f32=True)                       # every ResBlock's emb_layers
+        h = ops.conv3x3_direct(x_nhwc_f32, self.cin_w, self.cin_b)
+        hs = [h]
+        for blk in list(self.input_blocks)[1:]:
+            h = blk.run(h, None, emb_all, context_bf16)
+            hs.append(h)
+        h = self.middle_block.run(h, None, emb_all, context_bf16)
+        for blk in self.output_blocks:
+            h = blk.run(h, hs.pop(), emb_all, context_bf16)                                              # OAI:911-948
+        h = ops.groupnorm(h, self.out_g, self.out_beta, eps=1e-5, silu=True)
+        return ops.conv3x3_direct(h, self.out_w, self.out_b, out_nchw_f32=True)
+
+    def forward(self, x, timesteps=None, context=None, y=None, is_modulate_step=False, is_injected_step=False,
+                modulate_params=None, **kwargs):
+        """Reference signature (openaimodel.py:831-841): x NCHW."""
+        if is_modulate_step or is_injected_step:
+            raise NotImplementedError("modulated / injected passes (SURVEY.md a17) are not built yet")
+        if (y is not None) != (self.num_classes is not None):
+            raise AssertionError("must specify y if and only if the model is class-conditional")
+        if not x.is_cuda:
+            raise VidsegError("UNetModel runs on a HIP device only (no CPU fallback)")
+        xn = x.float().permute(0, 2, 3, 1).contiguous()
+        ctx = context if context.dtype == torch.bfloat16 else ops.to_bf16(context.float().contiguous())
+        return self.forward_nhwc(xn, timesteps, ctx, y)

@@ -1,0 +1,128 @@
+"""The reference's plug-in/config helpers on the path (sgm/util.py): instantiate_from_config :168-185,
+append_dims :192-199, default, load_target_features :277-296, load_xt :298-310,
+get_modulate_timestep_frames :313-326 -- plus `install_sgm_aliases`, which lets the reference's YAML
+`target:` strings (sgm.modules.diffusionmodules....) resolve to this package's classes."""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+import types
+from inspect import isfunction
+
+import torch
+
+
+def exists(x):
+    return x is not None
+
+
+def default(val, d):
+    if exists(val):
+        return val
+    return d() if isfunction(d) else d
+
+
+def append_zero(x):
+    return torch.cat([x, x.new_zeros([1])])
+
+
+def append_dims(x, target_dims):
+    dims_to_append = target_dims - x.ndim
+    if dims_to_append < 0:
+        raise ValueError(f"input has {x.ndim} dims but target_dims is {target_dims}, which is less")
+    return x[(...,) + (None,) * dims_to_append]
+
+
+_ALIASES = {
+    "sgm.modules.diffusionmodules.openaimodel": "vidseg_diffusion_amd.unet",
+    "sgm.modules.diffusionmodules.video_model": "vidseg_diffusion_amd.video_unet",
+    "sgm.modules.diffusionmodules.denoiser": "vidseg_diffusion_amd.sampling",
+    "sgm.modules.diffusionmodules.denoiser_scaling": "vidseg_diffusion_amd.sampling",
+    "sgm.modules.diffusionmodules.discretizer": "vidseg_diffusion_amd.sampling",
+    "sgm.modules.diffusionmodules.guiders": "vidseg_diffusion_amd.sampling",
+    "sgm.modules.diffusionmodules.sampling": "vidseg_diffusion_amd.sampling",
+    "sgm.modules.diffusionmodules.wrappers": "vidseg_diffusion_amd.sampling",
+    "sgm.util": "vidseg_diffusion_amd.util",
+    "scripts.sampling.feature_extraction": "vidseg_diffusion_amd.feature_extraction",
+}
+
+
+def get_obj_from_str(string, reload=False, invalidate_cache=True):
+    module, cls = string.rsplit(".", 1)
+    module = _ALIASES.get(module, module)
+    if invalidate_cache:
+        importlib.invalidate_caches()
+    if reload:
+        importlib.reload(importlib.import_module(module))
+    return getattr(importlib.import_module(module, package=None), cls)
+
+
+def instantiate_from_config(config):
+    if "target" not in config:
+        if config == "__is_first_stage__":
+            return None
+        elif config == "__is_unconditional__":
+            return None
+        raise KeyError("Expected key `target` to instantiate.")
+    return get_obj_from_str(config["target"])(**config.get("params", dict()))
+
+
+def install_sgm_aliases():
+    """Register `sgm.*` / `scripts.sampling.feature_extraction` module names that resolve to this package, so
+    `from sgm.util import instantiate_from_config` etc. in the unmodified drivers import the MI355X path."""
+    for pkg in ("sgm", "sgm.modules", "sgm.modules.diffusionmodules", "scripts", "scripts.sampling"):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = []
+            sys.modules[pkg] = m
+    for alias, real in _ALIASES.items():
+        try:
+            sys.modules[alias] = importlib.import_module(real)
+        except ImportError:
+            pass
+
+
+def _store_lookup(feature_maps_folder, exp_name, name):
+    from .feature_extraction import FeatureStore
+    return FeatureStore._stores.get(os.path.join(feature_maps_folder, exp_name, "feature_maps"), {}).get(name)
+
+
+def load_target_features(feature_maps_folder, exp_name, timestep, injected_block_type, injected_feature_types, block_idx, device):
+    """sgm/util.py:277-296, served from the in-HBM FeatureStore first, `.pt` files second."""
+    path = os.path.join(feature_maps_folder, exp_name, "feature_maps")
+    current = {}
+    for feature_type in injected_feature_types:
+        name = f"{injected_block_type}_block_{block_idx}_{feature_type}_time_{timestep}"
+        t = _store_lookup(feature_maps_folder, exp_name, name)
+        if t is None and os.path.exists(os.path.join(path, name + ".pt")):
+            t = torch.load(os.path.join(path, name + ".pt")).detach()
+        if t is not None:
+            current[name] = t.to(device)
+    if len(current) == 0:
+        raise ValueError(f"No feature maps found for block {injected_block_type}_block_{block_idx} at timestep {timestep} in {path}")
+    return current
+
+
+def load_xt(feature_maps_folder, exp_name, timestep, device):
+    """sgm/util.py:298-310."""
+    name = f"xt_time_{timestep}"
+    t = _store_lookup(feature_maps_folder, exp_name, name)
+    path = os.path.join(feature_maps_folder, exp_name, "feature_maps", name + ".pt")
+    if t is None and os.path.exists(path):
+        t = torch.load(path).detach()
+    if t is None:
+        raise ValueError(f"No feature maps found for xt at timestep {timestep} in {os.path.dirname(path)}")
+    return t.to(device)
+
+
+def get_modulate_timestep_frames(start_timestep, end_timestep=None, num_frames=14, schedule="constant"):
+    """sgm/util.py:313-326."""
+    if schedule == "constant":
+        return {}
+    elif schedule == "linear":
+        out = {t: [] for t in range(start_timestep, end_timestep - 1, -1)}
+        for frame_id in range(num_frames):
+            out[int(start_timestep + (end_timestep - start_timestep) * frame_id / (num_frames - 1))].append(frame_id)
+        return out
+    raise ValueError(f"Unknown modulate timestep frames schedule: {schedule}")
