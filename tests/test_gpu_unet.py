@@ -1,0 +1,130 @@
+"""GPU parity of the SD UNet / sampler / one-window pipeline (HIP kernels behind the reference's plug-in API)
+against the reference-produced golden vectors and the oracle.
+
+Tolerance statement (floating point, bf16 MFMA path).  Each kernel alone is within 2^-8|ref| + 1e-3 max|ref| of an
+fp32 evaluation of the same bf16 inputs (tests/test_gpu_ops.py).  Through the whole ~60-layer network with
+random synthetic weights the bf16 *format* itself moves the output by ~1.5e-2 (rms, normalised) relative to the
+fp32 reference -- measured below by the oracle's bf16-rounding mode -- so the network-level requirement is:
+the HIP path deviates from the fp32 reference by no more than 1.5x what bf16 rounding alone does, and by
+< 3e-2 absolute (normalised rms)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from vidseg_diffusion_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden", "unet_sd_narrow.npz")
+
+
+def nrms(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+@pytest.fixture(scope="module")
+def env():
+    assert torch.cuda.is_available()
+    from vidseg_diffusion_amd import _lib
+    from vidseg_diffusion_amd.unet import UNetModel
+    _lib.lib()
+    dev = torch.device("cuda:0")
+    z = np.load(G)
+    gold = {k: z[k] for k in z.files}
+    net = UNetModel(**synthetic.SD21_NARROW)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, 1234).items()}
+    net.load_state_dict(sd)
+    return dev, gold, net, sd
+
+
+def test_unet_forward_vs_reference(env):
+    from oracle.unet import UNetOracle
+    dev, g, net, sd = env
+    x, t, ctx = (torch.from_numpy(g[k]) for k in ("fw_x", "fw_t", "fw_ctx"))
+    out = net(x.to(dev), timesteps=t.to(dev), context=ctx.to(dev)).cpu().numpy()
+    fmt = nrms(UNetOracle(sd, round_bf16=True).forward(x, t, ctx).numpy(), g["fw_out"])      # what bf16 alone costs
+    err = nrms(out, g["fw_out"])
+    assert err < 3e-2 and err <= 1.5 * fmt, (err, fmt)
+    for b in range(3, 12):                                                                     # reference dump protocol
+        blk = net.output_blocks[b]
+        assert len(blk) > 1 and "SpatialTransformer" in str(type(blk[1]))
+        tb = blk[1].transformer_blocks[0]
+        for nm, a in (("self", tb.attn1), ("cross", tb.attn2)):
+            for w in ("q", "k"):
+                ref = g[f"fw_output_block_{b}_spatial_{nm}_attn_{w}"].astype(np.float32)
+                got = getattr(a, w)
+                assert got.dtype == torch.float16 and tuple(got.shape) == ref.shape
+                assert nrms(got.float().cpu().numpy(), ref) < 3e-2, (b, nm, w)
+    for b in range(0, 3):
+        assert len(net.output_blocks[b]) == 1 or "SpatialTransformer" not in str(type(net.output_blocks[b][1]))
+
+
+def test_sampler_steps_vs_reference(env):
+    from vidseg_diffusion_amd.pipeline import build_sd_engine
+    dev, g, net, sd = env
+    eng = build_sd_engine(net, num_steps=25, scale=5)
+    # 1-ulp fp32 differences in `** 0.5` between host CPUs are expected (torch vectorised pow)
+    np.testing.assert_allclose(eng.sampler.discretization(25).numpy(), g["sm_sigmas"], rtol=5e-7, atol=0)
+    c = {"crossattn": torch.from_numpy(g["sm_c"]).to(dev)}
+    uc = {"crossattn": torch.zeros_like(c["crossattn"])}
+    lat = torch.from_numpy(g["sm_latent"]).to(dev)
+    noised = eng.sampler.add_noise(lat, cond=c, uc=uc, num_steps=25, noise_level=22, noise=torch.from_numpy(g["sm_noise"]).to(dev))
+    assert np.abs(noised.cpu().numpy() - g["sm_noised"]).max() <= 1e-6 * np.abs(g["sm_noised"]).max() + 1e-7
+    xs, taps = [], {}
+
+    def cb(xt, i):
+        xs.append(xt.cpu().numpy())
+        if i == 24:
+            for b in (6, 7, 8):
+                taps[b] = net.output_blocks[b][1].transformer_blocks[0].attn1.q.float().cpu().numpy()
+
+    def denoiser(inp, sigma, cc, is_modulate_step=False, is_injected_step=False, modulate_params=None):
+        return eng.denoiser(eng.model, inp, sigma, cc)
+
+    final = eng.sampler(denoiser, noised.clone(), cond=c, uc=uc, img_callback=cb, t_start=22)
+    assert len(xs) == 3
+    for i in range(3):
+        assert nrms(xs[i], g["sm_x_steps"][i]) < 3e-2, i
+    assert nrms(final.cpu().numpy(), g["sm_final"]) < 3e-2
+    for b in (6, 7, 8):
+        assert nrms(taps[b], g[f"sm_q_block_{b}_time_24"].astype(np.float32)) < 3e-2
+
+
+def test_window_pipeline_vs_oracle(env):
+    """Steps 1-3b end to end on one 4-frame window; masks compared with the CPU oracle's (IoU), and -- the
+    bit-exact part -- the analysis stage re-run by the oracle on the HIP path's own taps must give identical ids."""
+    from oracle import analysis as OA
+    from oracle import pipeline as OP
+    from oracle.unet import UNetOracle
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import build_sd_engine, segment_window
+    dev, g, net, sd = env
+    Fn, K = 4, 5
+    lat = synthetic.latent_clip(Fn, 16, 16, seed=3)
+    c = np.random.Generator(np.random.PCG64(4)).standard_normal((Fn, 7, 64)).astype(np.float32)
+    noise = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).standard_normal(lat.shape).astype(np.float32))
+    ref = OP.segment_window(UNetOracle(sd), torch.from_numpy(lat), torch.from_numpy(c), torch.zeros(Fn, 7, 64), noise,
+                            num_masks=K, is_refine_mask=True, seed=17)
+    eng = build_sd_engine(net)
+    FE.FeatureStore.clear()
+    FE.MaskStore.clear()
+    cc = {"crossattn": torch.from_numpy(c).to(dev)}
+    uc = {"crossattn": torch.zeros_like(cc["crossattn"])}
+    labels, st = segment_window(eng, torch.from_numpy(lat).to(dev), cc, uc, num_masks=K, is_refine_mask=True, seed=17,
+                                noise=noise.to(dev), feature_folder="/nonexistent/vs", exp_name="w")
+    # bit-exact: oracle analysis on the device taps
+    store = FE.FeatureStore.folder("/nonexistent/vs", "w")
+    taps = {b: store[f"output_block_{b}_spatial_self_attn_q_time_24"].cpu().numpy() for b in (6, 7, 8)}
+    np.random.seed(17)
+    _, lab_o, _ = OA.match_gt_mask(OA.aggregate_blocks([taps[8], taps[7], taps[6]]), K, np.random.mtrand._rand)
+    th, tw = OA.dense_tracking(taps[7], Fn, 8, 8)
+    corr, _ = OA.correct_low_res_mask(lab_o.reshape(Fn, 8, 8), th, tw)
+    assert np.array_equal(labels.reshape(-1), corr)
+    # floating-point part: masks agree with the all-CPU oracle up to a label permutation
+    from tools_metrics import matched_iou
+    iou, exact = matched_iou(labels, ref["labels"], K)
+    print("pipeline mask IoU vs fp32 oracle", iou, "exact", exact)
+    assert iou >= 0.90

@@ -208,8 +208,8 @@ def rows_axpby(a, sa, b=None, sb=None):
     out = torch.empty_like(a)
     dsa = _rowvec(sa, B, a.device)
     dsb = _rowvec(sb, B, a.device) if b is not None else None
-    call("vidseg_rows_axpby", ptr(a), ptr(dsa), ptr(b.contiguous()) if b is not None else None, ptr(dsb), a.numel(),
-         a.numel() // B, ptr(out), stream())
+    bc = b.contiguous() if b is not None else None
+    call("vidseg_rows_axpby", ptr(a), ptr(dsa), ptr(bc), ptr(dsb), a.numel(), a.numel() // B, ptr(out), stream())
     return out
 
 
@@ -228,8 +228,9 @@ def euler_update(x, denoised, sigma, sigma_next):
     B = x.shape[0]
     x = x.contiguous()
     out = torch.empty_like(x)
-    call("vidseg_euler_update", ptr(x), ptr(denoised.contiguous()), ptr(_rowvec(sigma, B, x.device)),
-         ptr(_rowvec(sigma_next, B, x.device)), x.numel(), x.numel() // B, ptr(out), stream())
+    den = denoised.contiguous()
+    s0, s1 = _rowvec(sigma, B, x.device), _rowvec(sigma_next, B, x.device)   # keep alive until the launch is enqueued
+    call("vidseg_euler_update", ptr(x), ptr(den), ptr(s0), ptr(s1), x.numel(), x.numel() // B, ptr(out), stream())
     return out
 
 
@@ -237,7 +238,8 @@ def axpy(x, e, s, post=1.0):
     """(x + e * s) * post."""
     x = x.contiguous()
     out = torch.empty_like(x)
-    call("vidseg_axpy_f32", ptr(x), ptr(e.contiguous()), x.numel(), float(s), float(post), ptr(out), stream())
+    ec = e.contiguous()
+    call("vidseg_axpy_f32", ptr(x), ptr(ec), x.numel(), float(s), float(post), ptr(out), stream())
     return out
 
 
@@ -250,5 +252,6 @@ def scale(x, s):
 def blend(x, y, m):
     x = x.contiguous()
     out = torch.empty_like(x)
-    call("vidseg_blend_f32", ptr(x), ptr(y.contiguous()), ptr(m.contiguous()), x.numel(), ptr(out), stream())
+    yc, mc = y.contiguous(), m.contiguous()
+    call("vidseg_blend_f32", ptr(x), ptr(yc), ptr(mc), x.numel(), ptr(out), stream())
     return out

@@ -363,6 +363,6 @@ def latent_blend(x, xt, masks_fhw):
     from ._lib import call, ptr, stream
     F, C, h, w = x.shape
     out = x.contiguous().clone()
-    call("vidseg_latent_blend", ptr(out), ptr(xt.contiguous()), ptr(masks_fhw.contiguous()), F, C, h, w, masks_fhw.shape[1],
-         masks_fhw.shape[2], stream())
+    xtc, mc = xt.contiguous(), masks_fhw.contiguous()
+    call("vidseg_latent_blend", ptr(out), ptr(xtc), ptr(mc), F, C, h, w, mc.shape[1], mc.shape[2], stream())
     return out
