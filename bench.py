@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""Headline benchmark: segmented frames/s of the VidSeg hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one 14-frame 512x512 clip window per GPU (BASELINE config 2:
+SD 2.1, 20 masks, is_aggre_attn on): add-noise -> 3 Euler steps (i = 22,23,24) of the full-size SD 2.1 UNet with
+classifier-free guidance (batch 2x14) and the reference's Q/K taps on every decoder transformer block -> 3-block
+aggregation -> K-means (n_init 10) -> 4-NN label propagation  => cluster-id masks [14, 32*32].
+Latents / conditioning / weights are synthetic, seeded and already resident in HBM when the timed region
+starts (VAE + conditioner excluded).  N > 1: one window per GPU (weak scaling), see
+vidseg_diffusion_amd/parallel.py for the exchange.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel family = bf16 MFMA implicit-GEMM (k_gemm_conv: every conv + linear of the UNet);
+                achieved = algorithmic FLOPs (2*M*N*K per launch) / HIP-event time of those launches, live in
+                the timed region; peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md).
+  cpu_baseline  the oracle ("port") timed on this box's host cores on a bounded sample (see `sample`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_WIN, LAT, K_MASKS, T_START, NUM_STEPS = 14, 64, 20, 22, 25
+
+
+def make_inputs(dev, window_id, cfg):
+    from vidseg_diffusion_amd import synthetic
+    lat = torch.from_numpy(synthetic.latent_clip(F_WIN, LAT, LAT, seed=1 + window_id)).to(dev)
+    c, uc = synthetic.sd_conditioning(F_WIN, context_dim=cfg["context_dim"], seq=77, seed=1)
+    g = torch.Generator().manual_seed(100 + window_id)
+    noise = torch.randn(lat.shape, generator=g).to(dev)
+    return lat, {"crossattn": torch.from_numpy(c).to(dev)}, {"crossattn": torch.from_numpy(uc).to(dev)}, noise
+
+
+def cpu_baseline(sd_cpu, cfg):
+    """Oracle on the host: one full-size UNet evaluation for ONE frame (CFG pair, batch 2) + the full-size analysis
+    stage on synthetic dumps; scaled to a 14-frame window: t = 3 steps * 14 frames * t_unet_frame + t_analysis."""
+    from oracle import analysis as OA
+    from oracle.unet import UNetOracle
+    from vidseg_diffusion_amd import synthetic
+    torch.set_grad_enabled(False)
+    cores = torch.get_num_threads()
+    o = UNetOracle(sd_cpu)
+    x = torch.from_numpy(synthetic.latent_clip(1, LAT, LAT, seed=1)).repeat(2, 1, 1, 1)
+    c, uc = synthetic.sd_conditioning(1, context_dim=cfg["context_dim"])
+    ctx = torch.cat([torch.from_numpy(uc), torch.from_numpy(c)])
+    t0 = time.time()
+    o.forward(x, torch.tensor([958.0, 958.0]), ctx)
+    t_unet = time.time() - t0
+    blocks, _ = synthetic.attention_q_dumps(F_WIN, LAT // 2, LAT // 2, 640, num_blocks=3, seed=1)
+    t0 = time.time()
+    np.random.seed(17)
+    OA.match_gt_mask(OA.aggregate_blocks(blocks), K_MASKS, np.random.mtrand._rand)
+    t_an = time.time() - t0
+    t_window = 3 * F_WIN * t_unet + t_an
+    return {"value": round(F_WIN / t_window, 5), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 on host: 1 full-size UNet eval of 1 frame (CFG batch 2, {t_unet:.1f}s) + full 14x32x32x640 K=20 "
+                      f"analysis ({t_an:.1f}s); window time = 3*14*t_unet + t_analysis = {t_window:.0f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--refine", action="store_true", help="also run Step 3b (correct_low_res_mask)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--narrow", action="store_true", help="debug: narrow-width UNet (NOT the benchmark config)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd import ops, parallel, synthetic
+    from vidseg_diffusion_amd.pipeline import build_sd_engine
+    from vidseg_diffusion_amd.unet import UNetModel
+
+    cfg = dict(synthetic.SD21_NARROW if args.narrow else synthetic.SD21_FULL)
+    net = UNetModel(**cfg)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd_cpu = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=1234).items()}
+    net.load_state_dict(sd_cpu)
+    net.pack(dev)
+    eng = build_sd_engine(net, num_steps=NUM_STEPS, scale=5.0)
+    lat, c, uc, noise = make_inputs(dev, rank, cfg)
+    torch.cuda.synchronize()
+
+    def one_step():
+        FE.FeatureStore.clear()
+        FE.MaskStore.clear()
+        return parallel.segment_windows_sharded(eng, lat, c, uc, noise=noise, num_masks=K_MASKS, num_steps=NUM_STEPS, t_start=T_START,
+                                                is_aggre_attn=True, is_refine_mask=args.refine, seed=17, rank=rank, world=world)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    ops.gemm_profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        labels = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_flops, k_launches = ops.gemm_profile_end()
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        frames = F_WIN * world * args.steps
+        achieved = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
+        out = {
+            "metric": "segmented frames/sec (14-frame 512^2 clip, 20 masks)",
+            "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: SD 2.1 full-size UNet (865.9M params, random-init), 14-frame 512x512 window per GPU "
+                                   "(latent 14x4x64x64), 25-step schedule with t_start=22 (3 CFG UNet evals, batch 28), Q/K taps on decoder "
+                                   "blocks 3-11, is_aggre_attn (blocks 6,7,8), K-means K=20 n_init=10 + 4-NN"
+                                   + (", is_refine_mask" if args.refine else ""),
+                       "frames_per_gpu": F_WIN, "num_masks": K_MASKS, "unet_evals_per_step": 3, "parallelism": f"window-per-gpu x{world}"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(achieved / 2500.0, 4), "traffic": None, "kernel": "k_gemm_conv (bf16 MFMA implicit-GEMM conv/linear)",
+                         "launches_per_step": k_launches // max(args.steps, 1),
+                         "avg_launch_us": round(1e3 * k_ms / max(k_launches, 1), 2),
+                         "gemm_ms_per_step": round(k_ms / args.steps, 3)},
+            "unique_labels": int(len(np.unique(labels))),
+        }
+        if not args.no_cpu_baseline and not args.narrow:
+            out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

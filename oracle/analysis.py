@@ -206,28 +206,36 @@ def kmeans_predict(X16, centers):
 # --------------------------------------------------------------------------------------
 # scikit-learn KNeighborsClassifier(n_neighbors=4), brute force on fp16 storage
 # --------------------------------------------------------------------------------------
-def knn_predict(ref_X16, ref_y, query16, k=4, chunk=4096):
-    """neighbors/_classification.py predict with uniform weights.  fp16 storage disables the
-    ArgKmin fast path, so kneighbors goes through pairwise_distances_chunked ->
-    euclidean_distances: both sides up-cast to float64, d = |x|^2 - 2 x.y + |y|^2, clipped at
-    0, then argpartition(kth=k-1)[:, :k] and the mode of the neighbours' classes (smallest
-    class among the most frequent)."""
+def knn_top4(ref_X16, query16, k=4, chunk=4096):
+    """kneighbors(return_distance=False): indices of the k nearest reference rows per query.  fp16 storage disables
+    the ArgKmin fast path, so sklearn goes through pairwise_distances_chunked -> euclidean_distances: both sides
+    up-cast to float64, d = |x|^2 - 2 x.y + |y|^2 clipped at 0, then argpartition(kth=k-1)[:, :k]."""
     Y = np.ascontiguousarray(ref_X16, dtype=F64)
     yy = _row_norms_sq(Y)
-    classes, y_idx = np.unique(np.asarray(ref_y), return_inverse=True)
-    out = np.empty(query16.shape[0], dtype=classes.dtype)
+    out = np.empty((query16.shape[0], k), dtype=np.int64)
     for s in range(0, query16.shape[0], chunk):
         Xq = np.ascontiguousarray(query16[s:s + chunk], dtype=F64)
         d = -2.0 * (Xq @ Y.T)
         d += _row_norms_sq(Xq)[:, None]
         d += yy[None, :]
         np.maximum(d, 0, out=d)
-        nn = np.argpartition(d, k - 1, axis=1)[:, :k]
-        votes = y_idx[nn]                                        # [m, k]
-        counts = np.zeros((votes.shape[0], classes.size), dtype=np.int32)
-        np.add.at(counts, (np.arange(votes.shape[0])[:, None], votes), 1)
-        out[s:s + chunk] = classes[np.argmax(counts, axis=1)]   # first max == smallest class
+        out[s:s + chunk] = np.argpartition(d, k - 1, axis=1)[:, :k]
     return out
+
+
+def vote4(nn_idx, ref_y):
+    """neighbors/_classification.py predict with uniform weights: mode of the neighbours' classes,
+    smallest class among the most frequent."""
+    classes, y_idx = np.unique(np.asarray(ref_y), return_inverse=True)
+    votes = y_idx[nn_idx]
+    counts = np.zeros((votes.shape[0], classes.size), dtype=np.int32)
+    np.add.at(counts, (np.arange(votes.shape[0])[:, None], votes), 1)
+    return classes[np.argmax(counts, axis=1)]                     # first max == smallest class
+
+
+def knn_predict(ref_X16, ref_y, query16, k=4, chunk=4096):
+    """KNeighborsClassifier(n_neighbors=4).fit(ref, ref_y).predict(query) (feature_extraction.py:608-613)."""
+    return vote4(knn_top4(ref_X16, query16, k, chunk), ref_y)
 
 
 # --------------------------------------------------------------------------------------

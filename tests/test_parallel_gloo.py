@@ -1,0 +1,97 @@
+"""The N>1 path on CPU: world_size-2 gloo run of the window-sharded label chain (vidseg_diffusion_amd/parallel.py)
+with oracle compute callbacks, compared with the reference's sequential window loop restated by the oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import analysis as OA
+from vidseg_diffusion_amd import synthetic
+
+F, H, W, C, K = 3, 6, 5, 32, 4
+N = H * W
+
+
+def _window_inputs(win):
+    blocks, _ = synthetic.attention_q_dumps(F, H, W, C, num_blocks=3, seed=40 + 100 * win)
+    feat = OA.normalize_tokens(OA.aggregate_blocks(blocks)[F:]).reshape(F * N, C)
+    th, tw = OA.dense_tracking(blocks[1], F, H, W)
+    return feat, (th * W + tw).astype(np.int32)
+
+
+def _sequential_reference(world, refine):
+    ref_mask = ref_fm = None
+    out = []
+    for win in range(world):
+        blocks, _ = synthetic.attention_q_dumps(F, H, W, C, num_blocks=3, seed=40 + 100 * win)
+        np.random.seed(17)
+        _, labels, fm = OA.match_gt_mask(OA.aggregate_blocks(blocks), K, np.random.mtrand._rand, ref_mask=ref_mask, ref_feature_map=ref_fm)
+        if refine:
+            th, tw = OA.dense_tracking(blocks[1], F, H, W)
+            labels, _ = OA.correct_low_res_mask(labels.reshape(F, H, W), th, tw)
+        out.append(labels)
+        ref_mask, ref_fm = labels, fm
+    return np.stack(out)
+
+
+def _worker(rank, world, port, refine, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vidseg_diffusion_amd.parallel import ChainOps, resolve_windows
+    feat, tracks = _window_inputs(rank)
+
+    def first(feat0):
+        np.random.seed(17)
+        f0 = feat0.numpy()
+        centers, _, _ = OA.kmeans_fit(f0, K, np.random.mtrand._rand)
+        fake = OA.kmeans_predict(f0[:N], centers)
+        return torch.from_numpy(OA.knn_predict(f0[:N], fake, f0).astype(np.int32))
+
+    ops = ChainOps(first_window_labels=first,
+                   knn_top4=lambda r, qq: torch.from_numpy(OA.knn_top4(r.numpy(), qq.numpy()).astype(np.int32)),
+                   vote4=lambda i, l: torch.from_numpy(OA.vote4(i.numpy(), l.numpy()).astype(np.int32)),
+                   refine=(lambda t, l: torch.from_numpy(
+                       OA.correct_low_res_mask(l.numpy().reshape(F, H, W), t.numpy() // W, t.numpy() % W)[0].astype(np.int32)).view(F, N))
+                   if refine else None)
+    labels = resolve_windows(torch.from_numpy(feat), torch.from_numpy(tracks) if refine else None, ops, rank, world, F)
+    q.put((rank, labels.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("refine", [False, True])
+def test_two_rank_chain_matches_sequential_reference(refine):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, refine, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _sequential_reference(world, refine)
+    for r in range(world):
+        assert np.array_equal(res[r], ref), f"rank {r} labels differ from the sequential window loop"
+
+
+def test_window_slices_match_reference_loop():
+    from vidseg_diffusion_amd.pipeline import window_slices
+    # sd_pipeline_vspw.py:228-245: a 28-frame clip gives 3 windows, the last re-processing frames 14..27
+    assert window_slices(28, 14) == [(0, 14), (14, 28), (14, 28)]
+    assert window_slices(30, 14) == [(0, 14), (14, 28), (16, 30)]
+    assert window_slices(5, 14) == [(0, 5)]

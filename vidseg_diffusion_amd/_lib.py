@@ -32,6 +32,8 @@ _SIGS = {
     "vidseg_kmeans_inertia": [_P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P],
     "vidseg_add_mean_f64": [_P, _P, _I, _I, _P],
     "vidseg_knn_vote": [_P, _L, _P, _L, _I, _P, _P, _P, _P, _P],
+    "vidseg_knn_top4": [_P, _L, _P, _L, _I, _P, _P, _P, _P],
+    "vidseg_vote4": [_P, _P, _L, _P, _P],
     "vidseg_track_normalize": [_P, _L, _I, _I, _P, _P],
     "vidseg_track_step": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
     "vidseg_trajectory_vote": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P],

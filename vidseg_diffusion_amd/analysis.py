@@ -229,6 +229,30 @@ def knn_predict(ref16: torch.Tensor, ref_labels: torch.Tensor, query16: torch.Te
     return out
 
 
+def knn_top4(ref16: torch.Tensor, query16: torch.Tensor) -> torch.Tensor:
+    """Label-independent half of the classifier: indices of the 4 nearest reference rows, int32 [nq, 4]."""
+    require_gpu(ref16, query16)
+    nq, C = query16.shape
+    nr = ref16.shape[0]
+    dev = query16.device
+    qq = torch.empty(nq, dtype=F64, device=dev)
+    yy = torch.empty(nr, dtype=F64, device=dev)
+    st = stream()
+    call("vidseg_row_sqnorm_f64", ptr(query16), nq, C, ptr(qq), st)
+    call("vidseg_row_sqnorm_f64", ptr(ref16), nr, C, ptr(yy), st)
+    out = torch.empty((nq, 4), dtype=I32, device=dev)
+    call("vidseg_knn_top4", ptr(query16), nq, ptr(ref16), nr, C, ptr(qq), ptr(yy), ptr(out), st)
+    return out
+
+
+def vote4(nn_idx: torch.Tensor, ref_labels: torch.Tensor) -> torch.Tensor:
+    """Label-dependent half: mode of the 4 neighbours' labels, smallest label on ties."""
+    require_gpu(nn_idx, ref_labels)
+    out = torch.empty(nn_idx.shape[0], dtype=I32, device=nn_idx.device)
+    call("vidseg_vote4", ptr(nn_idx), ptr(ref_labels), nn_idx.shape[0], ptr(out), stream())
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # a16: dense tracking + trajectory vote
 # --------------------------------------------------------------------------------------

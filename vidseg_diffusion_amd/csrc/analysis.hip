@@ -490,8 +490,32 @@ __global__ void k_add_mean(double* __restrict__ centers, const double* __restric
 // ---------------------------------------------------------------------------------------------
 // 4-NN classifier (sklearn neighbors, brute force in float64): d = |q|^2 - 2 q.y + |y|^2 clipped at 0
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int vote4(const int* lab, int nn) {
+    // mode of the neighbours' classes, smallest class among the most frequent (sklearn _classification.py predict)
+    int bestc = 0, bestl = 0;
+    for (int p = 0; p < nn; ++p) {
+        int c = 0;
+        for (int q = 0; q < nn; ++q) c += (lab[q] == lab[p]);
+        if (c > bestc || (c == bestc && lab[p] < bestl)) {
+            bestc = c;
+            bestl = lab[p];
+        }
+    }
+    return bestl;
+}
+
+__global__ void k_vote4(const int32_t* __restrict__ idx, const int32_t* __restrict__ ylab, int64_t nq, int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    int lab[4], nn = 0;
+    for (int p = 0; p < 4; ++p)
+        if (idx[i * 4 + p] >= 0) lab[nn++] = ylab[idx[i * 4 + p]];
+    out[i] = vote4(lab, nn);
+}
+
 __global__ void __launch_bounds__(256) k_knn(RowsF16 Q, RowsF16 Y, const double* __restrict__ qq, const double* __restrict__ yy,
-                                             const int32_t* __restrict__ ylab, int32_t* __restrict__ out) {
+                                             const int32_t* __restrict__ ylab, int32_t* __restrict__ out,
+                                             int32_t* __restrict__ out_idx) {
     __shared__ double LA[KC][LDP];
     __shared__ double LB[KC][LDP];
     __shared__ double LD[TS][LDP];
@@ -536,19 +560,14 @@ __global__ void __launch_bounds__(256) k_knn(RowsF16 Q, RowsF16 Y, const double*
         }
     }
     if (threadIdx.x < TS && q0 + threadIdx.x < Q.nrows) {
-        int lab[4], nn = 0;
-        for (int p = 0; p < 4; ++p)
-            if (bi[p] >= 0) lab[nn++] = ylab[bi[p]];
-        int bestc = 0, bestl = 0;
-        for (int p = 0; p < nn; ++p) {
-            int c = 0;
-            for (int q = 0; q < nn; ++q) c += (lab[q] == lab[p]);
-            if (c > bestc || (c == bestc && lab[p] < bestl)) {
-                bestc = c;
-                bestl = lab[p];
-            }
+        if (out_idx)
+            for (int p = 0; p < 4; ++p) out_idx[(q0 + threadIdx.x) * 4 + p] = bi[p];
+        if (ylab) {
+            int lab[4], nn = 0;
+            for (int p = 0; p < 4; ++p)
+                if (bi[p] >= 0) lab[nn++] = ylab[bi[p]];
+            out[q0 + threadIdx.x] = vote4(lab, nn);
         }
-        out[q0 + threadIdx.x] = bestl;
     }
 }
 
@@ -942,8 +961,28 @@ int vidseg_knn_vote(const void* q16, int64_t nq, const void* ref16, int64_t nref
     VS_REQUIRE(nref >= 1, "knn_vote: empty reference set");
     RowsF16 Q{(const f16*)q16, nullptr, nullptr, nq, C};
     RowsF16 Y{(const f16*)ref16, nullptr, nullptr, nref, C};
-    k_knn<<<dim3((unsigned)cdiv64(nq, TS)), 256, 0, st>>>(Q, Y, qq, yy, ref_labels, out);
+    k_knn<<<dim3((unsigned)cdiv64(nq, TS)), 256, 0, st>>>(Q, Y, qq, yy, ref_labels, out, nullptr);
     VS_CHECK_LAUNCH("knn_vote");
+    return VS_OK;
+}
+
+// The two halves of the same classifier, split so that the distance search (label-independent) can run before the
+// labels exist: top-4 neighbour indices, then the vote.
+int vidseg_knn_top4(const void* q16, int64_t nq, const void* ref16, int64_t nref, int C, const double* qq, const double* yy,
+                    int32_t* out_idx, hipStream_t st) {
+    VS_REQUIRE(C % 8 == 0 && nref >= 1, "knn_top4: C=%d nref=%lld", C, (long long)nref);
+    if (nq == 0) return VS_OK;
+    RowsF16 Q{(const f16*)q16, nullptr, nullptr, nq, C};
+    RowsF16 Y{(const f16*)ref16, nullptr, nullptr, nref, C};
+    k_knn<<<dim3((unsigned)cdiv64(nq, TS)), 256, 0, st>>>(Q, Y, qq, yy, nullptr, nullptr, out_idx);
+    VS_CHECK_LAUNCH("knn_top4");
+    return VS_OK;
+}
+
+int vidseg_vote4(const int32_t* idx, const int32_t* ref_labels, int64_t nq, int32_t* out, hipStream_t st) {
+    if (nq == 0) return VS_OK;
+    k_vote4<<<dim3((unsigned)cdiv64(nq, 256)), 256, 0, st>>>(idx, ref_labels, nq, out);
+    VS_CHECK_LAUNCH("vote4");
     return VS_OK;
 }
 

@@ -268,7 +268,54 @@ __global__ void k_conv3x3_direct(const TI* __restrict__ x, const float* __restri
     if (out_nchw_f32) out_nchw_f32[(((long long)b * Cout + co) * H + oh) * W + ow] = acc;
 }
 
+// ---- live HIP-event timing of this kernel family (bench.py roofline) -------------------------------------
+// When enabled, every k_gemm_conv launch is bracketed by two events recorded on the launch stream; collect()
+// synchronises, sums the elapsed times and the algorithmic FLOPs (2*M*N*K per launch).
+#include <vector>
+struct GemmProf {
+    bool on = false;
+    std::vector<hipEvent_t> ev;      // pairs
+    size_t used = 0;
+    double flops = 0.0;
+    long long launches = 0;
+};
+static GemmProf g_prof;
+
+static inline hipEvent_t prof_event() {
+    if (g_prof.used == g_prof.ev.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        g_prof.ev.push_back(e);
+    }
+    return g_prof.ev[g_prof.used++];
+}
+
 extern "C" {
+
+int vidseg_gemm_profile_begin(void) {
+    g_prof.on = true;
+    g_prof.used = 0;
+    g_prof.flops = 0.0;
+    g_prof.launches = 0;
+    return VS_OK;
+}
+
+// out[0] = total kernel milliseconds, out[1] = algorithmic FLOPs, out[2] = launches
+int vidseg_gemm_profile_end(double* out) {
+    g_prof.on = false;
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        float t = 0.f;
+        hipError_t e = hipEventSynchronize(g_prof.ev[i + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
+        if (e != hipSuccess) VS_FAIL(VS_ERR_HIP, "gemm_profile_end: %s", hipGetErrorString(e));
+        ms += t;
+    }
+    out[0] = ms;
+    out[1] = g_prof.flops;
+    out[2] = (double)g_prof.launches;
+    return VS_OK;
+}
 
 static int launch_gemm(const GemmParams& p, hipStream_t st) {
     VS_REQUIRE(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
@@ -281,6 +328,11 @@ static int launch_gemm(const GemmParams& p, hipStream_t st) {
         attr = true;
     }
     const bool narrow = (p.N % 128 != 0) && (p.N % 128 <= 64) && p.act != 2 && p.M >= 256;
+    if (g_prof.on) {
+        (void)hipEventRecord(prof_event(), st);
+        g_prof.flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
+        g_prof.launches++;
+    }
     if (narrow) {
         const long long tiles = ((p.M + 255) / 256) * ((p.N + 63) / 64);
         k_gemm_conv<256, 64><<<dim3((unsigned)tiles), 256, 2 * (256 + 64) * BK * 2, st>>>(p);
@@ -288,6 +340,7 @@ static int launch_gemm(const GemmParams& p, hipStream_t st) {
         const long long tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
         k_gemm_conv<128, 128><<<dim3((unsigned)tiles), 256, 2 * (128 + 128) * BK * 2, st>>>(p);
     }
+    if (g_prof.on) (void)hipEventRecord(prof_event(), st);
     VS_CHECK_LAUNCH("gemm_conv");
     return VS_OK;
 }

@@ -35,6 +35,8 @@ _lib.register({
     "vidseg_euler_update": [_P, _P, _P, _P, _L, _L, _P, _P],
     "vidseg_axpy_f32": [_P, _P, _L, _F, _F, _P, _P],
     "vidseg_blend_f32": [_P, _P, _P, _L, _P, _P],
+    "vidseg_gemm_profile_begin": [],
+    "vidseg_gemm_profile_end": [_P],
 })
 
 BF16 = torch.bfloat16
@@ -255,3 +257,15 @@ def blend(x, y, m):
     yc, mc = y.contiguous(), m.contiguous()
     call("vidseg_blend_f32", ptr(x), ptr(yc), ptr(mc), x.numel(), ptr(out), stream())
     return out
+
+
+def gemm_profile_begin():
+    """Start HIP-event timing of every conv/linear MFMA launch (bench.py roofline)."""
+    call("vidseg_gemm_profile_begin")
+
+
+def gemm_profile_end():
+    """-> (kernel_ms_total, algorithmic_flops, launches)."""
+    out = (ctypes.c_double * 3)()
+    call("vidseg_gemm_profile_end", out)
+    return float(out[0]), float(out[1]), int(out[2])

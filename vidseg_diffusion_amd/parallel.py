@@ -1,0 +1,115 @@
+"""Multi-GPU execution of the hot path: one process per GPU, windows of a clip sharded across ranks
+(SURVEY.md §8(e)); `torch.distributed` backend "nccl" is RCCL over xGMI on this platform.
+
+What shards and what is exchanged
+---------------------------------
+* The UNet feature pass of a 14-frame window touches no other window -> embarrassingly parallel (for SVD the
+  window is the atomic unit because temporal layers mix its frames).
+* The reference chains windows through KNN label propagation (feature_extraction.py:603-613, 639-640;
+  sd_pipeline_vspw.py:381-387, 401): window b is labelled by a 4-NN vote against window b-1's tokens and
+  window b-1's FINAL labels.  Only the vote depends on labels; the neighbour search (the 263-GFLOP part)
+  depends on features alone.  So every rank searches its window's top-4 neighbours in window r-1's features
+  concurrently, and the label chain itself is a cheap gather resolved identically on every rank.
+* Exchange = ONE all-gather of the aggregated, normalised conditional-half features ([F*N, 640] fp16,
+  18.4 MB/rank at config 2) so each rank holds its predecessor's tokens, then one all-gather of the small
+  int32 results (neighbour indices [F*N,4], tracks [F,N]) and a broadcast of window 0's labels.  No other
+  data-path collective; no reduction.
+
+The orchestration below is backend-agnostic (tested under gloo, world_size 2, on CPU with oracle compute
+callbacks); `segment_windows_sharded` binds it to the HIP kernels.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+
+@dataclass
+class ChainOps:
+    """Compute callbacks of the cross-window stage (HIP-backed in the product, oracle-backed in CPU tests)."""
+    first_window_labels: Callable      # feat0 [F*N, C] -> labels int32 [F*N]      (K-means + predict + 4-NN vs frame 0)
+    knn_top4: Callable                 # (ref_feat, query_feat) -> int32 [nq, 4]
+    vote4: Callable                    # (nn_idx [nq,4], ref_labels [nref]) -> int32 [nq]
+    refine: Optional[Callable] = None  # (tracks [F,N] int32, labels [F,N] int32) -> int32 [F,N]
+
+
+def _all_gather(t: torch.Tensor, world: int):
+    import torch.distributed as dist
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous())                  # concatenated along dim 0 (gloo and RCCL agree on this form)
+    return out.view((world,) + tuple(t.shape))
+
+
+def resolve_windows(feat: torch.Tensor, tracks: Optional[torch.Tensor], ops: ChainOps, rank: int, world: int, num_frames: int):
+    """feat: this rank's normalised tokens fp16 [F*N, C]; tracks: this rank's dense tracks int32 [F, N] or None.
+    Returns final labels of ALL windows, int32 [world, F*N], identical on every rank."""
+    import torch.distributed as dist
+    FN = feat.shape[0]
+    all_feat = _all_gather(feat, world)                               # [W, F*N, C]   <- the RCCL all-gather over xGMI
+    if rank == 0:
+        labels0 = ops.first_window_labels(all_feat[0]).to(torch.int32)
+        nn_idx = torch.full((FN, 4), -1, dtype=torch.int32, device=feat.device)
+    else:
+        labels0 = torch.empty(FN, dtype=torch.int32, device=feat.device)
+        nn_idx = ops.knn_top4(all_feat[rank - 1], feat).to(torch.int32)
+    dist.broadcast(labels0, src=0)
+    all_idx = _all_gather(nn_idx, world)                              # [W, F*N, 4]
+    all_tracks = _all_gather(tracks, world) if tracks is not None else None
+    out = []
+    prev = labels0
+    for b in range(world):                                            # the sequential label chain, cheap integer work
+        lab = prev if b == 0 else ops.vote4(all_idx[b], prev)
+        if all_tracks is not None:
+            lab = ops.refine(all_tracks[b], lab.view(num_frames, -1)).reshape(-1)
+        out.append(lab)
+        prev = lab
+    return torch.stack(out)
+
+
+def segment_windows_sharded(engine, latent, c, uc, *, noise=None, num_masks=20, num_steps=25, t_start=22, is_aggre_attn=True,
+                            is_refine_mask=False, seed=17, rank=0, world=1, feature_folder="features_outputs_VSPW", exp_name=None):
+    """Each rank segments its own window (`latent` is THIS rank's [F,4,h,w]); returns int64 labels:
+    world == 1 -> [F, N] (exactly pipeline.segment_window); world > 1 -> [world, F, N], same on every rank."""
+    from . import analysis as A
+    from . import feature_extraction as FE
+    from .pipeline import save_feature_maps, seed_everything, segment_window
+    exp_name = exp_name or f"rank{rank}"
+    if world == 1:
+        labels, _ = segment_window(engine, latent, c, uc, num_masks=num_masks, num_steps=num_steps, t_start=t_start,
+                                   is_aggre_attn=is_aggre_attn, is_refine_mask=is_refine_mask, seed=seed, noise=noise,
+                                   feature_folder=feature_folder, exp_name=exp_name, keep_all_steps=False)
+        return labels
+    F, _, lh, lw = latent.shape
+    fh, fw = lh // 2, lw // 2
+    N = fh * fw
+    seed_everything(seed)
+    sampler, den_m, model = engine.sampler, engine.denoiser, engine.model
+
+    def denoiser(inp, sigma, cc, **kw):
+        return den_m(model, inp, sigma, cc)
+
+    x = sampler.add_noise(latent, cond=c, uc=uc, num_steps=num_steps, noise_level=t_start, noise=noise)
+    sampler(denoiser, x, cond=c, uc=uc, t_start=t_start,
+            img_callback=lambda xt, i: save_feature_maps(engine, feature_folder, exp_name, i, xt=xt, block_filter=(6, 7, 8)) if i == 24 else None)
+    store = FE.FeatureStore.folder(feature_folder, exp_name)
+    names = ["output_block_8", "output_block_7", "output_block_6"] if is_aggre_attn else ["output_block_7"]
+    blocks = [store[f"{n}_spatial_self_attn_q_time_24"] for n in names]
+    _, feat = A.mean_normalize(blocks, F * N, F * N)
+    tracks = None
+    if is_refine_mask:
+        q7 = store["output_block_7_spatial_self_attn_q_time_24"]
+        tracks, _ = A.dense_tracking(q7[F:2 * F].contiguous(), F, fh, fw)
+
+    def first_window(feat0):
+        np.random.seed(seed)                                              # window 0's seed_everything (SDP:255)
+        km = A.kmeans_fit(feat0, num_masks, n_init=10)
+        fake = A.kmeans_predict(feat0[:N], km.centers)                    # identity cluster->label map (no GT mask, FE:586-595)
+        return A.knn_predict(feat0[:N].contiguous(), fake, feat0)
+
+    ops = ChainOps(first_window_labels=first_window, knn_top4=A.knn_top4, vote4=A.vote4,
+                   refine=(lambda t, l: A.trajectory_vote(t.contiguous(), l.contiguous(), fw)) if is_refine_mask else None)
+    labels = resolve_windows(feat, tracks, ops, rank, world, F)
+    return labels.view(world, F, N).cpu().numpy().astype(np.int64)
