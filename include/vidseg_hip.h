@@ -1,0 +1,164 @@
+/* libvidseg_hip.so -- C ABI of the MI355X (gfx950) VidSeg hot path.
+ *
+ * The reference (QianWangX/VidSeg_diffusion) is 100 % Python and has no FFI; its replaceable seam is the
+ * `instantiate_from_config` plug-in mechanism (sgm/util.py:168-185).  This header is therefore the NEW boundary
+ * the Python host mirror (vidseg_diffusion_amd/*.py, same class/function names and signatures as the reference)
+ * binds with ctypes; each entry point cites the reference code whose arithmetic it replaces
+ * (paths relative to the reference root; FE = scripts/sampling/feature_extraction.py,
+ * OAI = sgm/modules/diffusionmodules/openaimodel.py, ATT = sgm/modules/attention.py,
+ * SAM = sgm/modules/diffusionmodules/sampling.py, DU = sgm/modules/diffusionmodules/util.py).
+ *
+ * Conventions: plain pointers and sizes only (device pointers unless said otherwise); every buffer is
+ * caller-owned, nothing is allocated or freed; calls are asynchronous on `stream`; the return value is 0 or a
+ * negative error code (VIDSEG_ERR_*), with a message available from vidseg_last_error() (thread-local);
+ * no exceptions cross the boundary; no global mutable state except the opt-in GEMM profiler.
+ * Layouts: activations NHWC bf16 (tokens [B][H*W][C] == images [B][H][W][C]); dumped features fp16 [2F][N][C]
+ * with the unconditional half first (sgm/modules/diffusionmodules/guiders.py:33-42); labels int32.
+ */
+#ifndef VIDSEG_HIP_H
+#define VIDSEG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* vidseg_stream_t; /* hipStream_t */
+
+#define VIDSEG_OK 0
+#define VIDSEG_ERR_ARG (-1)
+#define VIDSEG_ERR_HIP (-2)
+#define VIDSEG_ERR_UNSUPPORTED (-3)
+
+int vidseg_version(void);
+const char* vidseg_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Post-UNet analysis
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* FE:739-748 torch.mean(torch.stack(blocks)) in fp16 (fp32 accumulate, one rounding) fused with
+ * FE:550-555 / FE:38-45: keep rows [row0,row0+rows) (the conditional half) and divide every token by its
+ * max |.| over channels in fp16.  `blocks` is a HOST array of nblk device pointers to fp16 [*][C]. */
+int vidseg_mean_normalize_f16(const void* const* blocks, int nblk, int64_t row0, int64_t rows, int C, void* out_mean /*opt*/,
+                              void* out_norm, vidseg_stream_t stream);
+
+/* sklearn KMeans.fit preamble (cluster/_kmeans.py:1478-1485, :279-287) on fp16 x [n][C] up-cast to float64:
+ * column mean (numpy axis-0 order), squared row norms of the centred data, per-feature variances. */
+int vidseg_kmeans_prepare(const void* x16, int64_t n, int C, double* mean, double* xsq, double* colvar /*opt*/,
+                          vidseg_stream_t stream);
+int vidseg_row_sqnorm_f64(const void* x16, int64_t n, int C, double* xsq, vidseg_stream_t stream);
+
+/* One k-means++ round (cluster/_kmeans.py:174-274) for all R restarts at once; the uniforms are drawn on the
+ * host from numpy's RandomState in sklearn's order (FE:562 relies on np.random.seed, sd_pipeline_vspw.py:619-623).
+ * c = 0 evaluates the first centres (cand[r] preset, closest = +inf); c = 1..K-1 finalises centre c-1 (first
+ * minimum potential over the trials) and draws/evaluates Tnext candidates; c = K only finalises. */
+int vidseg_kpp_round(const void* x16, const double* mean, const double* xsq, int64_t n, int C, int R, int K, int c, int Tprev,
+                     int Tnext, int Tmax, const double* u, int ustride, double* closest, double* dcand, double* part,
+                     double* pot, int32_t* cand, int32_t* center_ids, vidseg_stream_t stream);
+int vidseg_gather_rows_f64(const void* x16, const double* mean, int C, const int32_t* ids, int J, double* out,
+                           vidseg_stream_t stream);
+
+/* One Lloyd iteration (cluster/_k_means_lloyd.pyx lloyd_iter_chunked_dense) for the restarts in bit mask
+ * `active`: E-step argmin_j(|c_j|^2 - 2 x.c_j) (labels in place, changed[r] += #changed), M-step with
+ * fixed-order partial sums, centres in place, shift2[r][k] = |c_new - c_old|^2, counts[r][k]. */
+int vidseg_lloyd_iter(const void* x16, const double* mean /*opt*/, int64_t n, int C, int R, int K, unsigned active,
+                      int update_centers, double* centers, double* cnorm, int32_t* labels, int32_t* changed, double* psum,
+                      int32_t* pcnt, int chunk, double* shift2, int32_t* counts, vidseg_stream_t stream);
+int vidseg_kmeans_inertia(const void* x16, const double* mean, int64_t n, int C, int R, int K, const double* centers,
+                          const int32_t* labels, double* part, double* inertia, vidseg_stream_t stream);
+int vidseg_add_mean_f64(double* centers, const double* mean, int K, int C, vidseg_stream_t stream);
+
+/* FE:608-613 KNeighborsClassifier(4).fit(ref).predict(q): brute-force float64 |q|^2 - 2 q.y + |y|^2 (what
+ * sklearn does for fp16 storage), 4 smallest, mode of their labels (smallest label on ties).
+ * knn_top4 + vote4 are the same classifier split at the label dependency (multi-GPU chain). */
+int vidseg_knn_vote(const void* q16, int64_t nq, const void* ref16, int64_t nref, int C, const double* qq, const double* yy,
+                    const int32_t* ref_labels, int32_t* out, vidseg_stream_t stream);
+int vidseg_knn_top4(const void* q16, int64_t nq, const void* ref16, int64_t nref, int C, const double* qq, const double* yy,
+                    int32_t* out_idx, vidseg_stream_t stream);
+int vidseg_vote4(const int32_t* idx, const int32_t* ref_labels, int64_t nq, int32_t* out, vidseg_stream_t stream);
+
+/* FE:272-274: x / torch.norm(x) on fp16 rows, applied 1..nb times (the reference re-normalises target/aux maps
+ * inside its 500-query batch loop): out[b][row][:] = row normalised b+1 times. */
+int vidseg_track_normalize(const void* x16, int64_t rows, int C, int nb, void* out, vidseg_stream_t stream);
+/* FE:218-300 for one frame pair f -> f+1: cosine maps against frame f+1 and frame 0 (exact dot, one fp16
+ * rounding), fp16 blend f/(f+1)*cos + 1/(f+1)*cos_aux (FE:290-291), row arg-max with numpy's
+ * argpartition(-1) tie behaviour (FE:293-296).  cur/next: flat cell index per track. */
+int vidseg_track_step(const void* normed, int F, int N, int w, int C, int f, int batch, const int32_t* cur, int use_aux,
+                      void* blend, int32_t* next, int32_t* tie_rows /*opt*/, vidseg_stream_t stream);
+/* FE:392-421: signed-jump spatial filter, Counter.most_common(1) vote along each trajectory, write-back with
+ * the last writer (largest point index) winning. */
+int vidseg_trajectory_vote(const int32_t* idx, const int32_t* labels, int F, int N, int w, int spatial_filter, int32_t* common,
+                           int32_t* winner, int32_t* out, vidseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * UNet operators
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* nn.Linear / 1x1 conv (ATT:274-280, 862, 886; OAI:317-324) as a bf16 MFMA GEMM: out = act(cat(a0,a1) @ w^T +
+ * bias + rowvec[sample]) + residual.  act: 0 none, 1 SiLU (OAI:605-609 time_embed), 2 GEGLU (ATT:89-96; w/bias
+ * packed in 32-row value|gate groups).  tap/tap2: fp16 copies of output columns [0,tap_cols) / [tap_cols,2*tap_cols)
+ * = the q / k dumps of ATT:330-331. */
+int vidseg_linear_bf16(const void* a0, const void* a1, int C0, int C1, long long M, const void* w, int N, const float* bias,
+                       const float* rowvec, int rv_stride, int rows_per_sample, const void* residual, int ldr, void* out,
+                       float* out_f32, int ldo, void* tap, void* tap2, int tap_cols, int tap_ld, int act,
+                       vidseg_stream_t stream);
+/* 3x3 conv, padding 1 (OAI:267-271, 302-315 ResBlock convs; OAI:202-217 Downsample stride 2; OAI:149-167
+ * Upsample = nearest x2 folded into the addressing) over the channel concat of x0 and x1 (skip connection,
+ * OAI:912), + bias + per-sample emb vector (OAI:353-365) + residual (OAI:369). */
+int vidseg_conv3x3_bf16(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up,
+                        const void* w, int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual,
+                        void* out, vidseg_stream_t stream);
+/* OAI:638-644 input conv (Cin 4/8, fp32 NHWC in) and OAI:825-829 output conv (Cout 4, fp32 NCHW out). */
+int vidseg_conv3x3_direct(const void* x, int in_is_f32, const float* w, const float* bias, int B, int H, int W, int Cin,
+                          int Cout, void* out_bf16_nhwc, float* out_f32_nchw, vidseg_stream_t stream);
+/* GroupNorm32 (DU:276-278, fp32 statistics; eps 1e-5) / ATT:127 Normalize (eps 1e-6), optional SiLU. */
+int vidseg_groupnorm_nhwc_bf16(const void* x0, const void* x1, int C0, int C1, int B, int HW, int G, const float* gamma,
+                               const float* beta, float eps, int silu, float* part, int part_floats, float* stats, void* out,
+                               vidseg_stream_t stream);
+int vidseg_layernorm_bf16(const void* x, long long M, int C, const float* gamma, const float* beta, float eps, void* out,
+                          vidseg_stream_t stream);
+/* ATT:352-356 F.scaled_dot_product_attention per 64-wide head; q/k/v/o are column slices with leading dims. */
+int vidseg_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B,
+                          int H, int Nq, int Nk, int head_dim, vidseg_stream_t stream);
+/* DU:209-233 */
+int vidseg_timestep_embedding(const float* t, int B, int dim, float max_period, void* out, vidseg_stream_t stream);
+int vidseg_silu_bf16(const void* x, long long n, void* out, vidseg_stream_t stream);
+int vidseg_f32_to_bf16(const float* x, long long n, void* out, vidseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Sampler arithmetic on fp32 latents (SURVEY.md rows a2-a6, a17 latent blending)
+ * ---------------------------------------------------------------------------------------------------- */
+/* denoiser.py:23-46: out = a*sa[row] (+ b*sb[row])  -- x*c_in and net*c_out + x*c_skip */
+int vidseg_rows_axpby(const float* a, const float* sa, const float* b, const float* sb, long long n, long long inner,
+                      float* out, vidseg_stream_t stream);
+/* guiders.py:28-31 / :82-91: x_u + s (x_c - x_u), s constant or per frame */
+int vidseg_cfg_combine(const float* x, long long half, long long inner, const float* frame_scale, int num_frames, float scale,
+                       float* out, vidseg_stream_t stream);
+/* sampling_utils.py:34 + SAM:88, 125-131: x + (x - denoised)/sigma * (sigma_next - sigma) */
+int vidseg_euler_update(const float* x, const float* den, const float* sigma, const float* sigma_next, long long n,
+                        long long inner, float* out, vidseg_stream_t stream);
+/* SAM:133-144 add_noise: (x + e*s) * post */
+int vidseg_axpy_f32(const float* x, const float* e, long long n, float s, float post, float* out, vidseg_stream_t stream);
+int vidseg_scale_f32(float* x, long long n, float s, vidseg_stream_t stream);
+int vidseg_blend_f32(const float* x, const float* y, const float* m, long long n, float* out, vidseg_stream_t stream);
+/* SAM:229-250: x = x*m + xt*(1-m), m nearest-upsampled from [F][fh][fw] */
+int vidseg_latent_blend(float* x, const float* xt, const float* mask, int F, int C, int h, int w, int fh, int fw,
+                        vidseg_stream_t stream);
+/* fused forms of the three steps above for a fixed sigma per launch */
+int vidseg_prepare_net_input(const float* x, const float* concat_u, const float* concat_c, int F, int C, int Cc, int HW,
+                             float c_in, float* out_nhwc, vidseg_stream_t stream);
+int vidseg_cfg_euler_step(float* x, const float* net_out, int F, int C, int HW, float c_out, float c_skip,
+                          const float* frame_scale, float scale, float sigma, float sigma_next, float* denoised_out,
+                          vidseg_stream_t stream);
+int vidseg_add_noise(float* x, const float* eps, long long n, float sigma, float inv_scale, vidseg_stream_t stream);
+
+/* opt-in HIP-event timing of the conv/linear MFMA kernel family (bench.py roofline); out = {ms, flops, launches} (host) */
+int vidseg_gemm_profile_begin(void);
+int vidseg_gemm_profile_end(double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIDSEG_HIP_H */
