@@ -47,7 +47,7 @@ int vidseg_mean_normalize_f16(const void* const* blocks, int nblk, int64_t row0,
 /* sklearn KMeans.fit preamble (cluster/_kmeans.py:1478-1485, :279-287) on fp16 x [n][C] up-cast to float64:
  * column mean (numpy axis-0 order), squared row norms of the centred data, per-feature variances. */
 int vidseg_kmeans_prepare(const void* x16, int64_t n, int C, double* mean, double* xsq, double* colvar /*opt*/,
-                          vidseg_stream_t stream);
+                          double* scratch /* 2*ceil(n/256)*C */, vidseg_stream_t stream);
 int vidseg_row_sqnorm_f64(const void* x16, int64_t n, int C, double* xsq, vidseg_stream_t stream);
 
 /* One k-means++ round (cluster/_kmeans.py:174-274) for all R restarts at once; the uniforms are drawn on the
@@ -110,9 +110,12 @@ int vidseg_linear_bf16(const void* a0, const void* a1, int C0, int C1, long long
 int vidseg_conv3x3_bf16(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up,
                         const void* w, int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual,
                         void* out, vidseg_stream_t stream);
-/* OAI:638-644 input conv (Cin 4/8, fp32 NHWC in) and OAI:825-829 output conv (Cout 4, fp32 NCHW out). */
-int vidseg_conv3x3_direct(const void* x, int in_is_f32, const float* w, const float* bias, int B, int H, int W, int Cin,
-                          int Cout, void* out_bf16_nhwc, float* out_f32_nchw, vidseg_stream_t stream);
+/* OAI:638-644 input conv (Cin 4/8): x fp32 NHWC, w fp32 [3][3][Cin][Cout] -> bf16 NHWC. */
+int vidseg_conv_in(const float* x, const float* w, const float* bias, int B, int H, int W, int Cin, int Cout,
+                   void* out_bf16_nhwc, vidseg_stream_t stream);
+/* OAI:825-829 output conv (Cout 4): x bf16 NHWC, w bf16 [4][3][3][Cin] -> fp32 NCHW. */
+int vidseg_conv_out4(const void* x, const void* w, const float* bias, int B, int H, int W, int Cin, float* out_f32_nchw,
+                     vidseg_stream_t stream);
 /* GroupNorm32 (DU:276-278, fp32 statistics; eps 1e-5) / ATT:127 Normalize (eps 1e-6), optional SiLU. */
 int vidseg_groupnorm_nhwc_bf16(const void* x0, const void* x1, int C0, int C1, int B, int HW, int G, const float* gamma,
                                const float* beta, float eps, int silu, float* part, int part_floats, float* stats, void* out,
@@ -153,6 +156,9 @@ int vidseg_cfg_euler_step(float* x, const float* net_out, int F, int C, int HW, 
                           const float* frame_scale, float scale, float sigma, float sigma_next, float* denoised_out,
                           vidseg_stream_t stream);
 int vidseg_add_noise(float* x, const float* eps, long long n, float sigma, float inv_scale, vidseg_stream_t stream);
+
+/* registers a caller-owned fp32 device scratch for split-K partials (optional; without it split-K is off) */
+int vidseg_set_workspace(float* ws, long long floats);
 
 /* opt-in HIP-event timing of the conv/linear MFMA kernel family (bench.py roofline); out = {ms, flops, launches} (host) */
 int vidseg_gemm_profile_begin(void);

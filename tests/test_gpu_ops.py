@@ -95,17 +95,17 @@ def test_conv3x3(dev, cfg):
     check(out, ref, f"conv3x3 {cfg}")
 
 
-def test_conv3x3_direct(dev):
+def test_conv_in_out(dev):
     from vidseg_diffusion_amd import ops
     x = rnd((2, 8, 8, 4), 1)
     w, b = rnd((64, 4, 3, 3), 2, 0.2), rnd((64,), 3)
     ref = TF.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1).permute(0, 2, 3, 1)
-    out = ops.conv3x3_direct(x.to(dev), ops.pack_conv3x3_direct(w, dev), b.to(dev))
-    check(out, ref, "conv_in direct")
-    x2 = rnd((2, 8, 8, 64), 4)
+    out = ops.conv_in(x.to(dev), ops.pack_conv_in(w, dev), b.to(dev))
+    check(out, ref, "conv_in")
+    x2 = rnd((2, 9, 7, 64), 4)
     w2, b2 = rnd((4, 64, 3, 3), 5, 0.05), rnd((4,), 6)
     ref2 = TF.conv2d(x2.permute(0, 3, 1, 2), w2, b2, padding=1)
-    out2 = ops.conv3x3_direct(x2.bfloat16().to(dev), ops.pack_conv3x3_direct(w2, dev), b2.to(dev), out_nchw_f32=True)
+    out2 = ops.conv_out4(x2.bfloat16().to(dev), ops.pack_conv_out(w2, dev), b2.to(dev))
     assert (out2.cpu() - ref2).abs().max() <= 1e-4 * ref2.abs().max() + 1e-5
 
 

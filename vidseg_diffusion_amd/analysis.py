@@ -93,7 +93,8 @@ def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: i
     mean = torch.empty(C, dtype=F64, device=dev)
     xsq = torch.empty(n, dtype=F64, device=dev)
     colvar = torch.empty(C, dtype=F64, device=dev)
-    call("vidseg_kmeans_prepare", ptr(x16), n, C, ptr(mean), ptr(xsq), ptr(colvar), st)
+    scratch = torch.empty(2 * ((n + 255) // 256) * C, dtype=F64, device=dev)
+    call("vidseg_kmeans_prepare", ptr(x16), n, C, ptr(mean), ptr(xsq), ptr(colvar), ptr(scratch), st)
 
     ntiles = (n + 63) // 64
     closest = torch.full((R, n), float("inf"), dtype=F64, device=dev)

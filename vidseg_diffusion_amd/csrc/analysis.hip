@@ -156,12 +156,34 @@ __device__ __forceinline__ void tile_gemm(double (&acc)[4][4], double (*LA)[LDP]
 // K-means preparation: column mean (numpy axis-0 order: sequential over rows), squared row norms of
 // the centred data, sum of per-feature variances (for sklearn's tol).
 // ---------------------------------------------------------------------------------------------
-__global__ void k_col_mean(const f16* __restrict__ x, int64_t n, int C, double* __restrict__ mean) {
+// Column sums in two fixed-order levels (chunks of 256 rows summed in ascending row order, then the chunk
+// partials in ascending chunk order): deterministic, differs from numpy's single sequential pass only in the
+// last bits of a float64 sum of fp16 values, far below anything a decision depends on.
+__global__ void __launch_bounds__(64) k_col_partial(const f16* __restrict__ x, const double* __restrict__ mean, int64_t n, int C,
+                                                    int sq, double* __restrict__ part) {
+    // grid (ceil(C/64), nchunk): part[chunk][c] = sum_i f(x[i][c]) over the chunk; f = identity or (x-mean)^2 / (x-mean)
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * 256, r1 = min(n, r0 + 256);
+    const double m = mean ? mean[c] : 0.0;
+    double s = 0.0;
+    for (int64_t i = r0; i < r1; ++i) {
+        const double v = (double)x[i * C + c] - m;
+        s += sq ? v * v : v;
+    }
+    part[(int64_t)blockIdx.y * C + c] = s;
+}
+
+__global__ void k_col_finish(const double* __restrict__ part, int nchunk, int C, double scale, const double* __restrict__ sub,
+                             double sub_scale, double* __restrict__ out) {
+    // out[c] = scale * sum_chunk part[chunk][c]  - sub_scale * sub[c]^2   (sub optional)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s = 0.0;
-    for (int64_t i = 0; i < n; ++i) s += (double)x[i * C + c];
-    mean[c] = s / (double)n;
+    for (int k = 0; k < nchunk; ++k) s += part[(int64_t)k * C + c];
+    s *= scale;
+    if (sub) s -= sub_scale * sub[c] * sub[c];
+    out[c] = s;
 }
 
 __global__ void __launch_bounds__(256) k_row_sqnorm(const f16* __restrict__ x, const double* __restrict__ mean, int64_t n, int C,
@@ -176,21 +198,6 @@ __global__ void __launch_bounds__(256) k_row_sqnorm(const f16* __restrict__ x, c
     }
     s = wave_sum_f64(s);
     if (lane == 0) xsq[row] = s;
-}
-
-// per-column sum of squares of centred data -> var_sum = sum_c mean_i (xc_ic - m2_c)^2
-__global__ void k_col_var(const f16* __restrict__ x, const double* __restrict__ mean, int64_t n, int C, double* __restrict__ colvar) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, m = mean[c];
-    for (int64_t i = 0; i < n; ++i) s += (double)x[i * C + c] - m;
-    const double m2 = s / (double)n;
-    double q = 0.0;
-    for (int64_t i = 0; i < n; ++i) {
-        double d = ((double)x[i * C + c] - m) - m2;
-        q = fma(d, d, q);
-    }
-    colvar[c] = q / (double)n;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -862,11 +869,24 @@ int vidseg_mean_normalize_f16(const void* const* blocks, int nblk, int64_t row0,
     return VS_OK;
 }
 
-int vidseg_kmeans_prepare(const void* x16, int64_t n, int C, double* mean, double* xsq, double* colvar, hipStream_t st) {
+int vidseg_kmeans_prepare(const void* x16, int64_t n, int C, double* mean, double* xsq, double* colvar, double* scratch,
+                          hipStream_t st) {
+    // scratch: 2 * ceil(n/256) * C doubles
     VS_REQUIRE(n > 0 && C % 8 == 0, "kmeans_prepare: n=%lld C=%d", (long long)n, C);
-    k_col_mean<<<dim3((C + 63) / 64), 64, 0, st>>>((const f16*)x16, n, C, mean);
+    const int nchunk = (int)cdiv64(n, 256);
+    const dim3 g((C + 63) / 64, nchunk);
+    double* p1 = scratch;
+    double* p2 = scratch + (int64_t)nchunk * C;
+    k_col_partial<<<g, 64, 0, st>>>((const f16*)x16, nullptr, n, C, 0, p1);
+    k_col_finish<<<dim3((C + 63) / 64), 64, 0, st>>>(p1, nchunk, C, 1.0 / (double)n, nullptr, 0.0, mean);
     k_row_sqnorm<<<dim3((unsigned)cdiv64(n, 4)), 256, 0, st>>>((const f16*)x16, mean, n, C, xsq);
-    if (colvar) k_col_var<<<dim3((C + 63) / 64), 64, 0, st>>>((const f16*)x16, mean, n, C, colvar);
+    if (colvar) {
+        // var_c = mean_i (xc_ic - m2_c)^2 with m2 = mean of the centred column = E[xc^2] - m2^2 evaluated from two sums
+        k_col_partial<<<g, 64, 0, st>>>((const f16*)x16, mean, n, C, 0, p1);
+        k_col_finish<<<dim3((C + 63) / 64), 64, 0, st>>>(p1, nchunk, C, 1.0 / (double)n, nullptr, 0.0, colvar);   // m2 (tmp in colvar)
+        k_col_partial<<<g, 64, 0, st>>>((const f16*)x16, mean, n, C, 1, p2);
+        k_col_finish<<<dim3((C + 63) / 64), 64, 0, st>>>(p2, nchunk, C, 1.0 / (double)n, colvar, 1.0, colvar);
+    }
     VS_CHECK_LAUNCH("kmeans_prepare");
     return VS_OK;
 }

@@ -39,6 +39,8 @@ struct GemmParams {
     f16* tap2;               // fp16 copy of columns [tap_cols, 2*tap_cols) (same leading dim), or nullptr
     int tap_cols, tap_ld;
     int act;                 // 0 none, 1 SiLU, 2 GEGLU (32-column interleaved x|gate groups)
+    int ksplit;              // >1: K range split over `ksplit` blocks per tile, fp32 partials in ws[split][M][N]
+    float* ws;
 };
 
 #define BK 64
@@ -61,7 +63,8 @@ __global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
     const long long tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = (p.N + BN - 1) / BN;
     const long long nwg = tiles_m * tiles_n;
-    long long bid = blockIdx.x;
+    const int split = p.ksplit > 1 ? (int)(blockIdx.x / nwg) : 0;
+    long long bid = p.ksplit > 1 ? (long long)(blockIdx.x % nwg) : (long long)blockIdx.x;
     {
         const long long q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -97,9 +100,19 @@ __global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
     }
     u32x4 ra[AR], rb[BR];
 
+    const int upsh = p.up - 1;                        // up is 1 or 2
+    const int Hup = p.Hin << upsh, Wup = p.Win << upsh;
+    const int nk_all = p.K / BK;
+    const int ks_begin = p.ksplit > 1 ? (int)((long long)nk_all * split / p.ksplit) : 0;
+    const int ks_end = p.ksplit > 1 ? (int)((long long)nk_all * (split + 1) / p.ksplit) : nk_all;
+    int ld_tap = (ks_begin * BK) / Cin, ld_c0 = (ks_begin * BK) % Cin;   // K cursor of the next load (tap-major, then channel chunk)
     auto load_regs = [&](int k0) {
-        const int tap = k0 / Cin;                      // uniform
-        const int c0 = k0 - tap * Cin;
+        const int tap = ld_tap, c0 = ld_c0;            // uniform
+        ld_c0 += BK;
+        if (ld_c0 >= Cin) {
+            ld_c0 = 0;
+            ld_tap++;
+        }
         const bf16_t* src = p.x0;
         int Cs = p.C0, cc = c0;
         if (c0 >= p.C0) {
@@ -118,8 +131,8 @@ __global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
                     pix = m0 + rbase + 32 * i;
                 } else {
                     const int ih = a_oh[i] * p.stride + kh - 1, iw = a_ow[i] * p.stride + kw - 1;
-                    ok = ih >= 0 && iw >= 0 && ih < p.Hin * p.up && iw < p.Win * p.up;
-                    pix = ((long long)a_b[i] * p.Hin + (ih / p.up)) * p.Win + (iw / p.up);
+                    ok = ih >= 0 && iw >= 0 && ih < Hup && iw < Wup;
+                    pix = ((long long)a_b[i] * p.Hin + (ih >> upsh)) * p.Win + (iw >> upsh);
                 }
                 if (ok) v = *reinterpret_cast<const u32x4*>(src + pix * Cs + cc + chunk * 8);
             }
@@ -139,12 +152,12 @@ __global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int r = rbase + 32 * i;
-            *reinterpret_cast<u32x4*>(A + r * 128 + ((chunk ^ (r & 7)) << 4)) = ra[i];
+            *reinterpret_cast<u32x4*>(A + r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4)) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
             const int r = rbase + 32 * i;
-            *reinterpret_cast<u32x4*>(B + r * 128 + ((chunk ^ (r & 7)) << 4)) = rb[i];
+            *reinterpret_cast<u32x4*>(B + r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4)) = rb[i];
         }
     };
 
@@ -156,13 +169,13 @@ __global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.K / BK;
-    load_regs(0);
+    const int nk = ks_end - ks_begin;
+    load_regs(ks_begin * BK);
     store_lds(0);
     __syncthreads();
     const int l31 = lane & 31, hi = lane >> 5;
     for (int ks = 0; ks < nk; ++ks) {
-        if (ks + 1 < nk) load_regs((ks + 1) * BK);
+        if (ks + 1 < nk) load_regs((ks_begin + ks + 1) * BK);
         const char* A = smem + (ks & 1) * BUF;
         const char* B = A + A_BYTES;
 #pragma unroll
@@ -172,12 +185,12 @@ __global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int r = wm * 64 + i * 32 + l31;
-                fa[i] = *reinterpret_cast<const bf16x8_t*>(A + r * 128 + ((ch ^ (r & 7)) << 4));
+                fa[i] = *reinterpret_cast<const bf16x8_t*>(A + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int r = wn * 64 + j * 32 + l31;
-                fb[j] = *reinterpret_cast<const bf16x8_t*>(B + r * 128 + ((ch ^ (r & 7)) << 4));
+                fb[j] = *reinterpret_cast<const bf16x8_t*>(B + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -190,45 +203,160 @@ __global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
     }
 
     // ---- epilogue -------------------------------------------------------------------------------
-    if (p.act == 2) {
-        // GEGLU: fragment j=0 holds x, j=1 holds gate for output column (n0 + wn*64)/2 + l31
-        const int oc = (n0 + wn * 64) / 2 + l31;
-        const bool cok = (n0 + wn * 64 + 32 + l31) < p.N;
-        const float bx = (p.bias && cok) ? p.bias[n0 + wn * 64 + l31] : 0.f;
-        const float bg = (p.bias && cok) ? p.bias[n0 + wn * 64 + 32 + l31] : 0.f;
+    // Values leave the MFMA accumulators in a column-per-lane layout (2-byte scattered stores).  Stage them
+    // through LDS as fp32 (same rounding points as a direct store) so that every lane reads 8 consecutive
+    // columns of one row and all global traffic of the epilogue (residual, out, taps) is 16 bytes per lane.
+    constexpr int EP_LD = 68;                                  // fp32 row stride of the staging tile (64 + 4 pad)
+    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
+    const bool geglu = p.act == 2;
+    const int wcol0 = n0 + wn * 64;                            // first GEMM column of this wave
+    const int ncols = geglu ? 32 : 64;                         // staged columns per row
+    const int ocol0 = geglu ? wcol0 / 2 : wcol0;               // first OUTPUT column of this wave
+    const int nout = geglu ? p.N / 2 : p.N;
+    __syncthreads();                                           // main-loop LDS reads are done
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        // ---- phase 1: accumulators (+bias, +emb vector, activation) -> LDS fp32 [32][ncols]
+        if (geglu) {
+            const bool cok = (wcol0 + 32 + l31) < p.N;
+            const float bx = (p.bias && cok) ? p.bias[wcol0 + l31] : 0.f;
+            const float bg = (p.bias && cok) ? p.bias[wcol0 + 32 + l31] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (m < p.M && cok) {
-                    const float xv = acc[i][0][r] + bx, gv = acc[i][1][r] + bg;
-                    p.out[m * p.ldo + oc] = f32_to_bf16(xv * gelu_erf(gv));
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float xv = acc[i][0][r] + bx, gv = acc[i][1][r] + bg;
+                stage[row * EP_LD + l31] = xv * gelu_erf(gv);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = wcol0 + j * 32 + l31;
+                const bool cok = n < p.N;
+                const bool fin = p.ksplit <= 1;                 // split-K partials carry no bias/emb/activation
+                const float bv = (p.bias && cok && fin) ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    float v = acc[i][j][r] + bv;
+                    if (p.rowvec && cok && fin) {
+                        const long long m = m0 + wm * 64 + i * 32 + row;
+                        if (m < p.M) v += p.rowvec[(m / p.rows_per_sample) * p.rv_stride + n];
+                    }
+                    if (p.act == 1 && fin) v = silu_f(v);
+                    stage[row * EP_LD + j * 32 + l31] = v;
                 }
             }
-        return;
+        }
+        __syncthreads();
+        // ---- phase 2: 8 columns per lane, coalesced 16-byte global accesses
+        const int lpr = ncols / 8;                             // lanes per row: 8 (or 4 for GEGLU)
+        const int rpp = 64 / lpr;                              // rows per pass
+        for (int r0 = 0; r0 < 32; r0 += rpp) {
+            const int row = r0 + lane / lpr, c8 = (lane % lpr) * 8;
+            const long long m = m0 + wm * 64 + i * 32 + row;
+            const int n = ocol0 + c8;                          // output column of element 0
+            if (m < p.M && n < nout) {
+                float v[8];
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + c8);
+                const f32x4 hi4 = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + c8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = lo[e];
+                    v[4 + e] = hi4[e];
+                }
+                if (p.ksplit > 1) {
+                    float* wp = p.ws + ((long long)split * p.M + m) * p.N + n;
+                    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+                    *reinterpret_cast<f32x4*>(wp) = a;
+                    *reinterpret_cast<f32x4*>(wp + 4) = b;
+                    continue;
+                }
+                if (p.tap && n < p.tap_cols) {
+                    f16x8 t;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
+                    *reinterpret_cast<f16x8*>(p.tap + m * p.tap_ld + n) = t;
+                }
+                if (p.tap2 && n >= p.tap_cols && n < 2 * p.tap_cols) {
+                    f16x8 t;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
+                    *reinterpret_cast<f16x8*>(p.tap2 + m * p.tap_ld + (n - p.tap_cols)) = t;
+                }
+                if (p.residual) {
+                    const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
+                }
+                if (p.out) {
+                    bf16x8_t o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(v[e]);
+                    *reinterpret_cast<bf16x8_t*>(p.out + m * p.ldo + n) = o;
+                }
+                if (p.out_f32) {
+                    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+                    *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldo + n) = a;
+                    *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldo + n + 4) = b;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Split-K finish: sum the fp32 partials in split order (deterministic), then the same epilogue as above.
+__global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
+    const long long i8 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int n8 = p.N / 8;
+    if (i8 >= p.M * n8) return;
+    const long long m = i8 / n8;
+    const int n = (int)(i8 % n8) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int s = 0; s < p.ksplit; ++s) {
+        const float* wp = p.ws + ((long long)s * p.M + m) * p.N + n;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wp), b = *reinterpret_cast<const f32x4*>(wp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] += a[e];
+            v[4 + e] += b[e];
+        }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + l31;
-        const bool cok = n < p.N;
-        const float bv = (p.bias && cok) ? p.bias[n] : 0.f;
+    for (int e = 0; e < 8; ++e) {
+        if (p.bias) v[e] += p.bias[n + e];
+        if (p.rowvec) v[e] += p.rowvec[(m / p.rows_per_sample) * p.rv_stride + n + e];
+        if (p.act == 1) v[e] = silu_f(v[e]);
+    }
+    if (p.tap && n < p.tap_cols) {
+        f16x8 t;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
+        *reinterpret_cast<f16x8*>(p.tap + m * p.tap_ld + n) = t;
+    }
+    if (p.tap2 && n >= p.tap_cols && n < 2 * p.tap_cols) {
+        f16x8 t;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (m < p.M && cok) {
-                    float v = acc[i][j][r] + bv;
-                    if (p.rowvec) v += p.rowvec[(m / p.rows_per_sample) * p.rv_stride + n];
-                    if (p.act == 1) v = silu_f(v);
-                    if (p.tap && n < p.tap_cols) p.tap[m * p.tap_ld + n] = (f16)v;
-                    if (p.tap2 && n >= p.tap_cols && n < 2 * p.tap_cols) p.tap2[m * p.tap_ld + (n - p.tap_cols)] = (f16)v;
-                    if (p.residual) v += bf16_to_f32(p.residual[m * p.ldr + n]);
-                    if (p.out) p.out[m * p.ldo + n] = f32_to_bf16(v);
-                    if (p.out_f32) p.out_f32[m * p.ldo + n] = v;
-                }
-            }
+        for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
+        *reinterpret_cast<f16x8*>(p.tap2 + m * p.tap_ld + (n - p.tap_cols)) = t;
+    }
+    if (p.residual) {
+        const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
+    }
+    if (p.out) {
+        bf16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(v[e]);
+        *reinterpret_cast<bf16x8_t*>(p.out + m * p.ldo + n) = o;
+    }
+    if (p.out_f32) {
+        f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldo + n) = a;
+        *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldo + n + 4) = b;
     }
 }
 
@@ -243,9 +371,10 @@ __device__ __forceinline__ float ld_in<float>(const float* p, long long i) { ret
 template <>
 __device__ __forceinline__ float ld_in<bf16_t>(const bf16_t* p, long long i) { return bf16_to_f32(p[i]); }
 
-template <typename TI>
-__global__ void k_conv3x3_direct(const TI* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int B, int H,
-                                 int W, int Cin, int Cout, bf16_t* __restrict__ out_bf16, float* __restrict__ out_nchw_f32) {
+// Input conv (Cin = 4/8): thread per (pixel, cout); weight packed [3][3][Cin][Cout] so consecutive threads
+// (consecutive cout) read consecutive weights and share the same 36 input values.
+__global__ void __launch_bounds__(256) k_conv_in(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                 int B, int H, int W, int Cin, int Cout, bf16_t* __restrict__ out) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)B * H * W * Cout;
     if (idx >= total) return;
@@ -259,19 +388,47 @@ __global__ void k_conv3x3_direct(const TI* __restrict__ x, const float* __restri
         for (int kw = 0; kw < 3; ++kw) {
             const int iw = ow + kw - 1;
             if (iw < 0 || iw >= W) continue;
-            const long long base = (((long long)b * H + ih) * W + iw) * Cin;
-            const float* wp = w + ((co * 3 + kh) * 3 + kw) * Cin;
-            for (int c = 0; c < Cin; ++c) acc = fmaf(ld_in<TI>(x, base + c), wp[c], acc);
+            const float* xp = x + (((long long)b * H + ih) * W + iw) * Cin;
+            const float* wp = w + ((kh * 3 + kw) * Cin) * Cout + co;
+            for (int c = 0; c < Cin; ++c) acc = fmaf(xp[c], wp[(long long)c * Cout], acc);
         }
     }
-    if (out_bf16) out_bf16[pix * Cout + co] = f32_to_bf16(acc);
-    if (out_nchw_f32) out_nchw_f32[(((long long)b * Cout + co) * H + oh) * W + ow] = acc;
+    out[pix * Cout + co] = f32_to_bf16(acc);
+}
+
+// Output conv (Cout = 4, Cin multiple of 8): one wave per output pixel; lanes split the 9*Cin reduction in
+// 16-byte pieces, weights [Cout][3][3][Cin] bf16, wave-shuffle reduction, fp32 NCHW result.
+__global__ void __launch_bounds__(256) k_conv_out4(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ bias,
+                                                   int B, int H, int W, int Cin, float* __restrict__ out_nchw) {
+    const int lane = threadIdx.x & 63;
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= (long long)B * H * W) return;
+    const int ow = (int)(pix % W), oh = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int c8 = Cin / 8;
+    for (int t = lane; t < 9 * c8; t += 64) {
+        const int tap = t / c8, c = (t % c8) * 8;
+        const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
+        if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+        const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(x + (((long long)b * H + ih) * W + iw) * Cin + c);
+#pragma unroll
+        for (int co = 0; co < 4; ++co) {
+            const bf16x8_t wv = *reinterpret_cast<const bf16x8_t*>(w + ((long long)co * 9 + tap) * Cin + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[co] = fmaf(bf16_to_f32((bf16_t)xv[e]), bf16_to_f32((bf16_t)wv[e]), acc[co]);
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < 4; ++co) acc[co] = wave_sum_f32(acc[co]);
+    if (lane == 0)
+        for (int co = 0; co < 4; ++co) out_nchw[(((long long)b * 4 + co) * H + oh) * W + ow] = acc[co] + (bias ? bias[co] : 0.f);
 }
 
 // ---- live HIP-event timing of this kernel family (bench.py roofline) -------------------------------------
 // When enabled, every k_gemm_conv launch is bracketed by two events recorded on the launch stream; collect()
 // synchronises, sums the elapsed times and the algorithmic FLOPs (2*M*N*K per launch).
 #include <vector>
+#include <stdlib.h>
 struct GemmProf {
     bool on = false;
     std::vector<hipEvent_t> ev;      // pairs
@@ -317,28 +474,63 @@ int vidseg_gemm_profile_end(double* out) {
     return VS_OK;
 }
 
-static int launch_gemm(const GemmParams& p, hipStream_t st) {
+static float* g_ws = nullptr;           // split-K workspace registered by the host (caller-owned device memory)
+static long long g_ws_floats = 0;
+
+int vidseg_set_workspace(float* ws, long long floats) {
+    g_ws = ws;
+    g_ws_floats = floats;
+    return VS_OK;
+}
+
+static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
+    GemmParams p = p_in;
     VS_REQUIRE(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
     VS_REQUIRE(p.C0 % BK == 0 && p.C1 % BK == 0, "gemm: source channels (%d,%d) must be multiples of %d", p.C0, p.C1, BK);
     VS_REQUIRE(p.M > 0 && p.N > 0, "gemm: empty problem");
+    VS_REQUIRE(p.N % 8 == 0 && p.ldo % 8 == 0 && (!p.residual || p.ldr % 8 == 0) && (!p.tap || (p.tap_ld % 8 == 0 && p.tap_cols % 8 == 0)),
+               "gemm: N=%d ldo=%d ldr=%d tap_ld=%d must be multiples of 8 (16-byte epilogue)", p.N, p.ldo, p.ldr, p.tap_ld);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)k_gemm_conv<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         (void)hipFuncSetAttribute((const void*)k_gemm_conv<256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
         attr = true;
     }
-    const bool narrow = (p.N % 128 != 0) && (p.N % 128 <= 64) && p.act != 2 && p.M >= 256;
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("VIDSEG_GEMM_TILE"); force = e ? atoi(e) : 0; }
+    bool narrow = p.N <= 64 && p.act != 2 && p.M >= 256;
+    if (force == 128) narrow = false;
     if (g_prof.on) {
         (void)hipEventRecord(prof_event(), st);
         g_prof.flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
         g_prof.launches++;
     }
+    p.ksplit = 1;
+    p.ws = nullptr;
     if (narrow) {
         const long long tiles = ((p.M + 255) / 256) * ((p.N + 63) / 64);
         k_gemm_conv<256, 64><<<dim3((unsigned)tiles), 256, 2 * (256 + 64) * BK * 2, st>>>(p);
     } else {
         const long long tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-        k_gemm_conv<128, 128><<<dim3((unsigned)tiles), 256, 2 * (128 + 128) * BK * 2, st>>>(p);
+        // too few tiles to fill 256 CUs x 2 blocks and a long K: split K, fp32 partials, deterministic finish
+        const int nk = p.K / BK;
+        static int nosplit = -1;
+        if (nosplit < 0) { const char* e = getenv("VIDSEG_NO_SPLITK"); nosplit = e ? atoi(e) : 0; }
+        if (!nosplit && tiles < 384 && nk >= 40 && p.act != 2 && g_ws) {
+            int S = (int)((512 + tiles - 1) / tiles);
+            if (S > nk / 8) S = nk / 8;
+            if (S > 8) S = 8;
+            while (S > 1 && (long long)S * p.M * p.N > g_ws_floats) --S;
+            if (S > 1) {
+                p.ksplit = S;
+                p.ws = g_ws;
+            }
+        }
+        k_gemm_conv<128, 128><<<dim3((unsigned)(tiles * p.ksplit)), 256, 2 * (128 + 128) * BK * 2, st>>>(p);
+        if (p.ksplit > 1) {
+            const long long n8 = p.M * (p.N / 8);
+            k_splitk_finish<<<dim3((unsigned)((n8 + 255) / 256)), 256, 0, st>>>(p);
+        }
     }
     if (g_prof.on) (void)hipEventRecord(prof_event(), st);
     VS_CHECK_LAUNCH("gemm_conv");
@@ -412,19 +604,24 @@ int vidseg_conv3x3_bf16(const void* x0, const void* x1, int C0, int C1, int B, i
     return launch_gemm(p, st);
 }
 
-// Tiny-channel 3x3 convs.  in_is_f32: x is NHWC fp32 (sampler latent) else NHWC bf16.
-int vidseg_conv3x3_direct(const void* x, int in_is_f32, const float* w, const float* bias, int B, int H, int W, int Cin, int Cout,
-                          void* out_bf16_nhwc, float* out_f32_nchw, hipStream_t st) {
+// Tiny-channel 3x3 convs.  conv_in: x NHWC fp32 [B][H][W][Cin], w fp32 [3][3][Cin][Cout] -> bf16 NHWC.
+int vidseg_conv_in(const float* x, const float* w, const float* bias, int B, int H, int W, int Cin, int Cout, void* out_bf16_nhwc,
+                   hipStream_t st) {
     const long long total = (long long)B * H * W * Cout;
     if (total == 0) return VS_OK;
-    const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (in_is_f32)
-        k_conv3x3_direct<float><<<dim3(blocks), 256, 0, st>>>((const float*)x, w, bias, B, H, W, Cin, Cout, (bf16_t*)out_bf16_nhwc,
-                                                             out_f32_nchw);
-    else
-        k_conv3x3_direct<bf16_t><<<dim3(blocks), 256, 0, st>>>((const bf16_t*)x, w, bias, B, H, W, Cin, Cout, (bf16_t*)out_bf16_nhwc,
-                                                              out_f32_nchw);
-    VS_CHECK_LAUNCH("conv3x3_direct");
+    k_conv_in<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(x, w, bias, B, H, W, Cin, Cout, (bf16_t*)out_bf16_nhwc);
+    VS_CHECK_LAUNCH("conv_in");
+    return VS_OK;
+}
+
+// conv_out: x NHWC bf16 [B][H][W][Cin], w bf16 [4][3][3][Cin] -> fp32 NCHW [B][4][H][W].
+int vidseg_conv_out4(const void* x, const void* w, const float* bias, int B, int H, int W, int Cin, float* out_f32_nchw,
+                     hipStream_t st) {
+    VS_REQUIRE(Cin % 8 == 0, "conv_out4: Cin=%d must be a multiple of 8", Cin);
+    const long long pix = (long long)B * H * W;
+    if (pix == 0) return VS_OK;
+    k_conv_out4<<<dim3((unsigned)((pix + 3) / 4)), 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, B, H, W, Cin, out_f32_nchw);
+    VS_CHECK_LAUNCH("conv_out4");
     return VS_OK;
 }
 

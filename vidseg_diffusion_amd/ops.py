@@ -18,7 +18,8 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 _lib.register({
     "vidseg_linear_bf16": [_P, _P, _I, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P],
     "vidseg_conv3x3_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
-    "vidseg_conv3x3_direct": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "vidseg_conv_in": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "vidseg_conv_out4": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "vidseg_groupnorm_nhwc_bf16": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _P, _P],
     "vidseg_layernorm_bf16": [_P, _L, _I, _P, _P, _F, _P, _P],
     "vidseg_attention_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -35,6 +36,7 @@ _lib.register({
     "vidseg_euler_update": [_P, _P, _P, _P, _L, _L, _P, _P],
     "vidseg_axpy_f32": [_P, _P, _L, _F, _F, _P, _P],
     "vidseg_blend_f32": [_P, _P, _P, _L, _P, _P],
+    "vidseg_set_workspace": [_P, _L],
     "vidseg_gemm_profile_begin": [],
     "vidseg_gemm_profile_end": [_P],
 })
@@ -56,9 +58,14 @@ def pack_conv3x3(weight: torch.Tensor, device) -> torch.Tensor:
     return weight.detach().permute(0, 2, 3, 1).reshape(co, kh * kw * ci).to(device=device, dtype=BF16).contiguous()
 
 
-def pack_conv3x3_direct(weight: torch.Tensor, device) -> torch.Tensor:
-    """Conv2d weight [Cout, Cin, 3, 3] -> fp32 [Cout, 3, 3, Cin] for the tiny-channel direct kernel."""
-    return weight.detach().permute(0, 2, 3, 1).to(device=device, dtype=F32).contiguous()
+def pack_conv_in(weight: torch.Tensor, device) -> torch.Tensor:
+    """Conv2d weight [Cout, Cin, 3, 3] (Cin = 4/8) -> fp32 [3, 3, Cin, Cout] (cout fastest)."""
+    return weight.detach().permute(2, 3, 1, 0).to(device=device, dtype=F32).contiguous()
+
+
+def pack_conv_out(weight: torch.Tensor, device) -> torch.Tensor:
+    """Conv2d weight [4, Cin, 3, 3] -> bf16 [4, 3, 3, Cin]."""
+    return weight.detach().permute(0, 2, 3, 1).to(device=device, dtype=BF16).contiguous()
 
 
 def pack_geglu(weight: torch.Tensor, bias: torch.Tensor, device):
@@ -81,6 +88,7 @@ def f32(t: torch.Tensor, device) -> torch.Tensor:
 def linear(a, w, bias=None, *, a1=None, rowvec=None, rows_per_sample=0, residual=None, act=ACT_NONE, out_f32=False,
            tap=None, tap2=None, tap_cols=0):
     """out = act(cat(a, a1) @ w.T + bias + rowvec[sample]) + residual.  a: bf16 [..., K0]."""
+    workspace(a.device)
     C0 = a.shape[-1]
     C1 = a1.shape[-1] if a1 is not None else 0
     M = a.numel() // C0
@@ -98,6 +106,7 @@ def linear(a, w, bias=None, *, a1=None, rowvec=None, rows_per_sample=0, residual
 def conv3x3(x0, w, bias, *, x1=None, stride=1, up=1, rowvec=None, residual=None):
     """3x3 conv, padding 1, on NHWC bf16 [B, H, W, C0] (+ channel-concat x1), optional fused nearest-2x
     upsample of the input (openaimodel.py:149-167) or stride 2 (openaimodel.py:202-217)."""
+    workspace(x0.device)
     B, H, W, C0 = x0.shape
     C1 = x1.shape[-1] if x1 is not None else 0
     Cout = w.shape[0]
@@ -109,27 +118,32 @@ def conv3x3(x0, w, bias, *, x1=None, stride=1, up=1, rowvec=None, residual=None)
     return out
 
 
-def conv3x3_direct(x, w_f32, bias, *, out_nchw_f32=False):
-    """Tiny-channel 3x3 conv (input conv Cin=4/8 from fp32 NHWC; output conv Cout=4 to fp32 NCHW)."""
+def conv_in(x_nhwc_f32, w, bias):
+    """Input conv (openaimodel.py:638-644): fp32 NHWC [B,H,W,4|8] -> bf16 NHWC [B,H,W,Cout]."""
+    B, H, W, Cin = x_nhwc_f32.shape
+    Cout = w.shape[-1]
+    out = torch.empty((B, H, W, Cout), dtype=BF16, device=x_nhwc_f32.device)
+    call("vidseg_conv_in", ptr(x_nhwc_f32), ptr(w), ptr(bias), B, H, W, Cin, Cout, ptr(out), stream())
+    return out
+
+
+def conv_out4(x, w, bias):
+    """Output conv (openaimodel.py:825-829): bf16 NHWC [B,H,W,Cin] -> fp32 NCHW [B,4,H,W]."""
     B, H, W, Cin = x.shape
-    Cout = w_f32.shape[0]
-    if out_nchw_f32:
-        out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
-        call("vidseg_conv3x3_direct", ptr(x), int(x.dtype == F32), ptr(w_f32), ptr(bias), B, H, W, Cin, Cout, None, ptr(out),
-             stream())
-    else:
-        out = torch.empty((B, H, W, Cout), dtype=BF16, device=x.device)
-        call("vidseg_conv3x3_direct", ptr(x), int(x.dtype == F32), ptr(w_f32), ptr(bias), B, H, W, Cin, Cout, ptr(out), None,
-             stream())
+    assert w.shape[0] == 4
+    out = torch.empty((B, 4, H, W), dtype=F32, device=x.device)
+    call("vidseg_conv_out4", ptr(x), ptr(w), ptr(bias), B, H, W, Cin, ptr(out), stream())
     return out
 
 
 class Workspace:
     """Scratch for GroupNorm partials, sized once per device."""
 
-    def __init__(self, device, floats=1 << 24):
+    def __init__(self, device, floats=1 << 24, splitk_floats=12 << 20):
         self.part = torch.empty(floats, dtype=F32, device=device)
         self.stats = torch.empty(64 * 32 * 2 * 4, dtype=F32, device=device)
+        self.splitk = torch.empty(splitk_floats, dtype=F32, device=device)   # fp32 split-K partials (48 MB)
+        call("vidseg_set_workspace", ptr(self.splitk), self.splitk.numel())
 
 
 _ws = {}

@@ -369,9 +369,9 @@ class UNetModel(nn.Module):
         self.emb_w = ops.pack_linear(torch.cat([rb.emb_layers[1].weight for rb in rbs], 0), device)
         self.emb_b = ops.f32(torch.cat([rb.emb_layers[1].bias for rb in rbs], 0), device)
         cin = self.input_blocks[0][0]
-        self.cin_w, self.cin_b = ops.pack_conv3x3_direct(cin.weight, device), ops.f32(cin.bias, device)
+        self.cin_w, self.cin_b = ops.pack_conv_in(cin.weight, device), ops.f32(cin.bias, device)
         self.out_g, self.out_beta = ops.f32(self.out[0].weight, device), ops.f32(self.out[0].bias, device)
-        self.out_w, self.out_b = ops.pack_conv3x3_direct(self.out[2].weight, device), ops.f32(self.out[2].bias, device)
+        self.out_w, self.out_b = ops.pack_conv_out(self.out[2].weight, device), ops.f32(self.out[2].bias, device)
         self._set_taps()
         self._packed_on = device
 
@@ -397,7 +397,7 @@ class UNetModel(nn.Module):
             self.pack(x_nhwc_f32.device)
         emb = self.embed(timesteps, y)
         emb_all = ops.linear(ops.silu(emb), self.emb_w, self.emb_b, out_f32=True)                       # every ResBlock's emb_layers
-        h = ops.conv3x3_direct(x_nhwc_f32, self.cin_w, self.cin_b)
+        h = ops.conv_in(x_nhwc_f32, self.cin_w, self.cin_b)
         hs = [h]
         for blk in list(self.input_blocks)[1:]:
             h = blk.run(h, None, emb_all, context_bf16)
@@ -406,7 +406,7 @@ class UNetModel(nn.Module):
         for blk in self.output_blocks:
             h = blk.run(h, hs.pop(), emb_all, context_bf16)                                              # OAI:911-948
         h = ops.groupnorm(h, self.out_g, self.out_beta, eps=1e-5, silu=True)
-        return ops.conv3x3_direct(h, self.out_w, self.out_b, out_nchw_f32=True)
+        return ops.conv_out4(h, self.out_w, self.out_b)
 
     def forward(self, x, timesteps=None, context=None, y=None, is_modulate_step=False, is_injected_step=False,
                 modulate_params=None, **kwargs):
