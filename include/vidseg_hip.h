@@ -125,6 +125,22 @@ int vidseg_layernorm_bf16(const void* x, long long M, int C, const float* gamma,
 /* ATT:352-356 F.scaled_dot_product_attention per 64-wide head; q/k/v/o are column slices with leading dims. */
 int vidseg_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B,
                           int H, int Nq, int Nk, int head_dim, vidseg_stream_t stream);
+/* SVD (video) operators -- video_model.py:15-89 VideoResBlock, video_attention.py:18-489 */
+/* Conv3d kernel [3,1,1], padding [1,0,0] over frames; x NHWC [(b t)][HW][C], w [Cout][dt*Cin+c] (video_model.py:45-58) */
+int vidseg_conv_temporal3_bf16(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
+                               const float* rowvec, int rv_stride, const void* residual, void* out, vidseg_stream_t stream);
+/* bias-free projection with fp16 taps in the reference's temporal layout [(b s), t, c] (video_attention.py:152, ATT:330) */
+int vidseg_linear_bf16_ttap(const void* a0, long long M, int C0, const void* w, int N, void* out, int ldo, void* tap, void* tap2,
+                            int tap_cols, int tap_ld, int tap_T, int tap_S, vidseg_stream_t stream);
+/* attention across the T frames of each (sample, location), tokens kept in spatial order (video_attention.py:166-195) */
+int vidseg_temporal_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
+                                   int Bv, int T, int S, int H, int head_dim, vidseg_stream_t stream);
+/* AlphaBlender 'learned_with_images', image_only_indicator == 0 (diffusionmodules/util.py:343-380) */
+int vidseg_alpha_blend_bf16(const void* x_spatial, const void* x_temporal, const float* mix_factor, long long n, void* out,
+                            vidseg_stream_t stream);
+/* tokens + frame-index embedding (video_attention.py:417-431) */
+int vidseg_add_rowvec_bf16(const void* x, const void* vec, long long rows, int C, int rows_per_sample, int nvec, void* out,
+                           vidseg_stream_t stream);
 /* DU:209-233 */
 int vidseg_timestep_embedding(const float* t, int B, int dim, float max_period, void* out, vidseg_stream_t stream);
 int vidseg_silu_bf16(const void* x, long long n, void* out, vidseg_stream_t stream);

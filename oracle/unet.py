@@ -68,7 +68,28 @@ class UNetOracle:
             skip = _bf(self.conv(x, p + ".skip_connection", pad=0), self.rb)
         else:
             skip = x
-        return _bf(self.conv(h, p + ".out_layers.3") + skip, self.rb)
+        out = _bf(self.conv(h, p + ".out_layers.3") + skip, self.rb)
+        if self.has(p + ".time_stack."):
+            out = self.video_resblock_tail(out, emb_silu, p)
+        return out
+
+    def video_resblock_tail(self, x, emb_silu, p):
+        """VideoResBlock.forward after the spatial ResBlock (video_model.py:66-89): 3-D ResBlock with kernel
+        [3,1,1] over time, per-frame emb (exchange_temb_dims), AlphaBlender 'learned_with_images' with
+        image_only_indicator = 0 -> alpha = sigmoid(mix_factor) (diffusionmodules/util.py:343-380)."""
+        T = self.T
+        BT, C, H, W = x.shape
+        x5 = x.view(BT // T, T, C, H, W).permute(0, 2, 1, 3, 4)                     # b c t h w
+        q = p + ".time_stack"
+        h = _bf(F.silu(F.group_norm(x5, 32, self.sd[q + ".in_layers.0.weight"], self.sd[q + ".in_layers.0.bias"], 1e-5)), self.rb)
+        h = F.conv3d(h, self.w(q + ".in_layers.2.weight"), self.sd[q + ".in_layers.2.bias"], padding=(1, 0, 0))
+        e = self.lin(emb_silu, q + ".emb_layers.1").view(BT // T, T, C).permute(0, 2, 1)[:, :, :, None, None]
+        h = _bf(h + e, self.rb)
+        h = _bf(F.silu(F.group_norm(h, 32, self.sd[q + ".out_layers.0.weight"], self.sd[q + ".out_layers.0.bias"], 1e-5)), self.rb)
+        h = _bf(F.conv3d(h, self.w(q + ".out_layers.3.weight"), self.sd[q + ".out_layers.3.bias"], padding=(1, 0, 0)) + x5, self.rb)
+        alpha = torch.sigmoid(self.sd[p + ".time_mixer.mix_factor"])
+        out = alpha * x5 + (1.0 - alpha) * h
+        return _bf(out.permute(0, 2, 1, 3, 4).reshape(BT, C, H, W), self.rb)
 
     def attention(self, x, ctx, p, tapname):
         q = self.lin(x, p + ".to_q", bias=False)
@@ -90,6 +111,13 @@ class UNetOracle:
         B, C, H, W = x.shape
         t = _bf(self.gn(x, p + ".norm", 1e-6), self.rb).permute(0, 2, 3, 1).reshape(B, H * W, C)
         t = _bf(self.lin(t, p + ".proj_in"), self.rb)
+        video = self.has(f"{p}.time_stack.0.")
+        if video:                                                                   # video_attention.py:408-427
+            T = self.T
+            tctx = context[::T]                                                     # first frame's context per sample
+            fr = torch.arange(T).repeat(B // T)
+            temb = self.lin(_bf(F.silu(self.lin(_bf(self.timestep_embedding(fr, C), self.rb), p + ".time_pos_embed.0")), self.rb),
+                            p + ".time_pos_embed.2")[:, None, :]
         d = 0
         while self.has(f"{p}.transformer_blocks.{d}."):
             b = f"{p}.transformer_blocks.{d}"
@@ -100,9 +128,33 @@ class UNetOracle:
             y = self.lin(self.ln(t, b + ".norm3"), b + ".ff.net.0.proj")
             val, gate = y.chunk(2, dim=-1)
             t = _bf(self.lin(_bf(val * F.gelu(gate), self.rb), b + ".ff.net.2") + t, self.rb)
+            if video:
+                tm = self.video_block(_bf(t + temb, self.rb), tctx, f"{p}.time_stack.{d}", tn, H * W)
+                alpha = torch.sigmoid(self.sd[p + ".time_mixer.mix_factor"])
+                t = _bf(alpha * t + (1.0 - alpha) * tm, self.rb)
             d += 1
         t = self.lin(t, p + ".proj_out")
         return _bf(t.reshape(B, H, W, C).permute(0, 3, 1, 2) + x, self.rb)
+
+    def geglu_ff(self, x, p):
+        y = self.lin(x, p + ".net.0.proj")
+        val, gate = y.chunk(2, dim=-1)
+        return self.lin(_bf(val * F.gelu(gate), self.rb), p + ".net.2")
+
+    def video_block(self, x, tctx, p, tapname, S):
+        """VideoTransformerBlock._forward (video_attention.py:145-285): (b t) s c -> (b s) t c, ff_in, temporal
+        self-attention, cross-attention to the first frame's context, ff, residuals, back to (b t) s c."""
+        T = self.T
+        BT, S_, C = x.shape
+        b = BT // T
+        xt = x.view(b, T, S, C).permute(0, 2, 1, 3).reshape(b * S, T, C)
+        xt = _bf(self.geglu_ff(self.ln(xt, p + ".norm_in"), p + ".ff_in") + xt, self.rb)
+        n1 = self.ln(xt, p + ".norm1")
+        xt = _bf(self.attention(n1, n1, p + ".attn1", tapname and tapname + "_temporal_self_attn") + xt, self.rb)
+        ctx = tctx[:, None].expand(b, S, *tctx.shape[1:]).reshape(b * S, *tctx.shape[1:])
+        xt = _bf(self.attention(self.ln(xt, p + ".norm2"), ctx, p + ".attn2", tapname and tapname + "_temporal_cross_attn") + xt, self.rb)
+        xt = _bf(self.geglu_ff(self.ln(xt, p + ".norm3"), p + ".ff") + xt, self.rb)
+        return xt.view(b, S, T, C).permute(0, 2, 1, 3).reshape(BT, S, C)
 
     def block(self, h, emb_silu, context, p, tapname):
         j = 0
@@ -127,10 +179,12 @@ class UNetOracle:
         args = t[:, None].float() * freqs[None]
         return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 
-    def forward(self, x, timesteps, context, y=None):
+    def forward(self, x, timesteps, context, y=None, num_video_frames=None):
         """x [B, Cin, h, w] fp32, context [B, L, ctx]; returns fp32 [B, Cout, h, w]; self.taps filled with
-        fp16 'output_block_{i}_spatial_{self,cross}_attn_{q,k}' like the reference's dump names."""
+        fp16 'output_block_{i}_spatial_{self,cross}_attn_{q,k}' like the reference's dump names (plus
+        '..._temporal_{self,cross}_attn_{q,k}' in the reference's [(b s), t, c] layout for VideoUNet weights)."""
         self.taps = {}
+        self.T = num_video_frames
         mc = self.sd["time_embed.0.weight"].shape[1]
         t_emb = _bf(self.timestep_embedding(timesteps, mc), self.rb)
         emb = self.lin(_bf(F.silu(self.lin(t_emb, "time_embed.0")), self.rb), "time_embed.2")

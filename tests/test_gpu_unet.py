@@ -128,3 +128,33 @@ def test_window_pipeline_vs_oracle(env):
     iou, exact = matched_iou(labels, ref["labels"], K)
     print("pipeline mask IoU vs fp32 oracle", iou, "exact", exact)
     assert iou >= 0.90
+
+
+def test_video_unet_forward_vs_reference():
+    """SVD VideoUNet on the GPU vs the reference-produced golden (narrow width, T=3): output, spatial and temporal taps."""
+    from oracle.unet import UNetOracle
+    from vidseg_diffusion_amd.video_unet import VideoUNet
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_svd_narrow.npz"))
+    g = {k: z[k] for k in z.files}
+    net = VideoUNet(**synthetic.SVD_NARROW)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=4321).items()}
+    net.load_state_dict(sd)
+    T = int(g["T"])
+    x, t, ctx, y = (torch.from_numpy(g[k]) for k in ("fw_x", "fw_t", "fw_ctx", "fw_y"))
+    out = net(x.to(dev), timesteps=t.to(dev), context=ctx.to(dev), y=y.to(dev), num_video_frames=T,
+              image_only_indicator=torch.zeros(2, T)).cpu().numpy()
+    fmt = nrms(UNetOracle(sd, round_bf16=True).forward(x, t, ctx, y=y, num_video_frames=T).numpy(), g["fw_out"])
+    err = nrms(out, g["fw_out"])
+    print("video unet nrms", err, "bf16 format", fmt)
+    assert err < 4e-2 and err <= 1.5 * fmt + 5e-3, (err, fmt)
+    for i in (3, 7, 8, 11):
+        blk = net.output_blocks[i]
+        assert "SpatialVideoTransformer" in str(type(blk[1]))
+        pairs = [("spatial_self_attn_q", blk[1].transformer_blocks[0].attn1.q), ("temporal_self_attn_q", blk[1].time_stack[0].attn1.q),
+                 ("temporal_self_attn_k", blk[1].time_stack[0].attn1.k), ("temporal_cross_attn_k", blk[1].time_stack[0].attn2.k)]
+        for name, got in pairs:
+            ref = g[f"fw_output_block_{i}_{name}"].astype(np.float32)
+            assert tuple(got.shape) == ref.shape, (i, name, got.shape, ref.shape)
+            assert nrms(got.float().cpu().numpy(), ref) < 4e-2, (i, name)

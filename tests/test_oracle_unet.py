@@ -77,3 +77,23 @@ def test_sampler_matches_reference(gold, narrow_sd):
     for b in (6, 7, 8):
         r = gold[f"sm_q_block_{b}_time_24"].astype(np.float32)
         assert np.abs(taps[b] - r).max() <= 2e-3 * np.abs(r).max()
+
+
+def test_video_unet_forward_matches_reference():
+    """SVD VideoUNet (VideoResBlock, SpatialVideoTransformer, temporal taps) restated by the oracle vs the reference."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_svd_narrow.npz"))
+    g = {k: z[k] for k in z.files}
+    from vidseg_diffusion_amd.video_unet import VideoUNet
+    net = VideoUNet(**synthetic.SVD_NARROW)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert synthetic.state_dict_signature(shapes) == str(g["state_dict_signature"])
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=4321).items()}
+    o = UNetOracle(sd)
+    out = o.forward(torch.from_numpy(g["fw_x"]), torch.from_numpy(g["fw_t"]), torch.from_numpy(g["fw_ctx"]),
+                    y=torch.from_numpy(g["fw_y"]), num_video_frames=int(g["T"]))
+    assert np.abs(out.numpy() - g["fw_out"]).max() <= 5e-5 * np.abs(g["fw_out"]).max()
+    for k, v in g.items():
+        if k.startswith("fw_output_block_"):
+            got = o.taps[k[3:]].float().numpy()
+            assert got.shape == v.shape, k
+            assert np.abs(got - v.astype(np.float32)).max() <= 2e-3 * np.abs(v.astype(np.float32)).max(), k

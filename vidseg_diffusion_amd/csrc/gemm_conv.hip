@@ -41,10 +41,19 @@ struct GemmParams {
     int act;                 // 0 none, 1 SiLU, 2 GEGLU (32-column interleaved x|gate groups)
     int ksplit;              // >1: K range split over `ksplit` blocks per tile, fp32 partials in ws[split][M][N]
     float* ws;
+    int tmode, T;            // tmode: ksize 3 taps run over TIME (Conv3d kernel [3,1,1], video_model.py:45-58): row m is
+                             // frame (m / (Hout*Wout)) % T, tap dt reads row m + (dt-1)*Hout*Wout if that frame exists
+    int tap_T, tap_S;        // >0: taps are written in the reference's temporal layout [(b s), t, c] (row permutation)
 };
 
 #define BK 64
 
+__device__ __forceinline__ long long tap_row(const GemmParams& p, long long m) {
+    if (p.tap_T <= 0) return m;
+    const long long TS = (long long)p.tap_T * p.tap_S;
+    const long long b = m / TS, r = m % TS;
+    return (b * p.tap_S + (r % p.tap_S)) * p.tap_T + r / p.tap_S;       // (b t) s -> (b s) t
+}
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
@@ -91,6 +100,10 @@ __global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
             a_b[i] = 0;
             a_oh[i] = 0;
             a_ow[i] = 0;
+        } else if (p.tmode) {
+            a_b[i] = 0;
+            a_oh[i] = (int)((mm / HWo) % p.T);
+            a_ow[i] = 0;
         } else {
             a_b[i] = (int)(mm / HWo);
             const int rem = (int)(mm % HWo);
@@ -129,6 +142,10 @@ __global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
                 bool ok = true;
                 if (p.ksize == 1) {
                     pix = m0 + rbase + 32 * i;
+                } else if (p.tmode) {
+                    const int tt = a_oh[i] + tap - 1;
+                    ok = tt >= 0 && tt < p.T;
+                    pix = m0 + rbase + 32 * i + (long long)(tap - 1) * HWo;
                 } else {
                     const int ih = a_oh[i] * p.stride + kh - 1, iw = a_ow[i] * p.stride + kw - 1;
                     ok = ih >= 0 && iw >= 0 && ih < Hup && iw < Wup;
@@ -275,13 +292,13 @@ __global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
                     f16x8 t;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
-                    *reinterpret_cast<f16x8*>(p.tap + m * p.tap_ld + n) = t;
+                    *reinterpret_cast<f16x8*>(p.tap + tap_row(p, m) * p.tap_ld + n) = t;
                 }
                 if (p.tap2 && n >= p.tap_cols && n < 2 * p.tap_cols) {
                     f16x8 t;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
-                    *reinterpret_cast<f16x8*>(p.tap2 + m * p.tap_ld + (n - p.tap_cols)) = t;
+                    *reinterpret_cast<f16x8*>(p.tap2 + tap_row(p, m) * p.tap_ld + (n - p.tap_cols)) = t;
                 }
                 if (p.residual) {
                     const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + m * p.ldr + n);
@@ -334,13 +351,13 @@ __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
         f16x8 t;
 #pragma unroll
         for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
-        *reinterpret_cast<f16x8*>(p.tap + m * p.tap_ld + n) = t;
+        *reinterpret_cast<f16x8*>(p.tap + tap_row(p, m) * p.tap_ld + n) = t;
     }
     if (p.tap2 && n >= p.tap_cols && n < 2 * p.tap_cols) {
         f16x8 t;
 #pragma unroll
         for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
-        *reinterpret_cast<f16x8*>(p.tap2 + m * p.tap_ld + (n - p.tap_cols)) = t;
+        *reinterpret_cast<f16x8*>(p.tap2 + tap_row(p, m) * p.tap_ld + (n - p.tap_cols)) = t;
     }
     if (p.residual) {
         const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + m * p.ldr + n);
@@ -569,6 +586,62 @@ int vidseg_linear_bf16(const void* a0, const void* a1, int C0, int C1, long long
     p.tap_ld = tap_ld;
     p.act = act;
     if (act == 2) VS_REQUIRE(N % 64 == 0 && out, "linear: GEGLU needs N %% 64 == 0 and a bf16 output");
+    return launch_gemm(p, st);
+}
+
+// Same as vidseg_linear_bf16 with the fp16 taps written in the temporal layout [(b s), t, c] (video_attention.py:152).
+int vidseg_linear_bf16_ttap(const void* a0, long long M, int C0, const void* w, int N, void* out, int ldo, void* tap, void* tap2,
+                            int tap_cols, int tap_ld, int tap_T, int tap_S, hipStream_t st) {
+    GemmParams p{};
+    p.x0 = (const bf16_t*)a0;
+    p.C0 = C0;
+    p.ksize = 1;
+    p.stride = 1;
+    p.up = 1;
+    p.Hin = p.Win = p.Hout = p.Wout = 1;
+    p.w = (const bf16_t*)w;
+    p.N = N;
+    p.K = C0;
+    p.M = M;
+    p.rows_per_sample = 1;
+    p.out = (bf16_t*)out;
+    p.ldo = ldo;
+    p.tap = (f16*)tap;
+    p.tap2 = (f16*)tap2;
+    p.tap_cols = tap_cols;
+    p.tap_ld = tap_ld;
+    p.tap_T = tap_T;
+    p.tap_S = tap_S;
+    return launch_gemm(p, st);
+}
+
+// Conv3d with kernel [3,1,1], padding [1,0,0] over frames (video_model.py:45-58): x NHWC bf16 [(b t)][HW][C],
+// w packed [Cout][dt*Cin + c], + bias + per-sample emb vector + residual.
+int vidseg_conv_temporal3_bf16(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
+                               const float* rowvec, int rv_stride, const void* residual, void* out, hipStream_t st) {
+    VS_REQUIRE(T >= 1 && BT % T == 0, "conv_temporal3: BT=%d T=%d", BT, T);
+    GemmParams p{};
+    p.x0 = (const bf16_t*)x;
+    p.C0 = C;
+    p.ksize = 3;
+    p.tmode = 1;
+    p.T = T;
+    p.stride = 1;
+    p.up = 1;
+    p.Hin = p.Hout = HW;
+    p.Win = p.Wout = 1;
+    p.w = (const bf16_t*)w;
+    p.N = Cout;
+    p.K = 3 * C;
+    p.M = (long long)BT * HW;
+    p.bias = bias;
+    p.rowvec = rowvec;
+    p.rv_stride = rv_stride;
+    p.rows_per_sample = HW;
+    p.residual = (const bf16_t*)residual;
+    p.ldr = Cout;
+    p.out = (bf16_t*)out;
+    p.ldo = Cout;
     return launch_gemm(p, st);
 }
 

@@ -416,6 +416,105 @@ __global__ void k_blend_f32(const float* __restrict__ x, const float* __restrict
     if (i < n) out[i] = x[i] * m[i] + y[i] * (1.0f - m[i]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Temporal attention (video_attention.py:166-195 after the "(b t) s c -> (b s) t c" rearrange, :152): for every
+// spatial location s of sample b, the T frames attend to each other.  Tokens stay in the spatial layout
+// (row (b*T + t)*S + s); one thread per (b, t, s, head) query, T <= 32 keys read through the cache.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_temporal_attention(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                                                            const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo,
+                                                            int Bv, int T, int S, int H, float scale) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)Bv * T * S * H;
+    if (idx >= total) return;
+    const int s = (int)(idx % S);
+    const int h = (int)((idx / S) % H);
+    const int t = (int)((idx / ((long long)S * H)) % T);
+    const int b = (int)(idx / ((long long)S * H * T));
+    const long long row = ((long long)b * T + t) * S + s;
+    float qf[64];
+    {
+        const bf16x8_t* qp = reinterpret_cast<const bf16x8_t*>(q + row * ldq + h * 64);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bf16x8_t x = qp[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[c * 8 + e] = bf16_to_f32((bf16_t)x[e]) * scale;
+        }
+    }
+    float sc[32];
+    float mx = -INFINITY;
+    for (int j = 0; j < T; ++j) {
+        const bf16x8_t* kp = reinterpret_cast<const bf16x8_t*>(k + (((long long)b * T + j) * S + s) * ldk + h * 64);
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bf16x8_t x = kp[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d = fmaf(qf[c * 8 + e], bf16_to_f32((bf16_t)x[e]), d);
+        }
+        sc[j] = d;
+        mx = fmaxf(mx, d);
+    }
+    float l = 0.f;
+    for (int j = 0; j < T; ++j) {
+        sc[j] = __expf(sc[j] - mx);
+        l += sc[j];
+    }
+    float acc[64];
+#pragma unroll
+    for (int e = 0; e < 64; ++e) acc[e] = 0.f;
+    for (int j = 0; j < T; ++j) {
+        const float pj = bf16_to_f32(f32_to_bf16(sc[j]));                       // P rounded to bf16 like the MFMA path
+        const bf16x8_t* vp = reinterpret_cast<const bf16x8_t*>(v + (((long long)b * T + j) * S + s) * ldv + h * 64);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bf16x8_t x = vp[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[c * 8 + e] = fmaf(pj, bf16_to_f32((bf16_t)x[e]), acc[c * 8 + e]);
+        }
+    }
+    const float inv = 1.f / l;
+    bf16x8_t* op = reinterpret_cast<bf16x8_t*>(o + row * ldo + h * 64);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        bf16x8_t x;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (short)f32_to_bf16(acc[c * 8 + e] * inv);
+        op[c] = x;
+    }
+}
+
+// AlphaBlender 'learned_with_images' with image_only_indicator == 0 (diffusionmodules/util.py:343-380):
+// out = alpha * spatial + (1 - alpha) * temporal, alpha = sigmoid(mix_factor) read from device memory.
+__global__ void k_alpha_blend(const bf16_t* __restrict__ xs, const bf16_t* __restrict__ xt, const float* __restrict__ mix, long long n8,
+                              bf16_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const float a = 1.f / (1.f + __expf(-mix[0]));
+    const bf16x8_t s = reinterpret_cast<const bf16x8_t*>(xs)[i], t = reinterpret_cast<const bf16x8_t*>(xt)[i];
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(a * bf16_to_f32((bf16_t)s[e]) + (1.f - a) * bf16_to_f32((bf16_t)t[e]));
+    reinterpret_cast<bf16x8_t*>(out)[i] = o;
+}
+
+// x + vec[(row / rows_per_sample) % nvec]  (video_attention.py:429-431: tokens + frame-index embedding)
+__global__ void k_add_rowvec(const bf16_t* __restrict__ x, const bf16_t* __restrict__ vec, long long rows, int C, int rows_per_sample,
+                             int nvec, bf16_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8 = C / 8;
+    if (i >= rows * c8) return;
+    const long long row = i / c8;
+    const int c = (int)(i % c8) * 8;
+    const int sidx = (int)((row / rows_per_sample) % nvec);
+    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(x + row * C + c), b = *reinterpret_cast<const bf16x8_t*>(vec + (long long)sidx * C + c);
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(bf16_to_f32((bf16_t)a[e]) + bf16_to_f32((bf16_t)b[e]));
+    *reinterpret_cast<bf16x8_t*>(out + row * C + c) = o;
+}
+
 extern "C" {
 
 int vidseg_groupnorm_nhwc_bf16(const void* x0, const void* x1, int C0, int C1, int B, int HW, int G, const float* gamma,
@@ -549,6 +648,39 @@ int vidseg_blend_f32(const float* x, const float* y, const float* m, long long n
     if (n == 0) return VS_OK;
     k_blend_f32<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(x, y, m, n, out);
     VS_CHECK_LAUNCH("blend_f32");
+    return VS_OK;
+}
+
+int vidseg_temporal_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int Bv,
+                                   int T, int S, int H, int head_dim, hipStream_t st) {
+    VS_REQUIRE(head_dim == 64 && T >= 1 && T <= 32, "temporal_attention: head_dim=%d T=%d (64, <=32)", head_dim, T);
+    VS_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "temporal_attention: strides must be multiples of 8");
+    const long long total = (long long)Bv * T * S * H;
+    if (total == 0) return VS_OK;
+    k_temporal_attention<<<dim3((unsigned)((total + 127) / 128)), 128, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                                                                               (const bf16_t*)v, ldv, (bf16_t*)o, ldo, Bv, T, S, H, 0.125f);
+    VS_CHECK_LAUNCH("temporal_attention");
+    return VS_OK;
+}
+
+int vidseg_alpha_blend_bf16(const void* x_spatial, const void* x_temporal, const float* mix_factor, long long n, void* out,
+                            hipStream_t st) {
+    VS_REQUIRE(n % 8 == 0, "alpha_blend: n must be a multiple of 8");
+    if (n == 0) return VS_OK;
+    k_alpha_blend<<<dim3((unsigned)((n / 8 + 255) / 256)), 256, 0, st>>>((const bf16_t*)x_spatial, (const bf16_t*)x_temporal, mix_factor,
+                                                                        n / 8, (bf16_t*)out);
+    VS_CHECK_LAUNCH("alpha_blend");
+    return VS_OK;
+}
+
+int vidseg_add_rowvec_bf16(const void* x, const void* vec, long long rows, int C, int rows_per_sample, int nvec, void* out,
+                           hipStream_t st) {
+    VS_REQUIRE(C % 8 == 0 && rows_per_sample > 0 && nvec > 0, "add_rowvec: C=%d", C);
+    const long long n = rows * (C / 8);
+    if (n == 0) return VS_OK;
+    k_add_rowvec<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)vec, rows, C, rows_per_sample, nvec,
+                                                                   (bf16_t*)out);
+    VS_CHECK_LAUNCH("add_rowvec");
     return VS_OK;
 }
 

@@ -37,6 +37,11 @@ _lib.register({
     "vidseg_axpy_f32": [_P, _P, _L, _F, _F, _P, _P],
     "vidseg_blend_f32": [_P, _P, _P, _L, _P, _P],
     "vidseg_set_workspace": [_P, _L],
+    "vidseg_linear_bf16_ttap": [_P, _L, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "vidseg_conv_temporal3_bf16": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
+    "vidseg_temporal_attention_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vidseg_alpha_blend_bf16": [_P, _P, _P, _L, _P, _P],
+    "vidseg_add_rowvec_bf16": [_P, _P, _L, _I, _I, _I, _P, _P],
     "vidseg_gemm_profile_begin": [],
     "vidseg_gemm_profile_end": [_P],
 })
@@ -283,3 +288,56 @@ def gemm_profile_end():
     out = (ctypes.c_double * 3)()
     call("vidseg_gemm_profile_end", out)
     return float(out[0]), float(out[1]), int(out[2])
+
+
+# ----------------------------------------------------------------------------- video (SVD) operators
+def pack_conv_temporal3(weight: torch.Tensor, device) -> torch.Tensor:
+    """Conv3d weight [Cout, Cin, 3, 1, 1] -> bf16 [Cout, dt*Cin + c]."""
+    co, ci = weight.shape[:2]
+    return weight.detach().reshape(co, ci, 3).permute(0, 2, 1).reshape(co, 3 * ci).to(device=device, dtype=BF16).contiguous()
+
+
+def conv_temporal3(x, w, bias, T, *, rowvec=None, residual=None):
+    """Conv3d kernel [3,1,1] over the frame axis of NHWC bf16 [(b t), H, W, C] (video_model.py:45-58)."""
+    workspace(x.device)
+    BT, H, W, C = x.shape
+    Cout = w.shape[0]
+    out = torch.empty((BT, H, W, Cout), dtype=BF16, device=x.device)
+    call("vidseg_conv_temporal3_bf16", ptr(x), C, BT, H * W, T, ptr(w), Cout, ptr(bias), ptr(rowvec),
+         rowvec.stride(0) if rowvec is not None else 0, ptr(residual), ptr(out), stream())
+    return out
+
+
+def linear_temporal_tap(a, w, T, S, tap, tap2, tap_cols):
+    """Bias-free projection whose fp16 q/k taps are written in the reference's [(b s), t, c] layout."""
+    workspace(a.device)
+    C0 = a.shape[-1]
+    M = a.numel() // C0
+    N = w.shape[0]
+    out = torch.empty(a.shape[:-1] + (N,), dtype=BF16, device=a.device)
+    call("vidseg_linear_bf16_ttap", ptr(a), M, C0, ptr(w), N, ptr(out), N, ptr(tap), ptr(tap2), tap_cols,
+         tap.shape[-1] if tap is not None else 0, T if tap is not None else 0, S, stream())
+    return out
+
+
+def temporal_attention(q, k, v, heads, Bv, T, S):
+    """Attention across the T frames of every (sample, location); q/k/v rows in spatial order (b t) s."""
+    out = torch.empty((Bv * T, S, heads * 64), dtype=BF16, device=q.device)
+    call("vidseg_temporal_attention_bf16", q.data_ptr(), q.stride(-2), k.data_ptr(), k.stride(-2), v.data_ptr(), v.stride(-2),
+         ptr(out), heads * 64, Bv, T, S, heads, 64, stream())
+    return out
+
+
+def alpha_blend(x_spatial, x_temporal, mix_factor):
+    """sigmoid(mix) * spatial + (1 - sigmoid(mix)) * temporal (AlphaBlender, image_only_indicator == 0)."""
+    out = torch.empty_like(x_spatial)
+    call("vidseg_alpha_blend_bf16", ptr(x_spatial), ptr(x_temporal), ptr(mix_factor), x_spatial.numel(), ptr(out), stream())
+    return out
+
+
+def add_rowvec(x, vec, rows_per_sample):
+    """x[(sample, row), :] + vec[sample % len(vec), :]  (bf16)."""
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    call("vidseg_add_rowvec_bf16", ptr(x), ptr(vec), x.numel() // C, C, rows_per_sample, vec.shape[0], ptr(out), stream())
+    return out

@@ -150,3 +150,11 @@ SD21_NARROW = dict(in_channels=4, out_channels=4, model_channels=64, attention_r
 SD21_FULL = dict(in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1], num_res_blocks=2,
                  channel_mult=[1, 2, 4, 4], num_head_channels=64, use_linear_in_transformer=True, transformer_depth=1,
                  context_dim=1024)                                     # configs/inference/sd_2_1.yaml:19-30
+SVD_NARROW = dict(in_channels=8, out_channels=4, model_channels=64, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+                  channel_mult=[1, 2, 4, 4], num_head_channels=64, use_linear_in_transformer=True, transformer_depth=1,
+                  context_dim=64, adm_in_channels=64, num_classes="sequential", extra_ff_mix_layer=True, use_spatial_context=True,
+                  merge_strategy="learned_with_images", video_kernel_size=[3, 1, 1])
+SVD_FULL = dict(in_channels=8, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+                channel_mult=[1, 2, 4, 4], num_head_channels=64, use_linear_in_transformer=True, transformer_depth=1,
+                context_dim=1024, adm_in_channels=768, num_classes="sequential", extra_ff_mix_layer=True, use_spatial_context=True,
+                merge_strategy="learned_with_images", video_kernel_size=[3, 1, 1])   # configs/inference/svd.yaml:16-34
