@@ -267,3 +267,42 @@ def euler_sample(unet: UNetOracle, latent, c_cross, uc_cross, num_steps=25, t_st
         if callback is not None:
             callback(x, i, unet.taps)
     return x
+
+
+def edm_sigmas(n, sigma_min=0.002, sigma_max=700.0, rho=7.0):
+    """EDMDiscretization (discretizer.py:28-40) + append_zero; svd.yaml:138-141 sets sigma_max = 700."""
+    ramp = torch.linspace(0, 1, n)
+    min_inv_rho, max_inv_rho = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
+    sig = (max_inv_rho + ramp * (min_inv_rho - max_inv_rho)) ** rho
+    return torch.cat([sig, sig.new_zeros([1])])
+
+
+def euler_sample_svd(unet: UNetOracle, latent, c, uc, num_steps=25, t_start=17, min_scale=1.0, max_scale=2.5, noise=None,
+                     callback=None):
+    """SVD feature pass: add_noise + EulerEDMSampler with LinearPredictionGuider (guiders.py:60-100), Denoiser +
+    VScalingWithEDMcNoise (denoiser_scaling.py:51-59), OpenAIWrapper channel-concat of c['concat'] (wrappers.py:27),
+    y = c['vector'], num_video_frames = F (svd_pipeline_vspw.py:307-311).  c/uc: dicts of crossattn, concat, vector."""
+    sigmas = edm_sigmas(num_steps)
+    x = latent.clone()
+    Fn = x.shape[0]
+    if noise is not None:
+        x = (x + noise * sigmas[t_start]) / torch.sqrt(1.0 + sigmas[0] ** 2.0)
+    x = x * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+    scale = torch.linspace(min_scale, max_scale, Fn)[:, None, None, None]
+    for i in range(t_start, num_steps):
+        sigma, nxt = sigmas[i], sigmas[i + 1]
+        c_skip = 1.0 / (sigma ** 2 + 1.0)
+        c_out = -sigma / (sigma ** 2 + 1.0) ** 0.5
+        c_in = 1.0 / (sigma ** 2 + 1.0) ** 0.5
+        c_noise = 0.25 * sigma.log()
+        xin = torch.cat([torch.cat([x, x]) * c_in, torch.cat([uc["concat"], c["concat"]])], dim=1)
+        net = unet.forward(xin, torch.full((2 * Fn,), float(c_noise)), torch.cat([uc["crossattn"], c["crossattn"]]),
+                           y=torch.cat([uc["vector"], c["vector"]]), num_video_frames=Fn)
+        den = net * c_out + torch.cat([x, x]) * c_skip
+        xu, xc = den.chunk(2)
+        den = xu + scale * (xc - xu)
+        d = (x - den) / sigma
+        x = x + d * (nxt - sigma)
+        if callback is not None:
+            callback(x, i, unet.taps)
+    return x

@@ -158,3 +158,40 @@ def test_video_unet_forward_vs_reference():
             ref = g[f"fw_output_block_{i}_{name}"].astype(np.float32)
             assert tuple(got.shape) == ref.shape, (i, name, got.shape, ref.shape)
             assert nrms(got.float().cpu().numpy(), ref) < 4e-2, (i, name)
+
+
+def test_svd_sampler_steps_vs_reference():
+    """8 Euler steps (17..24) of the SVD engine (VideoUNet + Denoiser/VScalingWithEDMcNoise + LinearPredictionGuider +
+    concat/vector conditioning) against the reference's own trajectory."""
+    from vidseg_diffusion_amd.pipeline import build_svd_engine
+    from vidseg_diffusion_amd.video_unet import VideoUNet
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "svd_sampler_narrow.npz"))
+    g = {k: z[k] for k in z.files}
+    net = VideoUNet(**synthetic.SVD_NARROW)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=4321).items()})
+    Fn = g["sm_latent"].shape[0]
+    eng = build_svd_engine(net, num_frames=Fn)
+    c = {k[2:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith("c_")}
+    uc = {k[3:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith("uc_")}
+    noised = eng.sampler.add_noise(torch.from_numpy(g["sm_latent"]).to(dev), cond=c, uc=uc, num_steps=25, noise_level=17,
+                                   noise=torch.from_numpy(g["sm_noise"]).to(dev))
+    assert np.abs(noised.cpu().numpy() - g["sm_noised"]).max() <= 1e-5 * np.abs(g["sm_noised"]).max() + 1e-7
+    xs, taps = [], {}
+    extra = {"image_only_indicator": torch.zeros(2, Fn), "num_video_frames": Fn}
+
+    def cb(xt, i):
+        xs.append(xt.cpu().numpy())
+        if i == 24:
+            taps["q8"] = net.output_blocks[8][1].transformer_blocks[0].attn1.q.float().cpu().numpy()
+            taps["tq8"] = net.output_blocks[8][1].time_stack[0].attn1.q.float().cpu().numpy()
+
+    final = eng.sampler(lambda inp, s, cc, **k: eng.denoiser(eng.model, inp, s, cc, **extra), noised.clone(), cond=c, uc=uc,
+                        img_callback=cb, t_start=17)
+    assert len(xs) == 8
+    errs = [nrms(xs[i], g["sm_x_steps"][i]) for i in range(8)]
+    print("svd step nrms", [round(e, 4) for e in errs])
+    assert max(errs) < 4e-2
+    assert nrms(taps["q8"], g["sm_q8"].astype(np.float32)) < 4e-2
+    assert nrms(taps["tq8"], g["sm_tq8"].astype(np.float32)) < 4e-2

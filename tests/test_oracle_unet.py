@@ -97,3 +97,22 @@ def test_video_unet_forward_matches_reference():
             got = o.taps[k[3:]].float().numpy()
             assert got.shape == v.shape, k
             assert np.abs(got - v.astype(np.float32)).max() <= 2e-3 * np.abs(v.astype(np.float32)).max(), k
+
+
+def test_svd_sampler_matches_reference():
+    from oracle.unet import edm_sigmas, euler_sample_svd
+    from vidseg_diffusion_amd.video_unet import VideoUNet
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "svd_sampler_narrow.npz"))
+    g = {k: z[k] for k in z.files}
+    net = VideoUNet(**synthetic.SVD_NARROW)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=4321).items()}
+    np.testing.assert_allclose(edm_sigmas(25).numpy(), g["sm_sigmas"], rtol=1e-6)
+    c = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("c_")}
+    uc = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("uc_")}
+    xs = []
+    final = euler_sample_svd(UNetOracle(sd), torch.from_numpy(g["sm_latent"]), c, uc, noise=torch.from_numpy(g["sm_noise"]),
+                             callback=lambda x, i, t: xs.append(x.numpy().copy()))
+    assert len(xs) == 8
+    assert np.abs(np.stack(xs) - g["sm_x_steps"]).max() <= 1e-4 * np.abs(g["sm_x_steps"]).max()
+    assert np.abs(final.numpy() - g["sm_final"]).max() <= 1e-4 * np.abs(g["sm_final"]).max()

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import feature_extraction as FE
-from .sampling import DiscreteDenoiser, EulerEDMSampler, OpenAIWrapper
+from .sampling import Denoiser, DiscreteDenoiser, EulerEDMSampler, OpenAIWrapper
 
 
 def seed_everything(seed):
@@ -55,12 +55,25 @@ def build_sd_engine(unet, num_steps=25, scale=5.0):
     return Engine(model=OpenAIWrapper(unet), denoiser=denoiser, sampler=sampler)
 
 
+def build_svd_engine(video_unet, num_frames=14, num_steps=25, min_scale=1.0, max_scale=2.5):
+    """configs/inference/svd.yaml:8-12 (Denoiser + VScalingWithEDMcNoise), :135-147 (EulerEDMSampler, EDMDiscretization
+    sigma_max 700, LinearPredictionGuider 1.0 -> 2.5 with num_frames injected by the driver, svd_pipeline_vspw.py:563-565)."""
+    dd = "sgm.modules.diffusionmodules."
+    denoiser = Denoiser(scaling_config={"target": dd + "denoiser_scaling.VScalingWithEDMcNoise"})
+    sampler = EulerEDMSampler(discretization_config={"target": dd + "discretizer.EDMDiscretization", "params": {"sigma_max": 700.0}},
+                              guider_config={"target": dd + "guiders.LinearPredictionGuider",
+                                             "params": {"max_scale": max_scale, "min_scale": min_scale, "num_frames": num_frames}},
+                              num_steps=num_steps, s_churn=0, s_tmin=0, s_tmax=999, s_noise=1, device="cuda")
+    return Engine(model=OpenAIWrapper(video_unet), denoiser=denoiser, sampler=sampler, video=True)
+
+
 @dataclass
 class Engine:
     """The slice of DiffusionEngine's attribute protocol the drivers touch (sgm/models/diffusion.py)."""
     model: OpenAIWrapper
-    denoiser: DiscreteDenoiser
+    denoiser: Denoiser
     sampler: EulerEDMSampler
+    video: bool = False
 
 
 @dataclass
@@ -74,13 +87,19 @@ def save_feature_maps(engine, store_folder, exp_name, i, xt=None, block_filter=N
     """ddim_sampler_callback -> save_feature_maps (sd_pipeline_vspw.py:103-139) into the FeatureStore."""
     blocks = engine.model.diffusion_model.output_blocks
     for idx, block in enumerate(blocks):
-        if len(block) > 1 and "SpatialTransformer" in str(type(block[1])):
+        # SD driver tests "SpatialTransformer", SVD driver "SpatialVideoTransformer" (SDP:112, SVP:111)
+        if len(block) > 1 and ("SpatialTransformer" in str(type(block[1])) or "SpatialVideoTransformer" in str(type(block[1]))):
             if block_filter is not None and idx not in block_filter:
                 continue
             tb = block[1].transformer_blocks[0]
             for an, a in (("self", tb.attn1), ("cross", tb.attn2)):
                 FE.FeatureStore.put(store_folder, exp_name, f"output_block_{idx}_spatial_{an}_attn_k_time_{i}", a.k)
                 FE.FeatureStore.put(store_folder, exp_name, f"output_block_{idx}_spatial_{an}_attn_q_time_{i}", a.q)
+            if hasattr(block[1], "time_stack"):                                   # SVP:116-119
+                ts = block[1].time_stack[0]
+                for an, a in (("self", ts.attn1), ("cross", ts.attn2)):
+                    FE.FeatureStore.put(store_folder, exp_name, f"output_block_{idx}_temporal_{an}_attn_k_time_{i}", a.k)
+                    FE.FeatureStore.put(store_folder, exp_name, f"output_block_{idx}_temporal_{an}_attn_q_time_{i}", a.q)
     if xt is not None:
         FE.FeatureStore.put(store_folder, exp_name, f"xt_time_{i}", xt)
 
@@ -98,9 +117,13 @@ def segment_window(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, n
     seed_everything(seed)                                                           # SDP:255
     sampler, denoiser_m, model = engine.sampler, engine.denoiser, engine.model
 
+    extra = {}
+    if engine.video:                                                                # svd_pipeline_vspw.py:307-311
+        extra = {"image_only_indicator": torch.zeros(2, F), "num_video_frames": F}
+
     def denoiser(inp, sigma, cc, is_modulate_step=False, is_injected_step=False, modulate_params=None):   # SDP:324-332
         return denoiser_m(model, inp, sigma, cc, is_modulate_step=is_modulate_step, is_injected_step=is_injected_step,
-                          modulate_params=modulate_params)
+                          modulate_params=modulate_params, **extra)
 
     x = sampler.add_noise(latent, cond=c, uc=uc, num_steps=num_steps, noise_level=t_start, noise=noise)   # Step 1, SDP:341
     want = int(feature_timestep)
@@ -111,7 +134,10 @@ def segment_window(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, n
 
     sampler(denoiser, x, cond=c, uc=uc, img_callback=callback, is_modulate=False, modulate_params=None, uc_list=None,
             t_start=t_start, is_latent_blending=False)                              # Step 2, SDP:357
-    block_name = "output_block_8,output_block_7,output_block_6" if is_aggre_attn else "output_block_7"   # SDP:367-370
+    if is_aggre_attn:
+        block_name = "output_block_8,output_block_7,output_block_6"                   # SDP:367-370 / SVP:351-354
+    else:
+        block_name = "output_block_8" if engine.video else "output_block_7"
     fh, fw = lh // 2, lw // 2                                                       # H // (F*2), SDP:374-375
     unique_labels, ref_mask, ref_fm = FE.feature_extraction_main(
         "match_gt_mask", num_masks, t_start, block_name, exp_name, exp_name, "spatial_self_attn_q", fh, fw, feature_timestep,
