@@ -102,7 +102,8 @@ int vidseg_trajectory_vote(const int32_t* idx, const int32_t* labels, int F, int
  * = the q / k dumps of ATT:330-331. */
 int vidseg_linear_bf16(const void* a0, const void* a1, int C0, int C1, long long M, const void* w, int N, const float* bias,
                        const float* rowvec, int rv_stride, int rows_per_sample, const void* residual, int ldr, void* out,
-                       float* out_f32, int ldo, void* tap, void* tap2, int tap_cols, int tap_ld, int act,
+                       float* out_f32, int ldo, void* tap, void* tap2, int tap_cols, int tap_ld,
+                       const float* rowadd /* per-row scalar: modulation lambda*mask[:,None], ATT:646-663, 697-719 */, int act,
                        vidseg_stream_t stream);
 /* 3x3 conv, padding 1 (OAI:267-271, 302-315 ResBlock convs; OAI:202-217 Downsample stride 2; OAI:149-167
  * Upsample = nearest x2 folded into the addressing) over the channel concat of x0 and x1 (skip connection,
@@ -145,6 +146,7 @@ int vidseg_add_rowvec_bf16(const void* x, const void* vec, long long rows, int C
 int vidseg_timestep_embedding(const float* t, int B, int dim, float max_period, void* out, vidseg_stream_t stream);
 int vidseg_silu_bf16(const void* x, long long n, void* out, vidseg_stream_t stream);
 int vidseg_f32_to_bf16(const float* x, long long n, void* out, vidseg_stream_t stream);
+int vidseg_f16_to_bf16(const void* x, long long n, void* out, vidseg_stream_t stream); /* injected fp16 dumps -> bf16 operands */
 
 /* ------------------------------------------------------------------------------------------------------
  * Sampler arithmetic on fp32 latents (SURVEY.md rows a2-a6, a17 latent blending)

@@ -91,9 +91,9 @@ class UNetOracle:
         out = alpha * x5 + (1.0 - alpha) * h
         return _bf(out.permute(0, 2, 1, 3, 4).reshape(BT, C, H, W), self.rb)
 
-    def attention(self, x, ctx, p, tapname):
-        q = self.lin(x, p + ".to_q", bias=False)
-        k = self.lin(ctx, p + ".to_k", bias=False)
+    def attention(self, x, ctx, p, tapname, inj_q=None, inj_k=None, rowadd=None):
+        q = self.lin(x, p + ".to_q", bias=False) if inj_q is None else inj_q.float()      # attention.py:305-315
+        k = self.lin(ctx, p + ".to_k", bias=False) if inj_k is None else inj_k.float()
         v = self.lin(ctx, p + ".to_v", bias=False)
         if tapname is not None:
             self.taps[tapname + "_q"] = q.half()
@@ -102,7 +102,10 @@ class UNetOracle:
         H = C // self.hc
         qh, kh, vh = (_bf(t, self.rb).view(B, -1, H, self.hc).transpose(1, 2) for t in (q, k, v))
         a = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, N, C)
-        return self.lin(_bf(a, self.rb), p + ".to_out.0")
+        out = self.lin(_bf(a, self.rb), p + ".to_out.0")
+        if rowadd is not None:                                                            # attention.py:646-663, 697-719
+            out = out + rowadd[:, :, None]
+        return out
 
     def ln(self, x, p):
         return _bf(F.layer_norm(x, (x.shape[-1],), self.sd[p + ".weight"], self.sd[p + ".bias"], 1e-5), self.rb)
@@ -122,12 +125,19 @@ class UNetOracle:
         while self.has(f"{p}.transformer_blocks.{d}."):
             b = f"{p}.transformer_blocks.{d}"
             tn = tapname if d == 0 else None
+            inj, ra = (self.mod or {}).get(tapname, ({}, {})) if tapname else ({}, {})
+            pick = lambda sub: next((v for kk, v in inj.items() if sub in kk), None)           # noqa: E731
             n1 = self.ln(t, b + ".norm1")
-            t = _bf(self.attention(n1, n1, b + ".attn1", tn and tn + "_spatial_self_attn") + t, self.rb)
-            t = _bf(self.attention(self.ln(t, b + ".norm2"), context, b + ".attn2", tn and tn + "_spatial_cross_attn") + t, self.rb)
+            t = _bf(self.attention(n1, n1, b + ".attn1", tn and tn + "_spatial_self_attn", pick("spatial_self_attn_q"),
+                                   pick("spatial_self_attn_k"), ra.get("self_attn")) + t, self.rb)
+            t = _bf(self.attention(self.ln(t, b + ".norm2"), context, b + ".attn2", tn and tn + "_spatial_cross_attn",
+                                   pick("spatial_cross_attn_q"), pick("spatial_cross_attn_k"), ra.get("cross_attn")) + t, self.rb)
             y = self.lin(self.ln(t, b + ".norm3"), b + ".ff.net.0.proj")
             val, gate = y.chunk(2, dim=-1)
-            t = _bf(self.lin(_bf(val * F.gelu(gate), self.rb), b + ".ff.net.2") + t, self.rb)
+            ffo = self.lin(_bf(val * F.gelu(gate), self.rb), b + ".ff.net.2")
+            if ra.get("ff_out") is not None:
+                ffo = ffo + ra["ff_out"][:, :, None]
+            t = _bf(ffo + t, self.rb)
             if video:
                 tm = self.video_block(_bf(t + temb, self.rb), tctx, f"{p}.time_stack.{d}", tn, H * W)
                 alpha = torch.sigmoid(self.sd[p + ".time_mixer.mix_factor"])
@@ -185,6 +195,7 @@ class UNetOracle:
         '..._temporal_{self,cross}_attn_{q,k}' in the reference's [(b s), t, c] layout for VideoUNet weights)."""
         self.taps = {}
         self.T = num_video_frames
+        self.mod = getattr(self, "mod", None)
         mc = self.sd["time_embed.0.weight"].shape[1]
         t_emb = _bf(self.timestep_embedding(timesteps, mc), self.rb)
         emb = self.lin(_bf(F.silu(self.lin(t_emb, "time_embed.0")), self.rb), "time_embed.2")
@@ -236,7 +247,7 @@ def sigma_to_idx(sigma, table):
 
 
 def euler_sample(unet: UNetOracle, latent, c_cross, uc_cross, num_steps=25, t_start=22, scale=5.0, noise=None,
-                 callback=None):
+                 callback=None, modulate=None):
     """add_noise (sampling.py:133-144) + EulerEDMSampler.__call__ (:146-262) with VanillaCFG (guiders.py:24-42),
     DiscreteDenoiser + EpsScaling (denoiser.py:23-82, denoiser_scaling.py:29-37), s_churn = 0.
     latent [F,4,h,w] fp32; returns the final x and calls callback(x, i, unet.taps) after every step."""
@@ -258,15 +269,43 @@ def euler_sample(unet: UNetOracle, latent, c_cross, uc_cross, num_steps=25, t_st
         c_noise = sigma_to_idx(sq, table)                                          # quantized c_noise = index
         xin = torch.cat([x, x]) * c_in[:, None, None, None]
         ctx = torch.cat([uc_cross, c_cross])
+        unet.mod = _step_modulation(modulate, i, Fn) if modulate is not None else None
         net = unet.forward(xin, c_noise.float(), ctx)
+        unet.mod = None
         den = net * c_out[:, None, None, None] + torch.cat([x, x])
         xu, xc = den.chunk(2)
         den = xu + scale * (xc - xu)
         d = (x - den) / sigma
         x = x + d * (nxt - sigma)
-        if callback is not None:
+        if modulate is not None and modulate.get("blend") and modulate["blend"][0] <= i <= modulate["blend"][1]:
+            m = modulate["masks"].float().reshape(Fn, 1, modulate["fh"], modulate["fw"])       # sampling.py:229-250
+            m = F.interpolate(m, size=x.shape[-2:], mode="nearest")
+            x = (x * m + modulate["xt"][i] * (1 - m)).float()
+        if callback is not None and (modulate is None or i >= min(modulate["timesteps"])):
             callback(x, i, unet.taps)
     return x
+
+
+def _step_modulation(m, i, Fn):
+    """Per-step view of the reference's modulate_params protocol (sampling.py:176-194, openaimodel.py:911-937,
+    attention.py:616-634, 697-719) for the oracle: {tapname: (inject dict, rowadd dict)}."""
+    out = {}
+    is_mod = i in m["timesteps"]
+    is_inj = m.get("inject_types") and i >= min(m["timesteps"])
+    for b in range(12):
+        inj, ra = {}, {}
+        if is_inj and b in m["inject_blocks"]:
+            for ft in m["inject_types"]:
+                name = f"output_block_{b}_{ft}_time_{i}"
+                if name in m["dumps"]:
+                    inj[name] = m["dumps"][name]
+        if is_mod and b in m["blocks"]:
+            row = (m["lambda"] * m["masks"].double()).float()                                   # [F, N]
+            full = torch.cat([row if m["modulate_uc"] else torch.zeros_like(row), row])          # uc half, c half
+            ra = {t: full for t in m["attn_types"]}
+        if inj or ra:
+            out[f"output_block_{b}"] = (inj, ra)
+    return out
 
 
 def edm_sigmas(n, sigma_min=0.002, sigma_max=700.0, rho=7.0):

@@ -195,3 +195,51 @@ def test_svd_sampler_steps_vs_reference():
     assert max(errs) < 4e-2
     assert nrms(taps["q8"], g["sm_q8"].astype(np.float32)) < 4e-2
     assert nrms(taps["tq8"], g["sm_tq8"].astype(np.float32)) < 4e-2
+
+
+def test_modulated_injected_pass_vs_reference(env):
+    """a17 on the GPU: feature pass fills the in-HBM FeatureStore, then the reference-style modulated pass
+    (is_modulate, injected q/k from the store, lambda*mask on block 7 cross-attn output, latent blending)."""
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import build_sd_engine, save_feature_maps
+    dev, _, net, sd = env
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sd_modulated_narrow.npz"))
+    g = {k: z[k] for k in z.files}
+    eng = build_sd_engine(net)
+    Fn = g["latent"].shape[0]
+    c = {"crossattn": torch.from_numpy(g["c"]).to(dev)}
+    uc = {"crossattn": torch.zeros_like(c["crossattn"])}
+    noised = eng.sampler.add_noise(torch.from_numpy(g["latent"]).to(dev), cond=c, uc=uc, num_steps=25, noise_level=22,
+                                   noise=torch.from_numpy(g["noise"]).to(dev))
+    FE.FeatureStore.clear()
+    base, exp = "/nonexistent/vs_mod", "exp"
+
+    def denoiser(inp, sigma, cc, is_modulate_step=False, is_injected_step=False, modulate_params=None):
+        return eng.denoiser(eng.model, inp, sigma, cc, is_modulate_step=is_modulate_step, is_injected_step=is_injected_step,
+                            modulate_params=modulate_params)
+
+    feat = eng.sampler(denoiser, noised.clone(), cond=c, uc=uc, t_start=22,
+                       img_callback=lambda xt, i: save_feature_maps(eng, base, exp, i, xt=xt))
+    assert nrms(feat.cpu().numpy(), g["feat_final"]) < 3e-2
+    for tag, lam in (("pos", 50.0), ("neg", -50.0)):
+        mp = {"feature_masks": [torch.from_numpy(m).to(dev) for m in g["masks"]], "modulate_block_idx": [7],
+              "modulate_layer_type": ["spatial"], "modulate_attn_type": ["cross_attn"], "modulate_timestep": [22],
+              "modulate_schedule": "constant", "modulate_lambda_start": lam, "modulate_lambda_end": lam, "num_frames": Fn,
+              "modulate_uc": True, "is_injected_features": True,
+              "injected_feature_types": ["spatial_cross_attn_k", "spatial_cross_attn_q", "spatial_self_attn_k", "spatial_self_attn_q"],
+              "injected_block_types": ["output"], "input_block_indices": [3, 4, 5, 6, 7, 8, 9, 10, 11],
+              "output_block_indices": list(range(1, 12)), "feature_folder": base, "exp_name": exp, "injected_features_group": {},
+              "modulate_layer_frames": {}, "modulate_block_frames": {}, "modulate_timestep_frames": {}, "modulate_lambda_layers": {},
+              "latent_mask_start": 22, "latent_mask_end": 23}
+        xs = []
+        final = eng.sampler(denoiser, noised.clone(), cond=c, uc=uc, img_callback=lambda xt, i: xs.append(xt.cpu().numpy()),
+                            is_modulate=True, modulate_params=mp, t_start=22, is_latent_blending=True, feature_height=8, feature_width=8)
+        ref = g[f"mod_{tag}_x_steps"]
+        assert len(xs) == ref.shape[0]
+        errs = [nrms(xs[i], ref[i]) for i in range(len(xs))]
+        print("modulated", tag, "step nrms", [round(e, 4) for e in errs])
+        assert max(errs) < 3e-2
+        # the modulation must actually have moved the sample the way the reference's did
+        d_ref = g[f"mod_{tag}_final"] - g["feat_final"]
+        d_got = final.cpu().numpy() - feat.cpu().numpy()
+        assert nrms(d_got, d_ref) < 0.35, nrms(d_got, d_ref)

@@ -116,3 +116,39 @@ def test_svd_sampler_matches_reference():
     assert len(xs) == 8
     assert np.abs(np.stack(xs) - g["sm_x_steps"]).max() <= 1e-4 * np.abs(g["sm_x_steps"]).max()
     assert np.abs(final.numpy() - g["sm_final"]).max() <= 1e-4 * np.abs(g["sm_final"]).max()
+
+
+def _oracle_modulated(o, g, lam):
+    lat, c, noise = (torch.from_numpy(g[k]) for k in ("latent", "c", "noise"))
+    Fn = lat.shape[0]
+    dumps, xts = {}, {}
+
+    def dump_cb(x, i, taps):
+        for k, v in taps.items():
+            dumps[f"{k}_time_{i}"] = v.clone()
+        xts[i] = x.clone()
+
+    feat = euler_sample(o, lat, c, torch.zeros_like(c), noise=noise, callback=dump_cb)
+    mod = dict(timesteps=[22], blocks=[7], attn_types=["cross_attn"], masks=torch.from_numpy(g["masks"]), modulate_uc=True,
+               inject_types=["spatial_cross_attn_k", "spatial_cross_attn_q", "spatial_self_attn_k", "spatial_self_attn_q"],
+               inject_blocks=list(range(1, 12)), dumps=dumps, xt=xts, blend=(22, 23), fh=8, fw=8)
+    mod["lambda"] = lam
+    xs = []
+    final = euler_sample(o, lat, c, torch.zeros_like(c), noise=noise, callback=lambda x, i, t: xs.append(x.numpy().copy()), modulate=mod)
+    return feat, np.stack(xs), final
+
+
+def test_modulated_injected_pass_matches_reference(narrow_sd):
+    """a17: injected q/k on decoder blocks, lambda*mask bias on block 7's cross-attention output at step 22, latent blending."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sd_modulated_narrow.npz"))
+    g = {k: z[k] for k in z.files}
+    _, sd = narrow_sd
+    o = UNetOracle(sd)
+    for tag, lam in (("pos", 50.0), ("neg", -50.0)):
+        feat, xs, final = _oracle_modulated(o, g, lam)
+        assert np.abs(feat.numpy() - g["feat_final"]).max() <= 5e-5 * np.abs(g["feat_final"]).max()
+        ref = g[f"mod_{tag}_x_steps"]
+        assert xs.shape == ref.shape
+        # injected q/k are the fp16 dumps here, fp32 tensors in the golden run -> 5e-3
+        assert np.abs(xs - ref).max() <= 5e-3 * np.abs(ref).max(), tag
+        assert np.abs(final.numpy() - g[f"mod_{tag}_final"]).max() <= 5e-3 * np.abs(ref).max()

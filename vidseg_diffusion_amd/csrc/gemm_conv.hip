@@ -44,6 +44,8 @@ struct GemmParams {
     int tmode, T;            // tmode: ksize 3 taps run over TIME (Conv3d kernel [3,1,1], video_model.py:45-58): row m is
                              // frame (m / (Hout*Wout)) % T, tap dt reads row m + (dt-1)*Hout*Wout if that frame exists
     int tap_T, tap_S;        // >0: taps are written in the reference's temporal layout [(b s), t, c] (row permutation)
+    const float* rowadd;     // per-row scalar added to every column before the residual (attention-output modulation
+                             // lambda*mask[:,None], attention.py:646-663, 697-719) or nullptr
 };
 
 #define BK 64
@@ -281,6 +283,11 @@ __global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
                     v[e] = lo[e];
                     v[4 + e] = hi4[e];
                 }
+                if (p.rowadd && p.ksplit <= 1) {
+                    const float ra = p.rowadd[m];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += ra;
+                }
                 if (p.ksplit > 1) {
                     float* wp = p.ws + ((long long)split * p.M + m) * p.N + n;
                     f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
@@ -346,6 +353,7 @@ __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
         if (p.bias) v[e] += p.bias[n + e];
         if (p.rowvec) v[e] += p.rowvec[(m / p.rows_per_sample) * p.rv_stride + n + e];
         if (p.act == 1) v[e] = silu_f(v[e]);
+        if (p.rowadd) v[e] += p.rowadd[m];
     }
     if (p.tap && n < p.tap_cols) {
         f16x8 t;
@@ -557,7 +565,8 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
 // out[M][N] = A[M][K] @ W[N][K]^T (+bias)(+rowvec)(act)(+residual); A may be the channel concat of two [M][C] tensors.
 int vidseg_linear_bf16(const void* a0, const void* a1, int C0, int C1, long long M, const void* w, int N, const float* bias,
                        const float* rowvec, int rv_stride, int rows_per_sample, const void* residual, int ldr, void* out,
-                       float* out_f32, int ldo, void* tap, void* tap2, int tap_cols, int tap_ld, int act, hipStream_t st) {
+                       float* out_f32, int ldo, void* tap, void* tap2, int tap_cols, int tap_ld, const float* rowadd, int act,
+                       hipStream_t st) {
     GemmParams p{};
     p.x0 = (const bf16_t*)a0;
     p.x1 = (const bf16_t*)a1;
@@ -584,6 +593,7 @@ int vidseg_linear_bf16(const void* a0, const void* a1, int C0, int C1, long long
     p.tap2 = (f16*)tap2;
     p.tap_cols = tap_cols;
     p.tap_ld = tap_ld;
+    p.rowadd = rowadd;
     p.act = act;
     if (act == 2) VS_REQUIRE(N % 64 == 0 && out, "linear: GEGLU needs N %% 64 == 0 and a bf16 output");
     return launch_gemm(p, st);

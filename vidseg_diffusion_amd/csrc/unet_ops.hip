@@ -300,6 +300,11 @@ __global__ void k_silu_bf16(const bf16_t* __restrict__ x, long long n, bf16_t* _
     if (i < n) out[i] = f32_to_bf16(silu_f(bf16_to_f32(x[i])));
 }
 
+__global__ void k_f16_to_bf16(const f16* __restrict__ x, long long n, bf16_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f32_to_bf16((float)x[i]);
+}
+
 __global__ void k_f32_to_bf16(const float* __restrict__ x, long long n, bf16_t* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = f32_to_bf16(x[i]);
@@ -567,6 +572,13 @@ int vidseg_timestep_embedding(const float* t, int B, int dim, float max_period, 
 int vidseg_silu_bf16(const void* x, long long n, void* out, hipStream_t st) {
     k_silu_bf16<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>((const bf16_t*)x, n, (bf16_t*)out);
     VS_CHECK_LAUNCH("silu");
+    return VS_OK;
+}
+
+int vidseg_f16_to_bf16(const void* x, long long n, void* out, hipStream_t st) {
+    if (n == 0) return VS_OK;
+    k_f16_to_bf16<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>((const f16*)x, n, (bf16_t*)out);
+    VS_CHECK_LAUNCH("f16_to_bf16");
     return VS_OK;
 }
 

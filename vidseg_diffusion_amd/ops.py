@@ -16,7 +16,7 @@ from ._lib import call, ptr, stream
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
 _lib.register({
-    "vidseg_linear_bf16": [_P, _P, _I, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P],
+    "vidseg_linear_bf16": [_P, _P, _I, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P],
     "vidseg_conv3x3_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
     "vidseg_conv_in": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "vidseg_conv_out4": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
@@ -26,6 +26,7 @@ _lib.register({
     "vidseg_timestep_embedding": [_P, _I, _I, _F, _P, _P],
     "vidseg_silu_bf16": [_P, _L, _P, _P],
     "vidseg_f32_to_bf16": [_P, _L, _P, _P],
+    "vidseg_f16_to_bf16": [_P, _L, _P, _P],
     "vidseg_prepare_net_input": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P],
     "vidseg_cfg_euler_step": [_P, _P, _I, _I, _I, _F, _F, _P, _F, _F, _F, _P, _P],
     "vidseg_add_noise": [_P, _P, _L, _F, _F, _P],
@@ -91,8 +92,8 @@ def f32(t: torch.Tensor, device) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- operators
 def linear(a, w, bias=None, *, a1=None, rowvec=None, rows_per_sample=0, residual=None, act=ACT_NONE, out_f32=False,
-           tap=None, tap2=None, tap_cols=0):
-    """out = act(cat(a, a1) @ w.T + bias + rowvec[sample]) + residual.  a: bf16 [..., K0]."""
+           tap=None, tap2=None, tap_cols=0, rowadd=None):
+    """out = act(cat(a, a1) @ w.T + bias + rowvec[sample]) + rowadd[row] + residual.  a: bf16 [..., K0]."""
     workspace(a.device)
     C0 = a.shape[-1]
     C1 = a1.shape[-1] if a1 is not None else 0
@@ -104,7 +105,7 @@ def linear(a, w, bias=None, *, a1=None, rowvec=None, rows_per_sample=0, residual
          rowvec.stride(0) if rowvec is not None else 0, rows_per_sample, ptr(residual),
          residual.shape[-1] if residual is not None else 0,
          None if out_f32 else ptr(out), ptr(out) if out_f32 else None, n_out,
-         ptr(tap), ptr(tap2), tap_cols, tap.shape[-1] if tap is not None else 0, act, stream())
+         ptr(tap), ptr(tap2), tap_cols, tap.shape[-1] if tap is not None else 0, ptr(rowadd), act, stream())
     return out
 
 
@@ -202,6 +203,13 @@ def timestep_embedding(t, dim, max_period=10000.0):
 def silu(x):
     out = torch.empty_like(x)
     call("vidseg_silu_bf16", ptr(x), x.numel(), ptr(out), stream())
+    return out
+
+
+def f16_to_bf16(x):
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    xc = x.contiguous()
+    call("vidseg_f16_to_bf16", ptr(xc), xc.numel(), ptr(out), stream())
     return out
 
 

@@ -143,8 +143,9 @@ class CrossAttention(nn.Module):
         self.w_o = ops.pack_linear(self.to_out[0].weight, dev)
         self.b_o = ops.f32(self.to_out[0].bias, dev)
 
-    def run(self, x, context, residual, tap):
-        """x: normed tokens bf16 [B, N, C]; returns to_out(attn) + residual."""
+    def run(self, x, context, residual, tap, inj_q=None, inj_k=None, rowadd=None):
+        """x: normed tokens bf16 [B, N, C]; returns to_out(attn) + rowadd[row] + residual.
+        inj_q / inj_k: fp16 dumps that replace the computed projections (attention.py:305-315)."""
         B, N, _ = x.shape
         C = self.inner
         dev = x.device
@@ -152,17 +153,26 @@ class CrossAttention(nn.Module):
             tq = torch.empty((B, N, C), dtype=F16, device=dev) if tap else None
             tk = torch.empty((B, N, C), dtype=F16, device=dev) if tap else None
             qkv = ops.linear(x, self.w_qkv, tap=tq, tap2=tk, tap_cols=C)
-            a = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], self.heads)
+            q = ops.f16_to_bf16(inj_q) if inj_q is not None else qkv[..., :C]
+            k = ops.f16_to_bf16(inj_k) if inj_k is not None else qkv[..., C:2 * C]
+            a = ops.attention(q, k, qkv[..., 2 * C:], self.heads)
         else:
             L = context.shape[1]
             tq = torch.empty((B, N, C), dtype=F16, device=dev) if tap else None
             tk = torch.empty((B, L, C), dtype=F16, device=dev) if tap else None
             q = ops.linear(x, self.w_q, tap=tq, tap_cols=C)
             kv = ops.linear(context, self.w_kv, tap=tk, tap_cols=C)
-            a = ops.attention(q, kv[..., :C], kv[..., C:], self.heads)
+            if inj_q is not None:
+                q = ops.f16_to_bf16(inj_q)
+            k = ops.f16_to_bf16(inj_k) if inj_k is not None else kv[..., :C]
+            a = ops.attention(q, k, kv[..., C:], self.heads)
         if tap:
             self.q, self.k = tq, tk
-        return ops.linear(a, self.w_o, self.b_o, residual=residual)
+        if inj_q is not None:
+            self.q = inj_q                                                       # ATT:330-331 stores what was used
+        if inj_k is not None:
+            self.k = inj_k
+        return ops.linear(a, self.w_o, self.b_o, residual=residual, rowadd=rowadd)
 
 
 class GEGLU(nn.Module):
@@ -182,9 +192,9 @@ class FeedForward(nn.Module):
         self.w1, self.b1 = ops.pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias, dev)
         self.w2, self.b2 = ops.pack_linear(self.net[2].weight, dev), ops.f32(self.net[2].bias, dev)
 
-    def run(self, x, residual):
+    def run(self, x, residual, rowadd=None):
         g = ops.linear(x, self.w1, self.b1, act=ops.ACT_GEGLU)
-        return ops.linear(g, self.w2, self.b2, residual=residual)
+        return ops.linear(g, self.w2, self.b2, residual=residual, rowadd=rowadd)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -204,10 +214,23 @@ class BasicTransformerBlock(nn.Module):
             m.pack(dev)
         self.ln = [(ops.f32(n.weight, dev), ops.f32(n.bias, dev)) for n in (self.norm1, self.norm2, self.norm3)]
 
-    def run(self, x, context, tap):
-        x = self.attn1.run(ops.layernorm(x, *self.ln[0]), None, x, tap)               # ATT:636-672
-        x = self.attn2.run(ops.layernorm(x, *self.ln[1]), context, x, tap)            # ATT:689-726
-        return self.ff.run(ops.layernorm(x, *self.ln[2]), x)                          # ATT:728-757
+    def run(self, x, context, tap, mod=None):
+        """mod: None, or (inject: dict|None, rowadd: dict attn_type -> fp32 [B*N]) for the modulated pass
+        (attention.py:616-634, 646-663, 674-687, 697-719, 733-755)."""
+        inj, ra = mod if mod is not None else (None, None)
+        inj, ra = inj or {}, ra or {}
+
+        def pick(sub):
+            for k, v in inj.items():
+                if sub in k:
+                    return v
+            return None
+
+        x = self.attn1.run(ops.layernorm(x, *self.ln[0]), None, x, tap, pick("spatial_self_attn_q"), pick("spatial_self_attn_k"),
+                           ra.get("self_attn"))                                         # ATT:636-672
+        x = self.attn2.run(ops.layernorm(x, *self.ln[1]), context, x, tap, pick("spatial_cross_attn_q"),
+                           pick("spatial_cross_attn_k"), ra.get("cross_attn"))          # ATT:689-726
+        return self.ff.run(ops.layernorm(x, *self.ln[2]), x, ra.get("ff_out"))          # ATT:728-757
 
 
 class SpatialTransformer(nn.Module):
@@ -231,26 +254,67 @@ class SpatialTransformer(nn.Module):
         for blk in self.transformer_blocks:
             blk.pack(dev)
 
-    def run(self, x, context):
+    def run(self, x, context, mod=None):
         B, H, W, C = x.shape
         t = ops.groupnorm(x, self.g, self.b, eps=1e-6, silu=False).view(B, H * W, C)  # ATT:897-903
         t = ops.linear(t, self.w_in, self.b_in)
+        bmod = block_modulation(mod, "spatial", H * W, x.device)                      # ATT:906-915
         for i, blk in enumerate(self.transformer_blocks):
-            t = blk.run(t, context, self.tap and i == 0)
+            t = blk.run(t, context, self.tap and i == 0, bmod)
         out = ops.linear(t, self.w_out, self.b_out, residual=x.view(B, H * W, C))     # ATT:921-927
         return out.view(B, H, W, C)
+
+
+def block_modulation(mod, layer_type, N, device):
+    """Translate the reference's mutable `modulate_params` protocol into (inject, rowadd) for one transformer:
+    mod = (is_modulate_step, is_injected_step, modulate_params) as decided per block by UNetModel.forward
+    (openaimodel.py:911-937).  rowadd[attn_type] is the fp32 [2F*N] vector lambda_i * mask_i on rows of frame i
+    of the conditional half (and of the unconditional half when modulate_uc), zero elsewhere."""
+    if mod is None:
+        return None
+    is_mod, is_inj, mp = mod
+    inject = mp["injected_features_group"] if is_inj else None
+    rowadd = None
+    if is_mod and layer_type in mp["modulate_layer_type"]:
+        frames = list(range(mp["num_frames"]))
+        mp["modulate_layer_frames_group"] = mp["modulate_layer_frames"].get(layer_type, frames)
+        masks = mp["feature_masks"]
+        Fm = len(masks)
+        ra = torch.zeros((2 * Fm, N), dtype=torch.float32, device=device)
+        for i, mask in enumerate(masks):
+            if i in mp["modulate_block_frames_group"] and i in mp["modulate_layer_frames_group"] and \
+                    i in mp["modulate_timestep_frames_group"]:
+                lam = get_modulate_lambda(mp["modulate_lambda_start"], mp["modulate_lambda_end"], mp["modulate_schedule"],
+                                          total_steps=mp["num_frames"], current_step=i)
+                row = (lam * mask.to(device=device, dtype=torch.float64)).to(torch.float32)
+                ra[i + Fm] = row
+                if mp["modulate_uc"]:
+                    ra[i] = row
+        ra = ra.reshape(-1).contiguous()
+        rowadd = {t: ra for t in ("self_attn", "cross_attn", "ff_out") if t in mp["modulate_attn_type"]}
+    if inject is None and rowadd is None:
+        return None
+    return inject, rowadd
+
+
+def get_modulate_lambda(modulate_lambda_start, modulate_lambda_end, modulate_schedule, total_steps, current_step):
+    """sgm/modules/diffusionmodules/util.py:383-392."""
+    assert modulate_schedule in ["constant", "linear"]
+    if modulate_schedule == "constant":
+        return modulate_lambda_start
+    return modulate_lambda_start + (modulate_lambda_end - modulate_lambda_start) * current_step / total_steps
 
 
 class TimestepEmbedSequential(nn.Sequential):
     """openaimodel.py:67-114: children dispatched by type."""
 
-    def run(self, x, x_skip, emb_all, context):
+    def run(self, x, x_skip, emb_all, context, mod=None):
         for layer in self:
             if isinstance(layer, ResBlock):
                 x = layer.run(x, x_skip, emb_all)
                 x_skip = None
             elif isinstance(layer, SpatialTransformer):
-                x = layer.run(x, context)
+                x = layer.run(x, context, mod)
             elif isinstance(layer, (Upsample, Downsample)):
                 x = layer.run(x)
             else:
@@ -391,32 +455,53 @@ class UNetModel(nn.Module):
             emb = ops.linear(ops.linear(yb, self.le_w1, self.le_b1, act=ops.ACT_SILU), self.le_w2, self.le_b2, residual=emb)
         return emb
 
-    def forward_nhwc(self, x_nhwc_f32, timesteps, context_bf16, y=None):
+    def _block_mod(self, kind, i, blk, is_modulate_step, is_injected_step, mp, device):
+        """Per-block flags of openaimodel.py:884-937 (input blocks: injection only; output blocks: both)."""
+        if not (is_modulate_step or is_injected_step):
+            return None
+        has_st = len(blk) > 1 and "SpatialTransformer" in str(type(blk[1]))
+        is_mod = False
+        if kind == "output" and is_modulate_step and i in mp["modulate_block_idx"] and has_st:
+            is_mod = True
+            mp["modulate_block_frames_group"] = mp["modulate_block_frames"].get(i, list(range(mp["num_frames"])))
+        is_inj = False
+        idx_key = "input_block_indices" if kind == "input" else "output_block_indices"
+        if is_injected_step and has_st and kind in mp["injected_block_types"] and i in mp[idx_key]:
+            from .util import load_target_features
+            mp["injected_features_group"] = load_target_features(mp["feature_folder"], mp["exp_name"], mp["timestep"], kind,
+                                                                 mp["injected_feature_types"], i, device)
+            is_inj = len(mp["injected_features_group"]) > 0
+        return (is_mod, is_inj, mp) if (is_mod or is_inj) else None
+
+    def forward_nhwc(self, x_nhwc_f32, timesteps, context_bf16, y=None, is_modulate_step=False, is_injected_step=False,
+                     modulate_params=None):
         """x: fp32 NHWC [B, h, w, Cin]; context: bf16 [B, L, ctx]; returns fp32 NCHW [B, Cout, h, w]."""
         if self._packed_on is None:
             self.pack(x_nhwc_f32.device)
+        dev = x_nhwc_f32.device
         emb = self.embed(timesteps, y)
         emb_all = ops.linear(ops.silu(emb), self.emb_w, self.emb_b, out_f32=True)                       # every ResBlock's emb_layers
         h = ops.conv_in(x_nhwc_f32, self.cin_w, self.cin_b)
         hs = [h]
-        for blk in list(self.input_blocks)[1:]:
-            h = blk.run(h, None, emb_all, context_bf16)
+        for i, blk in list(enumerate(self.input_blocks))[1:]:
+            h = blk.run(h, None, emb_all, context_bf16, self._block_mod("input", i, blk, False, is_injected_step, modulate_params, dev))
             hs.append(h)
         h = self.middle_block.run(h, None, emb_all, context_bf16)
-        for blk in self.output_blocks:
-            h = blk.run(h, hs.pop(), emb_all, context_bf16)                                              # OAI:911-948
+        for i, blk in enumerate(self.output_blocks):
+            mod = self._block_mod("output", i, blk, is_modulate_step, is_injected_step, modulate_params, dev)
+            h = blk.run(h, hs.pop(), emb_all, context_bf16, mod)                                         # OAI:911-948
         h = ops.groupnorm(h, self.out_g, self.out_beta, eps=1e-5, silu=True)
         return ops.conv_out4(h, self.out_w, self.out_b)
 
     def forward(self, x, timesteps=None, context=None, y=None, is_modulate_step=False, is_injected_step=False,
                 modulate_params=None, **kwargs):
         """Reference signature (openaimodel.py:831-841): x NCHW."""
-        if is_modulate_step or is_injected_step:
-            raise NotImplementedError("modulated / injected passes (SURVEY.md a17) are not built yet")
+        if (is_modulate_step or is_injected_step) and modulate_params is None:
+            raise AssertionError("modulate_params is required for a modulated / injected step")
         if (y is not None) != (self.num_classes is not None):
             raise AssertionError("must specify y if and only if the model is class-conditional")
         if not x.is_cuda:
             raise VidsegError("UNetModel runs on a HIP device only (no CPU fallback)")
         xn = x.float().permute(0, 2, 3, 1).contiguous()
         ctx = context if context.dtype == torch.bfloat16 else ops.to_bf16(context.float().contiguous())
-        return self.forward_nhwc(xn, timesteps, ctx, y)
+        return self.forward_nhwc(xn, timesteps, ctx, y, is_modulate_step, is_injected_step, modulate_params)
