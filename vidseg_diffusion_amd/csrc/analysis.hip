@@ -124,32 +124,40 @@ __device__ __forceinline__ void load_tile(double (*L)[LDP], const RowsF64& R, in
     }
 }
 
+// Tile product on the f64 matrix pipe: v_mfma_f64_16x16x4_f64, one 16-row slab per wave, four 16-column
+// blocks.  acc[i][j] of lane l (wave w) is element  row = 16 w + (l >> 4) + 4 j,  col = 16 i + (l & 15).
+typedef __attribute__((ext_vector_type(4))) double f64x4;
+#define TROW(i, j) (((threadIdx.x >> 6) << 4) + ((threadIdx.x & 63) >> 4) + 4 * (j))
+#define TCOL(i, j) (16 * (i) + (threadIdx.x & 15))
+
+__device__ __forceinline__ void tile_mma(f64x4 (&c)[4], double (*LA)[LDP], double (*LB)[LDP]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int k0 = 0; k0 < KC; k0 += 4) {
+        const double a = LA[k0 + lk][w * 16 + lr];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, LB[k0 + lk][i * 16 + lr], c[i], 0, 0, 0);
+    }
+}
+
 template <class RA, class RB>
 __device__ __forceinline__ void tile_gemm(double (&acc)[4][4], double (*LA)[LDP], double (*LB)[LDP], const RA& A, int64_t a0,
                                           const RB& B, int64_t b0, int C) {
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    f64x4 c[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int i = 0; i < 4; ++i) c[i] = f64x4{0.0, 0.0, 0.0, 0.0};
     for (int c0 = 0; c0 < C; c0 += KC) {
         __syncthreads();
         load_tile(LA, A, a0, c0);
         load_tile(LB, B, b0, c0);
         __syncthreads();
-#pragma unroll 8
-        for (int k = 0; k < KC; ++k) {
-            double a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = LA[k][ty * 4 + i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = LB[k][tx * 4 + j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
-        }
+        tile_mma(c, LA, LB);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = c[i][j];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -221,13 +229,12 @@ __global__ void __launch_bounds__(256) k_kpp_dist(RowsF16 X, const double* __res
     B.nrows = J;
     double acc[4][4];
     tile_gemm(acc, LA, LB, X, s0, B, (int64_t)j0, X.C);
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int64_t s = s0 + ty * 4 + i;
-            const int col = j0 + tx * 4 + j;
+            const int64_t s = s0 + TROW(i, j);
+            const int col = j0 + TCOL(i, j);
             double v = 0.0;
             if (s < n && col < J) {
                 const int r = col / T;
@@ -238,7 +245,7 @@ __global__ void __launch_bounds__(256) k_kpp_dist(RowsF16 X, const double* __res
                 v = fmin(closest[(int64_t)r * n + s], d);
                 dcand[(int64_t)col * n + s] = v;
             }
-            LD[ty * 4 + i][tx * 4 + j] = v;
+            LD[TROW(i, j)][TCOL(i, j)] = v;
         }
     __syncthreads();
     if (threadIdx.x < TJ && j0 + threadIdx.x < J) {
@@ -357,15 +364,14 @@ __global__ void __launch_bounds__(256) k_lloyd_assign(RowsF16 X, const double* _
     RowsF64 B{centers + (int64_t)rbase * K * X.C, ncol, X.C};
     double acc[4][4];
     tile_gemm(acc, LA, LB, X, s0, B, 0, X.C);
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int col = tx * 4 + j;
+            const int col = TCOL(i, j);
             double d = 0.0;
             if (col < ncol) d = cn[rbase * K + col] + (-2.0 * acc[i][j]);
-            LD[ty * 4 + i][col] = d;
+            LD[TROW(i, j)][col] = d;
         }
     __syncthreads();
     const int s = threadIdx.x & 63, q = threadIdx.x >> 6;      // 4 restarts handled per pass
@@ -527,7 +533,6 @@ __global__ void __launch_bounds__(256) k_knn(RowsF16 Q, RowsF16 Y, const double*
     __shared__ double LB[KC][LDP];
     __shared__ double LD[TS][LDP];
     const int64_t q0 = (int64_t)blockIdx.x * TS;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     double bd[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
     int bi[4] = {-1, -1, -1, -1};
     for (int64_t y0 = 0; y0 < Y.nrows; y0 += TJ) {
@@ -538,7 +543,7 @@ __global__ void __launch_bounds__(256) k_knn(RowsF16 Q, RowsF16 Y, const double*
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int64_t qi = q0 + ty * 4 + i, yi = y0 + tx * 4 + j;
+                const int64_t qi = q0 + TROW(i, j), yi = y0 + TCOL(i, j);
                 double d = INFINITY;
                 if (qi < Q.nrows && yi < Y.nrows) {
                     d = -2.0 * acc[i][j];
@@ -546,7 +551,7 @@ __global__ void __launch_bounds__(256) k_knn(RowsF16 Q, RowsF16 Y, const double*
                     d += yy[yi];
                     d = fmax(d, 0.0);
                 }
-                LD[ty * 4 + i][tx * 4 + j] = d;
+                LD[TROW(i, j)][TCOL(i, j)] = d;
             }
         __syncthreads();
         if (threadIdx.x < TS) {
@@ -630,44 +635,31 @@ __global__ void __launch_bounds__(256) k_track_cos(const f16* __restrict__ norme
     RowsF16 A{normed + (int64_t)f * N * C, cur, nullptr, (int64_t)qend, C};                      // version 0, gathered
     RowsF16 T{normed + ((int64_t)b * FN + (int64_t)(f + 1) * N) * C, nullptr, nullptr, (int64_t)N, C};
     RowsF16 X{normed + ((int64_t)b * FN) * C, nullptr, nullptr, (int64_t)N, C};
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    double acc[4][4], acx[4][4];
+    f64x4 cc[4], cx[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = acx[i][j] = 0.0;
+    for (int i = 0; i < 4; ++i) cc[i] = cx[i] = f64x4{0.0, 0.0, 0.0, 0.0};
     for (int c0 = 0; c0 < C; c0 += KC) {
         __syncthreads();
         load_tile(LA, A, (int64_t)q0, c0);
         load_tile(LB, T, (int64_t)t0, c0);
         if (use_aux) load_tile(LD, X, (int64_t)t0, c0);
         __syncthreads();
-#pragma unroll 4
-        for (int k = 0; k < KC; ++k) {
-            double a[4], bb[4], xx[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = LA[k][ty * 4 + i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bb[j] = LB[k][tx * 4 + j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], bb[j], acc[i][j]);
-            if (use_aux) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xx[j] = LD[k][tx * 4 + j];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acx[i][j] = fma(a[i], xx[j], acx[i][j]);
-            }
-        }
+        tile_mma(cc, LA, LB);
+        if (use_aux) tile_mma(cx, LA, LD);
     }
+    double acc[4][4], acx[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int q = q0 + ty * 4 + i, col = t0 + tx * 4 + j;
+            acc[i][j] = cc[i][j];
+            acx[i][j] = cx[i][j];
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + TROW(i, j), col = t0 + TCOL(i, j);
             if (q < qend && col < N) {
                 f16 c1 = f64_to_f16_rn(acc[i][j]);
                 if (use_aux) {
