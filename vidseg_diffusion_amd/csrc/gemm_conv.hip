@@ -60,7 +60,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 template <int BM, int BN>
-__global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
+__global__ void __launch_bounds__(256, 2) k_gemm_conv(GemmParams p) {
     constexpr int WN = BN / 64;                       // waves along N
     constexpr int AR = BM / 32;                       // A rows per thread (16-byte chunks)
     constexpr int BR = BN / 32;
@@ -89,83 +89,98 @@ __global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
     const int chunk = tid & 7;                        // 16-byte chunk inside the 128-byte K run
     const int rbase = tid >> 3;                       // 0..31
 
-    // per-thread A row descriptors
-    int a_b[AR], a_oh[AR], a_ow[AR];
+    // per-thread A row descriptors, all 32-bit: pixel-index base of the sample, top-left input coordinate of the 3x3
+    // window (conv), frame index (temporal conv) or the row itself (linear).  Element offsets stay below 2^31.
+    int a_base[AR], a_ih0[AR], a_iw0[AR];
     bool a_ok[AR];
     const int HWo = p.Hout * p.Wout;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const long long m = m0 + rbase + 32 * i;
         a_ok[i] = m < p.M;
-        const long long mm = a_ok[i] ? m : 0;
+        const int mm = a_ok[i] ? (int)m : 0;
         if (p.ksize == 1) {
-            a_b[i] = 0;
-            a_oh[i] = 0;
-            a_ow[i] = 0;
+            a_base[i] = mm;
+            a_ih0[i] = a_iw0[i] = 0;
         } else if (p.tmode) {
-            a_b[i] = 0;
-            a_oh[i] = (int)((mm / HWo) % p.T);
-            a_ow[i] = 0;
+            a_base[i] = mm;
+            a_ih0[i] = (mm / HWo) % p.T;               // frame index t
+            a_iw0[i] = 0;
         } else {
-            a_b[i] = (int)(mm / HWo);
-            const int rem = (int)(mm % HWo);
-            a_oh[i] = rem / p.Wout;
-            a_ow[i] = rem % p.Wout;
+            const int b = mm / HWo, rem = mm - b * HWo;
+            const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
+            a_base[i] = b * p.Hin * p.Win;
+            a_ih0[i] = oh * p.stride - 1;
+            a_iw0[i] = ow * p.stride - 1;
         }
     }
-    u32x4 ra[AR], rb[BR];
+    u32x4 ra0[AR], rb0[BR];
 
     const int upsh = p.up - 1;                        // up is 1 or 2
     const int Hup = p.Hin << upsh, Wup = p.Win << upsh;
     const int nk_all = p.K / BK;
     const int ks_begin = p.ksplit > 1 ? (int)((long long)nk_all * split / p.ksplit) : 0;
     const int ks_end = p.ksplit > 1 ? (int)((long long)nk_all * (split + 1) / p.ksplit) : nk_all;
+    int ld_k = ks_begin * BK;
     int ld_tap = (ks_begin * BK) / Cin, ld_c0 = (ks_begin * BK) % Cin;   // K cursor of the next load (tap-major, then channel chunk)
-    auto load_regs = [&](int k0) {
+    const char* wbase = reinterpret_cast<const char*>(p.w);
+    unsigned b_off[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) b_off[i] = (unsigned)(((long long)min(n0 + rbase + 32 * i, p.N - 1) * p.K + chunk * 8) * 2);
+    unsigned a_off[AR];                                // byte offset of the current (tap, source) pixel row, per A row
+    bool a_val[AR];
+    const char* a_src = reinterpret_cast<const char*>(p.x0);
+    bool first_load = true;
+    auto load_regs = [&](u32x4 (&ra)[AR], u32x4 (&rb)[BR]) {
         const int tap = ld_tap, c0 = ld_c0;            // uniform
+        const int k0 = ld_k;
+        // the pixel each A row reads changes only when the tap or the concat source changes (uniform branch)
+        if (first_load || c0 == 0 || c0 == p.C0) {
+            first_load = false;
+            const bool second = c0 >= p.C0;
+            a_src = reinterpret_cast<const char*>(second ? p.x1 : p.x0);
+            const int Cs = second ? p.C1 : p.C0;
+            const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                int pix;
+                bool ok = a_ok[i];
+                if (p.ksize == 1) {
+                    pix = a_base[i];
+                } else if (p.tmode) {
+                    const int tt = a_ih0[i] + tap - 1;
+                    ok = ok && tt >= 0 && tt < p.T;
+                    pix = a_base[i] + (tap - 1) * HWo;
+                } else {
+                    const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                    ok = ok && (unsigned)ih < (unsigned)Hup && (unsigned)iw < (unsigned)Wup;
+                    pix = a_base[i] + (ih >> upsh) * p.Win + (iw >> upsh);
+                }
+                a_val[i] = ok;
+                a_off[i] = (unsigned)(pix * Cs + chunk * 8) * 2u;
+            }
+        }
+        const unsigned cbyte = (unsigned)(c0 >= p.C0 ? c0 - p.C0 : c0) * 2u;
+        ld_k += BK;
         ld_c0 += BK;
         if (ld_c0 >= Cin) {
             ld_c0 = 0;
             ld_tap++;
         }
-        const bf16_t* src = p.x0;
-        int Cs = p.C0, cc = c0;
-        if (c0 >= p.C0) {
-            src = p.x1;
-            Cs = p.C1;
-            cc = c0 - p.C0;
-        }
-        const int kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (a_ok[i]) {
-                long long pix;
-                bool ok = true;
-                if (p.ksize == 1) {
-                    pix = m0 + rbase + 32 * i;
-                } else if (p.tmode) {
-                    const int tt = a_oh[i] + tap - 1;
-                    ok = tt >= 0 && tt < p.T;
-                    pix = m0 + rbase + 32 * i + (long long)(tap - 1) * HWo;
-                } else {
-                    const int ih = a_oh[i] * p.stride + kh - 1, iw = a_ow[i] * p.stride + kw - 1;
-                    ok = ih >= 0 && iw >= 0 && ih < Hup && iw < Wup;
-                    pix = ((long long)a_b[i] * p.Hin + (ih >> upsh)) * p.Win + (iw >> upsh);
-                }
-                if (ok) v = *reinterpret_cast<const u32x4*>(src + pix * Cs + cc + chunk * 8);
-            }
+            if (a_val[i]) v = *reinterpret_cast<const u32x4*>(a_src + (size_t)(a_off[i] + cbyte));
             ra[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            const int n = n0 + rbase + 32 * i;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (n < p.N) v = *reinterpret_cast<const u32x4*>(p.w + (long long)n * p.K + k0 + chunk * 8);
+            if (n0 + rbase + 32 * i < p.N) v = *reinterpret_cast<const u32x4*>(wbase + (size_t)(b_off[i] + (unsigned)k0 * 2u));
             rb[i] = v;
         }
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int buf, const u32x4 (&ra)[AR], const u32x4 (&rb)[BR]) {
         char* A = smem + buf * BUF;
         char* B = A + A_BYTES;
 #pragma unroll
@@ -189,13 +204,9 @@ __global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = ks_end - ks_begin;
-    load_regs(ks_begin * BK);
-    store_lds(0);
-    __syncthreads();
     const int l31 = lane & 31, hi = lane >> 5;
-    for (int ks = 0; ks < nk; ++ks) {
-        if (ks + 1 < nk) load_regs((ks_begin + ks + 1) * BK);
-        const char* A = smem + (ks & 1) * BUF;
+    auto compute = [&](int buf) {
+        const char* A = smem + buf * BUF;
         const char* B = A + A_BYTES;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -217,7 +228,16 @@ __global__ void __launch_bounds__(256) k_gemm_conv(GemmParams p) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (ks + 1 < nk) store_lds((ks + 1) & 1);
+    };
+    // Pipeline: chunk k is computed from LDS buffer k&1 while chunk k+1 is in flight into registers (issued before the
+    // MFMAs, written to the other LDS buffer after them); one barrier per chunk.
+    load_regs(ra0, rb0);
+    store_lds(0, ra0, rb0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks + 1 < nk) load_regs(ra0, rb0);
+        compute(ks & 1);
+        if (ks + 1 < nk) store_lds((ks + 1) & 1, ra0, rb0);
         __syncthreads();
     }
 
@@ -541,13 +561,23 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         const int nk = p.K / BK;
         static int nosplit = -1;
         if (nosplit < 0) { const char* e = getenv("VIDSEG_NO_SPLITK"); nosplit = e ? atoi(e) : 0; }
-        if (!nosplit && tiles < 384 && nk >= 40 && p.act != 2 && g_ws) {
-            int S = (int)((512 + tiles - 1) / tiles);
-            if (S > nk / 8) S = nk / 8;
-            if (S > 8) S = 8;
-            while (S > 1 && (long long)S * p.M * p.N > g_ws_floats) --S;
-            if (S > 1) {
-                p.ksplit = S;
+        if (!nosplit && nk >= 40 && p.act != 2 && g_ws && tiles < 2048) {
+            // 256 CUs x 2 resident blocks = 512 slots; blocks run in rounds, so the last round's fill decides the
+            // efficiency.  Pick the split that maximises fill / (1 + cost of writing+reading the fp32 partials).
+            double best = 0.0;
+            int bestS = 1;
+            for (int S = 1; S <= 8; ++S) {
+                if (S > 1 && (nk / S < 8 || (long long)S * p.M * p.N > g_ws_floats)) break;
+                const long long items = tiles * S;
+                const double fill = (double)items / (double)(((items + 511) / 512) * 512);
+                const double score = fill / (1.0 + (S > 1 ? 480.0 * S / (double)p.K : 0.0));
+                if (score > best * 1.03) {
+                    best = score;
+                    bestS = S;
+                }
+            }
+            if (bestS > 1) {
+                p.ksplit = bestS;
                 p.ws = g_ws;
             }
         }

@@ -145,10 +145,10 @@ def conv_out4(x, w, bias):
 class Workspace:
     """Scratch for GroupNorm partials, sized once per device."""
 
-    def __init__(self, device, floats=1 << 24, splitk_floats=12 << 20):
+    def __init__(self, device, floats=1 << 24, splitk_floats=40 << 20):
         self.part = torch.empty(floats, dtype=F32, device=device)
         self.stats = torch.empty(64 * 32 * 2 * 4, dtype=F32, device=device)
-        self.splitk = torch.empty(splitk_floats, dtype=F32, device=device)   # fp32 split-K partials (48 MB)
+        self.splitk = torch.empty(splitk_floats, dtype=F32, device=device)   # fp32 split-K partials (160 MB)
         call("vidseg_set_workspace", ptr(self.splitk), self.splitk.numel())
 
 
