@@ -41,10 +41,13 @@ typedef unsigned short bf16_t;   // raw bf16 bits
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {       // round-to-nearest-even, NaN-safe enough for finite data
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {       // round-to-nearest-even: v_cvt_pk_bf16_f32 on gfx950
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
+}
+typedef __attribute__((ext_vector_type(2))) __bf16 vs_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float vs_f32x2;
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {   // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(vs_f32x2{lo, hi}, vs_bf16x2));
 }
 
 __device__ __forceinline__ double wave_sum_f64(double v) {

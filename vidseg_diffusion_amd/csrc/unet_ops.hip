@@ -158,8 +158,8 @@ __global__ void __launch_bounds__(256) k_layernorm(const bf16_t* __restrict__ x,
 __global__ void __launch_bounds__(256) k_attention(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                    const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo, int Nq,
                                                    int Nk, int H, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) char sK[64 * 128];              // K tile [key][d], 16-B slot XOR swizzle
-    __shared__ __attribute__((aligned(16))) bf16_t sVt[64 * VT_LD];         // V tile transposed [d][key]
+    __shared__ __attribute__((aligned(16))) char sK2[2][64 * 128];          // K tile [key][d], 16-B slot XOR swizzle, double buffered
+    __shared__ __attribute__((aligned(16))) bf16_t sVt2[2][64 * VT_LD];     // V tile transposed [d][key]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
@@ -183,21 +183,36 @@ __global__ void __launch_bounds__(256) k_attention(const bf16_t* __restrict__ q,
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (Nk + 63) / 64;
-    for (int t = 0; t < ntiles; ++t) {
-        const int k0 = t * 64;
-        __syncthreads();
-        // stage K (row-major, swizzled) and V (transposed)
+    // K/V staging: global -> registers one tile ahead (issued before the MFMAs of the current tile), registers -> LDS
+    // (K row-major swizzled, V transposed) after them; one barrier per tile.
+    u32x4 rk[2];
+    bf16x8_t rv[2];
+    const int st_ch = tid & 7;
+    auto stage_load = [&](int t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = (tid >> 3) + 32 * i, ch = tid & 7;
-            const int key = min(k0 + r, Nk - 1);
-            const u32x4 kv = *reinterpret_cast<const u32x4*>(kp + (long long)key * ldk + ch * 8);
-            *reinterpret_cast<u32x4*>(sK + r * 128 + ((ch ^ (r & 7)) << 4)) = kv;
-            const bf16x8_t vv = *reinterpret_cast<const bf16x8_t*>(vp + (long long)key * ldv + ch * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sVt[(ch * 8 + e) * VT_LD + r] = (bf16_t)vv[e];
+            const int key = min(t * 64 + (tid >> 3) + 32 * i, Nk - 1);
+            rk[i] = *reinterpret_cast<const u32x4*>(kp + (long long)key * ldk + st_ch * 8);
+            rv[i] = *reinterpret_cast<const bf16x8_t*>(vp + (long long)key * ldv + st_ch * 8);
         }
-        __syncthreads();
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (tid >> 3) + 32 * i;
+            *reinterpret_cast<u32x4*>(sK2[buf] + r * 128 + ((st_ch ^ (r & 7)) << 4)) = rk[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sVt2[buf][(st_ch * 8 + e) * VT_LD + r] = (bf16_t)rv[i][e];
+        }
+    };
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * 64;
+        const char* sK = sK2[t & 1];
+        const bf16_t* sVt = sVt2[t & 1];
+        if (t + 1 < ntiles) stage_load(t + 1);
         // S^T[j] : rows = keys j*32 + .., cols = queries
         f32x16 sacc[2];
 #pragma unroll
@@ -212,56 +227,67 @@ __global__ void __launch_bounds__(256) k_attention(const bf16_t* __restrict__ q,
                 sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[s], sacc[j], 0, 0, 0);
             }
         }
-        // online softmax for this lane's query; key index of sacc[j][r] = k0 + j*32 + (r&3) + 8*(r>>2) + 4*hi
-        float mx = -INFINITY;
+        // online softmax for this lane's query; key index of sacc[j][r] = k0 + j*32 + (r&3) + 8*(r>>2) + 4*hi.
+        // VALU budget matters as much as MFMA here: max on raw scores, scale folded into one fma per element,
+        // masking only on the ragged last tile, O rescale skipped when no lane's running max moved.
+        if (k0 + 64 > Nk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= Nk) sacc[j][r] = -INFINITY;
+                }
+        }
+        float mx = sacc[0][0];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float sv = sacc[j][r] * scale_log2e;
-                if (key >= Nk) sv = -INFINITY;
-                sacc[j][r] = sv;
-                mx = fmaxf(mx, sv);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
         float psum = 0.f;
+        unsigned pk[2][8];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(sacc[j][r] - m_new);
-                sacc[j][r] = pv;
-                psum += pv;
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[j][r], scale_log2e, -m_new));
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[j][r + 1], scale_log2e, -m_new));
+                psum += p0 + p1;
+                pk[j][r >> 1] = pack2_bf16(p0, p1);
             }
         psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            m_run = m_new;
+        }
+        l_run += psum;
         // O^T[i] += V^T[d-block i] P^T : k-slices of 16 keys, lane's 8 k-slots = keys base + {0..3, 8..11} + 4*hi
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8_t fp;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) fp[e] = (short)f32_to_bf16(sacc[j][s * 8 + e]);
+                u32x4 pw = {pk[j][s * 4 + 0], pk[j][s * 4 + 1], pk[j][s * 4 + 2], pk[j][s * 4 + 3]};
+                const bf16x8_t fp = *reinterpret_cast<bf16x8_t*>(&pw);
                 const int kb = j * 32 + s * 16 + 4 * hi;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const bf16_t* vr = sVt + (i * 32 + l31) * VT_LD + kb;
                     const u32x2 lo = *reinterpret_cast<const u32x2*>(vr);
                     const u32x2 hi2 = *reinterpret_cast<const u32x2*>(vr + 8);
-                    u32x4 pk = {lo[0], lo[1], hi2[0], hi2[1]};
-                    const bf16x8_t fv = *reinterpret_cast<bf16x8_t*>(&pk);
+                    u32x4 pv = {lo[0], lo[1], hi2[0], hi2[1]};
+                    const bf16x8_t fv = *reinterpret_cast<bf16x8_t*>(&pv);
                     oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv, fp, oacc[i], 0, 0, 0);
                 }
             }
+        if (t + 1 < ntiles) stage_store((t + 1) & 1);
+        __syncthreads();
     }
     // write O: lane owns query q0 + l31; oacc[i][r] is d = i*32 + (r&3) + 8*(r>>2) + 4*hi
     const int qi = q0 + l31;
