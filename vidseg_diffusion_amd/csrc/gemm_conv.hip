@@ -80,8 +80,24 @@ __global__ void __launch_bounds__(256, 2) k_gemm_conv(GemmParams p) {
         const long long q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const long long tm = bid / tiles_n;
-    const int tn = (int)(bid % tiles_n);
+    // `bid` is a position in a chunk that stays on one XCD (private 4 MB L2).  Default order: N-tile fastest, so the
+    // tiles resident together share activation (A) rows.  For linears whose weight matrix is far larger than L2
+    // (GEGLU projections, 6-26 MB) the order is flipped inside bands of ~tiles_m/8 M-tiles: N-tile outer, M-tile
+    // inner, so one or two weight tiles stay L2-resident while A streams (+4..12 % measured on those shapes).
+    long long tm;
+    int tn;
+    if (p.ksize == 1 && (long long)p.N * p.K * 2 >= (6LL << 20) && tiles_m >= 16) {
+        const long long band = (tiles_m + 7) / 8;
+        const long long per_band = band * tiles_n;
+        const long long bnd = bid / per_band;
+        const long long inb = bid - bnd * per_band;
+        const long long bw = (bnd * band + band <= tiles_m) ? band : (tiles_m - bnd * band);
+        tn = (int)(inb / bw);
+        tm = bnd * band + inb % bw;
+    } else {
+        tm = bid / tiles_n;
+        tn = (int)(bid % tiles_n);
+    }
     const long long m0 = tm * BM;
     const int n0 = tn * BN;
 
