@@ -125,46 +125,35 @@ def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: i
     pcnt = torch.empty((R, nblk, K), dtype=I32, device=dev)
     shift2 = torch.zeros((R, K), dtype=F64, device=dev)
     counts = torch.zeros((R, K), dtype=I32, device=dev)
-    h_changed = torch.empty(R, dtype=I32).pin_memory()
-    h_shift2 = torch.empty((R, K), dtype=F64).pin_memory()
-    h_counts = torch.empty((R, K), dtype=I32).pin_memory()
-
-    active = (1 << R) - 1
-    strict = [False] * R
-    n_iter = [0] * R
+    # device-side convergence state: [active mask, strict mask, error flags, n_iter[R]]
+    h_state = torch.zeros(3 + R, dtype=I32)
+    h_state[0] = (1 << R) - 1
+    state = h_state.to(dev)
+    h_pin = torch.empty(3 + R, dtype=I32).pin_memory()
     total = 0
-    for it in range(max_iter):
-        changed.zero_()
-        call("vidseg_lloyd_iter", ptr(x16), ptr(mean), n, C, R, K, active, 1, ptr(centers), ptr(cnorm), ptr(labels),
-             ptr(changed), ptr(psum), ptr(pcnt), chunk, ptr(shift2), ptr(counts), st)
-        h_changed.copy_(changed, non_blocking=True)
-        h_shift2.copy_(shift2, non_blocking=True)
-        h_counts.copy_(counts, non_blocking=True)
+    poll = 4                                                            # iterations enqueued between host polls
+    it = 0
+    while it < max_iter:
+        for _ in range(min(poll, max_iter - it)):
+            call("vidseg_lloyd_iter", ptr(x16), ptr(mean), n, C, R, K, ptr(state), 1, ptr(centers), ptr(cnorm), ptr(labels),
+                 ptr(changed), ptr(psum), ptr(pcnt), chunk, ptr(shift2), ptr(counts), st)
+            call("vidseg_lloyd_status", R, K, it, tol_, ptr(changed), ptr(shift2), ptr(counts), ptr(state), st)
+            it += 1
+        h_pin.copy_(state, non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        total += 1
-        for r in range(R):
-            if not (active >> r) & 1:
-                continue
-            n_iter[r] = it + 1
-            if int(h_counts[r].min()) == 0:
-                raise _lib.VidsegError(
-                    "kmeans_fit: a cluster became empty; sklearn's _relocate_empty_clusters_dense path "
-                    "(_k_means_common.pyx:167-211) is not implemented on the device yet")
-            if int(h_changed[r]) == 0:
-                strict[r] = True
-                active &= ~(1 << r)
-            else:
-                shift_tot = float((np.sqrt(h_shift2[r].numpy()) ** 2).sum())
-                if shift_tot <= tol_:
-                    active &= ~(1 << r)
-        if active == 0:
+        total = it
+        if int(h_pin[2]) & 1:
+            raise _lib.VidsegError(
+                "kmeans_fit: a cluster became empty; sklearn's _relocate_empty_clusters_dense path "
+                "(_k_means_common.pyx:167-211) is not implemented on the device yet")
+        if int(h_pin[0]) == 0:
             break
-    rerun = 0
-    for r in range(R):
-        if not strict[r]:
-            rerun |= 1 << r
+    strict_mask = int(h_pin[1])
+    n_iter = [int(h_pin[3 + r]) for r in range(R)]
+    rerun = ((1 << R) - 1) & ~strict_mask
     if rerun:                                                          # _kmeans.py:736-748
-        call("vidseg_lloyd_iter", ptr(x16), ptr(mean), n, C, R, K, rerun, 0, ptr(centers), ptr(cnorm), ptr(labels),
+        rstate = torch.tensor([rerun], dtype=I32).to(dev)
+        call("vidseg_lloyd_iter", ptr(x16), ptr(mean), n, C, R, K, ptr(rstate), 0, ptr(centers), ptr(cnorm), ptr(labels),
              ptr(changed), ptr(psum), ptr(pcnt), chunk, ptr(shift2), ptr(counts), st)
     ipart = torch.empty((R, (n + 255) // 256), dtype=F64, device=dev)
     inertia = torch.empty(R, dtype=F64, device=dev)
@@ -206,7 +195,8 @@ def kmeans_predict(x16: torch.Tensor, centers: torch.Tensor) -> torch.Tensor:
     labels = torch.full((1, n), -1, dtype=I32, device=dev)
     changed = torch.zeros(1, dtype=I32, device=dev)
     cnorm = torch.empty(K, dtype=F64, device=dev)
-    call("vidseg_lloyd_iter", ptr(x16), None, n, C, 1, K, 1, 0, ptr(centers), ptr(cnorm), ptr(labels), ptr(changed),
+    one = torch.ones(1, dtype=I32, device=dev)
+    call("vidseg_lloyd_iter", ptr(x16), None, n, C, 1, K, ptr(one), 0, ptr(centers), ptr(cnorm), ptr(labels), ptr(changed),
          None, None, 256, None, None, stream())
     return labels[0]
 

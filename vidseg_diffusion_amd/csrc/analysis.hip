@@ -347,12 +347,13 @@ __global__ void k_center_sqnorm(const double* __restrict__ centers, int J, int C
 }
 
 __global__ void __launch_bounds__(256) k_lloyd_assign(RowsF16 X, const double* __restrict__ centers, const double* __restrict__ cn,
-                                                      int R, int K, int rpt, unsigned active, int32_t* __restrict__ labels,
+                                                      int R, int K, int rpt, const unsigned* __restrict__ d_active, int32_t* __restrict__ labels,
                                                       int32_t* __restrict__ changed) {
     // blockIdx.y selects `rpt` restarts (rpt*K <= 64 columns).  argmin_j (|c_j|^2 - 2 x.c_j), first min wins.
     __shared__ double LA[KC][LDP];
     __shared__ double LB[KC][LDP];
     __shared__ double LD[TS][LDP];
+    const unsigned active = *d_active;
     const int rbase = blockIdx.y * rpt;
     unsigned need = 0;
     for (int q = 0; q < rpt; ++q)
@@ -392,12 +393,12 @@ __global__ void __launch_bounds__(256) k_lloyd_assign(RowsF16 X, const double* _
     }
 }
 
-__global__ void __launch_bounds__(256) k_lloyd_accum(RowsF16 X, const int32_t* __restrict__ labels, int R, int K, unsigned active,
-                                                     int S, double* __restrict__ psum, int32_t* __restrict__ pcnt, int nblk) {
+__global__ void __launch_bounds__(256) k_lloyd_accum(RowsF16 X, const int32_t* __restrict__ labels, int R, int K,
+                                                     const unsigned* __restrict__ d_active, int S, double* __restrict__ psum, int32_t* __restrict__ pcnt, int nblk) {
     // block (chunk, restart): fixed-order partial sums of the chunk's samples per cluster.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int r = blockIdx.y;
-    if (!((active >> r) & 1u)) return;
+    if (!((*d_active >> r) & 1u)) return;
     const int C = X.C;
     constexpr int CCH = 256;                                     // channels per pass, one per thread
     double* acc = reinterpret_cast<double*>(smem);               // [K][CCH]
@@ -429,11 +430,11 @@ __global__ void __launch_bounds__(256) k_lloyd_accum(RowsF16 X, const int32_t* _
 }
 
 __global__ void __launch_bounds__(256) k_lloyd_update(const double* __restrict__ psum, const int32_t* __restrict__ pcnt, int nblk,
-                                                      int R, int K, int C, unsigned active, double* __restrict__ centers,
+                                                      int R, int K, int C, const unsigned* __restrict__ d_active, double* __restrict__ centers,
                                                       double* __restrict__ shift2, int32_t* __restrict__ counts) {
     // block (k, r): new centre = (sum over chunks, ascending) * (1/count); shift2 = |new-old|^2
     const int k = blockIdx.x, r = blockIdx.y;
-    if (!((active >> r) & 1u)) return;
+    if (!((*d_active >> r) & 1u)) return;
     __shared__ double red[256];
     int cnt = 0;
     for (int b = 0; b < nblk; ++b) cnt += pcnt[((int64_t)r * nblk + b) * K + k];
@@ -460,6 +461,37 @@ __global__ void __launch_bounds__(256) k_lloyd_update(const double* __restrict__
         shift2[r * K + k] = red[0];
         counts[r * K + k] = cnt;
     }
+}
+
+// Convergence bookkeeping of _kmeans_single_lloyd (cluster/_kmeans.py:715-734) on the device, so that a restart is
+// frozen at exactly the iteration sklearn would stop it without a host round trip per iteration:
+//   labels unchanged -> strict convergence;  else sum_k (sqrt(shift2_k))^2 <= tol -> tolerance convergence.
+// state[0] = active mask, state[1] = strict mask, state[2] = error flags (bit 0: empty cluster seen), state[3+r] = n_iter.
+__global__ void k_lloyd_status(int R, int K, int it, double tol, int32_t* __restrict__ changed, const double* __restrict__ shift2,
+                               const int32_t* __restrict__ counts, unsigned* __restrict__ state) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned active = state[0], strict = state[1], err = state[2];
+    for (int r = 0; r < R; ++r) {
+        if (!((active >> r) & 1u)) continue;
+        state[3 + r] = (unsigned)(it + 1);
+        for (int k = 0; k < K; ++k)
+            if (counts[r * K + k] == 0) err |= 1u;
+        if (changed[r] == 0) {
+            strict |= 1u << r;
+            active &= ~(1u << r);
+        } else {
+            double tot = 0.0;
+            for (int k = 0; k < K; ++k) {
+                const double sh = sqrt(shift2[r * K + k]);
+                tot += sh * sh;
+            }
+            if (tot <= tol) active &= ~(1u << r);
+        }
+        changed[r] = 0;
+    }
+    state[0] = active;
+    state[1] = strict;
+    state[2] = err;
 }
 
 __global__ void __launch_bounds__(256) k_inertia(RowsF16 X, const double* __restrict__ centers, const int32_t* __restrict__ labels,
@@ -923,14 +955,14 @@ int vidseg_gather_rows_f64(const void* x16, const double* mean, int C, const int
 
 // One Lloyd iteration for the restarts in `active`: E-step (labels updated in place, changed[r] += #changes),
 // M-step (fixed-order partial sums), centres updated in place, shift2[r][k] and counts[r][k] written.
-int vidseg_lloyd_iter(const void* x16, const double* mean, int64_t n, int C, int R, int K, unsigned active, int update_centers,
-                      double* centers, double* cnorm, int32_t* labels, int32_t* changed, double* psum, int32_t* pcnt, int chunk,
-                      double* shift2, int32_t* counts, hipStream_t st) {
-    VS_REQUIRE(K >= 1 && K <= 64 && R >= 1 && R <= 32, "lloyd_iter: K=%d R=%d unsupported", K, R);
+int vidseg_lloyd_iter(const void* x16, const double* mean, int64_t n, int C, int R, int K, const unsigned* d_active,
+                      int update_centers, double* centers, double* cnorm, int32_t* labels, int32_t* changed, double* psum,
+                      int32_t* pcnt, int chunk, double* shift2, int32_t* counts, hipStream_t st) {
+    VS_REQUIRE(K >= 1 && K <= 64 && R >= 1 && R <= 29, "lloyd_iter: K=%d R=%d unsupported", K, R);
     RowsF16 X{(const f16*)x16, nullptr, mean, n, C};
     const int rpt = 64 / K;
     k_center_sqnorm<<<dim3((R * K + 3) / 4), 256, 0, st>>>(centers, R * K, C, cnorm);
-    k_lloyd_assign<<<dim3((unsigned)cdiv64(n, TS), (R + rpt - 1) / rpt), 256, 0, st>>>(X, centers, cnorm, R, K, rpt, active, labels,
+    k_lloyd_assign<<<dim3((unsigned)cdiv64(n, TS), (R + rpt - 1) / rpt), 256, 0, st>>>(X, centers, cnorm, R, K, rpt, d_active, labels,
                                                                                     changed);
     VS_CHECK_LAUNCH("lloyd_assign");
     if (update_centers) {
@@ -939,14 +971,22 @@ int vidseg_lloyd_iter(const void* x16, const double* mean, int64_t n, int C, int
         VS_REQUIRE(lds <= 160 * 1024, "lloyd_iter: LDS %zu too large", lds);
         static bool attr_set = false;
         if (!attr_set) {
-            hipFuncSetAttribute((const void*)k_lloyd_accum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_lloyd_accum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        k_lloyd_accum<<<dim3(nblk, R), 256, lds, st>>>(X, labels, R, K, active, chunk, psum, pcnt, nblk);
+        k_lloyd_accum<<<dim3(nblk, R), 256, lds, st>>>(X, labels, R, K, d_active, chunk, psum, pcnt, nblk);
         VS_CHECK_LAUNCH("lloyd_accum");
-        k_lloyd_update<<<dim3(K, R), 256, 0, st>>>(psum, pcnt, nblk, R, K, C, active, centers, shift2, counts);
+        k_lloyd_update<<<dim3(K, R), 256, 0, st>>>(psum, pcnt, nblk, R, K, C, d_active, centers, shift2, counts);
         VS_CHECK_LAUNCH("lloyd_update");
     }
+    return VS_OK;
+}
+
+// state: device uint32 [3 + R] = {active mask, strict mask, error flags, n_iter[R]}; see k_lloyd_status.
+int vidseg_lloyd_status(int R, int K, int it, double tol, int32_t* changed, const double* shift2, const int32_t* counts,
+                        unsigned* state, hipStream_t st) {
+    k_lloyd_status<<<dim3(1), 64, 0, st>>>(R, K, it, tol, changed, shift2, counts, state);
+    VS_CHECK_LAUNCH("lloyd_status");
     return VS_OK;
 }
 
