@@ -1,0 +1,78 @@
+"""The window-sharded multi-rank path on REAL kernels: two ranks (both on cuda:0, gloo rendezvous with host-staged
+collectives, since one box has one GPU) must reproduce the single-process sequential window loop of the reference
+(segment_clip) bit for bit -- K-means on window 0, label chain by top-4 search + vote, refinement per window."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from vidseg_diffusion_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+F, K = 3, 5
+
+
+def _setup(dev):
+    from vidseg_diffusion_amd.pipeline import build_sd_engine
+    from vidseg_diffusion_amd.unet import UNetModel
+    net = UNetModel(**synthetic.SD21_NARROW)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, 1234).items()})
+    return build_sd_engine(net)
+
+
+def _inputs(win, dev):
+    lat = torch.from_numpy(synthetic.latent_clip(F, 16, 16, seed=50 + win)).to(dev)
+    c = torch.from_numpy(np.random.Generator(np.random.PCG64(7)).standard_normal((F, 7, 64)).astype(np.float32)).to(dev)
+    noise = torch.from_numpy(np.random.Generator(np.random.PCG64(90 + win)).standard_normal((F, 4, 16, 16)).astype(np.float32)).to(dev)
+    return lat, {"crossattn": c}, {"crossattn": torch.zeros_like(c)}, noise
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    from vidseg_diffusion_amd import parallel
+    eng = _setup(dev)
+    lat, c, uc, noise = _inputs(rank, dev)
+    labels = parallel.segment_windows_sharded(eng, lat, c, uc, noise=noise, num_masks=K, is_refine_mask=True, seed=17, rank=rank,
+                                              world=world, feature_folder="/nonexistent/par", exp_name=f"r{rank}")
+    q.put((rank, labels))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_sequential_windows():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # sequential reference loop in this process
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import WindowState, segment_window
+    dev = torch.device("cuda:0")
+    eng = _setup(dev)
+    FE.FeatureStore.clear()
+    FE.MaskStore.clear()
+    state, seq = WindowState(), []
+    for win in range(2):
+        lat, c, uc, noise = _inputs(win, dev)
+        labels, state = segment_window(eng, lat, c, uc, num_masks=K, is_refine_mask=True, seed=17, state=state, noise=noise,
+                                       feature_folder="/nonexistent/seq", exp_name=f"w{win}")
+        seq.append(labels)
+    seq = np.stack(seq)
+    for r in range(2):
+        assert np.array_equal(res[r], seq), f"rank {r}: sharded labels differ from the sequential window loop"

@@ -36,11 +36,29 @@ class ChainOps:
     refine: Optional[Callable] = None  # (tracks [F,N] int32, labels [F,N] int32) -> int32 [F,N]
 
 
+def _host_staged(t: torch.Tensor) -> bool:
+    """gloo cannot move device memory: stage through host buffers (CPU tests, and the 2-ranks-on-one-GPU test)."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def _all_gather(t: torch.Tensor, world: int):
     import torch.distributed as dist
+    if _host_staged(t):
+        return _all_gather(t.cpu(), world).to(t.device)
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t.contiguous())                  # concatenated along dim 0 (gloo and RCCL agree on this form)
     return out.view((world,) + tuple(t.shape))
+
+
+def _broadcast(t: torch.Tensor, src: int):
+    import torch.distributed as dist
+    if _host_staged(t):
+        h = t.cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
 
 
 def resolve_windows(feat: torch.Tensor, tracks: Optional[torch.Tensor], ops: ChainOps, rank: int, world: int, num_frames: int):
@@ -55,7 +73,7 @@ def resolve_windows(feat: torch.Tensor, tracks: Optional[torch.Tensor], ops: Cha
     else:
         labels0 = torch.empty(FN, dtype=torch.int32, device=feat.device)
         nn_idx = ops.knn_top4(all_feat[rank - 1], feat).to(torch.int32)
-    dist.broadcast(labels0, src=0)
+    _broadcast(labels0, 0)
     all_idx = _all_gather(nn_idx, world)                              # [W, F*N, 4]
     all_tracks = _all_gather(tracks, world) if tracks is not None else None
     out = []
