@@ -32,13 +32,21 @@ sys.path.insert(0, ROOT)
 F_WIN, LAT, K_MASKS, T_START, NUM_STEPS = 14, 64, 20, 22, 25
 
 
-def make_inputs(dev, window_id, cfg):
+def make_inputs(dev, window_id, cfg, svd=False, lat_hw=(LAT, LAT)):
     from vidseg_diffusion_amd import synthetic
-    lat = torch.from_numpy(synthetic.latent_clip(F_WIN, LAT, LAT, seed=1 + window_id)).to(dev)
-    c, uc = synthetic.sd_conditioning(F_WIN, context_dim=cfg["context_dim"], seq=77, seed=1)
+    lat = torch.from_numpy(synthetic.latent_clip(F_WIN, lat_hw[0], lat_hw[1], seed=1 + window_id)).to(dev)
     g = torch.Generator().manual_seed(100 + window_id)
     noise = torch.randn(lat.shape, generator=g).to(dev)
-    return lat, {"crossattn": torch.from_numpy(c).to(dev)}, {"crossattn": torch.from_numpy(uc).to(dev)}, noise
+    if not svd:
+        c, uc = synthetic.sd_conditioning(F_WIN, context_dim=cfg["context_dim"], seq=77, seed=1)
+        return lat, {"crossattn": torch.from_numpy(c).to(dev)}, {"crossattn": torch.from_numpy(uc).to(dev)}, noise
+    # SVD conditioning (svd_pipeline_vspw.py:300-311): CLIP-image token and frame-0 latent repeated over frames, fps/motion vector
+    ctx = torch.randn((1, 1, cfg["context_dim"]), generator=g).repeat(F_WIN, 1, 1).to(dev)
+    cat = lat[:1].repeat(F_WIN, 1, 1, 1) / 0.18215 * 0.2
+    vec = torch.randn((1, cfg["adm_in_channels"]), generator=g).repeat(F_WIN, 1).to(dev)
+    c = {"crossattn": ctx, "concat": cat, "vector": vec}
+    uc = {"crossattn": torch.zeros_like(ctx), "concat": torch.zeros_like(cat), "vector": vec.clone()}
+    return lat, c, uc, noise
 
 
 def cpu_baseline(sd_cpu, cfg):
@@ -75,6 +83,8 @@ def main():
     ap.add_argument("--refine", action="store_true", help="also run Step 3b (correct_low_res_mask)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--narrow", action="store_true", help="debug: narrow-width UNet (NOT the benchmark config)")
+    ap.add_argument("--config", default="sd", choices=["sd", "svd"],
+                    help="sd = BASELINE configs[1] (headline); svd = configs[2]: SVD 14x576x1024, t_start 17, is_refine_mask")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -93,14 +103,28 @@ def main():
     from vidseg_diffusion_amd.pipeline import build_sd_engine
     from vidseg_diffusion_amd.unet import UNetModel
 
-    cfg = dict(synthetic.SD21_NARROW if args.narrow else synthetic.SD21_FULL)
-    net = UNetModel(**cfg)
+    svd = args.config == "svd"
+    global T_START
+    if svd:
+        from vidseg_diffusion_amd.video_unet import VideoUNet
+        cfg = dict(synthetic.SVD_NARROW if args.narrow else synthetic.SVD_FULL)
+        net = VideoUNet(**cfg)
+        T_START = 17
+        args.refine = True
+    else:
+        cfg = dict(synthetic.SD21_NARROW if args.narrow else synthetic.SD21_FULL)
+        net = UNetModel(**cfg)
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     sd_cpu = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=1234).items()}
     net.load_state_dict(sd_cpu)
     net.pack(dev)
-    eng = build_sd_engine(net, num_steps=NUM_STEPS, scale=5.0)
-    lat, c, uc, noise = make_inputs(dev, rank, cfg)
+    if svd:
+        from vidseg_diffusion_amd.pipeline import build_svd_engine
+        eng = build_svd_engine(net, num_frames=F_WIN, num_steps=NUM_STEPS)
+        lat, c, uc, noise = make_inputs(dev, rank, cfg, svd=True, lat_hw=(72, 128))
+    else:
+        eng = build_sd_engine(net, num_steps=NUM_STEPS, scale=5.0)
+        lat, c, uc, noise = make_inputs(dev, rank, cfg)
     torch.cuda.synchronize()
 
     def one_step():
@@ -151,7 +175,13 @@ def main():
                          "gemm_ms_per_step": round(k_ms / args.steps, 3)},
             "unique_labels": int(len(np.unique(labels))),
         }
-        if not args.no_cpu_baseline and not args.narrow:
+        if svd:
+            out["metric"] = "segmented frames/sec (14-frame 576x1024 clip, 20 masks, SVD)"
+            out["config"]["workload"] = ("BASELINE configs[2]: SVD img2vid full-size VideoUNet (1524.6M params, random-init), 14-frame 576x1024 "
+                                         "window per GPU (latent 14x4x72x128), t_start=17 (8 CFG UNet evals, batch 28), spatial+temporal taps, "
+                                         "is_aggre_attn, K-means K=20 + 4-NN, is_refine_mask (dense tracking + vote)")
+            out["config"]["unet_evals_per_step"] = 8
+        if not args.no_cpu_baseline and not args.narrow and not svd:
             out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg)
         print(json.dumps(out))
     if world > 1:

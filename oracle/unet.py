@@ -286,6 +286,33 @@ def euler_sample(unet: UNetOracle, latent, c_cross, uc_cross, num_steps=25, t_st
     return x
 
 
+def euler_inversion(unet: UNetOracle, latent, c_cross, uc_cross, num_steps=25, scale=5.0):
+    """EDMSampler.inversion (sampling.py:264-296) with prepare_sampling_loop(inversion=True) (:49-51): sigmas flipped to
+    ascending, sigma[0] += 1e-8, the same Euler step over all pairs (the first skips the network: sigma_hat.mean() < 1e-6
+    -> denoised = x, :110-111), result / sqrt(1 + sigma_last^2).  Returns (x, list of latents)."""
+    sigmas = legacy_ddpm_sigmas(num_steps).flip(0).clone()
+    sigmas[0] += 1e-8
+    table = discrete_sigma_table(1000)
+    x = latent * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+    Fn = x.shape[0]
+    lats = [x]
+    for i in range(num_steps):
+        sigma, nxt = sigmas[i], sigmas[i + 1]
+        if float(sigma) < 1e-6:
+            den = x
+        else:
+            sq = table[sigma_to_idx(torch.full((2 * Fn,), float(sigma)), table)]
+            c_in, c_out = 1 / (sq ** 2 + 1.0) ** 0.5, -sq
+            net = unet.forward(torch.cat([x, x]) * c_in[:, None, None, None], sigma_to_idx(sq, table).float(),
+                               torch.cat([uc_cross, c_cross]))
+            d2 = net * c_out[:, None, None, None] + torch.cat([x, x])
+            xu, xc = d2.chunk(2)
+            den = xu + scale * (xc - xu)
+        x = x + (x - den) / sigma * (nxt - sigma)
+        lats.append(x)
+    return x / torch.sqrt(1.0 + sigmas[-1] ** 2.0), lats
+
+
 def _step_modulation(m, i, Fn):
     """Per-step view of the reference's modulate_params protocol (sampling.py:176-194, openaimodel.py:911-937,
     attention.py:616-634, 697-719) for the oracle: {tapname: (inject dict, rowadd dict)}."""

@@ -152,3 +152,12 @@ def test_modulated_injected_pass_matches_reference(narrow_sd):
         # injected q/k are the fp16 dumps here, fp32 tensors in the golden run -> 5e-3
         assert np.abs(xs - ref).max() <= 5e-3 * np.abs(ref).max(), tag
         assert np.abs(final.numpy() - g[f"mod_{tag}_final"]).max() <= 5e-3 * np.abs(ref).max()
+
+
+def test_inversion_matches_reference(gold, narrow_sd):
+    from oracle.unet import euler_inversion
+    _, sd = narrow_sd
+    c = torch.from_numpy(gold["sm_c"])
+    x, lats = euler_inversion(UNetOracle(sd), torch.from_numpy(gold["sm_latent"]), c, torch.zeros_like(c))
+    for got, ref in ((x, gold["inv_final"]), (lats[5], gold["inv_step5"]), (lats[24], gold["inv_step24"])):
+        assert np.abs(got.numpy() - ref).max() <= 2e-4 * np.abs(ref).max()

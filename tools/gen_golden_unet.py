@@ -81,6 +81,9 @@ def main():
                sm_final=final.numpy(), sm_sigmas=sampler.discretization(25, device="cpu").numpy())
     for b in (6, 7, 8):
         rec[f"sm_q_block_{b}_time_24"] = taps[b]
+    # --- a3b: EDM-form "DDIM inversion" (sampling.py:264-296), then it is the feature pass from t_start = 0
+    inv, lat_list = sampler.inversion(denoiser, torch.from_numpy(lat).clone(), cond=cond, uc=ucond, num_steps=25)
+    rec.update(inv_final=inv.numpy(), inv_step5=lat_list[5].numpy(), inv_step24=lat_list[24].numpy())
     rec["versions"] = np.array([f"torch {torch.__version__}"])
     path = os.path.join(ROOT, "tests", "golden", "unet_sd_narrow.npz")
     np.savez_compressed(path, **rec)

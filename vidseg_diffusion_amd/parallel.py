@@ -104,16 +104,16 @@ def segment_windows_sharded(engine, latent, c, uc, *, noise=None, num_masks=20, 
     fh, fw = lh // 2, lw // 2
     N = fh * fw
     seed_everything(seed)
-    sampler, den_m, model = engine.sampler, engine.denoiser, engine.model
-
-    def denoiser(inp, sigma, cc, **kw):
-        return den_m(model, inp, sigma, cc)
+    from .pipeline import make_denoiser
+    sampler = engine.sampler
+    denoiser = make_denoiser(engine, F)
 
     x = sampler.add_noise(latent, cond=c, uc=uc, num_steps=num_steps, noise_level=t_start, noise=noise)
     sampler(denoiser, x, cond=c, uc=uc, t_start=t_start,
             img_callback=lambda xt, i: save_feature_maps(engine, feature_folder, exp_name, i, xt=xt, block_filter=(6, 7, 8)) if i == 24 else None)
     store = FE.FeatureStore.folder(feature_folder, exp_name)
-    names = ["output_block_8", "output_block_7", "output_block_6"] if is_aggre_attn else ["output_block_7"]
+    names = ["output_block_8", "output_block_7", "output_block_6"] if is_aggre_attn else \
+        (["output_block_8"] if engine.video else ["output_block_7"])
     blocks = [store[f"{n}_spatial_self_attn_q_time_24"] for n in names]
     _, feat = A.mean_normalize(blocks, F * N, F * N)
     tracks = None

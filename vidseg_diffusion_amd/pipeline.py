@@ -104,6 +104,17 @@ def save_feature_maps(engine, store_folder, exp_name, i, xt=None, block_filter=N
         FE.FeatureStore.put(store_folder, exp_name, f"xt_time_{i}", xt)
 
 
+def make_denoiser(engine: Engine, num_frames: int):
+    """The driver's denoiser closure (sd_pipeline_vspw.py:324-332); SVD adds image_only_indicator / num_video_frames
+    (svd_pipeline_vspw.py:307-311)."""
+    extra = {"image_only_indicator": torch.zeros(2, num_frames), "num_video_frames": num_frames} if engine.video else {}
+
+    def denoiser(inp, sigma, cc, is_modulate_step=False, is_injected_step=False, modulate_params=None):
+        return engine.denoiser(engine.model, inp, sigma, cc, is_modulate_step=is_modulate_step, is_injected_step=is_injected_step,
+                               modulate_params=modulate_params, **extra)
+    return denoiser
+
+
 def segment_window(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, num_masks=20, num_steps=25, t_start=22,
                    feature_timestep="24", is_aggre_attn=True, is_refine_mask=False, seed=17, state: WindowState = None,
                    frame_names=None, feature_folder="features_outputs_VSPW", exp_name="exp", gt_mask_path=None, noise=None,
@@ -115,15 +126,9 @@ def segment_window(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, n
     state = state or WindowState()
     F, _, lh, lw = latent.shape
     seed_everything(seed)                                                           # SDP:255
-    sampler, denoiser_m, model = engine.sampler, engine.denoiser, engine.model
+    sampler = engine.sampler
 
-    extra = {}
-    if engine.video:                                                                # svd_pipeline_vspw.py:307-311
-        extra = {"image_only_indicator": torch.zeros(2, F), "num_video_frames": F}
-
-    def denoiser(inp, sigma, cc, is_modulate_step=False, is_injected_step=False, modulate_params=None):   # SDP:324-332
-        return denoiser_m(model, inp, sigma, cc, is_modulate_step=is_modulate_step, is_injected_step=is_injected_step,
-                          modulate_params=modulate_params, **extra)
+    denoiser = make_denoiser(engine, F)
 
     x = sampler.add_noise(latent, cond=c, uc=uc, num_steps=num_steps, noise_level=t_start, noise=noise)   # Step 1, SDP:341
     want = int(feature_timestep)
