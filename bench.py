@@ -155,6 +155,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")           # PMC pass (separate rocprofv3 --pmc runs), see file
+    if os.path.exists(tpath) and not svd and not args.narrow:
+        with open(tpath) as fh:
+            traffic = json.load(fh).get("traffic_bytes_per_launch")
     if rank == 0:
         frames = F_WIN * world * args.steps
         achieved = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
@@ -169,7 +174,7 @@ def main():
                                    + (", is_refine_mask" if args.refine else ""),
                        "frames_per_gpu": F_WIN, "num_masks": K_MASKS, "unet_evals_per_step": 3, "parallelism": f"window-per-gpu x{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": round(achieved / 2500.0, 4), "traffic": None, "kernel": "k_gemm_conv (bf16 MFMA implicit-GEMM conv/linear)",
+                         "frac": round(achieved / 2500.0, 4), "traffic": traffic, "kernel": "k_gemm_conv (bf16 MFMA implicit-GEMM conv/linear)",
                          "launches_per_step": k_launches // max(args.steps, 1),
                          "avg_launch_us": round(1e3 * k_ms / max(k_launches, 1), 2),
                          "gemm_ms_per_step": round(k_ms / args.steps, 3)},
