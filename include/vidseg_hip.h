@@ -64,7 +64,7 @@ int vidseg_gather_rows_f64(const void* x16, const double* mean, int C, const int
  * `active`: E-step argmin_j(|c_j|^2 - 2 x.c_j) (labels in place, changed[r] += #changed), M-step with
  * fixed-order partial sums, centres in place, shift2[r][k] = |c_new - c_old|^2, counts[r][k]. */
 int vidseg_lloyd_iter(const void* x16, const double* mean /*opt*/, int64_t n, int C, int R, int K, const unsigned* d_active,
-                      int update_centers, double* centers, double* cnorm, int32_t* labels, int32_t* changed, double* psum,
+                      const int32_t* slots, int nslots, const int32_t* colrow, int update_centers, double* centers, double* cnorm, int32_t* labels, int32_t* changed, double* psum,
                       int32_t* pcnt, int chunk, double* shift2, int32_t* counts, vidseg_stream_t stream);
 /* _kmeans.py:715-734 on the device: state = {active mask, strict mask, error flags, n_iter[R]} (uint32) */
 int vidseg_lloyd_status(int R, int K, int it, double tol, int32_t* changed, const double* shift2, const int32_t* counts,

@@ -28,7 +28,7 @@ _SIGS = {
     "vidseg_row_sqnorm_f64": [_P, _L, _I, _P, _P],
     "vidseg_kpp_round": [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "vidseg_gather_rows_f64": [_P, _P, _I, _P, _I, _P, _P],
-    "vidseg_lloyd_iter": [_P, _P, _L, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
+    "vidseg_lloyd_iter": [_P, _P, _L, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "vidseg_lloyd_status": [_I, _I, _I, _D, _P, _P, _P, _P, _P],
     "vidseg_kmeans_inertia": [_P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P],
     "vidseg_add_mean_f64": [_P, _P, _I, _I, _P],

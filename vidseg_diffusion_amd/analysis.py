@@ -10,6 +10,7 @@ features runs on the GPU.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -133,10 +134,12 @@ def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: i
     total = 0
     poll = 4                                                            # iterations enqueued between host polls
     it = 0
+    cur_mask = (1 << R) - 1
+    slots, colrow, nslots = _compact_slots(cur_mask, R, K, dev)
     while it < max_iter:
         for _ in range(min(poll, max_iter - it)):
-            call("vidseg_lloyd_iter", ptr(x16), ptr(mean), n, C, R, K, ptr(state), 1, ptr(centers), ptr(cnorm), ptr(labels),
-                 ptr(changed), ptr(psum), ptr(pcnt), chunk, ptr(shift2), ptr(counts), st)
+            call("vidseg_lloyd_iter", ptr(x16), ptr(mean), n, C, R, K, ptr(state), ptr(slots), nslots, ptr(colrow), 1, ptr(centers),
+                 ptr(cnorm), ptr(labels), ptr(changed), ptr(psum), ptr(pcnt), chunk, ptr(shift2), ptr(counts), st)
             call("vidseg_lloyd_status", R, K, it, tol_, ptr(changed), ptr(shift2), ptr(counts), ptr(state), st)
             it += 1
         h_pin.copy_(state, non_blocking=True)
@@ -148,13 +151,19 @@ def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: i
                 "(_k_means_common.pyx:167-211) is not implemented on the device yet")
         if int(h_pin[0]) == 0:
             break
+        if int(h_pin[0]) != cur_mask:                                    # drop converged restarts from the launch grids
+            cur_mask = int(h_pin[0])
+            slots, colrow, nslots = _compact_slots(cur_mask, R, K, dev)
     strict_mask = int(h_pin[1])
     n_iter = [int(h_pin[3 + r]) for r in range(R)]
+    if os.environ.get("VIDSEG_DEBUG_KMEANS"):
+        print("kmeans n_iter per restart", n_iter, "strict mask", bin(strict_mask), "total lock-step iterations", total)
     rerun = ((1 << R) - 1) & ~strict_mask
     if rerun:                                                          # _kmeans.py:736-748
         rstate = torch.tensor([rerun], dtype=I32).to(dev)
-        call("vidseg_lloyd_iter", ptr(x16), ptr(mean), n, C, R, K, ptr(rstate), 0, ptr(centers), ptr(cnorm), ptr(labels),
-             ptr(changed), ptr(psum), ptr(pcnt), chunk, ptr(shift2), ptr(counts), st)
+        slots, colrow, nslots = _compact_slots(rerun, R, K, dev)
+        call("vidseg_lloyd_iter", ptr(x16), ptr(mean), n, C, R, K, ptr(rstate), ptr(slots), nslots, ptr(colrow), 0, ptr(centers),
+             ptr(cnorm), ptr(labels), ptr(changed), ptr(psum), ptr(pcnt), chunk, ptr(shift2), ptr(counts), st)
     ipart = torch.empty((R, (n + 255) // 256), dtype=F64, device=dev)
     inertia = torch.empty(R, dtype=F64, device=dev)
     call("vidseg_kmeans_inertia", ptr(x16), ptr(mean), n, C, R, K, ptr(centers), ptr(labels), ptr(ipart), ptr(inertia), st)
@@ -179,6 +188,14 @@ def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: i
     return res
 
 
+def _compact_slots(mask, R, K, dev):
+    """Restart ids still running (bit mask) -> (slots int32 [ns], colrow int32 [ns*K] = centre row r*K+k per compact column, ns)."""
+    ids = [r for r in range(R) if (mask >> r) & 1]
+    slots = torch.tensor(ids, dtype=I32)
+    colrow = (slots[:, None] * K + torch.arange(K, dtype=I32)[None, :]).reshape(-1).to(I32)
+    return slots.to(dev), colrow.contiguous().to(dev), len(ids)
+
+
 def _is_same_clustering(l1, l2, K):
     """sklearn/cluster/_k_means_common.pyx:314-328 (vectorised: the map l1->l2 must be a function)."""
     pair = l1.astype(np.int64) * K + l2.astype(np.int64)
@@ -196,8 +213,9 @@ def kmeans_predict(x16: torch.Tensor, centers: torch.Tensor) -> torch.Tensor:
     changed = torch.zeros(1, dtype=I32, device=dev)
     cnorm = torch.empty(K, dtype=F64, device=dev)
     one = torch.ones(1, dtype=I32, device=dev)
-    call("vidseg_lloyd_iter", ptr(x16), None, n, C, 1, K, ptr(one), 0, ptr(centers), ptr(cnorm), ptr(labels), ptr(changed),
-         None, None, 256, None, None, stream())
+    slots, colrow, _ = _compact_slots(1, 1, K, dev)
+    call("vidseg_lloyd_iter", ptr(x16), None, n, C, 1, K, ptr(one), ptr(slots), 1, ptr(colrow), 0, ptr(centers), ptr(cnorm),
+         ptr(labels), ptr(changed), None, None, 256, None, None, stream())
     return labels[0]
 
 

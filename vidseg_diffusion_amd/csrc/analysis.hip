@@ -90,6 +90,7 @@ struct RowsF64 {
     const double* base;
     int64_t nrows;
     int C;
+    const int32_t* gather = nullptr;   // optional row map (compacted restarts)
 };
 
 __device__ __forceinline__ void load_tile(double (*L)[LDP], const RowsF16& R, int64_t r0, int c0) {
@@ -119,7 +120,7 @@ __device__ __forceinline__ void load_tile(double (*L)[LDP], const RowsF64& R, in
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         double v = 0.0;
-        if (row < R.nrows && c0 + sub + j < R.C) v = R.base[row * (int64_t)R.C + c0 + sub + j];
+        if (row < R.nrows && c0 + sub + j < R.C) v = R.base[(R.gather ? (int64_t)R.gather[row] : row) * (int64_t)R.C + c0 + sub + j];
         L[sub + j][r] = v;
     }
 }
@@ -347,22 +348,25 @@ __global__ void k_center_sqnorm(const double* __restrict__ centers, int J, int C
 }
 
 __global__ void __launch_bounds__(256) k_lloyd_assign(RowsF16 X, const double* __restrict__ centers, const double* __restrict__ cn,
-                                                      int R, int K, int rpt, const unsigned* __restrict__ d_active, int32_t* __restrict__ labels,
-                                                      int32_t* __restrict__ changed) {
-    // blockIdx.y selects `rpt` restarts (rpt*K <= 64 columns).  argmin_j (|c_j|^2 - 2 x.c_j), first min wins.
+                                                      int K, int rpt, const unsigned* __restrict__ d_active,
+                                                      const int32_t* __restrict__ slots, int nslots, const int32_t* __restrict__ colrow,
+                                                      int32_t* __restrict__ labels, int32_t* __restrict__ changed) {
+    // blockIdx.y selects `rpt` compacted restart slots (rpt*K <= 64 columns); slots[] lists the restarts that were still
+    // running at the last host poll, d_active is the device truth.  argmin_j (|c_j|^2 - 2 x.c_j), first min wins.
     __shared__ double LA[KC][LDP];
     __shared__ double LB[KC][LDP];
     __shared__ double LD[TS][LDP];
     const unsigned active = *d_active;
-    const int rbase = blockIdx.y * rpt;
+    const int sbase = blockIdx.y * rpt;
+    const int nloc = min(rpt, nslots - sbase);
     unsigned need = 0;
-    for (int q = 0; q < rpt; ++q)
-        if (rbase + q < R && ((active >> (rbase + q)) & 1u)) need = 1;
+    for (int q = 0; q < nloc; ++q)
+        if ((active >> slots[sbase + q]) & 1u) need = 1;
     if (!need) return;
     const int64_t n = X.nrows;
     const int64_t s0 = (int64_t)blockIdx.x * TS;
-    const int ncol = min(rpt, R - rbase) * K;
-    RowsF64 B{centers + (int64_t)rbase * K * X.C, ncol, X.C};
+    const int ncol = nloc * K;
+    RowsF64 B{centers, ncol, X.C, colrow + sbase * K};
     double acc[4][4];
     tile_gemm(acc, LA, LB, X, s0, B, 0, X.C);
 #pragma unroll
@@ -371,14 +375,14 @@ __global__ void __launch_bounds__(256) k_lloyd_assign(RowsF16 X, const double* _
         for (int j = 0; j < 4; ++j) {
             const int col = TCOL(i, j);
             double d = 0.0;
-            if (col < ncol) d = cn[rbase * K + col] + (-2.0 * acc[i][j]);
+            if (col < ncol) d = cn[colrow[sbase * K + col]] + (-2.0 * acc[i][j]);
             LD[TROW(i, j)][col] = d;
         }
     __syncthreads();
     const int s = threadIdx.x & 63, q = threadIdx.x >> 6;      // 4 restarts handled per pass
-    for (int qq = q; qq < rpt; qq += 4) {
-        const int r = rbase + qq;
-        if (r >= R || !((active >> r) & 1u) || s0 + s >= n) continue;
+    for (int qq = q; qq < nloc; qq += 4) {
+        const int r = slots[sbase + qq];
+        if (!((active >> r) & 1u) || s0 + s >= n) continue;
         const double* row = &LD[s][qq * K];
         double best = row[0];
         int lab = 0;
@@ -394,10 +398,11 @@ __global__ void __launch_bounds__(256) k_lloyd_assign(RowsF16 X, const double* _
 }
 
 __global__ void __launch_bounds__(256) k_lloyd_accum(RowsF16 X, const int32_t* __restrict__ labels, int R, int K,
-                                                     const unsigned* __restrict__ d_active, int S, double* __restrict__ psum, int32_t* __restrict__ pcnt, int nblk) {
+                                                     const unsigned* __restrict__ d_active, const int32_t* __restrict__ slots, int S,
+                                                     double* __restrict__ psum, int32_t* __restrict__ pcnt, int nblk) {
     // block (chunk, restart): fixed-order partial sums of the chunk's samples per cluster.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int r = blockIdx.y;
+    const int r = slots[blockIdx.y];
     if (!((*d_active >> r) & 1u)) return;
     const int C = X.C;
     constexpr int CCH = 256;                                     // channels per pass, one per thread
@@ -430,10 +435,11 @@ __global__ void __launch_bounds__(256) k_lloyd_accum(RowsF16 X, const int32_t* _
 }
 
 __global__ void __launch_bounds__(256) k_lloyd_update(const double* __restrict__ psum, const int32_t* __restrict__ pcnt, int nblk,
-                                                      int R, int K, int C, const unsigned* __restrict__ d_active, double* __restrict__ centers,
+                                                      int R, int K, int C, const unsigned* __restrict__ d_active, const int32_t* __restrict__ slots,
+                                                      double* __restrict__ centers,
                                                       double* __restrict__ shift2, int32_t* __restrict__ counts) {
     // block (k, r): new centre = (sum over chunks, ascending) * (1/count); shift2 = |new-old|^2
-    const int k = blockIdx.x, r = blockIdx.y;
+    const int k = blockIdx.x, r = slots[blockIdx.y];
     if (!((*d_active >> r) & 1u)) return;
     __shared__ double red[256];
     int cnt = 0;
@@ -956,14 +962,17 @@ int vidseg_gather_rows_f64(const void* x16, const double* mean, int C, const int
 // One Lloyd iteration for the restarts in `active`: E-step (labels updated in place, changed[r] += #changes),
 // M-step (fixed-order partial sums), centres updated in place, shift2[r][k] and counts[r][k] written.
 int vidseg_lloyd_iter(const void* x16, const double* mean, int64_t n, int C, int R, int K, const unsigned* d_active,
-                      int update_centers, double* centers, double* cnorm, int32_t* labels, int32_t* changed, double* psum,
-                      int32_t* pcnt, int chunk, double* shift2, int32_t* counts, hipStream_t st) {
-    VS_REQUIRE(K >= 1 && K <= 64 && R >= 1 && R <= 29, "lloyd_iter: K=%d R=%d unsupported", K, R);
+                      const int32_t* slots, int nslots, const int32_t* colrow, int update_centers, double* centers, double* cnorm,
+                      int32_t* labels, int32_t* changed, double* psum, int32_t* pcnt, int chunk, double* shift2, int32_t* counts,
+                      hipStream_t st) {
+    // slots[nslots]: restart ids to process (compacted by the host at its last poll); colrow[nslots*K]: centre row
+    // (r*K + k) of every compacted column.
+    VS_REQUIRE(K >= 1 && K <= 64 && R >= 1 && R <= 29 && nslots >= 1 && nslots <= R, "lloyd_iter: K=%d R=%d nslots=%d", K, R, nslots);
     RowsF16 X{(const f16*)x16, nullptr, mean, n, C};
     const int rpt = 64 / K;
     k_center_sqnorm<<<dim3((R * K + 3) / 4), 256, 0, st>>>(centers, R * K, C, cnorm);
-    k_lloyd_assign<<<dim3((unsigned)cdiv64(n, TS), (R + rpt - 1) / rpt), 256, 0, st>>>(X, centers, cnorm, R, K, rpt, d_active, labels,
-                                                                                    changed);
+    k_lloyd_assign<<<dim3((unsigned)cdiv64(n, TS), (nslots + rpt - 1) / rpt), 256, 0, st>>>(X, centers, cnorm, K, rpt, d_active, slots,
+                                                                                         nslots, colrow, labels, changed);
     VS_CHECK_LAUNCH("lloyd_assign");
     if (update_centers) {
         const int nblk = (int)cdiv64(n, chunk);
@@ -974,9 +983,9 @@ int vidseg_lloyd_iter(const void* x16, const double* mean, int64_t n, int C, int
             (void)hipFuncSetAttribute((const void*)k_lloyd_accum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        k_lloyd_accum<<<dim3(nblk, R), 256, lds, st>>>(X, labels, R, K, d_active, chunk, psum, pcnt, nblk);
+        k_lloyd_accum<<<dim3(nblk, nslots), 256, lds, st>>>(X, labels, R, K, d_active, slots, chunk, psum, pcnt, nblk);
         VS_CHECK_LAUNCH("lloyd_accum");
-        k_lloyd_update<<<dim3(K, R), 256, 0, st>>>(psum, pcnt, nblk, R, K, C, d_active, centers, shift2, counts);
+        k_lloyd_update<<<dim3(K, nslots), 256, 0, st>>>(psum, pcnt, nblk, R, K, C, d_active, slots, centers, shift2, counts);
         VS_CHECK_LAUNCH("lloyd_update");
     }
     return VS_OK;
