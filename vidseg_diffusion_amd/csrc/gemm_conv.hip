@@ -19,6 +19,7 @@ struct GemmParams {
     const bf16_t* x0;
     const bf16_t* x1;        // second concat source or nullptr
     int C0, C1;              // channels of each source (Cin = C0 + C1)
+    long long x0_bytes, x1_bytes;   // extents of the two sources (buffer descriptors: reads beyond them return 0)
     int Hin, Win;            // stored input height/width (conv) ; unused for ksize == 1
     int Hout, Wout;
     int ksize, stride, up;   // ksize 1 or 3; stride 1/2; up 1/2 (nearest upsample of the input before the conv)
@@ -58,6 +59,134 @@ __device__ __forceinline__ long long tap_row(const GemmParams& p, long long m) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------
+// Shared epilogue of the MFMA GEMM kernels: accumulators of a 64 x (NJ*32) wave tile -> global memory.
+// `wcol_base` = first GEMM column of the wave, `mrow_base` = first row of the wave.
+// Values leave the MFMA accumulators in a column-per-lane layout (2-byte scattered stores).  They are staged through
+// a PER-WAVE LDS tile as fp32 (same rounding points as a direct store), 32 rows x 64 columns at a time, so that every
+// lane then owns 8 consecutive columns of one row and all global traffic of the epilogue (residual, out, taps,
+// split-K partials) is 16 bytes per lane.  Only wave-level ordering is needed inside (LDS executes a wave's
+// instructions in order); the one block barrier separates the main loop's LDS reads from the staging writes.
+// ---------------------------------------------------------------------------------------------
+template <int NJ>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][NJ], char* smem, long long mrow_base, int wcol_base,
+                                              int lane, int wave, int split) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    constexpr int EP_LD = 68;                                  // fp32 row stride of the staging tile (64 + 4 pad)
+    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
+    const bool geglu = p.act == 2;
+    const int nout = geglu ? p.N / 2 : p.N;
+    const bool fin = p.ksplit <= 1;                            // split-K partials carry no bias/emb/activation
+    __syncthreads();                                           // main-loop LDS reads are done
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int g = 0; g < (NJ + 1) / 2; ++g) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const bool two = 2 * g + 1 < NJ;
+            const int wcol0 = wcol_base + g * 64;              // first GEMM column of this 64-column group
+            const int ncols = (geglu || !two) ? 32 : 64;       // staged columns per row
+            const int ocol0 = geglu ? wcol0 / 2 : wcol0;       // first OUTPUT column of the group
+            // ---- phase 1: accumulators (+bias, +emb vector, activation) -> LDS fp32 [32][ncols]
+            if (geglu) {
+                if constexpr (NJ % 2 == 0) {
+                    const bool cok = (wcol0 + 32 + l31) < p.N;
+                    const float bx = (p.bias && cok) ? p.bias[wcol0 + l31] : 0.f;
+                    const float bg = (p.bias && cok) ? p.bias[wcol0 + 32 + l31] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const float xv = acc[i][2 * g][r] + bx, gv = acc[i][2 * g + 1][r] + bg;
+                        stage[row * EP_LD + l31] = xv * gelu_erf(gv);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    if (2 * g + jj >= NJ) continue;
+                    const int n = wcol0 + jj * 32 + l31;
+                    const bool cok = n < p.N;
+                    const float bv = (p.bias && cok && fin) ? p.bias[n] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        float v = acc[i][(2 * g + jj) < NJ ? (2 * g + jj) : 0][r] + bv;
+                        if (p.rowvec && cok && fin) {
+                            const long long m = mrow_base + i * 32 + row;
+                            if (m < p.M) v += p.rowvec[(m / p.rows_per_sample) * p.rv_stride + n];
+                        }
+                        if (p.act == 1 && fin) v = silu_f(v);
+                        stage[row * EP_LD + jj * 32 + l31] = v;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            // ---- phase 2: 8 columns per lane, coalesced 16-byte global accesses
+            const int lpr = ncols / 8;                         // lanes per row: 8 or 4
+            const int rpp = 64 / lpr;                          // rows per pass
+            for (int r0 = 0; r0 < 32; r0 += rpp) {
+                const int row = r0 + lane / lpr, c8 = (lane % lpr) * 8;
+                const long long m = mrow_base + i * 32 + row;
+                const int n = ocol0 + c8;                      // output column of element 0
+                if (m < p.M && n < nout) {
+                    float v[8];
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + c8);
+                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + c8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = lo[e];
+                        v[4 + e] = hi4[e];
+                    }
+                    if (p.rowadd && fin) {
+                        const float ra = p.rowadd[m];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += ra;
+                    }
+                    if (!fin) {
+                        float* wp = p.ws + ((long long)split * p.M + m) * p.N + n;
+                        f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+                        *reinterpret_cast<f32x4*>(wp) = a;
+                        *reinterpret_cast<f32x4*>(wp + 4) = b;
+                        continue;
+                    }
+                    if (p.tap && n < p.tap_cols) {
+                        f16x8 t;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
+                        *reinterpret_cast<f16x8*>(p.tap + tap_row(p, m) * p.tap_ld + n) = t;
+                    }
+                    if (p.tap2 && n >= p.tap_cols && n < 2 * p.tap_cols) {
+                        f16x8 t;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
+                        *reinterpret_cast<f16x8*>(p.tap2 + tap_row(p, m) * p.tap_ld + (n - p.tap_cols)) = t;
+                    }
+                    if (p.residual) {
+                        const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + m * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
+                    }
+                    if (p.out) {
+                        bf16x8_t o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(v[e]);
+                        *reinterpret_cast<bf16x8_t*>(p.out + m * p.ldo + n) = o;
+                    }
+                    if (p.out_f32) {
+                        f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+                        *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldo + n) = a;
+                        *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldo + n + 4) = b;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
 
 template <int BM, int BN>
 __global__ void __launch_bounds__(256, 2) k_gemm_conv(GemmParams p) {
@@ -257,112 +386,335 @@ __global__ void __launch_bounds__(256, 2) k_gemm_conv(GemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue -------------------------------------------------------------------------------
-    // Values leave the MFMA accumulators in a column-per-lane layout (2-byte scattered stores).  Stage them
-    // through LDS as fp32 (same rounding points as a direct store) so that every lane reads 8 consecutive
-    // columns of one row and all global traffic of the epilogue (residual, out, taps) is 16 bytes per lane.
-    constexpr int EP_LD = 68;                                  // fp32 row stride of the staging tile (64 + 4 pad)
-    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
-    const bool geglu = p.act == 2;
-    const int wcol0 = n0 + wn * 64;                            // first GEMM column of this wave
-    const int ncols = geglu ? 32 : 64;                         // staged columns per row
-    const int ocol0 = geglu ? wcol0 / 2 : wcol0;               // first OUTPUT column of this wave
-    const int nout = geglu ? p.N / 2 : p.N;
-    __syncthreads();                                           // main-loop LDS reads are done
+    gemm_epilogue<2>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, lane, wave, split);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant: 128x128 block tile, BK = 32, operands go global -> LDS directly (buffer_load ... lds, 16 B per
+// lane, 1 KiB per wave instruction) with the bank swizzle applied on the SOURCE side; out-of-range buffer offsets
+// (padding pixels, rows >= M, weight rows >= N) land as zeros, so im2col needs no branches.  No staging VGPRs and
+// 36 KiB of LDS per block -> four resident blocks (16 waves) per CU instead of two.
+// LDS image of a [128][32] bf16 tile: row r at byte r*64, logical 16-byte chunk c stored at slot c ^ ((r >> 2) & 3)
+// (conflict-free for ds_read_b128 MFMA fragment reads).
+// ---------------------------------------------------------------------------------------------
+#define DK 32
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__global__ void __launch_bounds__(256, 4) k_gemm_dma(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = 128 * DK * 2;               // 8 KiB per operand tile
+    constexpr int BUF = 2 * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long tiles_m = (p.M + 127) / 128;
+    const int tiles_n = (p.N + 127) / 128;
+    const long long nwg = tiles_m * tiles_n;
+    const int split = p.ksplit > 1 ? (int)(blockIdx.x / nwg) : 0;
+    long long bid = p.ksplit > 1 ? (long long)(blockIdx.x % nwg) : (long long)blockIdx.x;
+    {
+        const long long q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long long tm = bid / tiles_n;
+    const int tn = (int)(bid % tiles_n);
+    const long long m0 = tm * 128;
+    const int n0 = tn * 128;
+
+    constexpr unsigned OOB = 0xF0000000u;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w), 0, (int)((long long)p.N * p.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x0), 0, (int)p.x0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x1 ? p.x1 : p.x0), 0, (int)p.x1_bytes, 0x00020000);
+
+    // this lane's two A rows and two B rows (DMA pieces 2*wave and 2*wave+1, 16 rows each, 4 lanes per row)
+    const int Cin = p.C0 + p.C1;
+    const int HWo = p.Hout * p.Wout;
+    const int upsh = p.up - 1;
+    const int Hup = p.Hin << upsh, Wup = p.Win << upsh;
+    int a_base[2], a_ih0[2], a_iw0[2];
+    bool a_ok[2];
+    unsigned a_sw[2], b_off[2];                        // swizzled chunk byte offset inside the 64-byte K run
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        // ---- phase 1: accumulators (+bias, +emb vector, activation) -> LDS fp32 [32][ncols]
-        if (geglu) {
-            const bool cok = (wcol0 + 32 + l31) < p.N;
-            const float bx = (p.bias && cok) ? p.bias[wcol0 + l31] : 0.f;
-            const float bg = (p.bias && cok) ? p.bias[wcol0 + 32 + l31] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float xv = acc[i][0][r] + bx, gv = acc[i][1][r] + bg;
-                stage[row * EP_LD + l31] = xv * gelu_erf(gv);
-            }
+        const int r = (2 * wave + i) * 16 + (lane >> 2);
+        const unsigned csw = (unsigned)(((lane & 3) ^ ((r >> 2) & 3)) * 16);
+        a_sw[i] = csw;
+        const long long m = m0 + r;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? (int)m : 0;
+        if (p.ksize == 1) {
+            a_base[i] = mm;
+            a_ih0[i] = a_iw0[i] = 0;
+        } else if (p.tmode) {
+            a_base[i] = mm;
+            a_ih0[i] = (mm / HWo) % p.T;
+            a_iw0[i] = 0;
         } else {
+            const int b = mm / HWo, rem = mm - b * HWo;
+            const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
+            a_base[i] = b * p.Hin * p.Win;
+            a_ih0[i] = oh * p.stride - 1;
+            a_iw0[i] = ow * p.stride - 1;
+        }
+        const int n = n0 + r;
+        b_off[i] = n < p.N ? (unsigned)((long long)n * p.K * 2) + csw : OOB;
+    }
+    const int nk_all = p.K / DK;
+    const int ks_begin = p.ksplit > 1 ? (int)((long long)nk_all * split / p.ksplit) : 0;
+    const int ks_end = p.ksplit > 1 ? (int)((long long)nk_all * (split + 1) / p.ksplit) : nk_all;
+    int ld_k = ks_begin * DK;
+    int ld_tap = ld_k / Cin, ld_c0 = ld_k % Cin;
+    unsigned a_off[2] = {OOB, OOB};
+    bool a_second = false, first = true;
+    auto issue = [&](int buf) {
+        const int tap = ld_tap, c0 = ld_c0, k0 = ld_k;
+        if (first || c0 == 0 || c0 == p.C0) {
+            first = false;
+            a_second = c0 >= p.C0;
+            const int Cs = a_second ? p.C1 : p.C0;
+            const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int pix;
+                bool ok = a_ok[i];
+                if (p.ksize == 1) {
+                    pix = a_base[i];
+                } else if (p.tmode) {
+                    const int tt = a_ih0[i] + tap - 1;
+                    ok = ok && tt >= 0 && tt < p.T;
+                    pix = a_base[i] + (tap - 1) * HWo;
+                } else {
+                    const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                    ok = ok && (unsigned)ih < (unsigned)Hup && (unsigned)iw < (unsigned)Wup;
+                    pix = a_base[i] + (ih >> upsh) * p.Win + (iw >> upsh);
+                }
+                a_off[i] = ok ? (unsigned)(pix * Cs) * 2u + a_sw[i] : OOB;
+            }
+        }
+        const unsigned cbyte = (unsigned)(c0 >= p.C0 ? c0 - p.C0 : c0) * 2u;
+        ld_k += DK;
+        ld_c0 += DK;
+        if (ld_c0 >= Cin) {
+            ld_c0 = 0;
+            ld_tap++;
+        }
+        char* A = smem + buf * BUF;
+        char* B = A + TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = 2 * wave + i;
+            if (a_second)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)(A + piece * 1024), 16, (int)(a_off[i] + cbyte), 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)(A + piece * 1024), 16, (int)(a_off[i] + cbyte), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(B + piece * 1024), 16, (int)(b_off[i] + (unsigned)k0 * 2u), 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int l31 = lane & 31, hi = lane >> 5;
+    auto compute = [&](int buf) {
+        const char* A = smem + buf * BUF;
+        const char* B = A + TILE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t fa[2], fb[2];
+            const int ch = s * 2 + hi;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wm * 64 + i * 32 + l31;
+                fa[i] = *reinterpret_cast<const bf16x8_t*>(A + r * 64 + ((ch ^ ((r >> 2) & 3)) << 4));
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int n = wcol0 + j * 32 + l31;
-                const bool cok = n < p.N;
-                const bool fin = p.ksplit <= 1;                 // split-K partials carry no bias/emb/activation
-                const float bv = (p.bias && cok && fin) ? p.bias[n] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    float v = acc[i][j][r] + bv;
-                    if (p.rowvec && cok && fin) {
-                        const long long m = m0 + wm * 64 + i * 32 + row;
-                        if (m < p.M) v += p.rowvec[(m / p.rows_per_sample) * p.rv_stride + n];
-                    }
-                    if (p.act == 1 && fin) v = silu_f(v);
-                    stage[row * EP_LD + j * 32 + l31] = v;
-                }
+                const int r = wn * 64 + j * 32 + l31;
+                fb[j] = *reinterpret_cast<const bf16x8_t*>(B + r * 64 + ((ch ^ ((r >> 2) & 3)) << 4));
             }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
-        // ---- phase 2: 8 columns per lane, coalesced 16-byte global accesses
-        const int lpr = ncols / 8;                             // lanes per row: 8 (or 4 for GEGLU)
-        const int rpp = 64 / lpr;                              // rows per pass
-        for (int r0 = 0; r0 < 32; r0 += rpp) {
-            const int row = r0 + lane / lpr, c8 = (lane % lpr) * 8;
-            const long long m = m0 + wm * 64 + i * 32 + row;
-            const int n = ocol0 + c8;                          // output column of element 0
-            if (m < p.M && n < nout) {
-                float v[8];
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + c8);
-                const f32x4 hi4 = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + c8 + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = lo[e];
-                    v[4 + e] = hi4[e];
-                }
-                if (p.rowadd && p.ksplit <= 1) {
-                    const float ra = p.rowadd[m];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += ra;
-                }
-                if (p.ksplit > 1) {
-                    float* wp = p.ws + ((long long)split * p.M + m) * p.N + n;
-                    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-                    *reinterpret_cast<f32x4*>(wp) = a;
-                    *reinterpret_cast<f32x4*>(wp + 4) = b;
-                    continue;
-                }
-                if (p.tap && n < p.tap_cols) {
-                    f16x8 t;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
-                    *reinterpret_cast<f16x8*>(p.tap + tap_row(p, m) * p.tap_ld + n) = t;
-                }
-                if (p.tap2 && n >= p.tap_cols && n < 2 * p.tap_cols) {
-                    f16x8 t;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
-                    *reinterpret_cast<f16x8*>(p.tap2 + tap_row(p, m) * p.tap_ld + (n - p.tap_cols)) = t;
-                }
-                if (p.residual) {
-                    const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + m * p.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
-                }
-                if (p.out) {
-                    bf16x8_t o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(v[e]);
-                    *reinterpret_cast<bf16x8_t*>(p.out + m * p.ldo + n) = o;
-                }
-                if (p.out_f32) {
-                    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-                    *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldo + n) = a;
-                    *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldo + n + 4) = b;
-                }
-            }
-        }
+    };
+    const int nk = ks_end - ks_begin;
+    issue(0);
+    __syncthreads();                                   // LDS-DMA outstanding -> the barrier carries s_waitcnt vmcnt(0)
+    for (int ks = 0; ks + 1 < nk; ++ks) {
+        issue((ks + 1) & 1);
+        compute(ks & 1);
         __syncthreads();
     }
+    compute((nk - 1) & 1);
+    gemm_epilogue<2>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, lane, wave, split);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Big-tile LDS-DMA variant: 256 x (NJ*64) block tile (NJ = 4 -> 256x256, NJ = 5 -> 256x320 for the N = 320/640/1280
+// layers of the UNet without padding waste), BK = 64, 8 waves as 4(M) x 2(N), wave tile 64 x (NJ*32), one block per
+// CU.  The 128x128 kernels read 1 byte of operand through the CU's vector-memory path (64 B/clk) per 64 MFMA flops --
+// exactly the MFMA rate, so they cannot pass ~50 % of peak; this tile reads 0.45-0.5 bytes per 64 flops.
+// LDS image per operand tile: [rows][64] bf16, 128-byte rows, 16-byte chunk c of row r stored at slot c ^ ((r>>1)&7).
+// ---------------------------------------------------------------------------------------------
+template <int NJ>
+__global__ void __launch_bounds__(512, 1) k_gemm_big(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BN = NJ * 64;
+    constexpr int A_BYTES = 256 * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long tiles_m = (p.M + 255) / 256;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const long long nwg = tiles_m * tiles_n;
+    const int split = p.ksplit > 1 ? (int)(blockIdx.x / nwg) : 0;
+    long long bid = p.ksplit > 1 ? (long long)(blockIdx.x % nwg) : (long long)blockIdx.x;
+    {
+        const long long q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long long tm = bid / tiles_n;
+    const int tn = (int)(bid % tiles_n);
+    const long long m0 = tm * 256;
+    const int n0 = tn * BN;
+
+    constexpr unsigned OOB = 0xF0000000u;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w), 0, (int)((long long)p.N * p.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x0), 0, (int)p.x0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x1 ? p.x1 : p.x0), 0, (int)p.x1_bytes, 0x00020000);
+
+    // DMA pieces are 8 rows x 128 B (one 1-KiB wave instruction); wave w stages A pieces 4w..4w+3 and B pieces NJ*w..
+    const int Cin = p.C0 + p.C1;
+    const int HWo = p.Hout * p.Wout;
+    const int upsh = p.up - 1;
+    const int Hup = p.Hin << upsh, Wup = p.Win << upsh;
+    const int lrow = lane >> 3, lch = lane & 7;
+    int a_base[4], a_ih0[4], a_iw0[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 32 + i * 8 + lrow;
+        const long long m = m0 + r;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? (int)m : 0;
+        if (p.ksize == 1) {
+            a_base[i] = mm;
+            a_ih0[i] = a_iw0[i] = 0;
+        } else if (p.tmode) {
+            a_base[i] = mm;
+            a_ih0[i] = (mm / HWo) % p.T;
+            a_iw0[i] = 0;
+        } else {
+            const int b = mm / HWo, rem = mm - b * HWo;
+            const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
+            a_base[i] = b * p.Hin * p.Win;
+            a_ih0[i] = oh * p.stride - 1;
+            a_iw0[i] = ow * p.stride - 1;
+        }
+    }
+    unsigned b_off[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        const int r = wave * (NJ * 8) + i * 8 + lrow;
+        const int n = n0 + r;
+        b_off[i] = n < p.N ? (unsigned)((long long)n * p.K * 2) + (unsigned)((lch ^ ((r >> 1) & 7)) * 16) : OOB;
+    }
+    const int nk_all = p.K / 64;
+    const int ks_begin = p.ksplit > 1 ? (int)((long long)nk_all * split / p.ksplit) : 0;
+    const int ks_end = p.ksplit > 1 ? (int)((long long)nk_all * (split + 1) / p.ksplit) : nk_all;
+    int ld_k = ks_begin * 64;
+    int ld_tap = ld_k / Cin, ld_c0 = ld_k % Cin;
+    unsigned a_off[4] = {OOB, OOB, OOB, OOB};
+    bool a_second = false, first = true;
+    auto issue = [&](int buf) {
+        const int tap = ld_tap, c0 = ld_c0, k0 = ld_k;
+        if (first || c0 == 0 || c0 == p.C0) {
+            first = false;
+            a_second = c0 >= p.C0;
+            const int Cs = a_second ? p.C1 : p.C0;
+            const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int pix;
+                bool ok = a_ok[i];
+                if (p.ksize == 1) {
+                    pix = a_base[i];
+                } else if (p.tmode) {
+                    const int tt = a_ih0[i] + tap - 1;
+                    ok = ok && tt >= 0 && tt < p.T;
+                    pix = a_base[i] + (tap - 1) * HWo;
+                } else {
+                    const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                    ok = ok && (unsigned)ih < (unsigned)Hup && (unsigned)iw < (unsigned)Wup;
+                    pix = a_base[i] + (ih >> upsh) * p.Win + (iw >> upsh);
+                }
+                const int r = i * 8 + lrow;                    // (wave*32 is a multiple of 16: no effect on (r>>1)&7)
+                a_off[i] = ok ? (unsigned)(pix * Cs) * 2u + (unsigned)((lch ^ ((r >> 1) & 7)) * 16) : OOB;
+            }
+        }
+        const unsigned cbyte = (unsigned)(c0 >= p.C0 ? c0 - p.C0 : c0) * 2u;
+        ld_k += 64;
+        ld_c0 += 64;
+        if (ld_c0 >= Cin) {
+            ld_c0 = 0;
+            ld_tap++;
+        }
+        char* A = smem + buf * BUF + wave * 4096;
+        char* B = smem + buf * BUF + A_BYTES + wave * (NJ * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (a_second)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)(A + i * 1024), 16, (int)(a_off[i] + cbyte), 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)(A + i * 1024), 16, (int)(a_off[i] + cbyte), 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NJ; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(B + i * 1024), 16, (int)(b_off[i] + (unsigned)k0 * 2u), 0, 0, 0);
+    };
+
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int sw = (l31 >> 1) & 7;                             // every fragment row is l31 + a multiple of 32
+    const int arow = (wm * 64 + l31) * 128, brow = (wn * (NJ * 32) + l31) * 128;
+    auto compute = [&](int buf) {
+        const char* A = smem + buf * BUF + arow;
+        const char* B = smem + buf * BUF + A_BYTES + brow;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8_t fa[2], fb[NJ];
+            const int co = ((s * 2 + hi) ^ sw) << 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(A + i * 4096 + co);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(B + j * 4096 + co);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    const int nk = ks_end - ks_begin;
+    issue(0);
+    __syncthreads();
+    for (int ks = 0; ks + 1 < nk; ++ks) {
+        issue((ks + 1) & 1);
+        compute(ks & 1);
+        __syncthreads();
+    }
+    compute((nk - 1) & 1);
+    gemm_epilogue<NJ>(p, acc, smem, m0 + wm * 64, n0 + wn * (NJ * 32), lane, wave, split);
 }
 
 // Split-K finish: sum the fp32 partials in split order (deterministic), then the same epilogue as above.
@@ -496,6 +848,8 @@ struct GemmProf {
     size_t used = 0;
     double flops = 0.0;
     long long launches = 0;
+    struct Shape { long long M; int N, K, ksize, up, stride, act, ksplit; };
+    std::vector<Shape> shapes;      // one per event pair
 };
 static GemmProf g_prof;
 
@@ -515,6 +869,7 @@ int vidseg_gemm_profile_begin(void) {
     g_prof.used = 0;
     g_prof.flops = 0.0;
     g_prof.launches = 0;
+    g_prof.shapes.clear();
     return VS_OK;
 }
 
@@ -528,6 +883,11 @@ int vidseg_gemm_profile_end(double* out) {
         if (e == hipSuccess) e = hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
         if (e != hipSuccess) VS_FAIL(VS_ERR_HIP, "gemm_profile_end: %s", hipGetErrorString(e));
         ms += t;
+        if (getenv("VIDSEG_GEMM_SHAPES") && i / 2 < g_prof.shapes.size()) {
+            const GemmProf::Shape& h = g_prof.shapes[i / 2];
+            fprintf(stderr, "GEMMSHAPE M=%lld N=%d K=%d ks=%d up=%d st=%d act=%d split=%d us=%.1f\n", h.M, h.N, h.K, h.ksize, h.up, h.stride,
+                    h.act, h.ksplit, t * 1e3);
+        }
     }
     out[0] = ms;
     out[1] = g_prof.flops;
@@ -572,38 +932,76 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         const long long tiles = ((p.M + 255) / 256) * ((p.N + 63) / 64);
         k_gemm_conv<256, 64><<<dim3((unsigned)tiles), 256, 2 * (256 + 64) * BK * 2, st>>>(p);
     } else {
-        const long long tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-        // too few tiles to fill 256 CUs x 2 blocks and a long K: split K, fp32 partials, deterministic finish
         const int nk = p.K / BK;
-        static int nosplit = -1;
-        if (nosplit < 0) { const char* e = getenv("VIDSEG_NO_SPLITK"); nosplit = e ? atoi(e) : 0; }
-        if (!nosplit && nk >= 40 && p.act != 2 && g_ws && tiles < 2048) {
-            // 256 CUs x 2 resident blocks = 512 slots; blocks run in rounds, so the last round's fill decides the
-            // efficiency.  Pick the split that maximises fill / (1 + cost of writing+reading the fp32 partials).
-            double best = 0.0;
+        static int nosplit = -1, use_dma = -1, big_mode = -1;
+        if (nosplit < 0) {
+            const char* e = getenv("VIDSEG_NO_SPLITK");
+            nosplit = e ? atoi(e) : 0;
+            e = getenv("VIDSEG_GEMM_DMA");
+            use_dma = e ? atoi(e) : 1;
+            e = getenv("VIDSEG_GEMM_BIG");                       // 0 never, 1 auto, 2 whenever legal
+            big_mode = e ? atoi(e) : 1;
+            (void)hipFuncSetAttribute((const void*)k_gemm_dma, hipFuncAttributeMaxDynamicSharedMemorySize, 36864);
+            (void)hipFuncSetAttribute((const void*)k_gemm_big<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
+            (void)hipFuncSetAttribute((const void*)k_gemm_big<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
+        }
+        // Blocks run in rounds over the resident slots, so the last round's fill decides the efficiency.  Pick the K
+        // split that maximises fill / (1 + cost of writing+reading the fp32 partials); deterministic finish kernel.
+        auto pick_split = [&](long long tiles, int slots) {
             int bestS = 1;
+            if (nosplit || nk < 40 || p.act == 2 || !g_ws || tiles >= 4 * slots) return bestS;
+            double best = 0.0;
             for (int S = 1; S <= 8; ++S) {
                 if (S > 1 && (nk / S < 8 || (long long)S * p.M * p.N > g_ws_floats)) break;
                 const long long items = tiles * S;
-                const double fill = (double)items / (double)(((items + 511) / 512) * 512);
+                const double fill = (double)items / (double)(((items + slots - 1) / slots) * slots);
                 const double score = fill / (1.0 + (S > 1 ? 480.0 * S / (double)p.K : 0.0));
                 if (score > best * 1.03) {
                     best = score;
                     bestS = S;
                 }
             }
-            if (bestS > 1) {
-                p.ksplit = bestS;
-                p.ws = g_ws;
-            }
+            return bestS;
+        };
+        const long long tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+        // big tile: 256 x 320 when that divides N better (320/640/960/1280/1920 ...), else 256 x 256 (GEGLU needs pairs)
+        const int NJ = (p.act != 2 && ((p.N + 319) / 320) * 320 <= ((p.N + 255) / 256) * 256) ? 5 : 4;
+        const long long tiles_b = ((p.M + 255) / 256) * ((p.N + NJ * 64 - 1) / (NJ * 64));
+        bool big = false;
+        int S = 1;
+        if (big_mode && p.M >= 256) {
+            S = pick_split(tiles_b, 256);
+            const long long items = tiles_b * S;
+            const double fill = (double)items / (double)(((items + 255) / 256) * 256);
+            // measured per shape (tools/dbg/shape_summary.py): the big tile wins once the K loop is long enough to amortise its
+            // unoverlapped prologue/epilogue (one block per CU) and the grid fills the chip
+            big = big_mode == 2 || (fill >= 0.70 && p.K >= 960 && (S == 1 || p.K / S >= 1440));
         }
-        k_gemm_conv<128, 128><<<dim3((unsigned)(tiles * p.ksplit)), 256, 2 * (128 + 128) * BK * 2, st>>>(p);
+        if (big) {
+            p.ksplit = S;
+            p.ws = S > 1 ? g_ws : nullptr;
+            if (NJ == 5)
+                k_gemm_big<5><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 320) * 128, st>>>(p);
+            else
+                k_gemm_big<4><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 256) * 128, st>>>(p);
+        } else {
+            S = pick_split(tiles, 512);
+            p.ksplit = S;
+            p.ws = S > 1 ? g_ws : nullptr;
+            if (use_dma)
+                k_gemm_dma<<<dim3((unsigned)(tiles * S)), 256, 36864, st>>>(p);
+            else
+                k_gemm_conv<128, 128><<<dim3((unsigned)(tiles * S)), 256, 2 * (128 + 128) * BK * 2, st>>>(p);
+        }
         if (p.ksplit > 1) {
             const long long n8 = p.M * (p.N / 8);
             k_splitk_finish<<<dim3((unsigned)((n8 + 255) / 256)), 256, 0, st>>>(p);
         }
     }
-    if (g_prof.on) (void)hipEventRecord(prof_event(), st);
+    if (g_prof.on) {
+        (void)hipEventRecord(prof_event(), st);
+        g_prof.shapes.push_back({p.M, p.N, p.K, p.ksize, p.up, p.stride, p.act, p.ksplit});
+    }
     VS_CHECK_LAUNCH("gemm_conv");
     return VS_OK;
 }
@@ -626,6 +1024,8 @@ int vidseg_linear_bf16(const void* a0, const void* a1, int C0, int C1, long long
     p.N = N;
     p.K = p.C0 + p.C1;
     p.M = M;
+    p.x0_bytes = M * p.C0 * 2;
+    p.x1_bytes = M * p.C1 * 2;
     p.bias = bias;
     p.rowvec = rowvec;
     p.rv_stride = rv_stride;
@@ -659,6 +1059,7 @@ int vidseg_linear_bf16_ttap(const void* a0, long long M, int C0, const void* w, 
     p.N = N;
     p.K = C0;
     p.M = M;
+    p.x0_bytes = M * C0 * 2;
     p.rows_per_sample = 1;
     p.out = (bf16_t*)out;
     p.ldo = ldo;
@@ -690,6 +1091,7 @@ int vidseg_conv_temporal3_bf16(const void* x, int C, int BT, int HW, int T, cons
     p.N = Cout;
     p.K = 3 * C;
     p.M = (long long)BT * HW;
+    p.x0_bytes = p.M * C * 2;
     p.bias = bias;
     p.rowvec = rowvec;
     p.rv_stride = rv_stride;
@@ -722,6 +1124,8 @@ int vidseg_conv3x3_bf16(const void* x0, const void* x1, int C0, int C1, int B, i
     p.N = Cout;
     p.K = 9 * (p.C0 + p.C1);
     p.M = (long long)B * p.Hout * p.Wout;
+    p.x0_bytes = (long long)B * Hin * Win * p.C0 * 2;
+    p.x1_bytes = (long long)B * Hin * Win * p.C1 * 2;
     p.bias = bias;
     p.rowvec = rowvec;
     p.rv_stride = rv_stride;

@@ -20,37 +20,59 @@ __device__ __forceinline__ const bf16_t* src_ptr(const bf16_t* x0, const bf16_t*
     return (c < C0) ? x0 + row * C0 + c : x1 + row * C1 + (c - C0);
 }
 
-__global__ void __launch_bounds__(256) k_gn_partial(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, int C0, int C1, int HW,
-                                                    int rows_per_chunk, int nchunk, float* __restrict__ part) {
-    // grid (nchunk, B, ceil(C/8/256)); thread owns 8 consecutive channels
-    const int C = C0 + C1;
-    const int c = (blockIdx.z * 256 + threadIdx.x) * 8;
-    if (c >= C) return;
+// Thread layout shared by pass 1 and pass 3: a block covers `rpb` consecutive rows at a time, thread t owns channels
+// 8*(t % (C/8)).. of row (t / (C/8)); the channel octet (and with it gamma/beta/scale/shift and the concat source) is
+// fixed for the thread's lifetime, rows advance by rpb.  A block touches rpb*C*2 contiguous bytes per iteration.
+#define GN_ROWS_PER_CHUNK 64
+
+__global__ void __launch_bounds__(1024) k_gn_partial(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, int C0, int C1, int HW,
+                                                     int rpb, int nchunk, float* __restrict__ part) {
+    extern __shared__ float gn_red[];                      // [rpb][2][C]
+    const int C = C0 + C1, c8n = C / 8;
+    const int tid = threadIdx.x;
+    const int lrow = tid / c8n, c = (tid - lrow * c8n) * 8;
     const int b = blockIdx.y, ch = blockIdx.x;
-    const int r0 = ch * rows_per_chunk, r1 = min(HW, r0 + rows_per_chunk);
+    const bool active = lrow < rpb;
+    const int r0 = ch * GN_ROWS_PER_CHUNK, r1 = min(HW, r0 + GN_ROWS_PER_CHUNK);
     float s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(src_ptr(x0, x1, C0, C1, (long long)b * HW + r, c));
+    if (active) {
+        const bool second = c >= C0;
+        const bf16_t* src = second ? x1 + (c - C0) : x0 + c;
+        const int Cs = second ? C1 : C0;
+        src += (long long)b * HW * Cs;
+        for (int r = r0 + lrow; r < r1; r += rpb) {
+            const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(src + (long long)r * Cs);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = bf16_to_f32((bf16_t)v[j]);
+                s[j] += f;
+                q[j] = fmaf(f, f, q[j]);
+            }
+        }
+        float* o = gn_red + (long long)lrow * 2 * C;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float f = bf16_to_f32((bf16_t)v[j]);
-            s[j] += f;
-            q[j] = fmaf(f, f, q[j]);
+            o[c + j] = s[j];
+            o[C + c + j] = q[j];
         }
     }
+    __syncthreads();
+    // fixed-order reduction over the rpb row lanes, coalesced write of the chunk's [2][C] partials
     float* o = part + (((long long)b * nchunk + ch) * 2) * C;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        o[c + j] = s[j];
-        o[C + c + j] = q[j];
+    for (int i = tid; i < 2 * C; i += blockDim.x) {
+        float acc = 0.f;
+        for (int l = 0; l < rpb; ++l) acc += gn_red[(long long)l * 2 * C + i];
+        o[i] = acc;
     }
 }
 
 __global__ void __launch_bounds__(64) k_gn_stats(const float* __restrict__ part, int C, int G, int HW, int nchunk, float eps,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                  float* __restrict__ stats) {
-    // grid (G, B), one wave: lanes stride over (chunk, channel-in-group); double accumulation, fixed order
+    // grid (G, B), one wave: lanes stride over (chunk, channel-in-group); double accumulation, fixed order.
+    // Output per (b, c): scale = rstd*gamma, shift = beta - mean*scale   -> stats[b][2][C]
     const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int cpg = C / G;
     double s = 0.0, q = 0.0;
@@ -63,36 +85,47 @@ __global__ void __launch_bounds__(64) k_gn_stats(const float* __restrict__ part,
     }
     s = wave_sum_f64(s);
     q = wave_sum_f64(q);
-    if (lane == 0) {
-        const double n = (double)HW * cpg;
-        const double mean = s / n;
-        const double var = fmax(q / n - mean * mean, 0.0);
-        stats[((long long)b * G + g) * 2] = (float)mean;
-        stats[((long long)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    const double n = (double)HW * cpg;
+    const double mean = s / n;
+    const double var = fmax(q / n - mean * mean, 0.0);
+    const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    float* o = stats + (long long)b * 2 * C;
+    for (int i = lane; i < cpg; i += 64) {
+        const int c = g * cpg + i;
+        const float sc = rstd * gamma[c];
+        o[c] = sc;
+        o[C + c] = fmaf(-meanf, sc, beta[c]);
     }
 }
 
-__global__ void __launch_bounds__(256) k_gn_apply(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, int C0, int C1, int HW,
-                                                  int G, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                  const float* __restrict__ beta, int silu, long long total8, bf16_t* __restrict__ out) {
-    const int C = C0 + C1;
-    const int cpg = C / G;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
-        const long long e = i * 8;
-        const long long row = e / C;
-        const int c = (int)(e % C);
-        const int b = (int)(row / HW);
-        const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(src_ptr(x0, x1, C0, C1, row, c));
-        bf16x8_t o;
+__global__ void __launch_bounds__(1024) k_gn_apply(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, int C0, int C1, int HW,
+                                                   int rpb, const float* __restrict__ stats, int silu, bf16_t* __restrict__ out) {
+    const int C = C0 + C1, c8n = C / 8;
+    const int tid = threadIdx.x;
+    const int lrow = tid / c8n, c = (tid - lrow * c8n) * 8;
+    if (lrow >= rpb) return;
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * GN_ROWS_PER_CHUNK, r1 = min(HW, r0 + GN_ROWS_PER_CHUNK);
+    const float* st = stats + (long long)b * 2 * C;
+    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(st + c), sc1 = *reinterpret_cast<const f32x4*>(st + c + 4);
+    const f32x4 sh0 = *reinterpret_cast<const f32x4*>(st + C + c), sh1 = *reinterpret_cast<const f32x4*>(st + C + c + 4);
+    const float sc[8] = {sc0[0], sc0[1], sc0[2], sc0[3], sc1[0], sc1[1], sc1[2], sc1[3]};
+    const float sh[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
+    const bool second = c >= C0;
+    const bf16_t* src = second ? x1 + (c - C0) : x0 + c;
+    const int Cs = second ? C1 : C0;
+    src += (long long)b * HW * Cs;
+    bf16_t* dst = out + (long long)b * HW * C + c;
+    for (int r = r0 + lrow; r < r1; r += rpb) {
+        const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(src + (long long)r * Cs);
+        float f[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int g = (c + j) / cpg;
-            const float mean = stats[((long long)b * G + g) * 2], rstd = stats[((long long)b * G + g) * 2 + 1];
-            float f = (bf16_to_f32((bf16_t)v[j]) - mean) * rstd * gamma[c + j] + beta[c + j];
-            if (silu) f = silu_f(f);
-            o[j] = (short)f32_to_bf16(f);
+            f[j] = fmaf(bf16_to_f32((bf16_t)v[j]), sc[j], sh[j]);
+            if (silu) f[j] = silu_f(f[j]);
         }
-        *reinterpret_cast<bf16x8_t*>(out + e) = o;
+        u32x4 o = {pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3]), pack2_bf16(f[4], f[5]), pack2_bf16(f[6], f[7])};
+        *reinterpret_cast<u32x4*>(dst + (long long)r * C) = o;
     }
 }
 
@@ -549,21 +582,23 @@ __global__ void k_add_rowvec(const bf16_t* __restrict__ x, const bf16_t* __restr
 extern "C" {
 
 int vidseg_groupnorm_nhwc_bf16(const void* x0, const void* x1, int C0, int C1, int B, int HW, int G, const float* gamma,
-                               const float* beta, float eps, int silu, float* part, int part_floats, float* stats, void* out,
-                               hipStream_t st) {
+                               const float* beta, float eps, int silu, float* part, int part_floats, float* stats, int stats_floats,
+                               void* out, hipStream_t st) {
     const int C = C0 + (x1 ? C1 : 0);
-    VS_REQUIRE(C % G == 0 && C0 % 8 == 0 && (!x1 || C1 % 8 == 0), "groupnorm: C0=%d C1=%d G=%d", C0, C1, G);
-    int rows_per_chunk = 64;
-    int nchunk = (HW + rows_per_chunk - 1) / rows_per_chunk;
+    VS_REQUIRE(C % G == 0 && C0 % 8 == 0 && (!x1 || C1 % 8 == 0) && C <= 8192, "groupnorm: C0=%d C1=%d G=%d", C0, C1, G);
+    const int nchunk = (HW + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK;
     VS_REQUIRE((long long)B * nchunk * 2 * C <= part_floats, "groupnorm: partial buffer too small (%lld > %d)",
                (long long)B * nchunk * 2 * C, part_floats);
-    k_gn_partial<<<dim3(nchunk, B, (C / 8 + 255) / 256), 256, 0, st>>>((const bf16_t*)x0, (const bf16_t*)x1, C0, x1 ? C1 : 0, HW,
-                                                                      rows_per_chunk, nchunk, part);
-    k_gn_stats<<<dim3(G, B), 64, 0, st>>>(part, C, G, HW, nchunk, eps, stats);
-    const long long total8 = (long long)B * HW * C / 8;
-    const unsigned blocks = (unsigned)((total8 + 255) / 256 < 4096 ? (total8 + 255) / 256 : 4096);
-    k_gn_apply<<<dim3(blocks), 256, 0, st>>>((const bf16_t*)x0, (const bf16_t*)x1, C0, x1 ? C1 : 0, HW, G, stats, gamma, beta, silu,
-                                             total8, (bf16_t*)out);
+    VS_REQUIRE((long long)B * 2 * C <= stats_floats, "groupnorm: scale/shift buffer too small (%lld > %d)", (long long)B * 2 * C,
+               stats_floats);
+    const int c8n = C / 8;
+    const int rpb = c8n >= 256 ? 1 : 256 / c8n;               // rows a block covers per iteration
+    const int nthr = ((c8n * rpb + 63) / 64) * 64;
+    k_gn_partial<<<dim3(nchunk, B), nthr, (size_t)rpb * 2 * C * sizeof(float), st>>>((const bf16_t*)x0, (const bf16_t*)x1, C0,
+                                                                                      x1 ? C1 : 0, HW, rpb, nchunk, part);
+    k_gn_stats<<<dim3(G, B), 64, 0, st>>>(part, C, G, HW, nchunk, eps, gamma, beta, stats);
+    k_gn_apply<<<dim3(nchunk, B), nthr, 0, st>>>((const bf16_t*)x0, (const bf16_t*)x1, C0, x1 ? C1 : 0, HW, rpb, stats, silu,
+                                                 (bf16_t*)out);
     VS_CHECK_LAUNCH("groupnorm");
     return VS_OK;
 }

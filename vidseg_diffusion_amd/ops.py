@@ -20,7 +20,7 @@ _lib.register({
     "vidseg_conv3x3_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
     "vidseg_conv_in": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "vidseg_conv_out4": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
-    "vidseg_groupnorm_nhwc_bf16": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _P, _P],
+    "vidseg_groupnorm_nhwc_bf16": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _I, _P, _P],
     "vidseg_layernorm_bf16": [_P, _L, _I, _P, _P, _F, _P, _P],
     "vidseg_attention_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "vidseg_timestep_embedding": [_P, _I, _I, _F, _P, _P],
@@ -147,7 +147,7 @@ class Workspace:
 
     def __init__(self, device, floats=1 << 24, splitk_floats=40 << 20):
         self.part = torch.empty(floats, dtype=F32, device=device)
-        self.stats = torch.empty(64 * 32 * 2 * 4, dtype=F32, device=device)
+        self.stats = torch.empty(1 << 20, dtype=F32, device=device)          # GroupNorm per-(sample, channel) scale/shift
         self.splitk = torch.empty(splitk_floats, dtype=F32, device=device)   # fp32 split-K partials (160 MB)
         call("vidseg_set_workspace", ptr(self.splitk), self.splitk.numel())
 
@@ -171,7 +171,7 @@ def groupnorm(x0, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True):
     ws = workspace(x0.device)
     out = torch.empty(x0.shape[:-1] + (C0 + C1,), dtype=BF16, device=x0.device)
     call("vidseg_groupnorm_nhwc_bf16", ptr(x0), ptr(x1), C0, C1, B, HW, groups, ptr(gamma), ptr(beta), eps, int(silu),
-         ptr(ws.part), ws.part.numel(), ptr(ws.stats), ptr(out), stream())
+         ptr(ws.part), ws.part.numel(), ptr(ws.stats), ws.stats.numel(), ptr(out), stream())
     return out
 
 
