@@ -132,8 +132,13 @@ def _relocate_empty(X, centers_old, centers_new, weight, labels):
         weight[old_id] -= 1.0
 
 
-def lloyd_single(X, centers_init, max_iter, tol):
-    """cluster/_kmeans.py:_kmeans_single_lloyd (:683-752).  Returns labels, inertia, centers, n_iter."""
+def lloyd_single(X, centers_init, max_iter, tol, raw=None, mean=None):
+    """cluster/_kmeans.py:_kmeans_single_lloyd (:683-752).  Returns labels, inertia, centers, n_iter.
+
+    M-step sums: sklearn adds the centred float64 rows chunk by chunk, thread by thread (_k_means_lloyd.pyx:140-170),
+    so its last bits depend on the OpenMP thread count.  With `raw` (the un-centred fp16-valued rows) and `mean` the
+    sums are taken over the RAW values -- float64 sums of fp16 values are exact, hence order-free -- and centred
+    afterwards: sum_k - count_k * mean.  This is the definition the HIP path implements (vidseg_lloyd_step)."""
     K = centers_init.shape[0]
     centers = centers_init.copy()
     labels_old = np.full(X.shape[0], -1, dtype=np.int32)
@@ -144,7 +149,10 @@ def lloyd_single(X, centers_init, max_iter, tol):
         onehot = np.zeros((X.shape[0], K), dtype=F64)
         onehot[np.arange(X.shape[0]), labels] = 1.0
         weight = onehot.sum(axis=0)
-        centers_new = onehot.T @ X
+        if raw is not None:
+            centers_new = onehot.T @ raw - weight[:, None] * mean[None, :]
+        else:
+            centers_new = onehot.T @ X
         _relocate_empty(X, centers, centers_new, weight, labels)
         # _average_centers (_k_means_common.pyx:274-295): centers *= 1/weight; a cluster that
         # is still empty (only when relocation bailed out) sits on the biggest cluster.
@@ -183,15 +191,15 @@ def kmeans_fit(X16, n_clusters, random_state, n_init=10, max_iter=300, tol=1e-4)
     up-cast to float64 by validate_data(dtype=[float64, float32]), mean-centred, tolerance
     scaled by the mean per-feature variance, best-of-n_init by strictly lower inertia unless
     the clustering is identical up to a permutation.  Returns (centers, labels, inertia)."""
-    X = np.ascontiguousarray(X16, dtype=F64)
-    mean = X.mean(axis=0)
-    X = X - mean
+    raw = np.ascontiguousarray(X16, dtype=F64)
+    mean = raw.mean(axis=0)
+    X = raw - mean
     tol_ = float(np.mean(np.var(X, axis=0)) * tol)
     x_sq = _row_norms_sq(X)
     best = None
     for _ in range(n_init):
         c0, _idx = kmeans_plusplus(X, n_clusters, x_sq, random_state)
-        labels, inertia, centers, n_iter = lloyd_single(X, c0, max_iter, tol_)
+        labels, inertia, centers, n_iter = lloyd_single(X, c0, max_iter, tol_, raw=raw, mean=mean)
         if best is None or (inertia < best[1] and not _is_same_clustering(labels, best[0], n_clusters)):
             best = (labels, inertia, centers, n_iter)
     labels, inertia, centers, _ = best

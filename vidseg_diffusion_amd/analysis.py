@@ -121,9 +121,14 @@ def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: i
     labels = torch.full((R, n), -1, dtype=I32, device=dev)
     changed = torch.zeros(R, dtype=I32, device=dev)
     cnorm = torch.empty(R * K, dtype=F64, device=dev)
-    nblk = (n + chunk - 1) // chunk
-    psum = torch.empty((R, nblk, K, C), dtype=F64, device=dev)
-    pcnt = torch.empty((R, nblk, K), dtype=I32, device=dev)
+    sums = torch.zeros((R, K, C), dtype=F64, device=dev)              # exact raw member sums (see vidseg_lloyd_step)
+    ub = torch.empty((R, n), dtype=F64, device=dev)
+    lb = torch.empty((R, n), dtype=F64, device=dev)
+    lst = torch.arange(n, dtype=I32, device=dev).repeat(R, 1).contiguous()
+    nlist = torch.full((R,), n, dtype=I32, device=dev)
+    chg = torch.empty((R, n, 2), dtype=I32, device=dev)
+    delta = torch.zeros((R, K), dtype=F64, device=dev)
+    dtop = torch.zeros((R, 3), dtype=F64, device=dev)
     shift2 = torch.zeros((R, K), dtype=F64, device=dev)
     counts = torch.zeros((R, K), dtype=I32, device=dev)
     # device-side convergence state: [active mask, strict mask, error flags, n_iter[R]]
@@ -138,9 +143,9 @@ def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: i
     slots, colrow, nslots = _compact_slots(cur_mask, R, K, dev)
     while it < max_iter:
         for _ in range(min(poll, max_iter - it)):
-            call("vidseg_lloyd_iter", ptr(x16), ptr(mean), n, C, R, K, ptr(state), ptr(slots), nslots, ptr(colrow), 1, ptr(centers),
-                 ptr(cnorm), ptr(labels), ptr(changed), ptr(psum), ptr(pcnt), chunk, ptr(shift2), ptr(counts), st)
-            call("vidseg_lloyd_status", R, K, it, tol_, ptr(changed), ptr(shift2), ptr(counts), ptr(state), st)
+            call("vidseg_lloyd_step", ptr(x16), ptr(mean), ptr(xsq), n, C, R, K, it, tol_, ptr(state), ptr(slots), nslots,
+                 ptr(centers), ptr(cnorm), ptr(sums), ptr(counts), ptr(labels), ptr(ub), ptr(lb), ptr(lst), ptr(nlist), ptr(chg),
+                 ptr(changed), ptr(shift2), ptr(delta), ptr(dtop), st)
             it += 1
         h_pin.copy_(state, non_blocking=True)
         torch.cuda.current_stream().synchronize()
@@ -163,7 +168,7 @@ def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: i
         rstate = torch.tensor([rerun], dtype=I32).to(dev)
         slots, colrow, nslots = _compact_slots(rerun, R, K, dev)
         call("vidseg_lloyd_iter", ptr(x16), ptr(mean), n, C, R, K, ptr(rstate), ptr(slots), nslots, ptr(colrow), 0, ptr(centers),
-             ptr(cnorm), ptr(labels), ptr(changed), ptr(psum), ptr(pcnt), chunk, ptr(shift2), ptr(counts), st)
+             ptr(cnorm), ptr(labels), ptr(changed), None, None, chunk, None, None, st)
     ipart = torch.empty((R, (n + 255) // 256), dtype=F64, device=dev)
     inertia = torch.empty(R, dtype=F64, device=dev)
     call("vidseg_kmeans_inertia", ptr(x16), ptr(mean), n, C, R, K, ptr(centers), ptr(labels), ptr(ipart), ptr(inertia), st)

@@ -131,6 +131,7 @@ typedef __attribute__((ext_vector_type(4))) double f64x4;
 #define TROW(i, j) (((threadIdx.x >> 6) << 4) + ((threadIdx.x & 63) >> 4) + 4 * (j))
 #define TCOL(i, j) (16 * (i) + (threadIdx.x & 15))
 
+template <int NCB = 4>
 __device__ __forceinline__ void tile_mma(f64x4 (&c)[4], double (*LA)[LDP], double (*LB)[LDP]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int lr = lane & 15, lk = lane >> 4;
@@ -138,11 +139,11 @@ __device__ __forceinline__ void tile_mma(f64x4 (&c)[4], double (*LA)[LDP], doubl
     for (int k0 = 0; k0 < KC; k0 += 4) {
         const double a = LA[k0 + lk][w * 16 + lr];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, LB[k0 + lk][i * 16 + lr], c[i], 0, 0, 0);
+        for (int i = 0; i < NCB; ++i) c[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, LB[k0 + lk][i * 16 + lr], c[i], 0, 0, 0);
     }
 }
 
-template <class RA, class RB>
+template <int NCB = 4, class RA, class RB>
 __device__ __forceinline__ void tile_gemm(double (&acc)[4][4], double (*LA)[LDP], double (*LB)[LDP], const RA& A, int64_t a0,
                                           const RB& B, int64_t b0, int C) {
     f64x4 c[4];
@@ -153,7 +154,7 @@ __device__ __forceinline__ void tile_gemm(double (&acc)[4][4], double (*LA)[LDP]
         load_tile(LA, A, a0, c0);
         load_tile(LB, B, b0, c0);
         __syncthreads();
-        tile_mma(c, LA, LB);
+        tile_mma<NCB>(c, LA, LB);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -494,6 +495,229 @@ __global__ void k_lloyd_status(int R, int K, int it, double tol, int32_t* __rest
             if (tot <= tol) active &= ~(1u << r);
         }
         changed[r] = 0;
+    }
+    state[0] = active;
+    state[1] = strict;
+    state[2] = err;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Accelerated Lloyd iteration -- same labels as the plain E-step by construction, far less work per iteration:
+//  (1) Hamerly-style bound filter: per (restart, sample) an upper bound ub on the distance to its own centre and a lower
+//      bound lb on the distance to every other centre.  After the centres moved by delta_k, ub += delta_a and
+//      lb -= max_{k != a} delta_k are still bounds (triangle inequality); if ub < lb with a safety margin nine orders of
+//      magnitude above float64 rounding the argmin cannot have changed and the sample is skipped.
+//  (2) the E-step proper runs on the gathered list of unsettled samples only (same MFMA tile arithmetic as
+//      k_lloyd_assign, so the scores are bit-identical to the full E-step's) and refreshes ub/lb/labels, recording every
+//      label change (sample, old, new).
+//  (3) M-step on EXACT sums: sums[r][k][c] = sum of the raw fp16 values of the members.  fp16 values are multiples of
+//      2^-24 below 2^16, so float64 adds/subtracts of up to 2^13 of them are exact in any order (2^20 for data in
+//      [-1, 1] such as the max-normalised tokens); the sums are therefore maintained incrementally from the change
+//      list (+x into the new cluster, -x out of the old one) and centre = (sum - count*mean) * (1/count).
+//      sklearn's own reduction order depends on its OpenMP thread count; this one has no order at all.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lloyd_filter(int64_t n, int K, const unsigned* __restrict__ d_active, const int32_t* __restrict__ slots,
+                                                      const int32_t* __restrict__ labels, double* __restrict__ ub, double* __restrict__ lb,
+                                                      const double* __restrict__ delta, const double* __restrict__ dtop,
+                                                      int32_t* __restrict__ list, int32_t* __restrict__ nlist) {
+    const int r = slots[blockIdx.y];
+    if (!((*d_active >> r) & 1u)) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t idx = (int64_t)r * n + i;
+    const int a = labels[idx];
+    const double d1 = dtop[r * 3], d2 = dtop[r * 3 + 1];
+    const int arg1 = (int)dtop[r * 3 + 2];
+    const double u = ub[idx] + delta[r * K + a];
+    const double l = lb[idx] - (a == arg1 ? d2 : d1);
+    ub[idx] = u;
+    lb[idx] = l;
+    if (!(u + 1e-9 * (u + l) < l)) {
+        const int pos = atomicAdd(&nlist[r], 1);
+        list[(int64_t)r * n + pos] = (int32_t)i;
+    }
+}
+
+template <int NCB>
+__global__ void __launch_bounds__(256) k_lloyd_assign_list(RowsF16 X, const double* __restrict__ centers, const double* __restrict__ cn,
+                                                           const double* __restrict__ xsq, int K, const unsigned* __restrict__ d_active,
+                                                           const int32_t* __restrict__ slots, const int32_t* __restrict__ list,
+                                                           const int32_t* __restrict__ nlist, int32_t* __restrict__ labels,
+                                                           double* __restrict__ ub, double* __restrict__ lb, int32_t* __restrict__ chg,
+                                                           int32_t* __restrict__ changed) {
+    __shared__ double LA[KC][LDP];
+    __shared__ double LB[KC][LDP];
+    __shared__ double LD[TS][LDP];
+    const int r = slots[blockIdx.y];
+    if (!((*d_active >> r) & 1u)) return;
+    const int64_t n = X.nrows;
+    const int m = nlist[r];
+    const int64_t s0 = (int64_t)blockIdx.x * TS;
+    if (s0 >= m) return;
+    RowsF16 Xr = X;
+    Xr.gather = list + (int64_t)r * n;
+    Xr.nrows = m;
+    RowsF64 B{centers + (int64_t)r * K * X.C, K, X.C};
+    double acc[4][4];
+    tile_gemm<NCB>(acc, LA, LB, Xr, s0, B, 0, X.C);
+#pragma unroll
+    for (int i = 0; i < NCB; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = TCOL(i, j);
+            double d = 0.0;
+            if (col < K) d = cn[r * K + col] + (-2.0 * acc[i][j]);
+            LD[TROW(i, j)][col] = d;
+        }
+    __syncthreads();
+    const int s = threadIdx.x;
+    if (s < TS && s0 + s < m) {
+        const int i = Xr.gather[s0 + s];
+        const double* row = &LD[s][0];
+        double best = row[0], second = INFINITY;
+        int lab = 0;
+        for (int j = 1; j < K; ++j) {
+            const double v = row[j];
+            if (v < best) {
+                second = best;
+                best = v;
+                lab = j;
+            } else if (v < second) {
+                second = v;
+            }
+        }
+        // conservative bounds: |error| of a computed squared distance is ~1e-13 (|x|^2 + |c|^2); widen by 1e-10 of that
+        const double xs = xsq[i];
+        const double e = 1e-10 * (xs + cn[r * K + lab]) + 1e-300;
+        const int64_t idx = (int64_t)r * n + i;
+        ub[idx] = sqrt(fmax(xs + best, 0.0) + e);
+        lb[idx] = sqrt(fmax(xs + second - e, 0.0));
+        const int old = labels[idx];
+        if (old != lab) {
+            const int pos = atomicAdd(&changed[r], 1);
+            chg[((int64_t)r * n + pos) * 2] = i;
+            chg[((int64_t)r * n + pos) * 2 + 1] = (old & 0xffff) | (lab << 16);
+            labels[idx] = lab;
+        }
+    }
+}
+
+// M-step part 1: apply the change list to the exact raw sums.  Block (channel tile of 64, restart) OWNS sums[r][:, tile]:
+// its 8 waves stream the entries (one channel per lane), accumulate the +-x deltas in one LDS array with ds_add_f64 (exact,
+// so order-free) and add them to the sums at the end -- no global atomics, deterministic.
+__global__ void __launch_bounds__(512) k_lloyd_accum_list(const f16* __restrict__ x, int64_t n, int C, int K, const unsigned* __restrict__ d_active,
+                                                          const int32_t* __restrict__ slots, const int32_t* __restrict__ chg,
+                                                          const int32_t* __restrict__ changed, double* __restrict__ sums,
+                                                          int32_t* __restrict__ counts) {
+    __shared__ double dl[64][64];                        // [k][channel in tile]
+    __shared__ int dc[64];
+    const int r = slots[blockIdx.y];
+    if (!((*d_active >> r) & 1u)) return;
+    const int m = changed[r];
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    for (int i = threadIdx.x; i < K * 64; i += 512) (&dl[0][0])[i] = 0.0;
+    if (threadIdx.x < 64) dc[threadIdx.x] = 0;
+    __syncthreads();
+    const int32_t* e = chg + (int64_t)r * n * 2;
+    const bool cok = c < C;
+    for (int q = wave; q < m; q += 8) {
+        const int i = e[q * 2], on = e[q * 2 + 1];
+        const int old = on & 0xffff, nw = on >> 16;
+        if (cok) {
+            const double v = (double)x[(int64_t)i * C + c];
+            __hip_atomic_fetch_add(&dl[nw][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old != 0xffff) __hip_atomic_fetch_add(&dl[old][lane], -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (blockIdx.x == 0 && lane == 0) {
+            atomicAdd(&dc[nw], 1);
+            if (old != 0xffff) atomicSub(&dc[old], 1);
+        }
+    }
+    __syncthreads();
+    if (cok)
+        for (int k = wave; k < K; k += 8) sums[((int64_t)r * K + k) * C + c] += dl[k][lane];
+    if (blockIdx.x == 0 && threadIdx.x < K) counts[r * K + threadIdx.x] += dc[threadIdx.x];
+}
+
+// M-step part 2, block (k, restart): centre = (sum - count*mean) * (1/count) (_average_centers), shift2 = |new - old|^2
+// (_center_shift), delta = sqrt(shift2) for the bound filter, |centre|^2 for the next E-step.
+__global__ void __launch_bounds__(256) k_lloyd_update_sums(const double* __restrict__ sums, const int32_t* __restrict__ counts,
+                                                           const double* __restrict__ mean, int K, int C, const unsigned* __restrict__ d_active,
+                                                           const int32_t* __restrict__ slots, double* __restrict__ centers,
+                                                           double* __restrict__ shift2, double* __restrict__ delta, double* __restrict__ cn) {
+    const int k = blockIdx.x, r = slots[blockIdx.y];
+    if (!((*d_active >> r) & 1u)) return;
+    __shared__ double red[2][256];
+    const int cnt = counts[r * K + k];
+    double sh = 0.0, sq = 0.0;
+    const double alpha = cnt > 0 ? 1.0 / (double)cnt : 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int64_t ci = ((int64_t)r * K + k) * C + c;
+        double v = centers[ci];
+        if (cnt > 0) {
+            const double t = (sums[ci] - (double)cnt * mean[c]) * alpha;
+            const double d = t - v;
+            sh = fma(d, d, sh);
+            centers[ci] = t;
+            v = t;
+        }
+        sq = fma(v, v, sq);
+    }
+    red[0][threadIdx.x] = sh;
+    red[1][threadIdx.x] = sq;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        shift2[r * K + k] = red[0][0];
+        delta[r * K + k] = sqrt(red[0][0]);
+        cn[r * K + k] = red[1][0];
+    }
+}
+
+// k_lloyd_status plus the bookkeeping of the accelerated path: the two largest centre movements per restart for the
+// filter, list/change counters reset for the next iteration.
+__global__ void k_lloyd_status_list(int R, int K, int it, double tol, int32_t* __restrict__ changed, const double* __restrict__ shift2,
+                                    const int32_t* __restrict__ counts, unsigned* __restrict__ state, const double* __restrict__ delta,
+                                    double* __restrict__ dtop, int32_t* __restrict__ nlist) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned active = state[0], strict = state[1], err = state[2];
+    for (int r = 0; r < R; ++r) {
+        if (!((active >> r) & 1u)) continue;
+        state[3 + r] = (unsigned)(it + 1);
+        double d1 = -1.0, d2 = -1.0, tot = 0.0;
+        int a1 = 0;
+        for (int k = 0; k < K; ++k) {
+            if (counts[r * K + k] == 0) err |= 1u;
+            const double sh = sqrt(shift2[r * K + k]);
+            tot += sh * sh;
+            const double d = delta[r * K + k];
+            if (d > d1) {
+                d2 = d1;
+                d1 = d;
+                a1 = k;
+            } else if (d > d2) {
+                d2 = d;
+            }
+        }
+        if (changed[r] == 0) {
+            strict |= 1u << r;
+            active &= ~(1u << r);
+        } else if (tot <= tol) {
+            active &= ~(1u << r);
+        }
+        dtop[r * 3] = d1;
+        dtop[r * 3 + 1] = d2 < 0.0 ? d1 : d2;
+        dtop[r * 3 + 2] = (double)a1;
+        changed[r] = 0;
+        nlist[r] = 0;
     }
     state[0] = active;
     state[1] = strict;
@@ -988,6 +1212,40 @@ int vidseg_lloyd_iter(const void* x16, const double* mean, int64_t n, int C, int
         k_lloyd_update<<<dim3(K, nslots), 256, 0, st>>>(psum, pcnt, nblk, R, K, C, d_active, slots, centers, shift2, counts);
         VS_CHECK_LAUNCH("lloyd_update");
     }
+    return VS_OK;
+}
+
+// One accelerated Lloyd iteration (see the kernels above) including the convergence bookkeeping of vidseg_lloyd_status.
+// Host-initialised state before it = 0: labels = -1, sums = 0, counts = 0, list[r] = 0..n-1, nlist[r] = n, changed = 0.
+int vidseg_lloyd_step(const void* x16, const double* mean, const double* xsq, int64_t n, int C, int R, int K, int it, double tol,
+                      unsigned* state, const int32_t* slots, int nslots, double* centers, double* cnorm, double* sums, int32_t* counts,
+                      int32_t* labels, double* ub, double* lb, int32_t* list, int32_t* nlist, int32_t* chg, int32_t* changed,
+                      double* shift2, double* delta, double* dtop, hipStream_t st) {
+    VS_REQUIRE(K >= 1 && K <= 64 && R >= 1 && R <= 29 && nslots >= 1 && nslots <= R, "lloyd_step: K=%d R=%d nslots=%d", K, R, nslots);
+    VS_REQUIRE(n < (1LL << 31) / 2, "lloyd_step: n=%lld too large", (long long)n);
+    RowsF16 X{(const f16*)x16, nullptr, mean, n, C};
+    const unsigned* d_active = state;
+    if (it == 0)
+        k_center_sqnorm<<<dim3((R * K + 3) / 4), 256, 0, st>>>(centers, R * K, C, cnorm);
+    else
+        k_lloyd_filter<<<dim3((unsigned)cdiv64(n, 256), nslots), 256, 0, st>>>(n, K, d_active, slots, labels, ub, lb, delta, dtop, list, nlist);
+    const dim3 ga((unsigned)cdiv64(n, TS), nslots);
+#define VS_ASSIGN_LIST(NCB) \
+    k_lloyd_assign_list<NCB><<<ga, 256, 0, st>>>(X, centers, cnorm, xsq, K, d_active, slots, list, nlist, labels, ub, lb, chg, changed)
+    switch ((K + 15) / 16) {
+        case 1: VS_ASSIGN_LIST(1); break;
+        case 2: VS_ASSIGN_LIST(2); break;
+        case 3: VS_ASSIGN_LIST(3); break;
+        default: VS_ASSIGN_LIST(4); break;
+    }
+#undef VS_ASSIGN_LIST
+    VS_CHECK_LAUNCH("lloyd_assign_list");
+    k_lloyd_accum_list<<<dim3((C + 63) / 64, nslots), 512, 0, st>>>((const f16*)x16, n, C, K, d_active, slots, chg, changed, sums, counts);
+    VS_CHECK_LAUNCH("lloyd_accum_list");
+    k_lloyd_update_sums<<<dim3(K, nslots), 256, 0, st>>>(sums, counts, mean, K, C, d_active, slots, centers, shift2, delta, cnorm);
+    VS_CHECK_LAUNCH("lloyd_update_sums");
+    k_lloyd_status_list<<<dim3(1), 64, 0, st>>>(R, K, it, tol, changed, shift2, counts, state, delta, dtop, nlist);
+    VS_CHECK_LAUNCH("lloyd_status_list");
     return VS_OK;
 }
 
