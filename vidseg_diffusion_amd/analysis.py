@@ -137,11 +137,11 @@ def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: i
     state = h_state.to(dev)
     h_pin = torch.empty(3 + R, dtype=I32).pin_memory()
     total = 0
-    poll = 4                                                            # iterations enqueued between host polls
     it = 0
     cur_mask = (1 << R) - 1
     slots, colrow, nslots = _compact_slots(cur_mask, R, K, dev)
     while it < max_iter:
+        poll = 4 if it < 16 else 8                                      # iterations enqueued between host polls
         for _ in range(min(poll, max_iter - it)):
             call("vidseg_lloyd_step", ptr(x16), ptr(mean), ptr(xsq), n, C, R, K, it, tol_, ptr(state), ptr(slots), nslots,
                  ptr(centers), ptr(cnorm), ptr(sums), ptr(counts), ptr(labels), ptr(ub), ptr(lb), ptr(lst), ptr(nlist), ptr(chg),

@@ -143,17 +143,121 @@ __device__ __forceinline__ void tile_mma(f64x4 (&c)[4], double (*LA)[LDP], doubl
     }
 }
 
+// Register-staged operand tiles: the global loads of K-chunk c+1 are issued before the MFMAs of chunk c (the row
+// pointer / gather index is resolved once per tile), then converted and written to LDS after them.  Same values as
+// load_tile, element for element.
+struct TileRegsF16 {
+    f16x8 h;
+    double m[8];
+    bool ok;
+};
+struct TileRegsF64 {
+    double v[8];
+    bool ok;
+};
+// Row pointer of this thread's tile row (thread t: row t>>2, 8 columns at (t&3)*8).  Out-of-range rows point at row 0
+// so that every load below is unconditional (no divergent branches in the K loop); `ok` zeroes the values afterwards.
+template <class T>
+struct TileRow {
+    const T* p;
+    bool ok;
+};
+__device__ __forceinline__ TileRow<f16> tile_row_ptr(const RowsF16& R, int64_t r0) {
+    const int64_t row = r0 + (threadIdx.x >> 2);
+    const bool ok = row < R.nrows;
+    const int64_t src = ok ? (R.gather ? (int64_t)R.gather[row] : row) : 0;
+    return {R.base + src * (int64_t)R.C + (threadIdx.x & 3) * 8, ok};
+}
+__device__ __forceinline__ TileRow<double> tile_row_ptr(const RowsF64& R, int64_t r0) {
+    const int64_t row = r0 + (threadIdx.x >> 2);
+    const bool ok = row < R.nrows;
+    const int64_t src = ok ? (R.gather ? (int64_t)R.gather[row] : row) : 0;
+    return {R.base + src * (int64_t)R.C + (threadIdx.x & 3) * 8, ok};
+}
+// C is a multiple of 8 everywhere these tiles are used (16-byte fp16 rows); chunks past C are clamped to chunk 0.
+__device__ __forceinline__ void tile_fetch(TileRegsF16& g, const RowsF16& R, const TileRow<f16>& rp, int c0) {
+    const int sub = (threadIdx.x & 3) * 8;
+    const bool inb = c0 + sub < R.C;
+    const int cc = inb ? c0 : 0;
+    g.ok = rp.ok && inb;
+    g.h = *reinterpret_cast<const f16x8*>(rp.p + cc);
+    if (R.mean) {
+        const double* mp = R.mean + cc + sub;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g.m[j] = mp[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g.m[j] = 0.0;
+    }
+}
+__device__ __forceinline__ void tile_fetch(TileRegsF64& g, const RowsF64& R, const TileRow<double>& rp, int c0) {
+    const int sub = (threadIdx.x & 3) * 8;
+    const bool inb = c0 + sub < R.C;
+    const int cc = inb ? c0 : 0;
+    g.ok = rp.ok && inb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g.v[j] = rp.p[cc + j];
+}
+// Barrier that orders LDS traffic only: __syncthreads() carries a fence that makes hipcc drain the prefetched global
+// loads (s_waitcnt vmcnt(0)) and with them the overlap this pipeline exists for.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void tile_commit(double (*L)[LDP], const TileRegsF16& g) {
+    const int r = threadIdx.x >> 2, sub = (threadIdx.x & 3) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) L[sub + j][r] = g.ok ? (double)g.h[j] - g.m[j] : 0.0;
+}
+__device__ __forceinline__ void tile_commit(double (*L)[LDP], const TileRegsF64& g) {
+    const int r = threadIdx.x >> 2, sub = (threadIdx.x & 3) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) L[sub + j][r] = g.ok ? g.v[j] : 0.0;
+}
+template <class R>
+struct TileRegsOf;
+template <>
+struct TileRegsOf<RowsF16> {
+    typedef TileRegsF16 type;
+};
+template <>
+struct TileRegsOf<RowsF64> {
+    typedef TileRegsF64 type;
+};
+
 template <int NCB = 4, class RA, class RB>
 __device__ __forceinline__ void tile_gemm(double (&acc)[4][4], double (*LA)[LDP], double (*LB)[LDP], const RA& A, int64_t a0,
                                           const RB& B, int64_t b0, int C) {
     f64x4 c[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) c[i] = f64x4{0.0, 0.0, 0.0, 0.0};
-    for (int c0 = 0; c0 < C; c0 += KC) {
-        __syncthreads();
-        load_tile(LA, A, a0, c0);
-        load_tile(LB, B, b0, c0);
-        __syncthreads();
+    // two K-chunks in flight (named register sets, static indexing): chunk c+2 is requested while chunk c is multiplied
+    typename TileRegsOf<RA>::type ga0, ga1;
+    typename TileRegsOf<RB>::type gb0, gb1;
+    const auto pa = tile_row_ptr(A, a0);
+    const auto pb = tile_row_ptr(B, b0);
+    tile_fetch(ga0, A, pa, 0);
+    tile_fetch(gb0, B, pb, 0);
+    if (KC < C) {
+        tile_fetch(ga1, A, pa, KC);
+        tile_fetch(gb1, B, pb, KC);
+    }
+    for (int c0 = 0; c0 < C; c0 += 2 * KC) {
+        lds_barrier();                                   // the previous chunk's MFMAs are done with LDS
+        tile_commit(LA, ga0);
+        tile_commit(LB, gb0);
+        if (c0 + 2 * KC < C) {
+            tile_fetch(ga0, A, pa, c0 + 2 * KC);
+            tile_fetch(gb0, B, pb, c0 + 2 * KC);
+        }
+        lds_barrier();
+        tile_mma<NCB>(c, LA, LB);
+        if (c0 + KC >= C) break;
+        lds_barrier();
+        tile_commit(LA, ga1);
+        tile_commit(LB, gb1);
+        if (c0 + 3 * KC < C) {
+            tile_fetch(ga1, A, pa, c0 + 3 * KC);
+            tile_fetch(gb1, B, pb, c0 + 3 * KC);
+        }
+        lds_barrier();
         tile_mma<NCB>(c, LA, LB);
     }
 #pragma unroll
@@ -516,26 +620,42 @@ __global__ void k_lloyd_status(int R, int K, int it, double tol, int32_t* __rest
 //      list (+x into the new cluster, -x out of the old one) and centre = (sum - count*mean) * (1/count).
 //      sklearn's own reduction order depends on its OpenMP thread count; this one has no order at all.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_lloyd_filter(int64_t n, int K, const unsigned* __restrict__ d_active, const int32_t* __restrict__ slots,
+__global__ void __launch_bounds__(1024) k_lloyd_filter(int64_t n, int K, const unsigned* __restrict__ d_active, const int32_t* __restrict__ slots,
                                                       const int32_t* __restrict__ labels, double* __restrict__ ub, double* __restrict__ lb,
                                                       const double* __restrict__ delta, const double* __restrict__ dtop,
                                                       int32_t* __restrict__ list, int32_t* __restrict__ nlist) {
     const int r = slots[blockIdx.y];
     if (!((*d_active >> r) & 1u)) return;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int64_t idx = (int64_t)r * n + i;
-    const int a = labels[idx];
-    const double d1 = dtop[r * 3], d2 = dtop[r * 3 + 1];
-    const int arg1 = (int)dtop[r * 3 + 2];
-    const double u = ub[idx] + delta[r * K + a];
-    const double l = lb[idx] - (a == arg1 ? d2 : d1);
-    ub[idx] = u;
-    lb[idx] = l;
-    if (!(u + 1e-9 * (u + l) < l)) {
-        const int pos = atomicAdd(&nlist[r], 1);
-        list[(int64_t)r * n + pos] = (int32_t)i;
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    double u = 0.0, l = 1.0;                               // out-of-range lanes: "settled"
+    if (i < n) {
+        const int64_t idx = (int64_t)r * n + i;
+        const int a = labels[idx];
+        const double d1 = dtop[r * 3], d2 = dtop[r * 3 + 1];
+        const int arg1 = (int)dtop[r * 3 + 2];
+        u = ub[idx] + delta[r * K + a];
+        l = lb[idx] - (a == arg1 ? d2 : d1);
+        ub[idx] = u;
+        lb[idx] = l;
     }
+    // block-aggregated append: one atomic per 1024 samples (same-address atomics serialise at the memory side)
+    __shared__ int wcnt[16], wbase[16];
+    const bool need = !(u + 1e-9 * (u + l) < l);
+    const unsigned long long bal = __ballot(need);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            wbase[w] = tot;
+            tot += wcnt[w];
+        }
+        const int base = tot ? atomicAdd(&nlist[r], tot) : 0;
+        for (int w = 0; w < 16; ++w) wbase[w] += base;
+    }
+    __syncthreads();
+    if (need) list[(int64_t)r * n + wbase[wave] + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)i;
 }
 
 template <int NCB>
@@ -602,9 +722,11 @@ __global__ void __launch_bounds__(256) k_lloyd_assign_list(RowsF16 X, const doub
     }
 }
 
-// M-step part 1: apply the change list to the exact raw sums.  Block (channel tile of 64, restart) OWNS sums[r][:, tile]:
-// its 8 waves stream the entries (one channel per lane), accumulate the +-x deltas in one LDS array with ds_add_f64 (exact,
-// so order-free) and add them to the sums at the end -- no global atomics, deterministic.
+// M-step part 1: apply the change list to the exact raw sums.  Block (channel tile of 64, restart, entry split): its 8
+// waves stream their share of the entries (one channel per lane, 4 entries in flight), accumulate the +-x deltas in
+// one LDS array with ds_add_f64 and add the non-zero ones to the sums with float64 atomics.  Every partial value is an
+// exact multiple of 2^-24, so neither the LDS nor the global accumulation order can change a bit of the result.
+#define ACC_SPLIT 8
 __global__ void __launch_bounds__(512) k_lloyd_accum_list(const f16* __restrict__ x, int64_t n, int C, int K, const unsigned* __restrict__ d_active,
                                                           const int32_t* __restrict__ slots, const int32_t* __restrict__ chg,
                                                           const int32_t* __restrict__ changed, double* __restrict__ sums,
@@ -614,31 +736,48 @@ __global__ void __launch_bounds__(512) k_lloyd_accum_list(const f16* __restrict_
     const int r = slots[blockIdx.y];
     if (!((*d_active >> r) & 1u)) return;
     const int m = changed[r];
-    if (m == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w0 = blockIdx.z * 8;                       // first global wave index of this block
+    if (w0 * 4 >= m) return;                             // fewer entries than 4 per preceding wave: nothing left for this split
     const int c = blockIdx.x * 64 + lane;
     for (int i = threadIdx.x; i < K * 64; i += 512) (&dl[0][0])[i] = 0.0;
     if (threadIdx.x < 64) dc[threadIdx.x] = 0;
     __syncthreads();
     const int32_t* e = chg + (int64_t)r * n * 2;
     const bool cok = c < C;
-    for (int q = wave; q < m; q += 8) {
-        const int i = e[q * 2], on = e[q * 2 + 1];
-        const int old = on & 0xffff, nw = on >> 16;
-        if (cok) {
-            const double v = (double)x[(int64_t)i * C + c];
-            __hip_atomic_fetch_add(&dl[nw][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (old != 0xffff) __hip_atomic_fetch_add(&dl[old][lane], -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const bool cnt_block = blockIdx.x == 0 && lane == 0;
+    for (int q0 = (w0 + wave) * 4; q0 < m; q0 += ACC_SPLIT * 8 * 4) {
+        int idx[4], on[4];
+        double v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool ok = q0 + t < m;
+            idx[t] = ok ? e[(q0 + t) * 2] : -1;
+            on[t] = ok ? e[(q0 + t) * 2 + 1] : 0;
         }
-        if (blockIdx.x == 0 && lane == 0) {
-            atomicAdd(&dc[nw], 1);
-            if (old != 0xffff) atomicSub(&dc[old], 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = (idx[t] >= 0 && cok) ? (double)x[(int64_t)idx[t] * C + c] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (idx[t] < 0) continue;
+            const int old = on[t] & 0xffff, nw = on[t] >> 16;
+            if (cok) {
+                __hip_atomic_fetch_add(&dl[nw][lane], v[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (old != 0xffff) __hip_atomic_fetch_add(&dl[old][lane], -v[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (cnt_block) {
+                atomicAdd(&dc[nw], 1);
+                if (old != 0xffff) atomicSub(&dc[old], 1);
+            }
         }
     }
     __syncthreads();
     if (cok)
-        for (int k = wave; k < K; k += 8) sums[((int64_t)r * K + k) * C + c] += dl[k][lane];
-    if (blockIdx.x == 0 && threadIdx.x < K) counts[r * K + threadIdx.x] += dc[threadIdx.x];
+        for (int k = wave; k < K; k += 8) {
+            const double d = dl[k][lane];
+            if (d != 0.0) __hip_atomic_fetch_add(&sums[((int64_t)r * K + k) * C + c], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    if (blockIdx.x == 0 && threadIdx.x < K && dc[threadIdx.x] != 0) atomicAdd(&counts[r * K + threadIdx.x], dc[threadIdx.x]);
 }
 
 // M-step part 2, block (k, restart): centre = (sum - count*mean) * (1/count) (_average_centers), shift2 = |new - old|^2
@@ -684,18 +823,21 @@ __global__ void __launch_bounds__(256) k_lloyd_update_sums(const double* __restr
 
 // k_lloyd_status plus the bookkeeping of the accelerated path: the two largest centre movements per restart for the
 // filter, list/change counters reset for the next iteration.
-__global__ void k_lloyd_status_list(int R, int K, int it, double tol, int32_t* __restrict__ changed, const double* __restrict__ shift2,
-                                    const int32_t* __restrict__ counts, unsigned* __restrict__ state, const double* __restrict__ delta,
-                                    double* __restrict__ dtop, int32_t* __restrict__ nlist) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    unsigned active = state[0], strict = state[1], err = state[2];
-    for (int r = 0; r < R; ++r) {
-        if (!((active >> r) & 1u)) continue;
+__global__ void __launch_bounds__(64) k_lloyd_status_list(int R, int K, int it, double tol, int32_t* __restrict__ changed,
+                                                          const double* __restrict__ shift2, const int32_t* __restrict__ counts,
+                                                          unsigned* __restrict__ state, const double* __restrict__ delta,
+                                                          double* __restrict__ dtop, int32_t* __restrict__ nlist) {
+    // one wave, lane r = restart r (R <= 29)
+    const int r = threadIdx.x;
+    const unsigned active = state[0];
+    const bool mine = r < R && ((active >> r) & 1u);
+    bool is_strict = false, stop = false, empty = false;
+    if (mine) {
         state[3 + r] = (unsigned)(it + 1);
         double d1 = -1.0, d2 = -1.0, tot = 0.0;
         int a1 = 0;
         for (int k = 0; k < K; ++k) {
-            if (counts[r * K + k] == 0) err |= 1u;
+            if (counts[r * K + k] == 0) empty = true;
             const double sh = sqrt(shift2[r * K + k]);
             tot += sh * sh;
             const double d = delta[r * K + k];
@@ -708,10 +850,10 @@ __global__ void k_lloyd_status_list(int R, int K, int it, double tol, int32_t* _
             }
         }
         if (changed[r] == 0) {
-            strict |= 1u << r;
-            active &= ~(1u << r);
+            is_strict = true;
+            stop = true;
         } else if (tot <= tol) {
-            active &= ~(1u << r);
+            stop = true;
         }
         dtop[r * 3] = d1;
         dtop[r * 3 + 1] = d2 < 0.0 ? d1 : d2;
@@ -719,9 +861,12 @@ __global__ void k_lloyd_status_list(int R, int K, int it, double tol, int32_t* _
         changed[r] = 0;
         nlist[r] = 0;
     }
-    state[0] = active;
-    state[1] = strict;
-    state[2] = err;
+    const unsigned m_strict = (unsigned)__ballot(is_strict), m_stop = (unsigned)__ballot(stop), m_empty = (unsigned)__ballot(empty);
+    if (threadIdx.x == 0) {
+        state[0] = active & ~m_stop;
+        state[1] |= m_strict;
+        if (m_empty) state[2] |= 1u;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_inertia(RowsF16 X, const double* __restrict__ centers, const int32_t* __restrict__ labels,
@@ -1228,7 +1373,7 @@ int vidseg_lloyd_step(const void* x16, const double* mean, const double* xsq, in
     if (it == 0)
         k_center_sqnorm<<<dim3((R * K + 3) / 4), 256, 0, st>>>(centers, R * K, C, cnorm);
     else
-        k_lloyd_filter<<<dim3((unsigned)cdiv64(n, 256), nslots), 256, 0, st>>>(n, K, d_active, slots, labels, ub, lb, delta, dtop, list, nlist);
+        k_lloyd_filter<<<dim3((unsigned)cdiv64(n, 1024), nslots), 1024, 0, st>>>(n, K, d_active, slots, labels, ub, lb, delta, dtop, list, nlist);
     const dim3 ga((unsigned)cdiv64(n, TS), nslots);
 #define VS_ASSIGN_LIST(NCB) \
     k_lloyd_assign_list<NCB><<<ga, 256, 0, st>>>(X, centers, cnorm, xsq, K, d_active, slots, list, nlist, labels, ub, lb, chg, changed)
@@ -1240,7 +1385,7 @@ int vidseg_lloyd_step(const void* x16, const double* mean, const double* xsq, in
     }
 #undef VS_ASSIGN_LIST
     VS_CHECK_LAUNCH("lloyd_assign_list");
-    k_lloyd_accum_list<<<dim3((C + 63) / 64, nslots), 512, 0, st>>>((const f16*)x16, n, C, K, d_active, slots, chg, changed, sums, counts);
+    k_lloyd_accum_list<<<dim3((C + 63) / 64, nslots, ACC_SPLIT), 512, 0, st>>>((const f16*)x16, n, C, K, d_active, slots, chg, changed, sums, counts);
     VS_CHECK_LAUNCH("lloyd_accum_list");
     k_lloyd_update_sums<<<dim3(K, nslots), 256, 0, st>>>(sums, counts, mean, K, C, d_active, slots, centers, shift2, delta, cnorm);
     VS_CHECK_LAUNCH("lloyd_update_sums");
