@@ -12,7 +12,7 @@ starts (VAE + conditioner excluded).  N > 1: one window per GP
 vidseg_diffusion_amd/parallel.py for the exchange.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel family = bf16 MFMA implicit-GEMM (k_gemm_conv: every conv + linear of the UNet);
+  roofline      dominant kernel family = bf16 MFMA implicit-GEMM (k_gemm_tile / k_gemm_dma: every conv + linear of the UNet);
                 achieved = algorithmic FLOPs (2*M*N*K per launch) / HIP-event time of those launches, live in
                 the timed region; peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md).
   cpu_baseline  the oracle ("port") timed on this box's host cores on a bounded sample (see `sample`).
@@ -174,7 +174,7 @@ def main():
                                    + (", is_refine_mask" if args.refine else ""),
                        "frames_per_gpu": F_WIN, "num_masks": K_MASKS, "unet_evals_per_step": 3, "parallelism": f"window-per-gpu x{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": round(achieved / 2500.0, 4), "traffic": traffic, "kernel": "k_gemm_conv (bf16 MFMA implicit-GEMM conv/linear)",
+                         "frac": round(achieved / 2500.0, 4), "traffic": traffic, "kernel": "bf16 MFMA implicit-GEMM family (k_gemm_tile 256x320/256x256 + k_gemm_dma 128x128, LDS-DMA staged)",
                          "launches_per_step": k_launches // max(args.steps, 1),
                          "avg_launch_us": round(1e3 * k_ms / max(k_launches, 1), 2),
                          "gemm_ms_per_step": round(k_ms / args.steps, 3)},

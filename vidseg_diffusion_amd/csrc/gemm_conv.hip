@@ -400,7 +400,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_conv(GemmParams p) {
 #define DK 32
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-__global__ void __launch_bounds__(256, 4) k_gemm_dma(GemmParams p) {
+template <int NST>
+__global__ void __launch_bounds__(256, NST == 2 ? 4 : 3) k_gemm_dma(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = 128 * DK * 2;               // 8 KiB per operand tile
     constexpr int BUF = 2 * TILE;
@@ -543,32 +544,64 @@ __global__ void __launch_bounds__(256, 4) k_gemm_dma(GemmParams p) {
         }
     };
     const int nk = ks_end - ks_begin;
-    issue(0);
-    __syncthreads();                                   // LDS-DMA outstanding -> the barrier carries s_waitcnt vmcnt(0)
-    for (int ks = 0; ks + 1 < nk; ++ks) {
-        issue((ks + 1) & 1);
-        compute(ks & 1);
-        __syncthreads();
+    if constexpr (NST == 2) {
+        issue(0);
+        __syncthreads();                               // LDS-DMA outstanding -> the barrier carries s_waitcnt vmcnt(0)
+        for (int ks = 0; ks + 1 < nk; ++ks) {
+            issue((ks + 1) & 1);
+            compute(ks & 1);
+            __syncthreads();
+        }
+        compute((nk - 1) & 1);
+    } else {
+        // three LDS buffers, two K-steps in flight: wait only for the OLDER step (4 DMA instructions per wave and step),
+        // raw barrier (a __syncthreads() fence would drain the younger one too), then refill the buffer freed two steps ago
+        issue(0);
+        if (nk > 1) issue(1);
+        int cb = 0, ib = 2;                            // compute / issue buffer indices (mod 3)
+        for (int ks = 0; ks < nk; ++ks) {
+            if (ks + 1 < nk)
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (ks + 2 < nk) issue(ib);
+            compute(cb);
+            cb = cb == 2 ? 0 : cb + 1;
+            ib = ib == 2 ? 0 : ib + 1;
+        }
     }
-    compute((nk - 1) & 1);
     gemm_epilogue<2>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, lane, wave, split);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Big-tile LDS-DMA variant: 256 x (NJ*64) block tile (NJ = 4 -> 256x256, NJ = 5 -> 256x320 for the N = 320/640/1280
-// layers of the UNet without padding waste), BK = 64, 8 waves as 4(M) x 2(N), wave tile 64 x (NJ*32), one block per
-// CU.  The 128x128 kernels read 1 byte of operand through the CU's vector-memory path (64 B/clk) per 64 MFMA flops --
-// exactly the MFMA rate, so they cannot pass ~50 % of peak; this tile reads 0.45-0.5 bytes per 64 flops.
-// LDS image per operand tile: [rows][64] bf16, 128-byte rows, 16-byte chunk c of row r stored at slot c ^ ((r>>1)&7).
+// Wide-tile LDS-DMA kernels: (WM*64) x (NJ*64) block tile, WM x 2 waves, wave tile 64 x (NJ*32).
+//   <NJ, 4, 64>  "big": 256 x 256 / 256 x 320, BK = 64, 8 waves, one block per CU -- long-K convolutions.
+//   <NJ, 2, 32>  "mid": 128 x 256 / 128 x 320, BK = 32, 4 waves, two blocks per CU: measured 1.1-2x SLOWER than the 128x128
+//                kernel at four blocks per CU on every transformer linear (K = 320..1280) -- not launched.
+// NJ = 5 covers N = 320/640/960/1280/1920 without padding waste.  The 128x128 kernels read 1 byte of operand through
+// the CU's vector-memory path (64 B/clk) per 64 MFMA flops -- exactly the MFMA rate, so they cannot pass ~50 % of
+// peak; these tiles read 0.45-0.7 bytes per 64 flops.
+// LDS image per operand tile: [rows][BK] bf16; 16-byte chunk c of row r is stored at slot c ^ ((r>>1)&7) for 128-byte
+// rows and c ^ ((r>>2)&3) for 64-byte rows (conflict-free ds_read_b128 fragment reads).
 // ---------------------------------------------------------------------------------------------
-template <int NJ>
-__global__ void __launch_bounds__(512, 1) k_gemm_big(GemmParams p) {
+template <int BKT>
+__device__ __forceinline__ int lds_swz(int r) {
+    return BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3);
+}
+
+template <int NJ, int WM, int BKT>
+__global__ void __launch_bounds__(WM * 128, WM == 4 ? 1 : 2) k_gemm_tile(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BN = NJ * 64;
-    constexpr int A_BYTES = 256 * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
+    constexpr int BM = WM * 64, BN = NJ * 64, NW = WM * 2;
+    constexpr int RB = BKT * 2;                            // bytes per LDS row
+    constexpr int RPP = 1024 / RB;                         // rows per 1-KiB DMA piece
+    constexpr int CPR = RB / 16;                           // 16-byte chunks per row
+    constexpr int APW = BM / RPP / NW, BPW = BN / RPP / NW;   // pieces per wave
+    constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, BUF = A_BYTES + B_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const long long tiles_m = (p.M + 255) / 256;
+    const long long tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = (p.N + BN - 1) / BN;
     const long long nwg = tiles_m * tiles_n;
     const int split = p.ksplit > 1 ? (int)(blockIdx.x / nwg) : 0;
@@ -579,7 +612,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_big(GemmParams p) {
     }
     const long long tm = bid / tiles_n;
     const int tn = (int)(bid % tiles_n);
-    const long long m0 = tm * 256;
+    const long long m0 = tm * BM;
     const int n0 = tn * BN;
 
     constexpr unsigned OOB = 0xF0000000u;
@@ -587,17 +620,17 @@ __global__ void __launch_bounds__(512, 1) k_gemm_big(GemmParams p) {
     const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x0), 0, (int)p.x0_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x1 ? p.x1 : p.x0), 0, (int)p.x1_bytes, 0x00020000);
 
-    // DMA pieces are 8 rows x 128 B (one 1-KiB wave instruction); wave w stages A pieces 4w..4w+3 and B pieces NJ*w..
+    // wave w stages A pieces APW*w .. and B pieces BPW*w ..; lane l of a piece: row l / CPR, chunk l % CPR
     const int Cin = p.C0 + p.C1;
     const int HWo = p.Hout * p.Wout;
     const int upsh = p.up - 1;
     const int Hup = p.Hin << upsh, Wup = p.Win << upsh;
-    const int lrow = lane >> 3, lch = lane & 7;
-    int a_base[4], a_ih0[4], a_iw0[4];
-    bool a_ok[4];
+    const int lrow = lane / CPR, lch = lane % CPR;
+    int a_base[APW], a_ih0[APW], a_iw0[APW];
+    bool a_ok[APW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wave * 32 + i * 8 + lrow;
+    for (int i = 0; i < APW; ++i) {
+        const int r = (wave * APW + i) * RPP + lrow;
         const long long m = m0 + r;
         a_ok[i] = m < p.M;
         const int mm = a_ok[i] ? (int)m : 0;
@@ -616,19 +649,21 @@ __global__ void __launch_bounds__(512, 1) k_gemm_big(GemmParams p) {
             a_iw0[i] = ow * p.stride - 1;
         }
     }
-    unsigned b_off[NJ];
+    unsigned b_off[BPW];
 #pragma unroll
-    for (int i = 0; i < NJ; ++i) {
-        const int r = wave * (NJ * 8) + i * 8 + lrow;
+    for (int i = 0; i < BPW; ++i) {
+        const int r = (wave * BPW + i) * RPP + lrow;
         const int n = n0 + r;
-        b_off[i] = n < p.N ? (unsigned)((long long)n * p.K * 2) + (unsigned)((lch ^ ((r >> 1) & 7)) * 16) : OOB;
+        b_off[i] = n < p.N ? (unsigned)((long long)n * p.K * 2) + (unsigned)((lch ^ lds_swz<BKT>(r)) * 16) : OOB;
     }
-    const int nk_all = p.K / 64;
+    const int nk_all = p.K / BKT;
     const int ks_begin = p.ksplit > 1 ? (int)((long long)nk_all * split / p.ksplit) : 0;
     const int ks_end = p.ksplit > 1 ? (int)((long long)nk_all * (split + 1) / p.ksplit) : nk_all;
-    int ld_k = ks_begin * 64;
+    int ld_k = ks_begin * BKT;
     int ld_tap = ld_k / Cin, ld_c0 = ld_k % Cin;
-    unsigned a_off[4] = {OOB, OOB, OOB, OOB};
+    unsigned a_off[APW];
+#pragma unroll
+    for (int i = 0; i < APW; ++i) a_off[i] = OOB;
     bool a_second = false, first = true;
     auto issue = [&](int buf) {
         const int tap = ld_tap, c0 = ld_c0, k0 = ld_k;
@@ -638,7 +673,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_big(GemmParams p) {
             const int Cs = a_second ? p.C1 : p.C0;
             const int kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < APW; ++i) {
                 int pix;
                 bool ok = a_ok[i];
                 if (p.ksize == 1) {
@@ -652,28 +687,28 @@ __global__ void __launch_bounds__(512, 1) k_gemm_big(GemmParams p) {
                     ok = ok && (unsigned)ih < (unsigned)Hup && (unsigned)iw < (unsigned)Wup;
                     pix = a_base[i] + (ih >> upsh) * p.Win + (iw >> upsh);
                 }
-                const int r = i * 8 + lrow;                    // (wave*32 is a multiple of 16: no effect on (r>>1)&7)
-                a_off[i] = ok ? (unsigned)(pix * Cs) * 2u + (unsigned)((lch ^ ((r >> 1) & 7)) * 16) : OOB;
+                const int r = (wave * APW + i) * RPP + lrow;
+                a_off[i] = ok ? (unsigned)(pix * Cs) * 2u + (unsigned)((lch ^ lds_swz<BKT>(r)) * 16) : OOB;
             }
         }
         const unsigned cbyte = (unsigned)(c0 >= p.C0 ? c0 - p.C0 : c0) * 2u;
-        ld_k += 64;
-        ld_c0 += 64;
+        ld_k += BKT;
+        ld_c0 += BKT;
         if (ld_c0 >= Cin) {
             ld_c0 = 0;
             ld_tap++;
         }
-        char* A = smem + buf * BUF + wave * 4096;
-        char* B = smem + buf * BUF + A_BYTES + wave * (NJ * 1024);
+        char* A = smem + buf * BUF + wave * (APW * 1024);
+        char* B = smem + buf * BUF + A_BYTES + wave * (BPW * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < APW; ++i) {
             if (a_second)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)(A + i * 1024), 16, (int)(a_off[i] + cbyte), 0, 0, 0);
             else
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)(A + i * 1024), 16, (int)(a_off[i] + cbyte), 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < NJ; ++i)
+        for (int i = 0; i < BPW; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(B + i * 1024), 16, (int)(b_off[i] + (unsigned)k0 * 2u), 0, 0, 0);
     };
 
@@ -685,19 +720,19 @@ __global__ void __launch_bounds__(512, 1) k_gemm_big(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int sw = (l31 >> 1) & 7;                             // every fragment row is l31 + a multiple of 32
-    const int arow = (wm * 64 + l31) * 128, brow = (wn * (NJ * 32) + l31) * 128;
+    const int sw = lds_swz<BKT>(l31);                          // every fragment row is l31 + a multiple of 32
+    const int arow = (wm * 64 + l31) * RB, brow = (wn * (NJ * 32) + l31) * RB;
     auto compute = [&](int buf) {
         const char* A = smem + buf * BUF + arow;
         const char* B = smem + buf * BUF + A_BYTES + brow;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < BKT / 16; ++s) {
             bf16x8_t fa[2], fb[NJ];
             const int co = ((s * 2 + hi) ^ sw) << 4;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(A + i * 4096 + co);
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(A + i * 32 * RB + co);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(B + j * 4096 + co);
+            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(B + j * 32 * RB + co);
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -848,7 +883,7 @@ struct GemmProf {
     size_t used = 0;
     double flops = 0.0;
     long long launches = 0;
-    struct Shape { long long M; int N, K, ksize, up, stride, act, ksplit; };
+    struct Shape { long long M; int N, K, ksize, up, stride, act, ksplit, kind; };
     std::vector<Shape> shapes;      // one per event pair
 };
 static GemmProf g_prof;
@@ -885,8 +920,8 @@ int vidseg_gemm_profile_end(double* out) {
         ms += t;
         if (getenv("VIDSEG_GEMM_SHAPES") && i / 2 < g_prof.shapes.size()) {
             const GemmProf::Shape& h = g_prof.shapes[i / 2];
-            fprintf(stderr, "GEMMSHAPE M=%lld N=%d K=%d ks=%d up=%d st=%d act=%d split=%d us=%.1f\n", h.M, h.N, h.K, h.ksize, h.up, h.stride,
-                    h.act, h.ksplit, t * 1e3);
+            fprintf(stderr, "GEMMSHAPE M=%lld N=%d K=%d ks=%d up=%d st=%d act=%d split=%d us=%.1f kind=%d\n", h.M, h.N, h.K, h.ksize, h.up,
+                    h.stride, h.act, h.ksplit, t * 1e3, h.kind);
         }
     }
     out[0] = ms;
@@ -928,7 +963,9 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     }
     p.ksplit = 1;
     p.ws = nullptr;
+    int kind = 0;                                              // 0: 128x128, 1: big, 2: mid, 3: narrow (profile log only)
     if (narrow) {
+        kind = 3;
         const long long tiles = ((p.M + 255) / 256) * ((p.N + 63) / 64);
         k_gemm_conv<256, 64><<<dim3((unsigned)tiles), 256, 2 * (256 + 64) * BK * 2, st>>>(p);
     } else {
@@ -941,9 +978,10 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             use_dma = e ? atoi(e) : 1;
             e = getenv("VIDSEG_GEMM_BIG");                       // 0 never, 1 auto, 2 whenever legal
             big_mode = e ? atoi(e) : 1;
-            (void)hipFuncSetAttribute((const void*)k_gemm_dma, hipFuncAttributeMaxDynamicSharedMemorySize, 36864);
-            (void)hipFuncSetAttribute((const void*)k_gemm_big<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
-            (void)hipFuncSetAttribute((const void*)k_gemm_big<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
+            (void)hipFuncSetAttribute((const void*)k_gemm_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 36864);
+            (void)hipFuncSetAttribute((const void*)k_gemm_dma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
+            (void)hipFuncSetAttribute((const void*)k_gemm_tile<4, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
+            (void)hipFuncSetAttribute((const void*)k_gemm_tile<5, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
         }
         // Blocks run in rounds over the resident slots, so the last round's fill decides the efficiency.  Pick the K
         // split that maximises fill / (1 + cost of writing+reading the fp32 partials); deterministic finish kernel.
@@ -981,15 +1019,20 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             p.ksplit = S;
             p.ws = S > 1 ? g_ws : nullptr;
             if (NJ == 5)
-                k_gemm_big<5><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 320) * 128, st>>>(p);
+                k_gemm_tile<5, 4, 64><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 320) * 128, st>>>(p);
             else
-                k_gemm_big<4><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 256) * 128, st>>>(p);
+                k_gemm_tile<4, 4, 64><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 256) * 128, st>>>(p);
+            kind = 1;
         } else {
             S = pick_split(tiles, 512);
             p.ksplit = S;
             p.ws = S > 1 ? g_ws : nullptr;
-            if (use_dma)
-                k_gemm_dma<<<dim3((unsigned)(tiles * S)), 256, 36864, st>>>(p);
+            // grids that do not fill the 4 x 256 block slots gain from two K-steps in flight per block (measured -10..-20 %);
+            // full grids prefer the fourth resident block (VIDSEG_GEMM_DMA=3 forces the 3-stage variant everywhere)
+            if (use_dma == 3 || (use_dma == 1 && tiles * S <= 512 && p.act != 2))
+                k_gemm_dma<3><<<dim3((unsigned)(tiles * S)), 256, 49152, st>>>(p);
+            else if (use_dma)
+                k_gemm_dma<2><<<dim3((unsigned)(tiles * S)), 256, 36864, st>>>(p);
             else
                 k_gemm_conv<128, 128><<<dim3((unsigned)(tiles * S)), 256, 2 * (128 + 128) * BK * 2, st>>>(p);
         }
@@ -1000,7 +1043,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     }
     if (g_prof.on) {
         (void)hipEventRecord(prof_event(), st);
-        g_prof.shapes.push_back({p.M, p.N, p.K, p.ksize, p.up, p.stride, p.act, p.ksplit});
+        g_prof.shapes.push_back({p.M, p.N, p.K, p.ksize, p.up, p.stride, p.act, p.ksplit, kind});
     }
     VS_CHECK_LAUNCH("gemm_conv");
     return VS_OK;
