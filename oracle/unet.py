@@ -91,10 +91,10 @@ class UNetOracle:
         out = alpha * x5 + (1.0 - alpha) * h
         return _bf(out.permute(0, 2, 1, 3, 4).reshape(BT, C, H, W), self.rb)
 
-    def attention(self, x, ctx, p, tapname, inj_q=None, inj_k=None, rowadd=None):
+    def attention(self, x, ctx, p, tapname, inj_q=None, inj_k=None, rowadd=None, inj_v=None):
         q = self.lin(x, p + ".to_q", bias=False) if inj_q is None else inj_q.float()      # attention.py:305-315
         k = self.lin(ctx, p + ".to_k", bias=False) if inj_k is None else inj_k.float()
-        v = self.lin(ctx, p + ".to_v", bias=False)
+        v = self.lin(ctx, p + ".to_v", bias=False) if inj_v is None else inj_v.float()
         if tapname is not None:
             self.taps[tapname + "_q"] = q.half()
             self.taps[tapname + "_k"] = k.half()
@@ -125,7 +125,10 @@ class UNetOracle:
         while self.has(f"{p}.transformer_blocks.{d}."):
             b = f"{p}.transformer_blocks.{d}"
             tn = tapname if d == 0 else None
-            inj, ra = (self.mod or {}).get(tapname, ({}, {})) if tapname else ({}, {})
+            inj, ra_all = (self.mod or {}).get(tapname, ({}, {})) if tapname else ({}, {})
+            layers = ra_all.get("_layers", ("spatial",))
+            ra = {k_: v_ for k_, v_ in ra_all.items() if k_ != "_layers"} if "spatial" in layers else {}
+            ra_t = {k_: v_ for k_, v_ in ra_all.items() if k_ != "_layers"} if "temporal" in layers else {}
             pick = lambda sub: next((v for kk, v in inj.items() if sub in kk), None)           # noqa: E731
             n1 = self.ln(t, b + ".norm1")
             t = _bf(self.attention(n1, n1, b + ".attn1", tn and tn + "_spatial_self_attn", pick("spatial_self_attn_q"),
@@ -139,7 +142,7 @@ class UNetOracle:
                 ffo = ffo + ra["ff_out"][:, :, None]
             t = _bf(ffo + t, self.rb)
             if video:
-                tm = self.video_block(_bf(t + temb, self.rb), tctx, f"{p}.time_stack.{d}", tn, H * W)
+                tm = self.video_block(_bf(t + temb, self.rb), tctx, f"{p}.time_stack.{d}", tn, H * W, inj, ra_t)
                 alpha = torch.sigmoid(self.sd[p + ".time_mixer.mix_factor"])
                 t = _bf(alpha * t + (1.0 - alpha) * tm, self.rb)
             d += 1
@@ -151,19 +154,33 @@ class UNetOracle:
         val, gate = y.chunk(2, dim=-1)
         return self.lin(_bf(val * F.gelu(gate), self.rb), p + ".net.2")
 
-    def video_block(self, x, tctx, p, tapname, S):
+    def video_block(self, x, tctx, p, tapname, S, inj=None, ra=None):
         """VideoTransformerBlock._forward (video_attention.py:145-285): (b t) s c -> (b s) t c, ff_in, temporal
-        self-attention, cross-attention to the first frame's context, ff, residuals, back to (b t) s c."""
+        self-attention, cross-attention to the first frame's context, ff, residuals, back to (b t) s c.
+        inj: injected temporal_self_attn_{q,k,v} dumps (already [(b s), t, c]); ra: attn_type -> [2F, S] row vector
+        lambda_i*mask_i, added as out[(b s), i] += ra[b*F + i, s] (video_attention.py:197-216, 231-250, 258-277)."""
         T = self.T
         BT, S_, C = x.shape
         b = BT // T
+        inj, ra = inj or {}, ra or {}
+        pick = lambda sub: next((v for kk, v in inj.items() if sub in kk), None)               # noqa: E731
+
+        def tl(name):                                                       # [2F, S] -> [(b s), t]
+            v = ra.get(name)
+            return None if v is None else v.view(b, T, S).permute(0, 2, 1).reshape(b * S, T)
+
         xt = x.view(b, T, S, C).permute(0, 2, 1, 3).reshape(b * S, T, C)
         xt = _bf(self.geglu_ff(self.ln(xt, p + ".norm_in"), p + ".ff_in") + xt, self.rb)
         n1 = self.ln(xt, p + ".norm1")
-        xt = _bf(self.attention(n1, n1, p + ".attn1", tapname and tapname + "_temporal_self_attn") + xt, self.rb)
+        xt = _bf(self.attention(n1, n1, p + ".attn1", tapname and tapname + "_temporal_self_attn", pick("temporal_self_attn_q"),
+                                pick("temporal_self_attn_k"), tl("self_attn"), pick("temporal_self_attn_v")) + xt, self.rb)
         ctx = tctx[:, None].expand(b, S, *tctx.shape[1:]).reshape(b * S, *tctx.shape[1:])
-        xt = _bf(self.attention(self.ln(xt, p + ".norm2"), ctx, p + ".attn2", tapname and tapname + "_temporal_cross_attn") + xt, self.rb)
-        xt = _bf(self.geglu_ff(self.ln(xt, p + ".norm3"), p + ".ff") + xt, self.rb)
+        xt = _bf(self.attention(self.ln(xt, p + ".norm2"), ctx, p + ".attn2", tapname and tapname + "_temporal_cross_attn",
+                                rowadd=tl("cross_attn")) + xt, self.rb)
+        ffo = self.geglu_ff(self.ln(xt, p + ".norm3"), p + ".ff")
+        if tl("ff_out") is not None:
+            ffo = ffo + tl("ff_out")[:, :, None]
+        xt = _bf(ffo + xt, self.rb)
         return xt.view(b, S, T, C).permute(0, 2, 1, 3).reshape(BT, S, C)
 
     def block(self, h, emb_silu, context, p, tapname):
@@ -330,6 +347,7 @@ def _step_modulation(m, i, Fn):
             row = (m["lambda"] * m["masks"].double()).float()                                   # [F, N]
             full = torch.cat([row if m["modulate_uc"] else torch.zeros_like(row), row])          # uc half, c half
             ra = {t: full for t in m["attn_types"]}
+            ra["_layers"] = tuple(m.get("layer_types", ("spatial",)))
         if inj or ra:
             out[f"output_block_{b}"] = (inj, ra)
     return out
@@ -344,7 +362,7 @@ def edm_sigmas(n, sigma_min=0.002, sigma_max=700.0, rho=7.0):
 
 
 def euler_sample_svd(unet: UNetOracle, latent, c, uc, num_steps=25, t_start=17, min_scale=1.0, max_scale=2.5, noise=None,
-                     callback=None):
+                     callback=None, modulate=None):
     """SVD feature pass: add_noise + EulerEDMSampler with LinearPredictionGuider (guiders.py:60-100), Denoiser +
     VScalingWithEDMcNoise (denoiser_scaling.py:51-59), OpenAIWrapper channel-concat of c['concat'] (wrappers.py:27),
     y = c['vector'], num_video_frames = F (svd_pipeline_vspw.py:307-311).  c/uc: dicts of crossattn, concat, vector."""
@@ -362,13 +380,19 @@ def euler_sample_svd(unet: UNetOracle, latent, c, uc, num_steps=25, t_start=17, 
         c_in = 1.0 / (sigma ** 2 + 1.0) ** 0.5
         c_noise = 0.25 * sigma.log()
         xin = torch.cat([torch.cat([x, x]) * c_in, torch.cat([uc["concat"], c["concat"]])], dim=1)
+        unet.mod = _step_modulation(modulate, i, Fn) if modulate is not None else None
         net = unet.forward(xin, torch.full((2 * Fn,), float(c_noise)), torch.cat([uc["crossattn"], c["crossattn"]]),
                            y=torch.cat([uc["vector"], c["vector"]]), num_video_frames=Fn)
+        unet.mod = None
         den = net * c_out + torch.cat([x, x]) * c_skip
         xu, xc = den.chunk(2)
         den = xu + scale * (xc - xu)
         d = (x - den) / sigma
         x = x + d * (nxt - sigma)
-        if callback is not None:
+        if modulate is not None and modulate.get("blend") and modulate["blend"][0] <= i <= modulate["blend"][1]:
+            m = modulate["masks"].float().reshape(Fn, 1, modulate["fh"], modulate["fw"])       # sampling.py:229-250
+            m = F.interpolate(m, size=x.shape[-2:], mode="nearest")
+            x = (x * m + modulate["xt"][i] * (1 - m)).float()
+        if callback is not None and (modulate is None or i >= min(modulate["timesteps"])):
             callback(x, i, unet.taps)
     return x

@@ -265,3 +265,61 @@ def test_inversion_vs_reference(env):
     err = nrms(x.cpu().numpy(), g["inv_final"])
     print("inversion nrms", err, "bf16 format", fmt)
     assert err <= 1.5 * fmt + 1e-2
+
+
+def test_svd_modulated_injected_pass_vs_reference():
+    """a17 on the VideoUNet: feature pass fills the FeatureStore (spatial + temporal taps), then the reference-style modulated
+    pass: lambda*mask on block 8's spatial and temporal self-attention outputs, injected temporal q/k, latent blending."""
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import build_svd_engine, save_feature_maps
+    from vidseg_diffusion_amd.video_unet import VideoUNet
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "svd_modulated_narrow.npz"))
+    g = {k: z[k] for k in z.files}
+    net = VideoUNet(**synthetic.SVD_NARROW)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=4321).items()})
+    Fn = g["latent"].shape[0]
+    eng = build_svd_engine(net, num_frames=Fn)
+    c = {k[2:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith("c_")}
+    uc = {k[3:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith("uc_")}
+    T0 = 22
+    noised = eng.sampler.add_noise(torch.from_numpy(g["latent"]).to(dev), cond=c, uc=uc, num_steps=25, noise_level=T0,
+                                   noise=torch.from_numpy(g["noise"]).to(dev))
+    FE.FeatureStore.clear()
+    base, exp = "/nonexistent/vs_svdmod", "exp"
+    extra = {"image_only_indicator": torch.zeros(2, Fn), "num_video_frames": Fn}
+
+    def denoiser(inp, sigma, cc, is_modulate_step=False, is_injected_step=False, modulate_params=None):
+        return eng.denoiser(eng.model, inp, sigma, cc, is_modulate_step=is_modulate_step, is_injected_step=is_injected_step,
+                            modulate_params=modulate_params, **extra)
+
+    feat = eng.sampler(denoiser, noised.clone(), cond=c, uc=uc, t_start=T0,
+                       img_callback=lambda xt, i: save_feature_maps(eng, base, exp, i, xt=xt))
+    assert nrms(feat.cpu().numpy(), g["feat_final"]) < 4e-2
+    for tag in [k[4:-6] for k in g if k.startswith("mod_") and k.endswith("_final")]:
+        lam = float(g[f"lam_{tag}"])
+        mp = {"feature_masks": [torch.from_numpy(m).to(dev) for m in g["masks"]], "modulate_block_idx": [8],
+              "modulate_layer_type": ["spatial", "temporal"], "modulate_attn_type": ["self_attn"], "modulate_timestep": [T0],
+              "modulate_schedule": "constant", "modulate_lambda_start": lam, "modulate_lambda_end": lam, "num_frames": Fn,
+              "modulate_uc": True, "is_injected_features": True,
+              "injected_feature_types": ["temporal_cross_attn_k", "temporal_cross_attn_q", "temporal_self_attn_k", "temporal_self_attn_q"],
+              "injected_block_types": ["output"], "input_block_indices": [3, 4, 5, 6, 7, 8, 10, 11],
+              "output_block_indices": list(range(1, 12)), "feature_folder": base, "exp_name": exp, "injected_features_group": {},
+              "modulate_layer_frames": {}, "modulate_block_frames": {}, "modulate_timestep_frames": {}, "modulate_lambda_layers": {},
+              "latent_mask_start": T0, "latent_mask_end": 25}
+        xs = []
+        final = eng.sampler(denoiser, noised.clone(), cond=c, uc=uc, img_callback=lambda xt, i: xs.append(xt.cpu().numpy()),
+                            is_modulate=True, modulate_params=mp, t_start=T0, is_latent_blending=True, feature_height=8, feature_width=8,
+                            model=None)
+        ref = g[f"mod_{tag}_x_steps"]
+        assert len(xs) == ref.shape[0]
+        errs = [nrms(xs[i], ref[i]) for i in range(len(xs))]
+        d_ref = g[f"mod_{tag}_final"] - g["feat_final"]
+        d_got = final.cpu().numpy() - feat.cpu().numpy()
+        print("svd modulated", tag, "lambda", lam, "step nrms", [round(e, 4) for e in errs], "delta nrms", round(nrms(d_got, d_ref), 4),
+              "delta/ref", round(float(np.abs(d_ref).mean() / np.abs(g["feat_final"]).mean()), 4))
+        assert max(errs) < 4e-2
+        # the modulation must actually have moved the sample the way the reference's did (large-lambda cases dominate rounding)
+        if abs(lam) >= 1000:
+            assert nrms(d_got, d_ref) < 0.35, nrms(d_got, d_ref)

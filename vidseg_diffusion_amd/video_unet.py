@@ -24,7 +24,7 @@ import torch.nn as nn
 from . import ops
 from ._lib import VidsegError
 from .unet import (BasicTransformerBlock, CrossAttention, Downsample, FeedForward, GroupNorm32, ResBlock, SpatialTransformer,
-                   TimestepEmbedSequential, UNetModel, Upsample, _ConvIn, _meta)
+                   TimestepEmbedSequential, UNetModel, Upsample, _ConvIn, _meta, block_modulation)
 
 F16 = torch.float16
 
@@ -120,19 +120,39 @@ class VideoTransformerBlock(nn.Module):
         self.ln = {n: (ops.f32(getattr(self, n).weight, dev), ops.f32(getattr(self, n).bias, dev))
                    for n in ("norm_in", "norm1", "norm2", "norm3")}
 
-    def run(self, x, time_context, T, tap):
-        """x: bf16 [(b t), S, C] in spatial order; time_context: bf16 [b, L, ctx] (first frame of each sample)."""
+    def run(self, x, time_context, T, tap, mod=None):
+        """x: bf16 [(b t), S, C] in spatial order; time_context: bf16 [b, L, ctx] (first frame of each sample).
+        mod: None or (inject, rowadd) from block_modulation(..., "temporal"): injected temporal_self_attn_{q,k,v} dumps
+        replace the projections of attn1 (VA:166-195) and rowadd[attn_type] = lambda_i * mask_i on the rows of frame i is
+        added to attn1_out / attn2_out / ff_out (VA:197-216, 231-250, 258-277).  In the reference's [(b s), t, c] layout
+        that is out[half_hw:, i] += lambda*mask[:, None]; here rows are (b t) s, the same vector the spatial blocks use."""
         BT, S, C = x.shape
         Bv = BT // T
         dev = x.device
+        inj, ra = mod if mod is not None else (None, None)
+        inj, ra = inj or {}, ra or {}
+
+        def pick(sub):
+            for k, v in inj.items():
+                if sub in k:
+                    return v
+            return None
+
+        def to_spatial(t16):                                        # fp16 [(b s), t, c] dump -> bf16 [(b t), s, c]
+            return ops.f16_to_bf16(t16.view(Bv, S, T, C).permute(0, 2, 1, 3).contiguous().view(BT, S, C))
+
         x = self.ff_in.run(ops.layernorm(x, *self.ln["norm_in"]), x)                       # VA:155-159
         n1 = ops.layernorm(x, *self.ln["norm1"])
         a1 = self.attn1
         tq = torch.empty((Bv * S, T, C), dtype=F16, device=dev) if tap else None
         tk = torch.empty((Bv * S, T, C), dtype=F16, device=dev) if tap else None
         qkv = ops.linear_temporal_tap(n1, a1.w_qkv, T, S, tq, tk, C)
-        att = ops.temporal_attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], self.heads, Bv, T, S)   # VA:166-195
-        x = ops.linear(att, a1.w_o, a1.b_o, residual=x)
+        iq, ik, iv = pick("temporal_self_attn_q"), pick("temporal_self_attn_k"), pick("temporal_self_attn_v")
+        q = to_spatial(iq) if iq is not None else qkv[..., :C]
+        k = to_spatial(ik) if ik is not None else qkv[..., C:2 * C]
+        v = to_spatial(iv) if iv is not None else qkv[..., 2 * C:]
+        att = ops.temporal_attention(q, k, v, self.heads, Bv, T, S)                          # VA:166-195
+        x = ops.linear(att, a1.w_o, a1.b_o, residual=x, rowadd=ra.get("self_attn"))         # VA:197-218
         a2 = self.attn2
         L = time_context.shape[1]
         n2 = ops.layernorm(x, *self.ln["norm2"])
@@ -141,12 +161,16 @@ class VideoTransformerBlock(nn.Module):
         tk2 = torch.empty((Bv, L, C), dtype=F16, device=dev) if tap else None
         kv = ops.linear(time_context, a2.w_kv, tap=tk2, tap_cols=C)
         att2 = ops.attention(q2.view(Bv, T * S, C), kv[..., :C], kv[..., C:], self.heads)   # VA:224-250
-        x = ops.linear(att2.view(BT, S, C), a2.w_o, a2.b_o, residual=x)
+        x = ops.linear(att2.view(BT, S, C), a2.w_o, a2.b_o, residual=x, rowadd=ra.get("cross_attn"))
         if tap:
             a1.q, a1.k = tq, tk
             a2.q = tq2
             a2.k = tk2[:, None].expand(Bv, S, L, C).reshape(Bv * S, L, C)                   # reference shape [(b s), L, C]
-        return self.ff.run(ops.layernorm(x, *self.ln["norm3"]), x)                          # VA:252-281
+        if iq is not None:
+            a1.q = iq                                                                       # ATT:330-331 stores what was used
+        if ik is not None:
+            a1.k = ik
+        return self.ff.run(ops.layernorm(x, *self.ln["norm3"]), x, ra.get("ff_out"))        # VA:252-281
 
 
 class SpatialVideoTransformer(SpatialTransformer):
@@ -180,7 +204,7 @@ class SpatialVideoTransformer(SpatialTransformer):
             self._temb[T] = ops.linear(ops.linear(te, self.tp_w1, self.tp_b1, act=ops.ACT_SILU), self.tp_w2, self.tp_b2)
         return self._temb[T]
 
-    def run(self, x, context, T=None):
+    def run(self, x, context, T=None, mod=None):
         B, H, W, C = x.shape
         S = H * W
         t = ops.groupnorm(x, self.g, self.b, eps=1e-6, silu=False).view(B, S, C)
@@ -188,8 +212,10 @@ class SpatialVideoTransformer(SpatialTransformer):
         time_context = context[::T].contiguous()                                            # VA:400-404
         emb = self._frame_emb(T, x.device)
         for i, (blk, mix) in enumerate(zip(self.transformer_blocks, self.time_stack)):
-            t = blk.run(t, context, self.tap and i == 0)
-            tm = mix.run(ops.add_rowvec(t, emb, S), time_context, T, self.tap and i == 0)   # VA:429-431, 453-460
+            # VA:432-451 / 456-472: the spatial and the temporal block each get their own layer-frames group
+            t = blk.run(t, context, self.tap and i == 0, block_modulation(mod, "spatial", S, x.device))
+            tm = mix.run(ops.add_rowvec(t, emb, S), time_context, T, self.tap and i == 0,
+                         block_modulation(mod, "temporal", S, x.device))                    # VA:429-431, 453-476
             t = self.time_mixer.run(t, tm)                                                  # VA:463-467
         out = ops.linear(t, self.w_out, self.b_out, residual=x.view(B, S, C))
         self.features_after_temporal = out
@@ -197,13 +223,13 @@ class SpatialVideoTransformer(SpatialTransformer):
 
 
 class VideoTimestepEmbedSequential(TimestepEmbedSequential):
-    def run(self, x, x_skip, emb_all, context, T=None):
+    def run(self, x, x_skip, emb_all, context, T=None, mod=None):
         for layer in self:
             if isinstance(layer, VideoResBlock):
                 x = layer.run(x, x_skip, emb_all, T)
                 x_skip = None
             elif isinstance(layer, SpatialVideoTransformer):
-                x = layer.run(x, context, T)
+                x = layer.run(x, context, T, mod)
             elif isinstance(layer, (Upsample, Downsample)):
                 x = layer.run(x)
             else:
@@ -291,7 +317,26 @@ class VideoUNet(UNetModel):
         # every emb_layers user, spatial and temporal, shares one batched GEMM
         return [m for m in self.modules() if isinstance(m, (ResBlock, _TimeStack))]
 
-    def forward_nhwc(self, x_nhwc_f32, timesteps, context_bf16, y=None, num_video_frames=None):
+    def _block_mod(self, kind, i, blk, is_modulate_step, is_injected_step, mp, device):
+        """video_model.py:480-545: as UNetModel._block_mod, keyed on SpatialVideoTransformer."""
+        if not (is_modulate_step or is_injected_step):
+            return None
+        has_st = len(blk) > 1 and "SpatialVideoTransformer" in str(type(blk[1]))
+        is_mod = False
+        if kind == "output" and is_modulate_step and i in mp["modulate_block_idx"] and has_st:
+            is_mod = True
+            mp["modulate_block_frames_group"] = mp["modulate_block_frames"].get(i, list(range(mp["num_frames"])))
+        is_inj = False
+        idx_key = "input_block_indices" if kind == "input" else "output_block_indices"
+        if is_injected_step and has_st and kind in mp["injected_block_types"] and i in mp[idx_key]:
+            from .util import load_target_features
+            mp["injected_features_group"] = load_target_features(mp["feature_folder"], mp["exp_name"], mp["timestep"], kind,
+                                                                 mp["injected_feature_types"], i, device)
+            is_inj = len(mp["injected_features_group"]) > 0
+        return (is_mod, is_inj, mp) if (is_mod or is_inj) else None
+
+    def forward_nhwc(self, x_nhwc_f32, timesteps, context_bf16, y=None, num_video_frames=None, is_modulate_step=False,
+                     is_injected_step=False, modulate_params=None):
         if num_video_frames is None:
             raise VidsegError("VideoUNet needs num_video_frames")
         T = int(num_video_frames)
@@ -301,20 +346,23 @@ class VideoUNet(UNetModel):
         emb_all = ops.linear(ops.silu(emb), self.emb_w, self.emb_b, out_f32=True)
         h = ops.conv_in(x_nhwc_f32, self.cin_w, self.cin_b)
         hs = [h]
-        for blk in list(self.input_blocks)[1:]:
-            h = blk.run(h, None, emb_all, context_bf16, T)
+        dev = x_nhwc_f32.device
+        for i, blk in list(enumerate(self.input_blocks))[1:]:
+            h = blk.run(h, None, emb_all, context_bf16, T,
+                        self._block_mod("input", i, blk, False, is_injected_step, modulate_params, dev))   # VM:480-510
             hs.append(h)
         h = self.middle_block.run(h, None, emb_all, context_bf16, T)
-        for blk in self.output_blocks:
-            h = blk.run(h, hs.pop(), emb_all, context_bf16, T)
+        for i, blk in enumerate(self.output_blocks):
+            mod = self._block_mod("output", i, blk, is_modulate_step, is_injected_step, modulate_params, dev)
+            h = blk.run(h, hs.pop(), emb_all, context_bf16, T, mod)                                       # VM:521-562
         h = ops.groupnorm(h, self.out_g, self.out_beta, eps=1e-5, silu=True)
         return ops.conv_out4(h, self.out_w, self.out_b)
 
     def forward(self, x, timesteps=None, context=None, y=None, time_context=None, num_video_frames=None, image_only_indicator=None,
                 is_modulate_step=False, is_injected_step=False, modulate_params=None, **kwargs):
         """Reference signature (video_model.py:451-463)."""
-        if is_modulate_step or is_injected_step:
-            raise NotImplementedError("modulated / injected passes (SURVEY.md a17) are not built yet")
+        if (is_modulate_step or is_injected_step) and modulate_params is None:
+            raise AssertionError("modulate_params is required for a modulated / injected step")
         if y is None:
             raise AssertionError("must specify y if and only if the model is class-conditional")
         if image_only_indicator is not None and bool(torch.as_tensor(image_only_indicator).any()):
@@ -323,4 +371,4 @@ class VideoUNet(UNetModel):
             raise VidsegError("VideoUNet runs on a HIP device only (no CPU fallback)")
         xn = x.float().permute(0, 2, 3, 1).contiguous()
         ctx = context if context.dtype == torch.bfloat16 else ops.to_bf16(context.float().contiguous())
-        return self.forward_nhwc(xn, timesteps, ctx, y, num_video_frames)
+        return self.forward_nhwc(xn, timesteps, ctx, y, num_video_frames, is_modulate_step, is_injected_step, modulate_params)
