@@ -73,12 +73,15 @@ int vidseg_lloyd_status(int R, int K, int it, double tol, int32_t* changed, cons
  * vidseg_lloyd_iter by construction): triangle-inequality bound filter (ub/lb per restart and sample), E-step on the
  * gathered list of unsettled samples, M-step on exact incrementally-maintained raw sums (float64 adds of fp16 values
  * are exact), centre = (sum - count*mean)/count.  Replaces _k_means_lloyd.pyx:lloyd_iter_chunked_dense + _kmeans.py:715-734.
+ * Empty clusters are relocated on the device (_k_means_common.pyx:167-211, numpy's argpartition replayed).
  * Before it = 0 the host sets labels = -1, sums = 0, counts = 0, list[r] = 0..n-1, nlist[r] = n, changed = 0.
- * chg: int32 [R][n][2] change list, delta: [R][K], dtop: [R][3]. */
+ * chg: int32 [R][n][2] change list, delta: [R][K], dtop: [R][3]; relocation scratch reloc_d f64 [R][n],
+ * reloc_t i32 [R][n], reloc i32 [R][64][3], nreloc i32 [R]. */
 int vidseg_lloyd_step(const void* x16, const double* mean, const double* xsq, int64_t n, int C, int R, int K, int it, double tol,
                       unsigned* state, const int32_t* slots, int nslots, double* centers, double* cnorm, double* sums, int32_t* counts,
                       int32_t* labels, double* ub, double* lb, int32_t* list, int32_t* nlist, int32_t* chg, int32_t* changed,
-                      double* shift2, double* delta, double* dtop, vidseg_stream_t stream);
+                      double* shift2, double* delta, double* dtop, double* reloc_d, int32_t* reloc_t, int32_t* reloc, int32_t* nreloc,
+                      vidseg_stream_t stream);
 int vidseg_kmeans_inertia(const void* x16, const double* mean, int64_t n, int C, int R, int K, const double* centers,
                           const int32_t* labels, double* part, double* inertia, vidseg_stream_t stream);
 int vidseg_add_mean_f64(double* centers, const double* mean, int K, int C, vidseg_stream_t stream);

@@ -156,10 +156,12 @@ def lloyd_single(X, centers_init, max_iter, tol, raw=None, mean=None):
         _relocate_empty(X, centers, centers_new, weight, labels)
         # _average_centers (_k_means_common.pyx:274-295): centers *= 1/weight; a cluster that
         # is still empty (only when relocation bailed out) sits on the biggest cluster.
-        nz = weight > 0
-        centers_new[nz] *= (1.0 / weight[nz])[:, None]
-        big = centers_new[int(np.argmax(weight))].copy()
-        centers_new[~nz] = big
+        amax = int(np.argmax(weight))
+        for j in range(K):                                   # in-place loop order matters for a still-empty cluster:
+            if weight[j] > 0:                                # it copies the biggest cluster's row as it is at that moment
+                centers_new[j] *= 1.0 / weight[j]            # (averaged only if amax < j), _k_means_common.pyx:286-295
+            else:
+                centers_new[j] = centers_new[amax]
         # _center_shift: per-cluster Euclidean norm, then (shift**2).sum() in _kmeans.py:725
         shift = np.sqrt(((centers_new - centers) ** 2).sum(axis=1))
         shift_tot = (shift ** 2).sum()
@@ -186,7 +188,7 @@ def _is_same_clustering(l1, l2, K):
     return True
 
 
-def kmeans_fit(X16, n_clusters, random_state, n_init=10, max_iter=300, tol=1e-4):
+def kmeans_fit(X16, n_clusters, random_state, n_init=10, max_iter=300, tol=1e-4, init=None):
     """KMeans(n_clusters, n_init=10).fit(X) (cluster/_kmeans.py:1451-1547): fp16 input is
     up-cast to float64 by validate_data(dtype=[float64, float32]), mean-centred, tolerance
     scaled by the mean per-feature variance, best-of-n_init by strictly lower inertia unless
@@ -197,8 +199,13 @@ def kmeans_fit(X16, n_clusters, random_state, n_init=10, max_iter=300, tol=1e-4)
     tol_ = float(np.mean(np.var(X, axis=0)) * tol)
     x_sq = _row_norms_sq(X)
     best = None
+    if init is not None:                                     # KMeans(init=ndarray): one run from the given centres (:1466-1474, :1490)
+        n_init = 1
     for _ in range(n_init):
-        c0, _idx = kmeans_plusplus(X, n_clusters, x_sq, random_state)
+        if init is not None:
+            c0 = np.ascontiguousarray(init, dtype=F64) - mean
+        else:
+            c0, _idx = kmeans_plusplus(X, n_clusters, x_sq, random_state)
         labels, inertia, centers, n_iter = lloyd_single(X, c0, max_iter, tol_, raw=raw, mean=mean)
         if best is None or (inertia < best[1] and not _is_same_clustering(labels, best[0], n_clusters)):
             best = (labels, inertia, centers, n_iter)

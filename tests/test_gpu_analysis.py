@@ -149,3 +149,19 @@ def test_full_size_c2_vs_oracle(dev):
     ref, _ = O.correct_low_res_mask(labels.reshape(F, h, w), th, tw)
     out = A.trajectory_vote(idx, _to(dev, labels.reshape(F, N).astype(np.int32)), w).cpu().numpy()
     assert np.array_equal(out.reshape(-1), ref)
+
+
+def test_empty_cluster_relocation_vs_sklearn_golden(dev):
+    """Device-side _relocate_empty_clusters_dense: initial centres that leave 1-3 clusters empty; labels must equal
+    scikit-learn's own (tests/golden/kmeans_relocate.npz) and the oracle's, centres within float64 rounding."""
+    from oracle import analysis as OA
+    from vidseg_diffusion_amd import analysis as A
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "kmeans_relocate.npz"))
+    for nm in "abc":
+        init, X = g[f"{nm}_init"], g[f"{nm}_X"]
+        res = A.kmeans_fit(torch.from_numpy(X).to(dev), init.shape[0], random_state=np.random.RandomState(0), init=init)
+        labels = res.labels.cpu().numpy()
+        assert np.array_equal(labels, g[f"{nm}_labels"]), nm
+        assert np.abs(res.centers.cpu().numpy() - g[f"{nm}_centers"]).max() < 1e-12, nm
+        oc, ol, _ = OA.kmeans_fit(X, init.shape[0], np.random.RandomState(0), init=init)
+        assert np.array_equal(labels, ol) and res.n_iter == int(g[f"{nm}_n_iter"])

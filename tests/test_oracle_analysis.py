@@ -72,3 +72,14 @@ def test_npselect_port_matches_numpy_on_ties():
             else:
                 x = (np.round(g.uniform(0.9, 1.0, size=n) * 2048) / 2048).astype(np.float16)
             assert argpartition_last(x) == int(np.argpartition(x, -1)[-1:][0])
+
+
+def test_empty_cluster_relocation_matches_sklearn():
+    """_relocate_empty_clusters_dense + _average_centers (cluster/_k_means_common.pyx:167-211, 274-295): initial centres
+    that leave 1-3 clusters empty; golden = scikit-learn's own KMeans(init=ndarray) (tools/gen_golden_kmeans_relocate.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "kmeans_relocate.npz"))
+    for nm in "abc":
+        init = g[f"{nm}_init"]
+        centers, labels, _ = A.kmeans_fit(g[f"{nm}_X"], init.shape[0], np.random.RandomState(0), init=init)
+        assert np.array_equal(labels, g[f"{nm}_labels"]), nm
+        assert np.abs(centers - g[f"{nm}_centers"]).max() < 1e-12, nm

@@ -30,7 +30,7 @@ _SIGS = {
     "vidseg_gather_rows_f64": [_P, _P, _I, _P, _I, _P, _P],
     "vidseg_lloyd_iter": [_P, _P, _L, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "vidseg_lloyd_status": [_I, _I, _I, _D, _P, _P, _P, _P, _P],
-    "vidseg_lloyd_step": [_P, _P, _P, _L, _I, _I, _I, _I, _D, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "vidseg_lloyd_step": [_P, _P, _P, _L, _I, _I, _I, _I, _D, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "vidseg_kmeans_inertia": [_P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P],
     "vidseg_add_mean_f64": [_P, _P, _I, _I, _P],
     "vidseg_knn_vote": [_P, _L, _P, _L, _I, _P, _P, _P, _P, _P],

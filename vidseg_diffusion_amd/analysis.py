@@ -70,33 +70,11 @@ def _draw_kpp_uniforms(n, K, R, random_state):
     return T, first, U
 
 
-def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: int = 300, tol: float = 1e-4,
-               random_state=None, chunk: int = 256) -> KMeansResult:
-    """KMeans(n_clusters, n_init).fit(x16) -- feature_extraction.py:562-570 / :52-54.
-
-    x16: fp16 [n, C] device tensor (normalised tokens).  float64 arithmetic on the device like
-    sklearn's (validate_data up-casts fp16 to float64, _kmeans.py:1458): centring, k-means++,
-    Lloyd, inertia.  `random_state=None` means numpy's global RandomState, as in the reference.
-    """
-    require_gpu(x16)
-    if x16.dtype != F16 or x16.dim() != 2:
-        raise _lib.VidsegError("kmeans_fit: x16 must be a 2-D fp16 tensor")
-    n, C = x16.shape
-    K, R = int(n_clusters), int(n_init)
-    if n < K:
-        raise ValueError(f"n_samples={n} should be >= n_clusters={K}.")     # sklearn's message
-    rs = np.random.mtrand._rand if random_state is None else random_state
-    dev = x16.device
-    st = stream()
+def _kmeanspp_init(x16, mean, xsq, n, C, K, R, rs, dev, st):
+    """k-means++ for R restarts (cluster/_kmeans.py:174-274): numpy's uniforms are pre-drawn on the host in sklearn's
+    order, distances / cumulative sums / candidate search run on the device.  Returns centres [R, K, C] f64 (centred)."""
     T, first, U = _draw_kpp_uniforms(n, K, R, rs)
     Tmax = max(T, 1)
-
-    mean = torch.empty(C, dtype=F64, device=dev)
-    xsq = torch.empty(n, dtype=F64, device=dev)
-    colvar = torch.empty(C, dtype=F64, device=dev)
-    scratch = torch.empty(2 * ((n + 255) // 256) * C, dtype=F64, device=dev)
-    call("vidseg_kmeans_prepare", ptr(x16), n, C, ptr(mean), ptr(xsq), ptr(colvar), ptr(scratch), st)
-
     ntiles = (n + 63) // 64
     closest = torch.full((R, n), float("inf"), dtype=F64, device=dev)
     dcand = torch.empty((R * Tmax, n), dtype=F64, device=dev)
@@ -115,7 +93,40 @@ def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: i
              ptr(closest), ptr(dcand), ptr(part), ptr(pot), ptr(cand), ptr(center_ids), st)
     centers = torch.empty((R, K, C), dtype=F64, device=dev)
     call("vidseg_gather_rows_f64", ptr(x16), ptr(mean), C, ptr(center_ids), R * K, ptr(centers), st)
-    del closest, dcand, part
+    return centers
+
+
+def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: int = 300, tol: float = 1e-4,
+               random_state=None, chunk: int = 256, init=None) -> KMeansResult:
+    """KMeans(n_clusters, n_init).fit(x16) -- feature_extraction.py:562-570 / :52-54.
+
+    x16: fp16 [n, C] device tensor (normalised tokens).  float64 arithmetic on the device like
+    sklearn's (validate_data up-casts fp16 to float64, _kmeans.py:1458): centring, k-means++,
+    Lloyd, inertia.  `random_state=None` means numpy's global RandomState, as in the reference.
+    """
+    require_gpu(x16)
+    if x16.dtype != F16 or x16.dim() != 2:
+        raise _lib.VidsegError("kmeans_fit: x16 must be a 2-D fp16 tensor")
+    n, C = x16.shape
+    K, R = int(n_clusters), int(n_init)
+    if init is not None:                                              # KMeans(init=ndarray): a single run from these centres
+        R = 1
+    if n < K:
+        raise ValueError(f"n_samples={n} should be >= n_clusters={K}.")     # sklearn's message
+    rs = np.random.mtrand._rand if random_state is None else random_state
+    dev = x16.device
+    st = stream()
+    mean = torch.empty(C, dtype=F64, device=dev)
+    xsq = torch.empty(n, dtype=F64, device=dev)
+    colvar = torch.empty(C, dtype=F64, device=dev)
+    scratch = torch.empty(2 * ((n + 255) // 256) * C, dtype=F64, device=dev)
+    call("vidseg_kmeans_prepare", ptr(x16), n, C, ptr(mean), ptr(xsq), ptr(colvar), ptr(scratch), st)
+
+    if init is not None:
+        init_t = torch.as_tensor(init, dtype=F64).to(dev).reshape(1, K, C)
+        centers = (init_t - mean[None, None, :]).contiguous()           # _kmeans.py:1490 `init -= X_mean`
+    else:
+        centers = _kmeanspp_init(x16, mean, xsq, n, C, K, R, rs, dev, st)
 
     tol_ = float(colvar.mean().item()) * tol                        # _tolerance(), _kmeans.py:279-287
     labels = torch.full((R, n), -1, dtype=I32, device=dev)
@@ -129,6 +140,10 @@ def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: i
     chg = torch.empty((R, n, 2), dtype=I32, device=dev)
     delta = torch.zeros((R, K), dtype=F64, device=dev)
     dtop = torch.zeros((R, 3), dtype=F64, device=dev)
+    reloc_d = torch.empty((R, n), dtype=F64, device=dev)               # empty-cluster relocation scratch (rarely touched)
+    reloc_t = torch.empty((R, n), dtype=I32, device=dev)
+    reloc = torch.zeros((R, 64, 3), dtype=I32, device=dev)
+    nreloc = torch.zeros(R, dtype=I32, device=dev)
     shift2 = torch.zeros((R, K), dtype=F64, device=dev)
     counts = torch.zeros((R, K), dtype=I32, device=dev)
     # device-side convergence state: [active mask, strict mask, error flags, n_iter[R]]
@@ -145,15 +160,13 @@ def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: i
         for _ in range(min(poll, max_iter - it)):
             call("vidseg_lloyd_step", ptr(x16), ptr(mean), ptr(xsq), n, C, R, K, it, tol_, ptr(state), ptr(slots), nslots,
                  ptr(centers), ptr(cnorm), ptr(sums), ptr(counts), ptr(labels), ptr(ub), ptr(lb), ptr(lst), ptr(nlist), ptr(chg),
-                 ptr(changed), ptr(shift2), ptr(delta), ptr(dtop), st)
+                 ptr(changed), ptr(shift2), ptr(delta), ptr(dtop), ptr(reloc_d), ptr(reloc_t), ptr(reloc), ptr(nreloc), st)
             it += 1
         h_pin.copy_(state, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         total = it
-        if int(h_pin[2]) & 1:
-            raise _lib.VidsegError(
-                "kmeans_fit: a cluster became empty; sklearn's _relocate_empty_clusters_dense path "
-                "(_k_means_common.pyx:167-211) is not implemented on the device yet")
+        if int(h_pin[2]) != 0:
+            raise _lib.VidsegError(f"kmeans_fit: device error flags {int(h_pin[2]):#x}")
         if int(h_pin[0]) == 0:
             break
         if int(h_pin[0]) != cur_mask:                                    # drop converged restarts from the launch grids

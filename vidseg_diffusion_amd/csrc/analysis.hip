@@ -781,24 +781,59 @@ __global__ void __launch_bounds__(512) k_lloyd_accum_list(const f16* __restrict_
 }
 
 // M-step part 2, block (k, restart): centre = (sum - count*mean) * (1/count) (_average_centers), shift2 = |new - old|^2
-// (_center_shift), delta = sqrt(shift2) for the bound filter, |centre|^2 for the next E-step.
-__global__ void __launch_bounds__(256) k_lloyd_update_sums(const double* __restrict__ sums, const int32_t* __restrict__ counts,
-                                                           const double* __restrict__ mean, int K, int C, const unsigned* __restrict__ d_active,
-                                                           const int32_t* __restrict__ slots, double* __restrict__ centers,
-                                                           double* __restrict__ shift2, double* __restrict__ delta, double* __restrict__ cn) {
+// (_center_shift), delta = sqrt(shift2) for the bound filter, |centre|^2 for the next E-step.  Relocation entries
+// {new, sample, old} move one sample's raw values between the sums for this iteration only.  A cluster that is still
+// empty (relocation bailed out) copies the biggest cluster exactly like _average_centers' in-place loop does: the
+// averaged centre if the biggest cluster has a smaller id, its raw centred sum otherwise (_k_means_common.pyx:286-295).
+__global__ void __launch_bounds__(256) k_lloyd_update_sums(const f16* __restrict__ x, const double* __restrict__ sums,
+                                                           const int32_t* __restrict__ counts, const double* __restrict__ mean, int K, int C,
+                                                           const unsigned* __restrict__ d_active, const int32_t* __restrict__ slots,
+                                                           const int32_t* __restrict__ reloc, const int32_t* __restrict__ nreloc,
+                                                           double* __restrict__ centers, double* __restrict__ shift2,
+                                                           double* __restrict__ delta, double* __restrict__ cn) {
     const int k = blockIdx.x, r = slots[blockIdx.y];
     if (!((*d_active >> r) & 1u)) return;
     __shared__ double red[2][256];
-    const int cnt = counts[r * K + k];
+    const int nr = nreloc[r];
+    const int32_t* rl = reloc + r * 64 * 3;
+    auto eff_count = [&](int j) {
+        int c = counts[r * K + j];
+        for (int e = 0; e < nr; ++e) c += (rl[e * 3] == j) - (rl[e * 3 + 2] == j);
+        return c;
+    };
+    auto eff_sum = [&](int j, int c) {
+        double v = sums[((int64_t)r * K + j) * C + c];
+        for (int e = 0; e < nr; ++e) {
+            if (rl[e * 3] == j) v += (double)x[(int64_t)rl[e * 3 + 1] * C + c];
+            if (rl[e * 3 + 2] == j) v -= (double)x[(int64_t)rl[e * 3 + 1] * C + c];
+        }
+        return v;
+    };
+    const int cnt = eff_count(k);
+    int src = k, scnt = cnt;
+    bool averaged = true;
+    if (cnt == 0) {                                         // np.argmax(weight_in_clusters): first maximum
+        src = 0;
+        scnt = eff_count(0);
+        for (int j = 1; j < K; ++j) {
+            const int cj = eff_count(j);
+            if (cj > scnt) {
+                scnt = cj;
+                src = j;
+            }
+        }
+        averaged = src < k;
+    }
     double sh = 0.0, sq = 0.0;
-    const double alpha = cnt > 0 ? 1.0 / (double)cnt : 0.0;
+    const double alpha = (scnt > 0 && averaged) ? 1.0 / (double)scnt : 1.0;
     for (int c = threadIdx.x; c < C; c += 256) {
         const int64_t ci = ((int64_t)r * K + k) * C + c;
         double v = centers[ci];
-        if (cnt > 0) {
-            const double t = (sums[ci] - (double)cnt * mean[c]) * alpha;
-            const double d = t - v;
-            sh = fma(d, d, sh);
+        if (scnt > 0) {
+            double t = eff_sum(src, c) - (double)scnt * mean[c];
+            if (averaged) t *= alpha;
+            const double dd = t - v;
+            sh = fma(dd, dd, sh);
             centers[ci] = t;
             v = t;
         }
@@ -837,7 +872,6 @@ __global__ void __launch_bounds__(64) k_lloyd_status_list(int R, int K, int it, 
         double d1 = -1.0, d2 = -1.0, tot = 0.0;
         int a1 = 0;
         for (int k = 0; k < K; ++k) {
-            if (counts[r * K + k] == 0) empty = true;
             const double sh = sqrt(shift2[r * K + k]);
             tot += sh * sh;
             const double d = delta[r * K + k];
@@ -1081,17 +1115,26 @@ __global__ void __launch_bounds__(256) k_track_cos(const f16* __restrict__ norme
 }
 
 // ---- numpy arg-introselect replay (oracle/npselect.py documents the algorithm) -------------------
-struct SelCtx {
-    const float* v;
-    short* t;
+template <class V, class I>
+struct SelCtxT {
+    typedef V value_t;
+    const V* v;
+    I* t;
 };
-__device__ __forceinline__ float sv(const SelCtx& s, int i) { return s.v[s.t[i]]; }
-__device__ __forceinline__ void ssw(const SelCtx& s, int a, int b) {
-    short x = s.t[a];
+typedef SelCtxT<float, short> SelCtx;           // fp16 rows widened to float, 16-bit indices (tracking)
+typedef SelCtxT<double, int32_t> SelCtxD;       // float64 keys, 32-bit indices (empty-cluster relocation)
+template <class S>
+__device__ __forceinline__ typename S::value_t sv(const S& s, int i) {
+    return s.v[s.t[i]];
+}
+template <class S>
+__device__ __forceinline__ void ssw(const S& s, int a, int b) {
+    auto x = s.t[a];
     s.t[a] = s.t[b];
     s.t[b] = x;
 }
-__device__ int sel_median5(const SelCtx& s, int o) {
+template <class S>
+__device__ int sel_median5(const S& s, int o) {
     if (sv(s, o + 1) < sv(s, o + 0)) ssw(s, o + 1, o + 0);
     if (sv(s, o + 4) < sv(s, o + 3)) ssw(s, o + 4, o + 3);
     if (sv(s, o + 3) < sv(s, o + 0)) ssw(s, o + 3, o + 0);
@@ -1100,13 +1143,13 @@ __device__ int sel_median5(const SelCtx& s, int o) {
     if (sv(s, o + 3) < sv(s, o + 2)) return (sv(s, o + 3) < sv(s, o + 1)) ? 1 : 3;
     return 2;
 }
-template <int LVL>
-__device__ void sel_introselect(const SelCtx& s, int off, int num, int kth) {
+template <int LVL, class S>
+__device__ void sel_introselect(const S& s, int off, int num, int kth) {
     int low = 0, high = num - 1;
     if (kth - low < 3) {
         for (int i = 0; i <= kth; ++i) {
             int minidx = i;
-            float minval = sv(s, off + i);
+            auto minval = sv(s, off + i);
             for (int k = i + 1; k < num; ++k)
                 if (sv(s, off + k) < minval) {
                     minidx = k;
@@ -1143,7 +1186,7 @@ __device__ void sel_introselect(const SelCtx& s, int off, int num, int kth) {
             hh++;
         }
         depth--;
-        const float pivot = sv(s, off + low);
+        const auto pivot = sv(s, off + low);
         for (;;) {
             do { ll++; } while (sv(s, off + ll) < pivot);
             do { hh--; } while (pivot < sv(s, off + hh));
@@ -1156,6 +1199,66 @@ __device__ void sel_introselect(const SelCtx& s, int off, int num, int kth) {
     }
     if (high == low + 1)
         if (sv(s, off + high) < sv(s, off + low)) ssw(s, off + high, off + low);
+}
+
+// Empty-cluster relocation (sklearn/cluster/_k_means_common.pyx:167-211), one block per running restart, a no-op unless
+// the M-step left a cluster without members: squared distance of every sample to its own (old) centre, numpy's
+// argpartition(distances, -n_empty) replayed on the device, the n_empty farthest samples (taken from the END of the
+// partitioned index array, reversed) become the centres of the empty clusters (ascending cluster id) and leave their old
+// clusters.  Labels are NOT touched (exactly like sklearn: the next E-step re-labels), so the exact member sums stay
+// consistent; the adjustment lives in reloc[r] = {new cluster, sample, old cluster} and is applied by k_lloyd_update_sums.
+__global__ void __launch_bounds__(256) k_lloyd_relocate(const f16* __restrict__ x, const double* __restrict__ mean, int64_t n, int C, int K,
+                                                        const unsigned* __restrict__ d_active, const int32_t* __restrict__ slots,
+                                                        const int32_t* __restrict__ labels, const double* __restrict__ centers,
+                                                        const int32_t* __restrict__ counts, double* __restrict__ rd,
+                                                        int32_t* __restrict__ rt, int32_t* __restrict__ reloc,
+                                                        int32_t* __restrict__ nreloc) {
+    const int r = slots[blockIdx.x];
+    if (!((*d_active >> r) & 1u)) return;
+    __shared__ int empties[64];
+    __shared__ int n_empty;
+    __shared__ double wmax[4];
+    if (threadIdx.x == 0) {
+        int ne = 0;
+        for (int k = 0; k < K; ++k)
+            if (counts[r * K + k] == 0) empties[ne++] = k;
+        n_empty = ne;
+        nreloc[r] = 0;
+    }
+    __syncthreads();
+    if (n_empty == 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* d = rd + (int64_t)r * n;
+    int32_t* t = rt + (int64_t)r * n;
+    double mx = 0.0;
+    for (int64_t i = wave; i < n; i += 4) {
+        const double* cen = centers + ((int64_t)r * K + labels[(int64_t)r * n + i]) * C;
+        double acc = 0.0;
+        for (int c = lane; c < C; c += 64) {
+            const double v = ((double)x[i * C + c] - mean[c]) - cen[c];
+            acc = fma(v, v, acc);
+        }
+        acc = wave_sum_f64(acc);
+        if (lane == 0) {
+            d[i] = acc;
+            t[i] = (int32_t)i;
+        }
+        mx = fmax(mx, acc);
+    }
+    if (lane == 0) wmax[wave] = mx;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    __threadfence_block();
+    if (fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3])) == 0.0) return;       // more clusters than distinct samples (:186-189)
+    SelCtxD sc{d, t};
+    sel_introselect<0>(sc, 0, (int)n, (int)n - n_empty);
+    for (int idx = 0; idx < n_empty; ++idx) {
+        const int far = t[n - 1 - idx];
+        reloc[(r * 64 + idx) * 3 + 0] = empties[idx];
+        reloc[(r * 64 + idx) * 3 + 1] = far;
+        reloc[(r * 64 + idx) * 3 + 2] = labels[(int64_t)r * n + far];
+    }
+    nreloc[r] = n_empty;
 }
 
 __global__ void __launch_bounds__(64) k_row_select(const f16* __restrict__ blend, int N, int w, int32_t* __restrict__ next,
@@ -1362,10 +1465,12 @@ int vidseg_lloyd_iter(const void* x16, const double* mean, int64_t n, int C, int
 
 // One accelerated Lloyd iteration (see the kernels above) including the convergence bookkeeping of vidseg_lloyd_status.
 // Host-initialised state before it = 0: labels = -1, sums = 0, counts = 0, list[r] = 0..n-1, nlist[r] = n, changed = 0.
+// Relocation scratch: reloc_d [R][n] f64, reloc_t [R][n] i32, reloc [R][64][3] i32, nreloc [R] i32.
 int vidseg_lloyd_step(const void* x16, const double* mean, const double* xsq, int64_t n, int C, int R, int K, int it, double tol,
                       unsigned* state, const int32_t* slots, int nslots, double* centers, double* cnorm, double* sums, int32_t* counts,
                       int32_t* labels, double* ub, double* lb, int32_t* list, int32_t* nlist, int32_t* chg, int32_t* changed,
-                      double* shift2, double* delta, double* dtop, hipStream_t st) {
+                      double* shift2, double* delta, double* dtop, double* reloc_d, int32_t* reloc_t, int32_t* reloc, int32_t* nreloc,
+                      hipStream_t st) {
     VS_REQUIRE(K >= 1 && K <= 64 && R >= 1 && R <= 29 && nslots >= 1 && nslots <= R, "lloyd_step: K=%d R=%d nslots=%d", K, R, nslots);
     VS_REQUIRE(n < (1LL << 31) / 2, "lloyd_step: n=%lld too large", (long long)n);
     RowsF16 X{(const f16*)x16, nullptr, mean, n, C};
@@ -1387,7 +1492,11 @@ int vidseg_lloyd_step(const void* x16, const double* mean, const double* xsq, in
     VS_CHECK_LAUNCH("lloyd_assign_list");
     k_lloyd_accum_list<<<dim3((C + 63) / 64, nslots, ACC_SPLIT), 512, 0, st>>>((const f16*)x16, n, C, K, d_active, slots, chg, changed, sums, counts);
     VS_CHECK_LAUNCH("lloyd_accum_list");
-    k_lloyd_update_sums<<<dim3(K, nslots), 256, 0, st>>>(sums, counts, mean, K, C, d_active, slots, centers, shift2, delta, cnorm);
+    k_lloyd_relocate<<<dim3(nslots), 256, 0, st>>>((const f16*)x16, mean, n, C, K, d_active, slots, labels, centers, counts, reloc_d, reloc_t,
+                                                   reloc, nreloc);
+    VS_CHECK_LAUNCH("lloyd_relocate");
+    k_lloyd_update_sums<<<dim3(K, nslots), 256, 0, st>>>((const f16*)x16, sums, counts, mean, K, C, d_active, slots, reloc, nreloc, centers,
+                                                         shift2, delta, cnorm);
     VS_CHECK_LAUNCH("lloyd_update_sums");
     k_lloyd_status_list<<<dim3(1), 64, 0, st>>>(R, K, it, tol, changed, shift2, counts, state, delta, dtop, nlist);
     VS_CHECK_LAUNCH("lloyd_status_list");
