@@ -188,7 +188,8 @@ __global__ void __launch_bounds__(256) k_layernorm(const bf16_t* __restrict__ x,
 // ---------------------------------------------------------------------------------------------
 #define VT_LD 68   // Vt[d][key] row stride in bf16 (136 B): conflict-free ds_read_b64 across d rows
 
-__global__ void __launch_bounds__(256) k_attention(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+template <bool RAGGED>
+__global__ void __launch_bounds__(256, 3) k_attention(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                    const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo, int Nq,
                                                    int Nk, int H, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) char sK2[2][64 * 128];          // K tile [key][d], 16-B slot XOR swizzle, double buffered
@@ -250,20 +251,22 @@ __global__ void __launch_bounds__(256) k_attention(const bf16_t* __restrict__ q,
         f32x16 sacc[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[j][r] = 0.f;
             const int r = j * 32 + l31;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int ch = s * 2 + hi;
                 const bf16x8_t fk = *reinterpret_cast<const bf16x8_t*>(sK + r * 128 + ((ch ^ (r & 7)) << 4));
-                sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[s], sacc[j], 0, 0, 0);
+                if (s == 0)                                            // C = inline 0: no accumulator initialisation moves
+                    sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[s], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                                                                       0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                else
+                    sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[s], sacc[j], 0, 0, 0);
             }
         }
         // online softmax for this lane's query; key index of sacc[j][r] = k0 + j*32 + (r&3) + 8*(r>>2) + 4*hi.
         // VALU budget matters as much as MFMA here: max on raw scores, scale folded into one fma per element,
         // masking only on the ragged last tile, O rescale skipped when no lane's running max moved.
-        if (k0 + 64 > Nk) {
+        if (RAGGED && k0 + 64 > Nk) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -279,17 +282,19 @@ __global__ void __launch_bounds__(256) k_attention(const bf16_t* __restrict__ q,
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
         const float m_new = fmaxf(m_run, mx);
-        float psum = 0.f;
+        vs_f32x2 psum2 = {0.f, 0.f};
+        const vs_f32x2 sc2 = {scale_log2e, scale_log2e}, mn2 = {-m_new, -m_new};
         unsigned pk[2][8];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[j][r], scale_log2e, -m_new));
-                const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[j][r + 1], scale_log2e, -m_new));
-                psum += p0 + p1;
-                pk[j][r >> 1] = pack2_bf16(p0, p1);
+                const vs_f32x2 a = vs_f32x2{sacc[j][r], sacc[j][r + 1]} * sc2 + mn2;        // v_pk_fma_f32
+                const vs_f32x2 p = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                psum2 += p;                                                               // v_pk_add_f32
+                pk[j][r >> 1] = pack2_bf16(p[0], p[1]);
             }
+        float psum = psum2[0] + psum2[1];
         psum += __shfl_xor(psum, 32, 64);
         if (__any(m_new != m_run)) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -617,8 +622,12 @@ int vidseg_attention_bf16(const void* q, int ldq, const void* k, int ldk, const 
     VS_REQUIRE(head_dim == 64, "attention: head_dim=%d (only 64 is on the path)", head_dim);
     VS_REQUIRE(Nq > 0 && Nk > 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attention: bad sizes/strides");
     const float scale_log2e = 0.125f * 1.44269504088896340736f;           // dim_head ** -0.5 * log2(e)
-    k_attention<<<dim3((Nq + 127) / 128, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
-                                                                (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
+    if (Nk % 64 == 0)
+        k_attention<false><<<dim3((Nq + 127) / 128, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
+                                                                           (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
+    else
+        k_attention<true><<<dim3((Nq + 127) / 128, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
+                                                                          (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
     VS_CHECK_LAUNCH("attention");
     return VS_OK;
 }
