@@ -69,8 +69,8 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 // split-K partials) is 16 bytes per lane.  Only wave-level ordering is needed inside (LDS executes a wave's
 // instructions in order); the one block barrier separates the main loop's LDS reads from the staging writes.
 // ---------------------------------------------------------------------------------------------
-template <int NJ>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][NJ], char* smem, long long mrow_base, int wcol_base,
+template <int NJ, int MI = 2>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[MI][NJ], char* smem, long long mrow_base, int wcol_base,
                                               int lane, int wave, int split) {
     const int l31 = lane & 31, hi = lane >> 5;
     constexpr int EP_LD = 68;                                  // fp32 row stride of the staging tile (64 + 4 pad)
@@ -80,7 +80,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     const bool fin = p.ksplit <= 1;                            // split-K partials carry no bias/emb/activation
     __syncthreads();                                           // main-loop LDS reads are done
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int g = 0; g < (NJ + 1) / 2; ++g) {
             constexpr int dummy = 0;
@@ -577,8 +577,9 @@ __global__ void __launch_bounds__(256, NST == 2 ? 4 : 3) k_gemm_dma(GemmParams p
 // ---------------------------------------------------------------------------------------------
 // Wide-tile LDS-DMA kernels: (WM*64) x (NJ*64) block tile, WM x 2 waves, wave tile 64 x (NJ*32).
 //   <NJ, 4, 64>  "big": 256 x 256 / 256 x 320, BK = 64, 8 waves, one block per CU -- long-K convolutions.
-//   <NJ, 2, 32>  "mid": 128 x 256 / 128 x 320, BK = 32, 4 waves, two blocks per CU: measured 1.1-2x SLOWER than the 128x128
-//                kernel at four blocks per CU on every transformer linear (K = 320..1280) -- not launched.
+//   <NJ, 4, 32, 1> "mid": 128 x 256 / 128 x 320, BK = 32, 8 waves (wave tile 32 x 160), two blocks per CU: A is read once per
+//                row tile instead of once per 128 columns.  Wins only on 28672 x 640 x 640 (-17 %); a 4-wave variant of the
+//                same tile was 1.1-2x slower everywhere (half the resident waves).
 // NJ = 5 covers N = 320/640/960/1280/1920 without padding waste.  The 128x128 kernels read 1 byte of operand through
 // the CU's vector-memory path (64 B/clk) per 64 MFMA flops -- exactly the MFMA rate, so they cannot pass ~50 % of
 // peak; these tiles read 0.45-0.7 bytes per 64 flops.
@@ -590,14 +591,15 @@ __device__ __forceinline__ int lds_swz(int r) {
     return BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3);
 }
 
-template <int NJ, int WM, int BKT>
-__global__ void __launch_bounds__(WM * 128, WM == 4 ? 1 : 2) k_gemm_tile(GemmParams p) {
+template <int NJ, int WM, int BKT, int MI = 2>
+__global__ void __launch_bounds__(WM * 128, MI == 1 ? 4 : (WM == 4 ? 1 : 2)) k_gemm_tile(GemmParams p) {   // 2nd = min waves per SIMD
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = WM * 64, BN = NJ * 64, NW = WM * 2;
+    constexpr int BM = WM * MI * 32, BN = NJ * 64, NW = WM * 2;
     constexpr int RB = BKT * 2;                            // bytes per LDS row
     constexpr int RPP = 1024 / RB;                         // rows per 1-KiB DMA piece
     constexpr int CPR = RB / 16;                           // 16-byte chunks per row
-    constexpr int APW = BM / RPP / NW, BPW = BN / RPP / NW;   // pieces per wave
+    constexpr int APIECES = BM / RPP, BPIECES = BN / RPP;
+    constexpr int APW = (APIECES + NW - 1) / NW, BPW = (BPIECES + NW - 1) / NW;   // pieces per wave (piece = wave + i*NW)
     constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, BUF = A_BYTES + B_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -620,7 +622,7 @@ __global__ void __launch_bounds__(WM * 128, WM == 4 ? 1 : 2) k_gemm_tile(GemmPar
     const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x0), 0, (int)p.x0_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x1 ? p.x1 : p.x0), 0, (int)p.x1_bytes, 0x00020000);
 
-    // wave w stages A pieces APW*w .. and B pieces BPW*w ..; lane l of a piece: row l / CPR, chunk l % CPR
+    // wave w stages A pieces w, w+NW, .. and B pieces w, w+NW, ..; lane l of a piece: row l / CPR, chunk l % CPR
     const int Cin = p.C0 + p.C1;
     const int HWo = p.Hout * p.Wout;
     const int upsh = p.up - 1;
@@ -630,9 +632,9 @@ __global__ void __launch_bounds__(WM * 128, WM == 4 ? 1 : 2) k_gemm_tile(GemmPar
     bool a_ok[APW];
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
-        const int r = (wave * APW + i) * RPP + lrow;
+        const int r = (wave + i * NW) * RPP + lrow;
         const long long m = m0 + r;
-        a_ok[i] = m < p.M;
+        a_ok[i] = m < p.M && (wave + i * NW) < APIECES;
         const int mm = a_ok[i] ? (int)m : 0;
         if (p.ksize == 1) {
             a_base[i] = mm;
@@ -652,9 +654,9 @@ __global__ void __launch_bounds__(WM * 128, WM == 4 ? 1 : 2) k_gemm_tile(GemmPar
     unsigned b_off[BPW];
 #pragma unroll
     for (int i = 0; i < BPW; ++i) {
-        const int r = (wave * BPW + i) * RPP + lrow;
+        const int r = (wave + i * NW) * RPP + lrow;
         const int n = n0 + r;
-        b_off[i] = n < p.N ? (unsigned)((long long)n * p.K * 2) + (unsigned)((lch ^ lds_swz<BKT>(r)) * 16) : OOB;
+        b_off[i] = (n < p.N && (wave + i * NW) < BPIECES) ? (unsigned)((long long)n * p.K * 2) + (unsigned)((lch ^ lds_swz<BKT>(r)) * 16) : OOB;
     }
     const int nk_all = p.K / BKT;
     const int ks_begin = p.ksplit > 1 ? (int)((long long)nk_all * split / p.ksplit) : 0;
@@ -687,7 +689,7 @@ __global__ void __launch_bounds__(WM * 128, WM == 4 ? 1 : 2) k_gemm_tile(GemmPar
                     ok = ok && (unsigned)ih < (unsigned)Hup && (unsigned)iw < (unsigned)Wup;
                     pix = a_base[i] + (ih >> upsh) * p.Win + (iw >> upsh);
                 }
-                const int r = (wave * APW + i) * RPP + lrow;
+                const int r = (wave + i * NW) * RPP + lrow;
                 a_off[i] = ok ? (unsigned)(pix * Cs) * 2u + (unsigned)((lch ^ lds_swz<BKT>(r)) * 16) : OOB;
             }
         }
@@ -698,46 +700,58 @@ __global__ void __launch_bounds__(WM * 128, WM == 4 ? 1 : 2) k_gemm_tile(GemmPar
             ld_c0 = 0;
             ld_tap++;
         }
-        char* A = smem + buf * BUF + wave * (APW * 1024);
-        char* B = smem + buf * BUF + A_BYTES + wave * (BPW * 1024);
+        char* A = smem + buf * BUF + wave * 1024;
+        char* B = smem + buf * BUF + A_BYTES + wave * 1024;
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
+            if (APIECES % NW != 0 && wave + i * NW >= APIECES) break;           // wave-uniform
             if (a_second)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)(A + i * 1024), 16, (int)(a_off[i] + cbyte), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)(A + i * (NW * 1024)), 16, (int)(a_off[i] + cbyte), 0, 0, 0);
             else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)(A + i * 1024), 16, (int)(a_off[i] + cbyte), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)(A + i * (NW * 1024)), 16, (int)(a_off[i] + cbyte), 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < BPW; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(B + i * 1024), 16, (int)(b_off[i] + (unsigned)k0 * 2u), 0, 0, 0);
+        for (int i = 0; i < BPW; ++i) {
+            if (BPIECES % NW != 0 && wave + i * NW >= BPIECES) break;           // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(B + i * (NW * 1024)), 16, (int)(b_off[i] + (unsigned)k0 * 2u), 0, 0, 0);
+        }
     };
 
-    f32x16 acc[2][NJ];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int l31 = lane & 31, hi = lane >> 5;
     const int sw = lds_swz<BKT>(l31);                          // every fragment row is l31 + a multiple of 32
-    const int arow = (wm * 64 + l31) * RB, brow = (wn * (NJ * 32) + l31) * RB;
+    const int arow = (wm * (MI * 32) + l31) * RB, brow = (wn * (NJ * 32) + l31) * RB;
     auto compute = [&](int buf) {
         const char* A = smem + buf * BUF + arow;
         const char* B = smem + buf * BUF + A_BYTES + brow;
 #pragma unroll
         for (int s = 0; s < BKT / 16; ++s) {
-            bf16x8_t fa[2], fb[NJ];
+            bf16x8_t fa[MI];
             const int co = ((s * 2 + hi) ^ sw) << 4;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(A + i * 32 * RB + co);
+            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(A + i * 32 * RB + co);
+            if constexpr (MI == 1) {                               // 128-VGPR budget: one B fragment live at a time
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(B + j * 32 * RB + co);
+                for (int j = 0; j < NJ; ++j) {
+                    const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(B + j * 32 * RB + co);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb, acc[0][j], 0, 0, 0);
+                }
+            } else {
+                bf16x8_t fb[NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+                for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(B + j * 32 * RB + co);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
         }
     };
     const int nk = ks_end - ks_begin;
@@ -749,7 +763,7 @@ __global__ void __launch_bounds__(WM * 128, WM == 4 ? 1 : 2) k_gemm_tile(GemmPar
         __syncthreads();
     }
     compute((nk - 1) & 1);
-    gemm_epilogue<NJ>(p, acc, smem, m0 + wm * 64, n0 + wn * (NJ * 32), lane, wave, split);
+    gemm_epilogue<NJ, MI>(p, acc, smem, m0 + wm * (MI * 32), n0 + wn * (NJ * 32), lane, wave, split);
 }
 
 // Split-K finish: sum the fp32 partials in split order (deterministic), then the same epilogue as above.
@@ -995,7 +1009,8 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         k_gemm_conv<256, 64><<<dim3((unsigned)tiles), 256, 2 * (256 + 64) * BK * 2, st>>>(p);
     } else {
         const int nk = p.K / BK;
-        static int nosplit = -1, use_dma = -1, big_mode = -1;
+        static int nosplit = -1, use_dma = -1, big_mode = -1, mid_mode = -1;
+        constexpr int MID_LDS = 8 * 32 * 68 * 4;               // epilogue staging of 8 waves (69.6 KiB) > 2 x (128+320) x 64 B
         if (nosplit < 0) {
             const char* e = getenv("VIDSEG_NO_SPLITK");
             nosplit = e ? atoi(e) : 0;
@@ -1005,6 +1020,10 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             big_mode = e ? atoi(e) : 1;
             (void)hipFuncSetAttribute((const void*)k_gemm_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 36864);
             (void)hipFuncSetAttribute((const void*)k_gemm_dma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
+            e = getenv("VIDSEG_GEMM_MID");                       // 0 never, 1 auto, 2 whenever the big tile is not chosen
+            mid_mode = e ? atoi(e) : 1;
+            (void)hipFuncSetAttribute((const void*)k_gemm_tile<4, 4, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS);
+            (void)hipFuncSetAttribute((const void*)k_gemm_tile<5, 4, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS);
             (void)hipFuncSetAttribute((const void*)k_gemm_tile<4, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
             (void)hipFuncSetAttribute((const void*)k_gemm_tile<5, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
         }
@@ -1030,6 +1049,10 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         // big tile: 256 x 320 when that divides N better (320/640/960/1280/1920 ...), else 256 x 256 (GEGLU needs pairs)
         const int NJ = (p.act != 2 && ((p.N + 319) / 320) * 320 <= ((p.N + 255) / 256) * 256) ? 5 : 4;
         const long long tiles_b = ((p.M + 255) / 256) * ((p.N + NJ * 64 - 1) / (NJ * 64));
+        const long long tiles_mid = ((p.M + 127) / 128) * ((p.N + NJ * 64 - 1) / (NJ * 64));
+        // measured (tools/dbg/shape_summary.py): the 128 x 320 8-wave tile only beats 128 x 128 on the 32x32-level projections
+        // (28672 x 640 x 640: 61 -> 50 us); K = 320 layers and under-filled grids lose
+        const bool mid_ok = tiles_mid >= 448 && p.K >= 640 && p.N <= 640 && p.act == 0;
         bool big = false;
         int S = 1;
         if (big_mode && p.M >= 256) {
@@ -1048,6 +1071,14 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             else
                 k_gemm_tile<4, 4, 64><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 256) * 128, st>>>(p);
             kind = 1;
+        } else if (mid_mode && p.M >= 128 && (mid_mode == 2 || mid_ok)) {
+            p.ksplit = 1;
+            p.ws = nullptr;
+            if (NJ == 5)
+                k_gemm_tile<5, 4, 32, 1><<<dim3((unsigned)tiles_mid), 512, MID_LDS, st>>>(p);
+            else
+                k_gemm_tile<4, 4, 32, 1><<<dim3((unsigned)tiles_mid), 512, MID_LDS, st>>>(p);
+            kind = 2;
         } else {
             S = pick_split(tiles, 512);
             p.ksplit = S;
