@@ -53,3 +53,31 @@ def test_no_oracle_import_in_product():
             if f == "smoke_unet.py":
                 continue
             assert "oracle" not in re.sub(r'""".*?"""', "", open(os.path.join(pkg, f)).read(), flags=re.S).replace("oracle-backed", ""), f
+
+
+def test_checkpoint_and_dump_file_formats(tmp_path):
+    """upstream checkpoint keys load into the mirror UNet; the FeatureStore exports the reference's
+    ``feature_maps/*.pt`` layout (host-side file handling only, no device needed)."""
+    import torch
+    from safetensors.torch import save_file
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd import synthetic
+    from vidseg_diffusion_amd.unet import UNetModel
+    from vidseg_diffusion_amd.util import load_checkpoint_state_dict
+    net = UNetModel(**synthetic.SD21_NARROW)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = {"model.diffusion_model." + k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=7).items()}
+    sd["first_stage_model.encoder.conv_in.weight"] = torch.zeros(2, 2)          # other modules of the checkpoint are ignored
+    path = str(tmp_path / "ckpt.safetensors")
+    save_file(sd, path)
+    got = load_checkpoint_state_dict(path)
+    assert set(got) == set(shapes)
+    missing, unexpected = net.load_state_dict(got, strict=False)
+    assert not missing and not unexpected
+    FE.FeatureStore.clear()
+    q = torch.arange(2 * 3 * 4, dtype=torch.float16).reshape(2, 3, 4)
+    FE.FeatureStore.put(str(tmp_path), "exp", "output_block_7_spatial_self_attn_q_time_24", q)
+    files = FE.FeatureStore.export_pt(str(tmp_path), "exp")
+    assert files == [str(tmp_path / "exp" / "feature_maps" / "output_block_7_spatial_self_attn_q_time_24.pt")]
+    assert torch.equal(torch.load(files[0]), q)
+    FE.FeatureStore.clear()

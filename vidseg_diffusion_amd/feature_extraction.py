@@ -46,6 +46,23 @@ class FeatureStore:
         else:
             cls._stores.pop(os.path.join(base_folder, exp, "feature_maps"), None)
 
+    @classmethod
+    def export_pt(cls, base_folder, exp, names=None):
+        """Write the store as the reference's dump directory: ``{base}/{exp}/feature_maps/{name}.pt`` holding the same
+        tensors ``save_feature_map`` would have saved (sd_pipeline_vspw.py:131-139: fp16 q/k [2F, N, C], xt fp32
+        [F, 4, h, w]) so that the unmodified reference scripts (Steps 4-5, feature_extraction_main) can read them.
+        Returns the list of files written."""
+        folder = os.path.join(base_folder, exp, "feature_maps")
+        os.makedirs(folder, exist_ok=True)
+        written = []
+        for name, t in cls.folder(base_folder, exp).items():
+            if names is not None and name not in names:
+                continue
+            path = os.path.join(folder, name + ".pt")
+            torch.save(t.detach().cpu(), path)
+            written.append(path)
+        return written
+
 
 class MaskStore:
     """int32 [F, N] label maps keyed by the reference's mask folder path."""

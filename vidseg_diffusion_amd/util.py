@@ -126,3 +126,22 @@ def get_modulate_timestep_frames(start_timestep, end_timestep=None, num_frames=1
             out[int(start_timestep + (end_timestep - start_timestep) * frame_id / (num_frames - 1))].append(frame_id)
         return out
     raise ValueError(f"Unknown modulate timestep frames schedule: {schedule}")
+
+
+def load_checkpoint_state_dict(path, prefix="model.diffusion_model."):
+    """The UNet part of an upstream checkpoint as a plain state dict for ``UNetModel/VideoUNet.load_state_dict`` --
+    what ``load_model_from_config`` + ``DiffusionEngine.init_from_ckpt`` do for the network (sd_pipeline_vspw.py:553-580,
+    sgm/models/diffusion.py:87-103): ``.safetensors`` via safetensors, ``.ckpt`` via torch.load(...)["state_dict"]; keys
+    carry the ``model.diffusion_model.`` prefix of the Lightning module, which is stripped here.  Host-side file parsing
+    only; weights reach the device in ``pack()``."""
+    import torch
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        sd = load_file(path, device="cpu")
+    else:
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+    out = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    if not out:                                                  # already a bare UNet state dict
+        out = dict(sd)
+    return out
