@@ -323,3 +323,49 @@ def test_svd_modulated_injected_pass_vs_reference():
         # the modulation must actually have moved the sample the way the reference's did (large-lambda cases dominate rounding)
         if abs(lam) >= 1000:
             assert nrms(d_got, d_ref) < 0.35, nrms(d_got, d_ref)
+
+
+def test_modulation_sweep_step4(env):
+    """Step 4 harness on the narrow SD engine: segment_window leaves dumps + masks, modulation_sweep runs 2*K modulated passes;
+    one entry is re-run by hand through the (reference-parity-tested) sampler call and must be bit-identical, +/- lambda and
+    different labels must give different latents, everything finite."""
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import build_sd_engine, load_feature_masks, make_denoiser, modulation_sweep, segment_window
+    dev, g, net, sd = env
+    eng = build_sd_engine(net)
+    Fn = 3
+    lat = torch.from_numpy(synthetic.latent_clip(Fn, 16, 16, seed=5)).to(dev)
+    cc, ucc = synthetic.sd_conditioning(Fn, context_dim=64, seq=7, seed=2)
+    c, uc = {"crossattn": torch.from_numpy(cc).to(dev)}, {"crossattn": torch.from_numpy(ucc).to(dev)}
+    noise = torch.randn(lat.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+    FE.FeatureStore.clear(); FE.MaskStore.clear()
+    base, exp = "/nonexistent/vs_sweep", "exp"
+    labels, st = segment_window(eng, lat, c, uc, num_masks=3, t_start=22, is_aggre_attn=True, seed=17, noise=noise,
+                                feature_folder=base, exp_name=exp, keep_all_steps=True)
+    folder = os.path.join(base, exp, "match_gt_mask", "output_block_8_output_block_7_output_block_6_spatial_self_attn_q_masks_3")
+    assert FE.MaskStore.get(folder) is not None
+    uniq = np.unique(labels)
+    m = load_feature_masks(folder, int(uniq[0]), num_frames=Fn, modulate_block_idx=7, base_height=2, base_width=2, device=dev)
+    assert len(m) == Fn and m[0].shape == (64,) and m[0].dtype == torch.float64
+    assert np.array_equal(m[1].cpu().numpy(), (labels[1] == uniq[0]).astype(np.float64))
+    res = modulation_sweep(eng, lat, c, uc, uniq, folder, t_start=22, feature_folder=base, exp_name=exp, noise=noise, seed=17)
+    assert set(res) == {(s, int(l)) for s in (1, -1) for l in uniq}
+    for v in res.values():
+        assert v.shape == lat.shape and torch.isfinite(v).all()
+    a, b = res[(1, int(uniq[0]))], res[(-1, int(uniq[0]))]
+    assert (a - b).abs().max() > 0
+    if len(uniq) > 1:
+        assert (a - res[(1, int(uniq[1]))]).abs().max() > 0
+    # manual re-run of one entry
+    mp = {"feature_masks": m, "modulate_block_idx": [7], "modulate_layer_type": ["spatial"], "modulate_attn_type": ["cross_attn"],
+          "modulate_timestep": [22], "modulate_schedule": "constant", "modulate_lambda_start": 50.0, "modulate_lambda_end": 50.0,
+          "num_frames": Fn, "modulate_uc": True, "is_injected_features": True,
+          "injected_feature_types": ["spatial_cross_attn_k", "spatial_cross_attn_q", "spatial_self_attn_k", "spatial_self_attn_q"],
+          "injected_block_types": ["output"], "input_block_indices": [3, 4, 5, 6, 7, 8, 9, 10, 11],
+          "output_block_indices": list(range(1, 12)), "feature_folder": base, "exp_name": exp, "injected_features_group": {},
+          "modulate_layer_frames": {}, "modulate_block_frames": {}, "modulate_timestep_frames": {}, "modulate_lambda_layers": {},
+          "latent_mask_start": 22, "latent_mask_end": 23}
+    x0 = eng.sampler.add_noise(lat, cond=c, uc=uc, num_steps=25, noise_level=22, noise=noise)
+    ref = eng.sampler(make_denoiser(eng, Fn), x0.clone(), cond=c, uc=uc, is_modulate=True, modulate_params=mp, t_start=22,
+                      is_latent_blending=True, feature_height=8, feature_width=8)
+    assert torch.equal(ref, a)

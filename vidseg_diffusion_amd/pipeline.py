@@ -171,3 +171,92 @@ def segment_clip(engine, latents, c_fn, *, batch_size=14, **kw):
         labels, state = segment_window(engine, latents[s:e].contiguous(), c, uc, state=state, **kw)
         out.append((s, e, labels))
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Step 4 of sample(): the modulation sweep (sd_pipeline_vspw.py:412-507, svd_pipeline_vspw.py:396-487)
+# ----------------------------------------------------------------------------------------------------------------------
+_BLOCK_SCALE = {0: 1, 1: 1, 2: 1, 3: 2, 4: 2, 5: 2, 6: 4, 7: 4, 8: 4, 9: 8, 10: 8, 11: 8}
+
+
+def load_feature_masks(masks_path, mask_id, num_frames=14, feature_timestep="24", modulate_block_idx=7, base_height=8, base_width=8,
+                       frame_name_list=None, device=None):
+    """sd_pipeline_vspw.py:64-101: the binary mask of label `mask_id` per frame as float64 [h*w] in {0, 1}, at the token
+    resolution of the modulated decoder block (base * {1,2,4,8}).  Source: the MaskStore entry for `masks_path` (the label
+    maps Step 3/3b left there) or, if absent, the reference's PNG folder.  When the mask resolution equals the target the
+    PIL resize of the reference is the identity; other block groups go through the same PIL resize (host, tiny)."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    rh, rw = base_height * _BLOCK_SCALE[modulate_block_idx], base_width * _BLOCK_SCALE[modulate_block_idx]
+    entry = FE.MaskStore.get(masks_path)
+    out = []
+    if entry is not None:
+        labels = entry[0]
+        labels = labels.cpu().numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels)
+        labels = labels.reshape(labels.shape[0], -1)
+        if labels.shape[0] < num_frames:
+            raise FileNotFoundError(f"{masks_path}: only {labels.shape[0]} frames of masks")
+        n = labels.shape[1]
+        for f in range(num_frames):
+            m = (labels[f] == mask_id).astype(np.uint8) * 255
+            if n != rh * rw:
+                from PIL import Image
+                src_w = int(round((n * rw / rh) ** 0.5))
+                img = Image.fromarray(m.reshape(n // src_w, src_w)).resize((rw, rh))
+                m = np.array(img).reshape(-1)
+            out.append(torch.from_numpy(m / 255.0).to(device))
+        return out
+    from PIL import Image
+    for f in range(num_frames):
+        name = frame_name_list[f] if frame_name_list is not None else f
+        img = Image.open(os.path.join(masks_path, f"kmeans_time_{feature_timestep}_frame_{name}", f"mask_{mask_id}.png"))
+        out.append(torch.from_numpy(np.array(img.resize((rw, rh))) / 255.0).reshape(-1).to(device))
+    return out
+
+
+def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder, *, t_start=22, num_steps=25, feature_timestep="24",
+                     modulate_block_idx=(7,), modulate_layer_type=("spatial",), modulate_attn_type=("cross_attn",),
+                     modulate_timestep=None, modulate_schedule="constant", modulate_lambda_start=50.0, modulate_lambda_end=50.0,
+                     is_injected_features=True, is_latent_blending=True, feature_folder="features_outputs_VSPW", exp_name="exp",
+                     frame_names=None, noise=None, seed=17):
+    """Step 4 for one window: 2*K modulated sampler passes (+lambda then -lambda, one per label in `unique_labels`), each
+    with the dumped Q/K injected, lambda*mask added to the chosen attention outputs of the chosen decoder block(s) at the
+    modulation timestep(s) and, if asked, the latent blended with the feature pass's x_t outside the mask.  The feature pass
+    (Step 2, `segment_window(..., keep_all_steps=True)`) must have left its dumps in the FeatureStore under
+    (feature_folder, exp_name) and Step 3 its label maps under `masks_folder`.
+    Returns {(sign, label): final latent fp32 [F,4,h,w]} -- what the reference hands to decode_first_stage (SDP:150-151)."""
+    F, _, lh, lw = latent.shape
+    modulate_timestep = [t_start] if modulate_timestep is None else [int(t) for t in modulate_timestep]
+    blocks = [int(b) for b in modulate_block_idx]
+    video = engine.video
+    if is_injected_features:                                            # SDP:420-428 / SVP:404-411
+        types = (["temporal_cross_attn_k", "temporal_cross_attn_q", "temporal_self_attn_k", "temporal_self_attn_q"] if video else
+                 ["spatial_cross_attn_k", "spatial_cross_attn_q", "spatial_self_attn_k", "spatial_self_attn_q"])
+        inj = dict(injected_block_types=["output"], injected_feature_types=types,
+                   input_block_indices=[3, 4, 5, 6, 7, 8, 10, 11] if video else [3, 4, 5, 6, 7, 8, 9, 10, 11],
+                   output_block_indices=list(range(1, 12)))
+    else:
+        inj = dict(injected_block_types=None, injected_feature_types=None, input_block_indices=None, output_block_indices=None)
+    scale = _BLOCK_SCALE[blocks[0]]
+    base_h, base_w = lh // 8, lw // 8                                   # H // (F*8) of the driver (latent = image / 8)
+    sampler, denoiser = engine.sampler, make_denoiser(engine, F)
+    seed_everything(seed)
+    x0 = sampler.add_noise(latent, cond=c, uc=uc, num_steps=num_steps, noise_level=t_start, noise=noise)   # same start as Step 2
+    out = {}
+    for sign in (1.0, -1.0):                                            # SDP:436-442
+        for mask_id in [int(v) for v in np.asarray(unique_labels).reshape(-1)]:
+            masks = load_feature_masks(masks_folder, mask_id, num_frames=F, feature_timestep=feature_timestep,
+                                       modulate_block_idx=blocks[0], base_height=base_h, base_width=base_w,
+                                       frame_name_list=frame_names, device=latent.device)
+            mp = {"feature_masks": masks, "modulate_block_idx": blocks, "modulate_layer_type": list(modulate_layer_type),
+                  "modulate_attn_type": list(modulate_attn_type), "modulate_timestep": modulate_timestep,
+                  "modulate_schedule": modulate_schedule, "modulate_lambda_start": sign * modulate_lambda_start,
+                  "modulate_lambda_end": sign * modulate_lambda_end, "num_frames": F, "modulate_uc": True,
+                  "is_injected_features": is_injected_features, **inj, "feature_folder": feature_folder, "exp_name": exp_name,
+                  "injected_features_group": {}, "modulate_layer_frames": {}, "modulate_block_frames": {},
+                  "modulate_timestep_frames": {}, "modulate_lambda_layers": {}, "latent_mask_start": min(modulate_timestep),
+                  "latent_mask_end": num_steps if video else min(modulate_timestep) + 1}                     # SVP:467 / SDP:484
+            out[(int(sign), mask_id)] = sampler(denoiser, x0.clone(), cond=c, uc=uc, img_callback=None, is_modulate=True,
+                                                modulate_params=mp, uc_list=None, t_start=t_start,
+                                                is_latent_blending=is_latent_blending, feature_height=base_h * scale,
+                                                feature_width=base_w * scale)
+    return out
