@@ -123,10 +123,18 @@ int vidseg_linear_bf16(const void* a0, const void* a1, int C0, int C1, long long
                        vidseg_stream_t stream);
 /* 3x3 conv, padding 1 (OAI:267-271, 302-315 ResBlock convs; OAI:202-217 Downsample stride 2; OAI:149-167
  * Upsample = nearest x2 folded into the addressing) over the channel concat of x0 and x1 (skip connection,
- * OAI:912), + bias + per-sample emb vector (OAI:353-365) + residual (OAI:369). */
+ * OAI:912), + bias + per-sample emb vector (OAI:353-365) + residual (OAI:369).  pad = 1, or 0 for the first stage's
+ * (0,1,0,1)-padded stride-2 Downsample (sgm/modules/diffusionmodules/model.py:84-91); out_f32 (optional) receives an fp32
+ * copy of the result (the VAE's conv_out moments). */
 int vidseg_conv3x3_bf16(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up,
                         const void* w, int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual,
-                        void* out, vidseg_stream_t stream);
+                        void* out, int pad, float* out_f32 /*opt*/, vidseg_stream_t stream);
+/* First stage (VAE encoder, model.py:487-600): row softmax of fp32 logits (the single-head dim-512 mid attention runs as
+ * GEMM -> softmax -> GEMM, model.py:161-202) and DiagonalGaussianDistribution.sample * scale_factor
+ * (distributions.py:24-41, sgm/models/diffusion.py:138-151); moments NHWC [B][HW][2Z] fp32, noise / out NCHW [B][Z][HW]. */
+int vidseg_softmax_rows_bf16(const float* x, long long rows, int cols, float scale, void* out_bf16, vidseg_stream_t stream);
+int vidseg_gaussian_sample(const float* moments_nhwc, const float* noise_nchw, int B, int HW, int Z, float scale, float* out_nchw,
+                           vidseg_stream_t stream);
 /* OAI:638-644 input conv (Cin 4/8): x fp32 NHWC, w fp32 [3][3][Cin][Cout] -> bf16 NHWC. */
 int vidseg_conv_in(const float* x, const float* w, const float* bias, int B, int H, int W, int Cin, int Cout,
                    void* out_bf16_nhwc, vidseg_stream_t stream);

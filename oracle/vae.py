@@ -1,0 +1,80 @@
+"""Oracle (CPU restatement) of the first stage's encode side -- test infrastructure only.
+
+    sgm/modules/diffusionmodules/model.py:487-600  Encoder.forward (ResnetBlock :94-151, Downsample :72-91, AttnBlock :161-202)
+    sgm/models/autoencoder.py:469-489              AutoencodingEngineLegacy.encode (quant_conv, regularizer)
+    sgm/modules/distributions/distributions.py:24-41  DiagonalGaussianDistribution (clamp, std, sample)
+    sgm/models/diffusion.py:138-151                encode_first_stage (* scale_factor)
+
+Functional torch-CPU fp32, driven by the reference's state-dict keys.  Pinned by tests/golden/vae_encoder_narrow.npz
+(tools/gen_golden_vae.py runs the reference's own Encoder / DiagonalGaussianDistribution).
+`round_bf16=True` rounds activations where the HIP path stores bf16 (format-error yardstick for the GPU tests).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def _bf(x, on):
+    return x.bfloat16().float() if on else x
+
+
+class VAEEncoderOracle:
+    def __init__(self, state_dict, round_bf16=False):
+        self.sd = {k: v.float() for k, v in state_dict.items()}
+        self.rb = round_bf16
+
+    def has(self, p):
+        return any(k.startswith(p) for k in self.sd)
+
+    def gn(self, x, p):
+        return F.group_norm(x, 32, self.sd[p + ".weight"], self.sd[p + ".bias"], 1e-6)
+
+    def conv(self, x, p, stride=1, pad=1):
+        return F.conv2d(x, self.sd[p + ".weight"], self.sd[p + ".bias"], stride=stride, padding=pad)
+
+    def swish(self, x):
+        return x * torch.sigmoid(x)
+
+    def resnet(self, x, p):
+        h = _bf(self.swish(self.gn(x, p + ".norm1")), self.rb)
+        h = _bf(self.conv(h, p + ".conv1"), self.rb)
+        h = _bf(self.swish(self.gn(h, p + ".norm2")), self.rb)
+        h = self.conv(h, p + ".conv2")
+        if self.has(p + ".nin_shortcut."):
+            x = _bf(self.conv(x, p + ".nin_shortcut", pad=0), self.rb)
+        return _bf(x + h, self.rb)
+
+    def attn(self, x, p):
+        h = _bf(self.gn(x, p + ".norm"), self.rb)
+        q, k, v = (_bf(self.conv(h, f"{p}.{n}", pad=0), self.rb) for n in "qkv")
+        b, c, hh, ww = q.shape
+        q, k, v = (t.reshape(b, c, hh * ww).transpose(1, 2) for t in (q, k, v))
+        w = torch.softmax((q @ k.transpose(1, 2)) * (c ** -0.5), dim=-1)
+        o = _bf(_bf(w, self.rb) @ v, self.rb).transpose(1, 2).reshape(b, c, hh, ww)
+        return _bf(x + self.conv(o, p + ".proj_out", pad=0), self.rb)
+
+    def moments(self, x):
+        """x [B, 3, H, W] fp32 -> [B, 2*embed, H/8, W/8] (quant_conv applied)."""
+        h = _bf(self.conv(x, "encoder.conv_in"), self.rb)
+        lvl = 0
+        while self.has(f"encoder.down.{lvl}."):
+            j = 0
+            while self.has(f"encoder.down.{lvl}.block.{j}."):
+                h = self.resnet(h, f"encoder.down.{lvl}.block.{j}")
+                j += 1
+            if self.has(f"encoder.down.{lvl}.downsample."):
+                h = _bf(self.conv(F.pad(h, (0, 1, 0, 1)), f"encoder.down.{lvl}.downsample.conv", stride=2, pad=0), self.rb)
+            lvl += 1
+        h = self.resnet(h, "encoder.mid.block_1")
+        h = self.attn(h, "encoder.mid.attn_1")
+        h = self.resnet(h, "encoder.mid.block_2")
+        h = _bf(self.swish(self.gn(h, "encoder.norm_out")), self.rb)
+        h = self.conv(h, "encoder.conv_out")
+        return self.conv(h, "quant_conv", pad=0)
+
+    def encode(self, x, noise, scale_factor=1.0):
+        mom = self.moments(x)
+        mean, logvar = torch.chunk(mom, 2, dim=1)
+        std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+        return scale_factor * (mean + std * noise)

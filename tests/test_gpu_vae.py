@@ -1,0 +1,54 @@
+"""HIP first-stage encoder vs the reference golden and the oracle's bf16-format yardstick."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from vidseg_diffusion_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def nrms(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)) / (np.sqrt(np.mean(np.asarray(b, np.float64) ** 2)) + 1e-30))
+
+
+def test_vae_encoder_vs_reference():
+    from oracle.vae import VAEEncoderOracle
+    from tests.test_oracle_vae import narrow_state_dict
+    from vidseg_diffusion_amd.vae import encode_first_stage
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vae_encoder_narrow.npz"))
+    net, shapes, sd = narrow_state_dict()
+    net.load_state_dict(sd)
+    x = torch.from_numpy(g["x"]).to(dev)
+    mom = net.moments(x).permute(0, 3, 1, 2).cpu().numpy()
+    fmt = nrms(VAEEncoderOracle(sd, round_bf16=True).moments(torch.from_numpy(g["x"])).numpy(), g["moments"])
+    err = nrms(mom, g["moments"])
+    print("vae moments nrms", err, "bf16 format", fmt)
+    assert err < 3e-2 and err <= 1.5 * fmt + 5e-3, (err, fmt)
+    z = encode_first_stage(net, x, 0.18215, noise=torch.from_numpy(g["noise"]))
+    assert z.shape == (2, 4, 8, 8) and nrms(z.cpu().numpy(), g["z"]) < 3e-2
+    # default noise path = host torch.randn under the caller's seed, like posterior.sample()
+    torch.manual_seed(11)
+    z2 = encode_first_stage(net, x, 0.18215)
+    assert torch.equal(z2, z)
+
+
+def test_asymmetric_downsample_and_softmax_ops():
+    from vidseg_diffusion_amd import ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 10, 12, 64, generator=gen).bfloat16()
+    w = (torch.randn(64, 64, 3, 3, generator=gen) * 0.05)
+    b = torch.randn(64, generator=gen)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x.float().permute(0, 3, 1, 2), (0, 1, 0, 1)), w.bfloat16().float(), b, stride=2)
+    out, out32 = ops.conv3x3(x.to(dev), ops.pack_conv3x3(w, dev), b.to(dev), stride=2, pad=0, want_f32=True)
+    got = out32.permute(0, 3, 1, 2).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max() <= 2e-3 * ref.abs().max()
+    assert (out.float().cpu() - out32.cpu()).abs().max() <= 2 ** -8 * out32.abs().max().cpu()
+    lg = torch.randn(37, 256, generator=gen) * 8
+    p = ops.softmax_rows(lg.to(dev), 0.25).float().cpu()
+    assert (p - torch.softmax(lg * 0.25, -1)).abs().max() < 4e-3

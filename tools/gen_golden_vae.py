@@ -1,0 +1,47 @@
+"""tests/golden/vae_encoder_narrow.npz: the REFERENCE's first-stage Encoder (sgm/modules/diffusionmodules/model.py) +
+quant_conv + DiagonalGaussianDistribution on a narrow configuration (ch 64, same topology as sd_2_1.yaml:44-61).
+Build-container only."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from ref_import import import_reference  # noqa: E402
+from vidseg_diffusion_amd import synthetic  # noqa: E402
+
+VAE_NARROW = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2, 4, 4],
+                  num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+
+
+def main():
+    import_reference()
+    from sgm.modules.diffusionmodules.model import Encoder
+    from sgm.modules.distributions.distributions import DiagonalGaussianDistribution
+    torch.set_grad_enabled(False)
+    enc = Encoder(**VAE_NARROW).eval()
+    quant = torch.nn.Conv2d(8, 8, 1)
+    shapes = {"encoder." + k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    shapes.update({"quant_conv." + k: tuple(v.shape) for k, v in quant.state_dict().items()})
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=2468, gain=1.0).items()}
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")})
+    quant.load_state_dict({k[len("quant_conv."):]: v for k, v in sd.items() if k.startswith("quant_conv.")})
+    g = np.random.Generator(np.random.PCG64(77))
+    x = np.clip(g.standard_normal((2, 3, 64, 64)).astype(np.float32) * 0.5, -1, 1)
+    mom = quant(enc(torch.from_numpy(x)))
+    torch.manual_seed(11)
+    noise = torch.randn(2, 4, 8, 8)
+    torch.manual_seed(11)
+    z = DiagonalGaussianDistribution(mom).sample() * 0.18215
+    rec = dict(x=x, moments=mom.numpy(), noise=noise.numpy(), z=z.numpy(), state_dict_signature=synthetic.state_dict_signature(shapes))
+    path = os.path.join(ROOT, "tests", "golden", "vae_encoder_narrow.npz")
+    np.savez_compressed(path, **rec)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; moments absmax", float(np.abs(rec["moments"]).max()),
+          "logvar range", float(mom[:, 4:].min()), float(mom[:, 4:].max()))
+
+
+if __name__ == "__main__":
+    main()

@@ -23,6 +23,8 @@ struct GemmParams {
     int Hin, Win;            // stored input height/width (conv) ; unused for ksize == 1
     int Hout, Wout;
     int ksize, stride, up;   // ksize 1 or 3; stride 1/2; up 1/2 (nearest upsample of the input before the conv)
+    int pad;                 // top/left zero padding of a 3x3 conv: 1, or 0 for the VAE's (0,1,0,1)-padded stride-2 Downsample
+                             // (sgm/modules/diffusionmodules/model.py:84-91); bottom/right padding is whatever falls off the input
     // B operand
     const bf16_t* w;         // [N][K]
     int N, K;
@@ -255,8 +257,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_conv(GemmParams p) {
             const int b = mm / HWo, rem = mm - b * HWo;
             const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
             a_base[i] = b * p.Hin * p.Win;
-            a_ih0[i] = oh * p.stride - 1;
-            a_iw0[i] = ow * p.stride - 1;
+            a_ih0[i] = oh * p.stride - p.pad;
+            a_iw0[i] = ow * p.stride - p.pad;
         }
     }
     u32x4 ra0[AR], rb0[BR];
@@ -453,8 +455,8 @@ __global__ void __launch_bounds__(256, NST == 2 ? 4 : 3) k_gemm_dma(GemmParams p
             const int b = mm / HWo, rem = mm - b * HWo;
             const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
             a_base[i] = b * p.Hin * p.Win;
-            a_ih0[i] = oh * p.stride - 1;
-            a_iw0[i] = ow * p.stride - 1;
+            a_ih0[i] = oh * p.stride - p.pad;
+            a_iw0[i] = ow * p.stride - p.pad;
         }
         const int n = n0 + r;
         b_off[i] = n < p.N ? (unsigned)((long long)n * p.K * 2) + csw : OOB;
@@ -647,8 +649,8 @@ __global__ void __launch_bounds__(WM * 128, MI == 1 ? 4 : (WM == 4 ? 1 : 2)) k_g
             const int b = mm / HWo, rem = mm - b * HWo;
             const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
             a_base[i] = b * p.Hin * p.Win;
-            a_ih0[i] = oh * p.stride - 1;
-            a_iw0[i] = ow * p.stride - 1;
+            a_ih0[i] = oh * p.stride - p.pad;
+            a_iw0[i] = ow * p.stride - p.pad;
         }
     }
     unsigned b_off[BPW];
@@ -1205,8 +1207,9 @@ int vidseg_conv_temporal3_bf16(const void* x, int C, int BT, int HW, int T, cons
 // 3x3 convolution, padding 1, NHWC bf16 activations, weight packed [Cout][(kh*3+kw)*Cin + c].
 int vidseg_conv3x3_bf16(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up, const void* w,
                         int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual, void* out,
-                        hipStream_t st) {
-    VS_REQUIRE((stride == 1 || stride == 2) && (up == 1 || up == 2), "conv3x3: stride=%d up=%d", stride, up);
+                        int pad, float* out_f32, hipStream_t st) {
+    VS_REQUIRE((stride == 1 || stride == 2) && (up == 1 || up == 2) && (pad == 0 || pad == 1), "conv3x3: stride=%d up=%d pad=%d", stride,
+               up, pad);
     GemmParams p{};
     p.x0 = (const bf16_t*)x0;
     p.x1 = (const bf16_t*)x1;
@@ -1217,6 +1220,8 @@ int vidseg_conv3x3_bf16(const void* x0, const void* x1, int C0, int C1, int B, i
     p.ksize = 3;
     p.stride = stride;
     p.up = up;
+    p.pad = pad;
+    p.out_f32 = out_f32;
     p.Hout = (Hin * up + 2 - 3) / stride + 1;
     p.Wout = (Win * up + 2 - 3) / stride + 1;
     p.w = (const bf16_t*)w;

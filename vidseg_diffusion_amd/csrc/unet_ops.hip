@@ -584,6 +584,54 @@ __global__ void k_add_rowvec(const bf16_t* __restrict__ x, const bf16_t* __restr
     *reinterpret_cast<bf16x8_t*>(out + row * C + c) = o;
 }
 
+// ---------------------------------------------------------------------------------------------
+// First-stage (VAE) helpers.  The encoder's single mid-block attention has ONE head of dim 512 over (H/8 * W/8) tokens
+// (sgm/modules/diffusionmodules/model.py:161-202): it runs as two GEMMs around this row softmax (fp32 logits in, bf16
+// probabilities out), once per frame.  k_gaussian_sample is DiagonalGaussianDistribution.sample (distributions.py:24-41)
+// times the scale factor of encode_first_stage (sgm/models/diffusion.py:138-151): moments NHWC [B][hw][2z] fp32.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_softmax_rows(const float* __restrict__ x, long long rows, int cols, float scale_log2e,
+                                                      bf16_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * cols;
+    float mx = -INFINITY;
+    for (int c = lane * 4; c < cols; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    }
+    mx = wave_max_f32(mx) * scale_log2e;
+    float sum = 0.f;
+    for (int c = lane * 4; c < cols; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum += __builtin_amdgcn_exp2f(fmaf(v[j], scale_log2e, -mx));
+    }
+    const float inv = 1.0f / wave_sum_f32(sum);
+    bf16_t* o = out + row * cols;
+    for (int c = lane * 4; c < cols; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(fmaf(v[j], scale_log2e, -mx)) * inv;
+        u32x2 w = {pack2_bf16(e[0], e[1]), pack2_bf16(e[2], e[3])};
+        *reinterpret_cast<u32x2*>(o + c) = w;
+    }
+}
+
+__global__ void k_gaussian_sample(const float* __restrict__ moments, const float* __restrict__ noise_nchw, int B, int HW, int Z, float scale,
+                                  float* __restrict__ out_nchw) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;        // over [B][Z][HW]
+    if (i >= (long long)B * Z * HW) return;
+    const int s = (int)(i % HW), z = (int)((i / HW) % Z), b = (int)(i / ((long long)HW * Z));
+    const float* m = moments + ((long long)b * HW + s) * (2 * Z);
+    const float mean = m[z];
+    const float logvar = fminf(fmaxf(m[Z + z], -30.0f), 20.0f);
+    const float std = expf(0.5f * logvar);
+    out_nchw[i] = scale * (mean + std * noise_nchw[i]);
+}
+
 extern "C" {
 
 int vidseg_groupnorm_nhwc_bf16(const void* x0, const void* x1, int C0, int C1, int B, int HW, int G, const float* gamma,
@@ -629,6 +677,23 @@ int vidseg_attention_bf16(const void* q, int ldq, const void* k, int ldk, const 
         k_attention<true><<<dim3((Nq + 127) / 128, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
                                                                           (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
     VS_CHECK_LAUNCH("attention");
+    return VS_OK;
+}
+
+int vidseg_softmax_rows_bf16(const float* x, long long rows, int cols, float scale, void* out_bf16, hipStream_t st) {
+    VS_REQUIRE(cols % 4 == 0 && cols > 0, "softmax_rows: cols=%d must be a positive multiple of 4", cols);
+    if (rows == 0) return VS_OK;
+    k_softmax_rows<<<dim3((unsigned)((rows + 3) / 4)), 256, 0, st>>>(x, rows, cols, scale * 1.44269504088896340736f, (bf16_t*)out_bf16);
+    VS_CHECK_LAUNCH("softmax_rows");
+    return VS_OK;
+}
+
+int vidseg_gaussian_sample(const float* moments_nhwc, const float* noise_nchw, int B, int HW, int Z, float scale, float* out_nchw,
+                           hipStream_t st) {
+    const long long n = (long long)B * Z * HW;
+    if (n == 0) return VS_OK;
+    k_gaussian_sample<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(moments_nhwc, noise_nchw, B, HW, Z, scale, out_nchw);
+    VS_CHECK_LAUNCH("gaussian_sample");
     return VS_OK;
 }
 

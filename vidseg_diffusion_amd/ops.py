@@ -17,7 +17,9 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
 _lib.register({
     "vidseg_linear_bf16": [_P, _P, _I, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P],
-    "vidseg_conv3x3_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
+    "vidseg_conv3x3_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P],
+    "vidseg_softmax_rows_bf16": [_P, _L, _I, _F, _P, _P],
+    "vidseg_gaussian_sample": [_P, _P, _I, _I, _I, _F, _P, _P],
     "vidseg_conv_in": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "vidseg_conv_out4": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "vidseg_groupnorm_nhwc_bf16": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _I, _P, _P],
@@ -109,9 +111,10 @@ def linear(a, w, bias=None, *, a1=None, rowvec=None, rows_per_sample=0, residual
     return out
 
 
-def conv3x3(x0, w, bias, *, x1=None, stride=1, up=1, rowvec=None, residual=None):
+def conv3x3(x0, w, bias, *, x1=None, stride=1, up=1, rowvec=None, residual=None, pad=1, want_f32=False):
     """3x3 conv, padding 1, on NHWC bf16 [B, H, W, C0] (+ channel-concat x1), optional fused nearest-2x
-    upsample of the input (openaimodel.py:149-167) or stride 2 (openaimodel.py:202-217)."""
+    upsample of the input (openaimodel.py:149-167) or stride 2 (openaimodel.py:202-217).  pad=0: the first stage's
+    (0,1,0,1)-padded Downsample (model.py:84-91).  want_f32: also return the result in fp32 (same shape)."""
     workspace(x0.device)
     B, H, W, C0 = x0.shape
     C1 = x1.shape[-1] if x1 is not None else 0
@@ -119,8 +122,25 @@ def conv3x3(x0, w, bias, *, x1=None, stride=1, up=1, rowvec=None, residual=None)
     Ho = (H * up + 2 - 3) // stride + 1
     Wo = (W * up + 2 - 3) // stride + 1
     out = torch.empty((B, Ho, Wo, Cout), dtype=BF16, device=x0.device)
+    out32 = torch.empty((B, Ho, Wo, Cout), dtype=F32, device=x0.device) if want_f32 else None
     call("vidseg_conv3x3_bf16", ptr(x0), ptr(x1), C0, C1, B, H, W, stride, up, ptr(w), Cout, ptr(bias), ptr(rowvec),
-         rowvec.stride(0) if rowvec is not None else 0, ptr(residual), ptr(out), stream())
+         rowvec.stride(0) if rowvec is not None else 0, ptr(residual), ptr(out), pad, ptr(out32), stream())
+    return (out, out32) if want_f32 else out
+
+
+def softmax_rows(x_f32, scale):
+    """softmax(scale * x) over the last dim of an fp32 matrix -> bf16 (first-stage mid attention)."""
+    cols = x_f32.shape[-1]
+    out = torch.empty(x_f32.shape, dtype=BF16, device=x_f32.device)
+    call("vidseg_softmax_rows_bf16", ptr(x_f32), x_f32.numel() // cols, cols, float(scale), ptr(out), stream())
+    return out
+
+
+def gaussian_sample(moments_nhwc_f32, noise_nchw, scale):
+    """(mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) * scale; moments [B, h, w, 2z] fp32 -> fp32 NCHW [B, z, h, w]."""
+    B, H, W, Z2 = moments_nhwc_f32.shape
+    out = torch.empty((B, Z2 // 2, H, W), dtype=F32, device=moments_nhwc_f32.device)
+    call("vidseg_gaussian_sample", ptr(moments_nhwc_f32), ptr(noise_nchw), B, H * W, Z2 // 2, float(scale), ptr(out), stream())
     return out
 
 

@@ -1,0 +1,244 @@
+"""First stage, encode side: `AutoencoderKL.encode` of the reference on MI355X.
+
+    sgm/models/autoencoder.py:437-522   AutoencodingEngineLegacy / AutoencoderKL: encoder -> quant_conv -> regularizer
+    sgm/modules/diffusionmodules/model.py:84-91 (Downsample), 94-151 (ResnetBlock), 161-202 (AttnBlock),
+                                          487-600 (Encoder)
+    sgm/modules/distributions/distributions.py:24-41  DiagonalGaussianDistribution.sample
+    sgm/models/diffusion.py:138-151     encode_first_stage (* scale_factor)
+
+Same constructor kwargs and state-dict keys as the reference (`encoder.*`, `quant_conv.*`; `decoder.*` /
+`post_quant_conv.*` keys of a checkpoint are ignored by `load_state_dict(strict=False)`), NHWC bf16 activations on the
+same kernels as the UNet: k_conv_in (Cin = 3), implicit-GEMM 3x3 convs (the (0,1,0,1)-padded stride-2 Downsample is the
+`pad=0` form), GroupNorm(eps 1e-6)+swish, 1x1 convs as linears.  The one single-head attention of dim `block_in` (512)
+over H/8*W/8 tokens runs per frame as GEMM (fp32 logits) -> row softmax -> GEMM.  `quant_conv` (1x1, 8 -> 8) is folded
+into `conv_out`'s weights at pack time (exact algebra: W' = Wq Wc, b' = Wq bc + bq).  The decoder is not built.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import VidsegError
+from .unet import _meta
+
+
+def Normalize(in_channels, num_groups=32):
+    return _meta(nn.GroupNorm, num_groups, in_channels, eps=1e-6, affine=True)
+
+
+class Downsample(nn.Module):
+    """model.py:72-91 with_conv=True: pad (0,1,0,1) then 3x3 stride 2 without padding."""
+
+    def __init__(self, in_channels, with_conv=True):
+        super().__init__()
+        if not with_conv:
+            raise NotImplementedError("Downsample(with_conv=False) (avg_pool) is not on the path")
+        self.conv = _meta(nn.Conv2d, in_channels, in_channels, 3, stride=2, padding=0)
+
+    def pack(self, dev):
+        self.w, self.b = ops.pack_conv3x3(self.conv.weight, dev), ops.f32(self.conv.bias, dev)
+
+    def run(self, x):
+        return ops.conv3x3(x, self.w, self.b, stride=2, pad=0)
+
+
+class ResnetBlock(nn.Module):
+    """model.py:94-151 with temb_channels = 0 (the autoencoder has no timestep embedding)."""
+
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=0):
+        super().__init__()
+        if conv_shortcut or temb_channels:
+            raise NotImplementedError("ResnetBlock(conv_shortcut / temb) is not used by the first stage")
+        self.in_channels = in_channels
+        self.out_channels = in_channels if out_channels is None else out_channels
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = _meta(nn.Conv2d, in_channels, self.out_channels, 3, padding=1)
+        self.norm2 = Normalize(self.out_channels)
+        self.conv2 = _meta(nn.Conv2d, self.out_channels, self.out_channels, 3, padding=1)
+        if self.in_channels != self.out_channels:
+            self.nin_shortcut = _meta(nn.Conv2d, in_channels, self.out_channels, 1)
+
+    def pack(self, dev):
+        self.g1, self.b1 = ops.f32(self.norm1.weight, dev), ops.f32(self.norm1.bias, dev)
+        self.g2, self.b2 = ops.f32(self.norm2.weight, dev), ops.f32(self.norm2.bias, dev)
+        self.w1, self.cb1 = ops.pack_conv3x3(self.conv1.weight, dev), ops.f32(self.conv1.bias, dev)
+        self.w2, self.cb2 = ops.pack_conv3x3(self.conv2.weight, dev), ops.f32(self.conv2.bias, dev)
+        if self.in_channels != self.out_channels:
+            self.ws = ops.pack_linear(self.nin_shortcut.weight.reshape(self.out_channels, self.in_channels), dev)
+            self.bs = ops.f32(self.nin_shortcut.bias, dev)
+
+    def run(self, x):
+        h = ops.groupnorm(x, self.g1, self.b1, eps=1e-6, silu=True)
+        h = ops.conv3x3(h, self.w1, self.cb1)
+        h = ops.groupnorm(h, self.g2, self.b2, eps=1e-6, silu=True)
+        res = x if self.in_channels == self.out_channels else ops.linear(x, self.ws, self.bs)
+        return ops.conv3x3(h, self.w2, self.cb2, residual=res)
+
+
+class AttnBlock(nn.Module):
+    """model.py:161-202: GroupNorm -> q/k/v 1x1 convs -> softmax(q k^T / sqrt(C)) v (one head of dim C) -> proj_out -> + x."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = Normalize(in_channels)
+        self.q = _meta(nn.Conv2d, in_channels, in_channels, 1)
+        self.k = _meta(nn.Conv2d, in_channels, in_channels, 1)
+        self.v = _meta(nn.Conv2d, in_channels, in_channels, 1)
+        self.proj_out = _meta(nn.Conv2d, in_channels, in_channels, 1)
+
+    def pack(self, dev):
+        C = self.in_channels
+        self.g, self.b = ops.f32(self.norm.weight, dev), ops.f32(self.norm.bias, dev)
+        self.w_qkv = ops.pack_linear(torch.cat([m.weight.reshape(C, C) for m in (self.q, self.k, self.v)], 0), dev)
+        self.b_qkv = ops.f32(torch.cat([self.q.bias, self.k.bias, self.v.bias], 0), dev)
+        self.w_o, self.b_o = ops.pack_linear(self.proj_out.weight.reshape(C, C), dev), ops.f32(self.proj_out.bias, dev)
+
+    def run(self, x):
+        B, H, W, C = x.shape
+        N = H * W
+        t = ops.groupnorm(x, self.g, self.b, eps=1e-6, silu=False).view(B, N, C)
+        qkv = ops.linear(t, self.w_qkv, self.b_qkv)                                   # [B, N, 3C]
+        att = torch.empty((B, N, C), dtype=torch.bfloat16, device=x.device)
+        for b in range(B):                                                             # one frame at a time: N x N fp32 logits
+            q = qkv[b, :, :C].contiguous()
+            k = qkv[b, :, C:2 * C].contiguous()
+            vt = qkv[b, :, 2 * C:].t().contiguous()                                    # [C, N]: the K-contiguous "weight" of P @ V
+            logits = ops.linear(q, k, out_f32=True)                                    # q k^T, fp32 [N, N]
+            p = ops.softmax_rows(logits, float(C) ** -0.5)                             # SDPA's default scale (model.py:189-191)
+            att[b] = ops.linear(p, vt)
+        out = ops.linear(att, self.w_o, self.b_o, residual=x.view(B, N, C))
+        return out.view(B, H, W, C)
+
+
+class _Level(nn.Module):
+    pass
+
+
+class Encoder(nn.Module):
+    """model.py:487-600 (attn_resolutions = [], attn_type "vanilla")."""
+
+    def __init__(self, *, ch, out_ch=None, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions=(), dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, double_z=True, use_linear_attn=False,
+                 attn_type="vanilla", **ignore_kwargs):
+        super().__init__()
+        if list(attn_resolutions) or use_linear_attn or attn_type not in ("vanilla", "vanilla-xformers"):
+            raise NotImplementedError("Encoder: only the AutoencoderKL configuration (no per-level attention) is on the path")
+        if ch % 64 != 0:
+            raise NotImplementedError("Encoder: ch must be a multiple of 64 (implicit-GEMM K chunking)")
+        self.ch, self.num_resolutions, self.num_res_blocks = ch, len(ch_mult), num_res_blocks
+        self.in_channels, self.z_channels, self.double_z = in_channels, z_channels, double_z
+        self.conv_in = _meta(nn.Conv2d, in_channels, ch, 3, padding=1)
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        block_in = ch
+        for i_level in range(self.num_resolutions):
+            block_in = ch * in_ch_mult[i_level]
+            block_out = ch * ch_mult[i_level]
+            level = _Level()
+            level.block = nn.ModuleList()
+            level.attn = nn.ModuleList()
+            for _ in range(num_res_blocks):
+                level.block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, dropout=dropout))
+                block_in = block_out
+            if i_level != self.num_resolutions - 1:
+                level.downsample = Downsample(block_in, resamp_with_conv)
+            self.down.append(level)
+        self.mid = _Level()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, dropout=dropout)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, dropout=dropout)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = _meta(nn.Conv2d, block_in, 2 * z_channels if double_z else z_channels, 3, padding=1)
+
+
+class AutoencoderKL(nn.Module):
+    """sgm/models/autoencoder.py:508-522 (+ :437-506), encode side, with DiagonalGaussianRegularizer(sample=True)."""
+
+    def __init__(self, embed_dim=4, ddconfig=None, lossconfig=None, loss_config=None, monitor=None, ckpt_path=None,
+                 ckpt_engine=None, max_batch_size=None, **ignored):
+        super().__init__()
+        if ddconfig is None:
+            raise ValueError("AutoencoderKL needs ddconfig")
+        self.encoder = Encoder(**ddconfig)
+        zc = (1 + bool(ddconfig.get("double_z", True))) * ddconfig["z_channels"]
+        self.quant_conv = _meta(nn.Conv2d, zc, (1 + bool(ddconfig.get("double_z", True))) * embed_dim, 1)
+        self.embed_dim = embed_dim
+        self.max_batch_size = max_batch_size
+        self._packed_on = None
+
+    # ------------------------------------------------------------------ packing
+    def load_state_dict(self, state_dict, strict=False, assign=True):
+        own = {k: v for k, v in state_dict.items() if k.startswith("encoder.") or k.startswith("quant_conv.")}
+        return super().load_state_dict(own, strict=strict, assign=True)
+
+    def pack(self, dev):
+        e = self.encoder
+        self.cin_w, self.cin_b = ops.pack_conv_in(e.conv_in.weight, dev), ops.f32(e.conv_in.bias, dev)
+        for level in e.down:
+            for blk in level.block:
+                blk.pack(dev)
+            if hasattr(level, "downsample"):
+                level.downsample.pack(dev)
+        for m in (e.mid.block_1, e.mid.attn_1, e.mid.block_2):
+            m.pack(dev)
+        self.no_g, self.no_b = ops.f32(e.norm_out.weight, dev), ops.f32(e.norm_out.bias, dev)
+        # conv_out (3x3, C -> 2z) followed by quant_conv (1x1, 2z -> 2*embed): one conv with W' = Wq Wc, b' = Wq bc + bq
+        wq = self.quant_conv.weight.detach().double().reshape(self.quant_conv.weight.shape[0], -1)
+        wc = e.conv_out.weight.detach().double()
+        wf = torch.einsum("oz,zikl->oikl", wq, wc)
+        bf = wq @ e.conv_out.bias.detach().double() + self.quant_conv.bias.detach().double()
+        n_out = wf.shape[0]
+        self.n_mom = n_out
+        pad = (-n_out) % 8                                           # the GEMM epilogue writes 8 columns per lane
+        if pad:
+            wf = torch.cat([wf, wf.new_zeros((pad,) + tuple(wf.shape[1:]))], 0)
+            bf = torch.cat([bf, bf.new_zeros(pad)], 0)
+        self.out_w, self.out_b = ops.pack_conv3x3(wf.float(), dev), ops.f32(bf.float(), dev)
+        self._packed_on = dev
+
+    # ------------------------------------------------------------------ forward
+    def moments(self, x):
+        """x: fp32 NCHW [B, 3, H, W] in [-1, 1] on the device -> fp32 NHWC [B, H/8, W/8, 2*embed] (mean | logvar)."""
+        if not x.is_cuda:
+            raise VidsegError("AutoencoderKL runs on a HIP device only (no CPU fallback)")
+        if self._packed_on is None:
+            self.pack(x.device)
+        e = self.encoder
+        h = ops.conv_in(x.float().permute(0, 2, 3, 1).contiguous(), self.cin_w, self.cin_b)
+        for level in e.down:
+            for blk in level.block:
+                h = blk.run(h)
+            if hasattr(level, "downsample"):
+                h = level.downsample.run(h)
+        h = e.mid.block_1.run(h)
+        h = e.mid.attn_1.run(h)
+        h = e.mid.block_2.run(h)
+        h = ops.groupnorm(h, self.no_g, self.no_b, eps=1e-6, silu=True)
+        _, mom = ops.conv3x3(h, self.out_w, self.out_b, want_f32=True)
+        return mom[..., :self.n_mom].contiguous() if mom.shape[-1] != self.n_mom else mom
+
+    def encode(self, x, return_reg_log=False, noise=None, scale=1.0):
+        """z = mean + std * randn (autoencoder.py:469-489, regularizers/__init__.py:21-31).  `noise` defaults to
+        torch.randn(mean.shape) drawn on the HOST like the reference's posterior.sample() (so torch.manual_seed governs it)."""
+        outs = []
+        bs = self.max_batch_size or x.shape[0]
+        for i in range(0, x.shape[0], bs):
+            mom = self.moments(x[i:i + bs])
+            B, h, w, Z2 = mom.shape
+            nz = torch.randn((B, Z2 // 2, h, w)) if noise is None else noise[i:i + bs]
+            outs.append(ops.gaussian_sample(mom, nz.to(mom.device, torch.float32).contiguous(), scale))
+        z = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+        return (z, {}) if return_reg_log else z
+
+    def decode(self, z, **kw):
+        raise NotImplementedError("the first-stage decoder is not built (SURVEY.md §8(f) rank 1/2)")
+
+
+def encode_first_stage(first_stage_model: AutoencoderKL, x, scale_factor=0.18215, n_samples=None, noise=None):
+    """sgm/models/diffusion.py:138-151: chunked encode, then * scale_factor (folded into the sampling kernel)."""
+    n = n_samples or x.shape[0]
+    outs = [first_stage_model.encode(x[i:i + n], noise=None if noise is None else noise[i:i + n], scale=scale_factor)
+            for i in range(0, x.shape[0], n)]
+    return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
