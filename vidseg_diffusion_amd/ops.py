@@ -189,6 +189,11 @@ def groupnorm(x0, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True):
     C1 = x1.shape[-1] if x1 is not None else 0
     HW = x0.numel() // (B * C0)
     ws = workspace(x0.device)
+    need = B * ((HW + 63) // 64) * 2 * (C0 + C1)                     # per-chunk partial sums (GN_ROWS_PER_CHUNK = 64)
+    if need > ws.part.numel():                                        # first-stage activations at 576x1024 need 33 M floats
+        ws.part = torch.empty(need, dtype=F32, device=x0.device)
+    if B * 2 * (C0 + C1) > ws.stats.numel():
+        ws.stats = torch.empty(B * 2 * (C0 + C1), dtype=F32, device=x0.device)
     out = torch.empty(x0.shape[:-1] + (C0 + C1,), dtype=BF16, device=x0.device)
     call("vidseg_groupnorm_nhwc_bf16", ptr(x0), ptr(x1), C0, C1, B, HW, groups, ptr(gamma), ptr(beta), eps, int(silu),
          ptr(ws.part), ws.part.numel(), ptr(ws.stats), ws.stats.numel(), ptr(out), stream())
