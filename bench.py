@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--refine", action="store_true", help="also run Step 3b (correct_low_res_mask)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--narrow", action="store_true", help="debug: narrow-width UNet (NOT the benchmark config)")
+    ap.add_argument("--vae", action="store_true", help="also time the first-stage encode of one window (reported beside the metric)")
     ap.add_argument("--config", default="sd", choices=["sd", "svd"],
                     help="sd = BASELINE configs[1] (headline); svd = configs[2]: SVD 14x576x1024, t_start 17, is_refine_mask")
     args = ap.parse_args()
@@ -186,6 +187,25 @@ def main():
                                          "window per GPU (latent 14x4x72x128), t_start=17 (8 CFG UNet evals, batch 28), spatial+temporal taps, "
                                          "is_aggre_attn, K-means K=20 + 4-NN, is_refine_mask (dense tracking + vote)")
             out["config"]["unet_evals_per_step"] = 8
+        if args.vae:                                                     # outside the timed region, never part of `value`
+            from vidseg_diffusion_amd.vae import AutoencoderKL, encode_first_stage
+            dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+                      num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+            vae = AutoencoderKL(embed_dim=4, ddconfig=dd)
+            vshapes = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+            vae.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(vshapes, seed=99).items()})
+            ih, iw = (576, 1024) if svd else (512, 512)
+            frames = (torch.rand(F_WIN, 3, ih, iw) * 2 - 1).to(dev)
+            nz = torch.randn(F_WIN, 4, ih // 8, iw // 8)
+            for _ in range(2):
+                encode_first_stage(vae, frames, 0.18215, noise=nz)
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(3):
+                encode_first_stage(vae, frames, 0.18215, noise=nz)
+            torch.cuda.synchronize()
+            out["first_stage"] = {"encode_ms_per_window": round(1e3 * (time.perf_counter() - tv) / 3, 2), "frames": F_WIN,
+                                  "image": [ih, iw], "note": "AutoencoderKL.encode, synthetic weights; excluded from `value`"}
         if not args.no_cpu_baseline and not args.narrow and not svd:
             out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg)
         print(json.dumps(out))

@@ -260,3 +260,17 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
                                                 is_latent_blending=is_latent_blending, feature_height=base_h * scale,
                                                 feature_width=base_w * scale)
     return out
+
+
+def segment_clip_from_frames(engine: Engine, first_stage_model, frames, c_fn, *, scale_factor=0.18215, batch_size=14, **kw):
+    """Image-in variant of `segment_clip`: frames fp32 [T, 3, H, W] in [-1, 1] on the device are encoded window by window
+    with `vae.encode_first_stage` (sgm/models/diffusion.py:138-151; sd_pipeline_vspw.py:294-307) before Steps 1-3b."""
+    from .vae import encode_first_stage
+    state = WindowState()
+    out = []
+    for (s, e) in window_slices(frames.shape[0], batch_size):
+        latent = encode_first_stage(first_stage_model, frames[s:e].contiguous(), scale_factor)
+        c, uc = c_fn(s, e)
+        labels, state = segment_window(engine, latent, c, uc, state=state, **kw)
+        out.append((s, e, labels))
+    return out
