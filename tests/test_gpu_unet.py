@@ -369,3 +369,48 @@ def test_modulation_sweep_step4(env):
     ref = eng.sampler(make_denoiser(eng, Fn), x0.clone(), cond=c, uc=uc, is_modulate=True, modulate_params=mp, t_start=22,
                       is_latent_blending=True, feature_height=8, feature_width=8)
     assert torch.equal(ref, a)
+
+
+def test_c1_full_width_window_vs_oracle():
+    """BASELINE configs[0] (the reference's CPU-runnable case): FULL-size SD 2.1 UNet, 4 frames at 256x256 (latent 32x32),
+    K = 5, one step (t_start = 24), aggregated blocks.  HIP pipeline vs the all-fp32 CPU oracle: Q taps of blocks 6-8 within the
+    bf16 tolerance, masks by IoU up to a label permutation; and the analysis of the device's own taps re-run by the oracle must
+    give bit-identical masks."""
+    from oracle import analysis as OA
+    from oracle import pipeline as OP
+    from oracle.unet import UNetOracle
+    from tools_metrics import matched_iou
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import build_sd_engine, segment_window
+    from vidseg_diffusion_amd.unet import UNetModel
+    dev = torch.device("cuda:0")
+    cfg = dict(synthetic.SD21_FULL)
+    net = UNetModel(**cfg)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=1234).items()}
+    net.load_state_dict(sd)
+    Fn, K, T0 = 4, 5, 24
+    lat = synthetic.latent_clip(Fn, 32, 32, seed=1)
+    c, ucn = synthetic.sd_conditioning(Fn, context_dim=cfg["context_dim"], seq=77, seed=1)
+    noise = torch.from_numpy(np.random.Generator(np.random.PCG64(9)).standard_normal(lat.shape).astype(np.float32))
+    torch.set_grad_enabled(False)
+    ref = OP.segment_window(UNetOracle(sd), torch.from_numpy(lat), torch.from_numpy(c), torch.from_numpy(ucn), noise, num_masks=K,
+                            t_start=T0, seed=17)
+    eng = build_sd_engine(net)
+    FE.FeatureStore.clear(); FE.MaskStore.clear()
+    cc, uc = {"crossattn": torch.from_numpy(c).to(dev)}, {"crossattn": torch.from_numpy(ucn).to(dev)}
+    labels, _ = segment_window(eng, torch.from_numpy(lat).to(dev), cc, uc, num_masks=K, t_start=T0, seed=17, noise=noise.to(dev),
+                               feature_folder="/nonexistent/c1", exp_name="w")
+    store = FE.FeatureStore.folder("/nonexistent/c1", "w")
+    taps = {b: store[f"output_block_{b}_spatial_self_attn_q_time_24"].cpu().numpy() for b in (6, 7, 8)}
+    for b in (6, 7, 8):
+        e = nrms(taps[b].astype(np.float32), ref["q_taps"][b].astype(np.float32))
+        print("C1 tap", b, "nrms", round(e, 4))
+        assert taps[b].shape == (2 * Fn, 256, 640) and e < 4e-2
+    np.random.seed(17)
+    _, lab_o, _ = OA.match_gt_mask(OA.aggregate_blocks([taps[8], taps[7], taps[6]]), K, np.random.mtrand._rand)
+    assert np.array_equal(labels.reshape(-1), lab_o)
+    iou, exact = matched_iou(labels, ref["labels"], K)
+    print("C1 full-width mask IoU vs fp32 oracle", iou, "exact", exact)
+    assert iou >= 0.90
+    FE.FeatureStore.clear(); FE.MaskStore.clear()
