@@ -165,3 +165,42 @@ def test_empty_cluster_relocation_vs_sklearn_golden(dev):
         assert np.abs(res.centers.cpu().numpy() - g[f"{nm}_centers"]).max() < 1e-12, nm
         oc, ol, _ = OA.kmeans_fit(X, init.shape[0], np.random.RandomState(0), init=init)
         assert np.array_equal(labels, ol) and res.n_iter == int(g[f"{nm}_n_iter"])
+
+
+def test_edge_cases_vs_oracle(dev):
+    """Degenerate and ragged inputs the reference's third-party code defines behaviour for: n_samples < n_clusters (sklearn's
+    ValueError), K = 1, n = K (every sample its own cluster), duplicated rows (zero distances), a single-frame window (no
+    tracking pairs), a token count that is not a multiple of any tile size, empty query sets, wrong dtypes / CPU tensors."""
+    from oracle import analysis as O
+    from vidseg_diffusion_amd import _lib, analysis as A
+    g = np.random.Generator(np.random.PCG64(123))
+    X = (g.standard_normal((37, 24)) * 0.3).astype(np.float16)
+    with pytest.raises(ValueError, match="should be >= n_clusters"):
+        A.kmeans_fit(_to(dev, X[:3]), 5, random_state=np.random.RandomState(0))
+    with pytest.raises(_lib.VidsegError):
+        A.kmeans_fit(torch.from_numpy(X), 3)                                       # CPU tensor: no fallback
+    with pytest.raises(_lib.VidsegError):
+        A.kmeans_fit(_to(dev, X.astype(np.float32)), 3)                            # not fp16
+    for K in (1, 37, 6):                                                          # K = 1, n = K, ragged n
+        oc, ol, oi = O.kmeans_fit(X, K, np.random.RandomState(3))
+        km = A.kmeans_fit(_to(dev, X), K, random_state=np.random.RandomState(3))
+        assert np.array_equal(km.labels.cpu().numpy(), ol), K
+        np.testing.assert_allclose(km.centers.cpu().numpy(), oc, rtol=0, atol=1e-11)
+    Xd = np.repeat(X[:9], 5, axis=0)                                              # duplicates: 9 distinct rows, 45 samples
+    oc, ol, _ = O.kmeans_fit(Xd, 4, np.random.RandomState(1))
+    km = A.kmeans_fit(_to(dev, Xd), 4, random_state=np.random.RandomState(1))
+    assert np.array_equal(km.labels.cpu().numpy(), ol)
+    # 4-NN with fewer distinct neighbours than k and an empty query set
+    ref, lab = X[:5], np.array([3, 1, 3, 0, 1], dtype=np.int32)
+    assert np.array_equal(A.knn_predict(_to(dev, ref), _to(dev, lab), _to(dev, X)).cpu().numpy(), O.knn_predict(ref, lab, X))
+    assert A.knn_predict(_to(dev, ref), _to(dev, lab), _to(dev, X[:0])).numel() == 0
+    # single-frame window: dense tracking has no pairs, the vote leaves the labels alone
+    blocks, _ = synthetic.attention_q_dumps(1, 5, 7, 32, num_blocks=1, seed=8)
+    q = blocks[0][1:]                                                             # conditional half, F = 1
+    tr, _ = A.dense_tracking(_to(dev, q), 1, 5, 7)
+    th, tw = O.dense_tracking(q, 1, 5, 7)
+    assert tr.shape == (1, 35) and np.array_equal(tr.cpu().numpy()[0] // 7, th[0]) and np.array_equal(tr.cpu().numpy()[0] % 7, tw[0])
+    labs = g.integers(0, 3, size=(1, 35)).astype(np.int32)
+    out = A.trajectory_vote(tr, _to(dev, labs), 7).cpu().numpy()
+    corr, _ = O.correct_low_res_mask(labs.reshape(1, 5, 7).astype(np.int64), th, tw)
+    assert np.array_equal(out.reshape(-1), corr)
