@@ -68,16 +68,18 @@ __global__ void __launch_bounds__(1024) k_gn_partial(const bf16_t* __restrict__ 
     }
 }
 
-__global__ void __launch_bounds__(64) k_gn_stats(const float* __restrict__ part, int C, int G, int HW, int nchunk, float eps,
-                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                 float* __restrict__ stats) {
-    // grid (G, B), one wave: lanes stride over (chunk, channel-in-group); double accumulation, fixed order.
+__global__ void __launch_bounds__(256) k_gn_stats(const float* __restrict__ part, int C, int G, int HW, int nchunk, float eps,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  float* __restrict__ stats) {
+    // grid (G, B), four waves: threads stride over (chunk, channel-in-group); double accumulation in a fixed order
+    // (thread-strided partial sums, wave butterfly, then the four wave totals in ascending order).
     // Output per (b, c): scale = rstd*gamma, shift = beta - mean*scale   -> stats[b][2][C]
-    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    __shared__ double red[2][4];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int cpg = C / G;
     double s = 0.0, q = 0.0;
     const int total = nchunk * cpg;
-    for (int i = lane; i < total; i += 64) {
+    for (int i = tid; i < total; i += 256) {
         const int ch = i / cpg, c = g * cpg + i % cpg;
         const float* o = part + (((long long)b * nchunk + ch) * 2) * C;
         s += (double)o[c];
@@ -85,12 +87,19 @@ __global__ void __launch_bounds__(64) k_gn_stats(const float* __restrict__ part,
     }
     s = wave_sum_f64(s);
     q = wave_sum_f64(q);
+    if ((tid & 63) == 0) {
+        red[0][tid >> 6] = s;
+        red[1][tid >> 6] = q;
+    }
+    __syncthreads();
+    s = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    q = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
     const double n = (double)HW * cpg;
     const double mean = s / n;
     const double var = fmax(q / n - mean * mean, 0.0);
     const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
     float* o = stats + (long long)b * 2 * C;
-    for (int i = lane; i < cpg; i += 64) {
+    for (int i = tid; i < cpg; i += 256) {
         const int c = g * cpg + i;
         const float sc = rstd * gamma[c];
         o[c] = sc;
@@ -490,67 +499,69 @@ __global__ void k_blend_f32(const float* __restrict__ x, const float* __restrict
 // spatial location s of sample b, the T frames attend to each other.  Tokens stay in the spatial layout
 // (row (b*T + t)*S + s); one thread per (b, t, s, head) query, T <= 32 keys read through the cache.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(128) k_temporal_attention(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+// Block = (16 consecutive locations, one head, one sample): the K and V rows of all T frames are staged once in LDS
+// ([t][location][64] bf16, 2*T*2 KiB), then every query (t, location) is handled by 8 lanes, 8 of the 64 dims each (one
+// 16-byte chunk per lane: all global and LDS accesses are whole 128-byte rows), dot products closed by three lane
+// exchanges.  q, k, v and o are each touched exactly once.
+#define TA_LOC 16
+__global__ void __launch_bounds__(256) k_temporal_attention(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                             const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo,
                                                             int Bv, int T, int S, int H, float scale) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)Bv * T * S * H;
-    if (idx >= total) return;
-    const int s = (int)(idx % S);
-    const int h = (int)((idx / S) % H);
-    const int t = (int)((idx / ((long long)S * H)) % T);
-    const int b = (int)(idx / ((long long)S * H * T));
-    const long long row = ((long long)b * T + t) * S + s;
-    float qf[64];
-    {
-        const bf16x8_t* qp = reinterpret_cast<const bf16x8_t*>(q + row * ldq + h * 64);
+    extern __shared__ __attribute__((aligned(16))) char ta_smem[];
+    bf16_t* sK = reinterpret_cast<bf16_t*>(ta_smem);                 // [T][TA_LOC][64]
+    bf16_t* sV = sK + T * TA_LOC * 64;
+    const int tid = threadIdx.x;
+    const int s0 = blockIdx.x * TA_LOC, h = blockIdx.y, b = blockIdx.z;
+    for (int i = tid; i < T * TA_LOC * 8; i += 256) {
+        const int c = i & 7, sl = (i >> 3) % TA_LOC, t = i / (8 * TA_LOC);
+        const int sg = min(s0 + sl, S - 1);
+        const long long row = ((long long)b * T + t) * S + sg;
+        *reinterpret_cast<u32x4*>(sK + (t * TA_LOC + sl) * 64 + c * 8) = *reinterpret_cast<const u32x4*>(k + row * ldk + h * 64 + c * 8);
+        *reinterpret_cast<u32x4*>(sV + (t * TA_LOC + sl) * 64 + c * 8) = *reinterpret_cast<const u32x4*>(v + row * ldv + h * 64 + c * 8);
+    }
+    __syncthreads();
+    const int c = tid & 7, grp = tid >> 3;
+    for (int qi = grp; qi < T * TA_LOC; qi += 32) {
+        const int t = qi / TA_LOC, sl = qi % TA_LOC;
+        if (s0 + sl >= S) continue;                                  // whole 8-lane groups drop out together
+        const long long row = ((long long)b * T + t) * S + s0 + sl;
+        float qf[8];
+        {
+            const bf16x8_t x = *reinterpret_cast<const bf16x8_t*>(q + row * ldq + h * 64 + c * 8);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const bf16x8_t x = qp[c];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qf[c * 8 + e] = bf16_to_f32((bf16_t)x[e]) * scale;
+            for (int e = 0; e < 8; ++e) qf[e] = bf16_to_f32((bf16_t)x[e]) * scale;
         }
-    }
-    float sc[32];
-    float mx = -INFINITY;
-    for (int j = 0; j < T; ++j) {
-        const bf16x8_t* kp = reinterpret_cast<const bf16x8_t*>(k + (((long long)b * T + j) * S + s) * ldk + h * 64);
-        float d = 0.f;
+        float sc[32];
+        float mx = -INFINITY;
+        for (int j = 0; j < T; ++j) {
+            const bf16x8_t x = *reinterpret_cast<const bf16x8_t*>(sK + (j * TA_LOC + sl) * 64 + c * 8);
+            float d = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const bf16x8_t x = kp[c];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) d = fmaf(qf[c * 8 + e], bf16_to_f32((bf16_t)x[e]), d);
+            for (int e = 0; e < 8; ++e) d = fmaf(qf[e], bf16_to_f32((bf16_t)x[e]), d);
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            sc[j] = d;
+            mx = fmaxf(mx, d);
         }
-        sc[j] = d;
-        mx = fmaxf(mx, d);
-    }
-    float l = 0.f;
-    for (int j = 0; j < T; ++j) {
-        sc[j] = __expf(sc[j] - mx);
-        l += sc[j];
-    }
-    float acc[64];
-#pragma unroll
-    for (int e = 0; e < 64; ++e) acc[e] = 0.f;
-    for (int j = 0; j < T; ++j) {
-        const float pj = bf16_to_f32(f32_to_bf16(sc[j]));                       // P rounded to bf16 like the MFMA path
-        const bf16x8_t* vp = reinterpret_cast<const bf16x8_t*>(v + (((long long)b * T + j) * S + s) * ldv + h * 64);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const bf16x8_t x = vp[c];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[c * 8 + e] = fmaf(pj, bf16_to_f32((bf16_t)x[e]), acc[c * 8 + e]);
+        float l = 0.f;
+        for (int j = 0; j < T; ++j) {
+            sc[j] = __expf(sc[j] - mx);
+            l += sc[j];
         }
-    }
-    const float inv = 1.f / l;
-    bf16x8_t* op = reinterpret_cast<bf16x8_t*>(o + row * ldo + h * 64);
+        float acc[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        bf16x8_t x;
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int j = 0; j < T; ++j) {
+            const float pj = bf16_to_f32(f32_to_bf16(sc[j]));                       // P rounded to bf16 like the MFMA path
+            const bf16x8_t x = *reinterpret_cast<const bf16x8_t*>(sV + (j * TA_LOC + sl) * 64 + c * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = (short)f32_to_bf16(acc[c * 8 + e] * inv);
-        op[c] = x;
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, bf16_to_f32((bf16_t)x[e]), acc[e]);
+        }
+        const float inv = 1.f / l;
+        u32x4 w = {pack2_bf16(acc[0] * inv, acc[1] * inv), pack2_bf16(acc[2] * inv, acc[3] * inv), pack2_bf16(acc[4] * inv, acc[5] * inv),
+                   pack2_bf16(acc[6] * inv, acc[7] * inv)};
+        *reinterpret_cast<u32x4*>(o + row * ldo + h * 64 + c * 8) = w;
     }
 }
 
@@ -583,6 +594,7 @@ __global__ void k_add_rowvec(const bf16_t* __restrict__ x, const bf16_t* __restr
     for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(bf16_to_f32((bf16_t)a[e]) + bf16_to_f32((bf16_t)b[e]));
     *reinterpret_cast<bf16x8_t*>(out + row * C + c) = o;
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // First-stage (VAE) helpers.  The encoder's single mid-block attention has ONE head of dim 512 over (H/8 * W/8) tokens
@@ -649,7 +661,7 @@ int vidseg_groupnorm_nhwc_bf16(const void* x0, const void* x1, int C0, int C1, i
     const int nthr = ((c8n * rpb + 63) / 64) * 64;
     k_gn_partial<<<dim3(nchunk, B), nthr, (size_t)rpb * 2 * C * sizeof(float), st>>>((const bf16_t*)x0, (const bf16_t*)x1, C0,
                                                                                       x1 ? C1 : 0, HW, rpb, nchunk, part);
-    k_gn_stats<<<dim3(G, B), 64, 0, st>>>(part, C, G, HW, nchunk, eps, gamma, beta, stats);
+    k_gn_stats<<<dim3(G, B), 256, 0, st>>>(part, C, G, HW, nchunk, eps, gamma, beta, stats);
     k_gn_apply<<<dim3(nchunk, B), nthr, 0, st>>>((const bf16_t*)x0, (const bf16_t*)x1, C0, x1 ? C1 : 0, HW, rpb, stats, silu,
                                                  (bf16_t*)out);
     VS_CHECK_LAUNCH("groupnorm");
@@ -804,8 +816,14 @@ int vidseg_temporal_attention_bf16(const void* q, int ldq, const void* k, int ld
     VS_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "temporal_attention: strides must be multiples of 8");
     const long long total = (long long)Bv * T * S * H;
     if (total == 0) return VS_OK;
-    k_temporal_attention<<<dim3((unsigned)((total + 127) / 128)), 128, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
-                                                                               (const bf16_t*)v, ldv, (bf16_t*)o, ldo, Bv, T, S, H, 0.125f);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_temporal_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    const size_t lds = (size_t)2 * T * TA_LOC * 64 * 2;
+    k_temporal_attention<<<dim3((unsigned)((S + TA_LOC - 1) / TA_LOC), H, Bv), 256, lds, st>>>(
+        (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, Bv, T, S, H, 0.125f);
     VS_CHECK_LAUNCH("temporal_attention");
     return VS_OK;
 }
