@@ -835,10 +835,11 @@ __device__ __forceinline__ float ld_in<float>(const float* p, long long i) { ret
 template <>
 __device__ __forceinline__ float ld_in<bf16_t>(const bf16_t* p, long long i) { return bf16_to_f32(p[i]); }
 
-// Input conv (Cin = 4/8, Cout multiple of 8): the [3][3][Cin][Cout] fp32 weights live in LDS for the block's lifetime;
-// thread t owns 8 consecutive output channels (t % (Cout/8)) of pixel slot t / (Cout/8) and walks the block's pixels,
-// so a pixel's 9*Cin inputs are broadcast loads and the bf16 result leaves as one 16-byte store.  HBM-bound (output).
-#define CONV_IN_PIX 128
+// Input conv (Cin = 3/4/8, Cout multiple of 8): the [3][3][Cin][Cout] fp32 weights live in LDS for the block's lifetime;
+// thread t owns 8 consecutive output channels (t % (Cout/8)) of a QUAD of 4 horizontally adjacent pixels: per (kh, c) it
+// loads the 6 inputs the quad's three kw taps touch (same address for all threads of a quad: broadcast) and reuses every
+// weight vector for the 4 pixels -- 96 FMAs per 6 LDS reads, VALU-bound.  The bf16 result leaves as 16-byte stores.
+#define CONV_IN_QUADS 32
 __global__ void __launch_bounds__(256) k_conv_in(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                  int B, int H, int W, int Cin, int Cout, bf16_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float wl[];           // [9*Cin][Cout]
@@ -846,42 +847,56 @@ __global__ void __launch_bounds__(256) k_conv_in(const float* __restrict__ x, co
     for (int i = threadIdx.x; i < K * Cout / 4; i += 256) reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(w)[i];
     __syncthreads();
     const int c8n = Cout / 8;
-    const int slots = 256 / c8n;                                         // pixels in flight per pass
+    const int slots = 256 / c8n;                                         // quads in flight per pass
     const int slot = threadIdx.x / c8n, co = (threadIdx.x - slot * c8n) * 8;
     if (slot >= slots) return;
-    const long long npix = (long long)B * H * W;
-    const long long p0 = (long long)blockIdx.x * CONV_IN_PIX;
+    const int W4 = W / 4;
+    const long long nquad = (long long)B * H * W4;
+    const long long q0 = (long long)blockIdx.x * CONV_IN_QUADS;
     float bv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bv[j] = bias ? bias[co + j] : 0.f;
-    for (int q = slot; q < CONV_IN_PIX; q += slots) {
-        const long long pix = p0 + q;
-        if (pix >= npix) break;
-        const int ow = (int)(pix % W), oh = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
-        float acc[8];
+    for (int qi = slot; qi < CONV_IN_QUADS; qi += slots) {
+        const long long quad = q0 + qi;
+        if (quad >= nquad) break;
+        const int ow0 = (int)(quad % W4) * 4, oh = (int)((quad / W4) % H), b = (int)(quad / ((long long)W4 * H));
+        float acc[4][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = bv[j];
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[p][j] = bv[j];
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = oh + kh - 1;
             if (ih < 0 || ih >= H) continue;
-            for (int kw = 0; kw < 3; ++kw) {
-                const int iw = ow + kw - 1;
-                if (iw < 0 || iw >= W) continue;
-                const float* xp = x + (((long long)b * H + ih) * W + iw) * Cin;
-                const float* wp = wl + ((kh * 3 + kw) * Cin) * Cout + co;
-                for (int c = 0; c < Cin; ++c) {
-                    const float xv = xp[c];
-                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp + c * Cout), w1 = *reinterpret_cast<const f32x4*>(wp + c * Cout + 4);
+            const float* xrow = x + ((long long)b * H + ih) * W * Cin;
+            for (int c = 0; c < Cin; ++c) {
+                float xv[6];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[j] = fmaf(xv, w0[j], acc[j]);
-                        acc[4 + j] = fmaf(xv, w1[j], acc[4 + j]);
-                    }
+                for (int t = 0; t < 6; ++t) {
+                    const int iw = ow0 - 1 + t;
+                    xv[t] = (iw >= 0 && iw < W) ? xrow[(long long)iw * Cin + c] : 0.f;
+                }
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float* wp = wl + ((kh * 3 + kw) * Cin + c) * Cout + co;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[p][j] = fmaf(xv[kw + p], w0[j], acc[p][j]);
+                            acc[p][4 + j] = fmaf(xv[kw + p], w1[j], acc[p][4 + j]);
+                        }
                 }
             }
         }
-        u32x4 o = {pack2_bf16(acc[0], acc[1]), pack2_bf16(acc[2], acc[3]), pack2_bf16(acc[4], acc[5]), pack2_bf16(acc[6], acc[7])};
-        *reinterpret_cast<u32x4*>(out + pix * Cout + co) = o;
+        bf16_t* op = out + (((long long)b * H + oh) * W + ow0) * Cout + co;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            u32x4 o = {pack2_bf16(acc[p][0], acc[p][1]), pack2_bf16(acc[p][2], acc[p][3]), pack2_bf16(acc[p][4], acc[p][5]),
+                       pack2_bf16(acc[p][6], acc[p][7])};
+            *reinterpret_cast<u32x4*>(op + (long long)p * Cout) = o;
+        }
     }
 }
 
@@ -1246,14 +1261,16 @@ int vidseg_conv_in(const float* x, const float* w, const float* bias, int B, int
                    hipStream_t st) {
     const long long npix = (long long)B * H * W;
     if (npix == 0 || Cout == 0) return VS_OK;
-    VS_REQUIRE(Cout % 8 == 0 && Cout <= 2048 && 9 * Cin * Cout * 4 <= 160 * 1024, "conv_in: Cin=%d Cout=%d", Cin, Cout);
+    VS_REQUIRE(Cout % 8 == 0 && Cout <= 2048 && 9 * Cin * Cout * 4 <= 160 * 1024 && W % 4 == 0, "conv_in: Cin=%d Cout=%d W=%d", Cin, Cout, W);
     const size_t lds = (size_t)9 * Cin * Cout * 4;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)k_conv_in, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    k_conv_in<<<dim3((unsigned)((npix + CONV_IN_PIX - 1) / CONV_IN_PIX)), 256, lds, st>>>(x, w, bias, B, H, W, Cin, Cout, (bf16_t*)out_bf16_nhwc);
+    const long long nquad = npix / 4;
+    k_conv_in<<<dim3((unsigned)((nquad + CONV_IN_QUADS - 1) / CONV_IN_QUADS)), 256, lds, st>>>(x, w, bias, B, H, W, Cin, Cout,
+                                                                                                (bf16_t*)out_bf16_nhwc);
     VS_CHECK_LAUNCH("conv_in");
     return VS_OK;
 }
