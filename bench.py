@@ -12,9 +12,11 @@ starts (VAE + conditioner excluded).  N > 1: one window per GP
 vidseg_diffusion_amd/parallel.py for the exchange.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel family = bf16 MFMA implicit-GEMM (k_gemm_tile / k_gemm_dma: every conv + linear of the UNet);
-                achieved = algorithmic FLOPs (2*M*N*K per launch) / HIP-event time of those launches, live in
-                the timed region; peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md).
+  roofline      the single kernel with the most time in the timed region (normally k_gemm_tile<NJ,4,64,2>, the 256x320 /
+                256x256 LDS-DMA implicit-GEMM tile): achieved = algorithmic FLOPs (2*M*N*K per launch) / HIP-event time of its
+                launches, recorded on the launch stream inside the timed region; peak = 2500 TFLOP/s dense bf16
+                (MI355X_MICROARCH.md); traffic = PMC bytes per launch of that kernel (profiles/r01_traffic.json).
+                `family` = the same figures over ALL conv/linear launches (three kernels share the work).
   cpu_baseline  the oracle ("port") timed on this box's host cores on a bounded sample (see `sample`).
 """
 import argparse
@@ -150,6 +152,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     k_ms, k_flops, k_launches = ops.gemm_profile_end()
+    kinds = ops.gemm_profile_kinds()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -160,10 +163,19 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")           # PMC pass (separate rocprofv3 --pmc runs), see file
     if os.path.exists(tpath) and not svd and not args.narrow:
         with open(tpath) as fh:
-            traffic = json.load(fh).get("traffic_bytes_per_launch")
+            tj = json.load(fh)
+            traffic = tj.get("traffic_bytes_per_launch")
     if rank == 0:
         frames = F_WIN * world * args.steps
-        achieved = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
+        fam_tf = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
+        dom = max(kinds, key=lambda r: r[1])                                  # the single kernel with the most time in the region
+        if traffic is not None:                                               # PMC pass: per-launch bytes of that kernel if recorded
+            for kname, rec in tj.get("per_kernel", {}).items():
+                if ("k_gemm_tile<5, 4, 64" in kname and dom[0].startswith("k_gemm_tile<NJ,4,64")) or \
+                        ("k_gemm_dma<2>" in kname and dom[0].startswith("k_gemm_dma")):
+                    traffic = rec["traffic_bytes_per_launch"]
+                    break
+        achieved = (dom[2] / (dom[1] * 1e-3)) / 1e12 if dom[1] > 0 else 0.0
         out = {
             "metric": "segmented frames/sec (14-frame 512^2 clip, 20 masks)",
             "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -175,10 +187,15 @@ def main():
                                    + (", is_refine_mask" if args.refine else ""),
                        "frames_per_gpu": F_WIN, "num_masks": K_MASKS, "unet_evals_per_step": 3, "parallelism": f"window-per-gpu x{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": round(achieved / 2500.0, 4), "traffic": traffic, "kernel": "bf16 MFMA implicit-GEMM family (k_gemm_tile 256x320/256x256 + k_gemm_dma 128x128, LDS-DMA staged)",
-                         "launches_per_step": k_launches // max(args.steps, 1),
-                         "avg_launch_us": round(1e3 * k_ms / max(k_launches, 1), 2),
-                         "gemm_ms_per_step": round(k_ms / args.steps, 3)},
+                         "frac": round(achieved / 2500.0, 4), "traffic": traffic, "kernel": dom[0],
+                         "launches_per_step": dom[3] // max(args.steps, 1),
+                         "avg_launch_us": round(1e3 * dom[1] / max(dom[3], 1), 2),
+                         "ms_per_step": round(dom[1] / args.steps, 3),
+                         # every conv / linear of the UNet runs on this kernel family; the family-wide figures:
+                         "family": {"achieved": round(fam_tf, 2), "frac": round(fam_tf / 2500.0, 4),
+                                    "launches_per_step": k_launches // max(args.steps, 1), "gemm_ms_per_step": round(k_ms / args.steps, 3),
+                                    "by_kernel": {n: {"ms_per_step": round(ms / args.steps, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 else 0.0,
+                                                      "launches_per_step": ln // max(args.steps, 1)} for (n, ms, fl, ln) in kinds if ln}}},
             "unique_labels": int(len(np.unique(labels))),
         }
         if svd:

@@ -206,6 +206,8 @@ int vidseg_set_workspace(float* ws, long long floats);
 /* opt-in HIP-event timing of the conv/linear MFMA kernel family (bench.py roofline); out = {ms, flops, launches} (host) */
 int vidseg_gemm_profile_begin(void);
 int vidseg_gemm_profile_end(double* out);
+/* per-kernel split of the same region: out[12] = {ms, flops, launches} x {128x128 LDS-DMA, big tile, mid tile, 256x64} */
+int vidseg_gemm_profile_kinds(double* out);
 
 #ifdef __cplusplus
 }

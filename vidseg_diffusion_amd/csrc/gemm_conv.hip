@@ -943,6 +943,7 @@ struct GemmProf {
     std::vector<Shape> shapes;      // one per event pair
 };
 static GemmProf g_prof;
+static double g_kind_stats[12];
 
 static inline hipEvent_t prof_event() {
     if (g_prof.used == g_prof.ev.size()) {
@@ -968,12 +969,20 @@ int vidseg_gemm_profile_begin(void) {
 int vidseg_gemm_profile_end(double* out) {
     g_prof.on = false;
     double ms = 0.0;
+    for (int i = 0; i < 12; ++i) g_kind_stats[i] = 0.0;
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
         float t = 0.f;
         hipError_t e = hipEventSynchronize(g_prof.ev[i + 1]);
         if (e == hipSuccess) e = hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
         if (e != hipSuccess) VS_FAIL(VS_ERR_HIP, "gemm_profile_end: %s", hipGetErrorString(e));
         ms += t;
+        if (i / 2 < g_prof.shapes.size()) {
+            const GemmProf::Shape& h = g_prof.shapes[i / 2];
+            const int kd = h.kind >= 0 && h.kind < 4 ? h.kind : 0;
+            g_kind_stats[kd * 3] += t;
+            g_kind_stats[kd * 3 + 1] += 2.0 * (double)h.M * (double)h.N * (double)h.K;
+            g_kind_stats[kd * 3 + 2] += 1.0;
+        }
         if (getenv("VIDSEG_GEMM_SHAPES") && i / 2 < g_prof.shapes.size()) {
             const GemmProf::Shape& h = g_prof.shapes[i / 2];
             fprintf(stderr, "GEMMSHAPE M=%lld N=%d K=%d ks=%d up=%d st=%d act=%d split=%d us=%.1f kind=%d\n", h.M, h.N, h.K, h.ksize, h.up,
@@ -983,6 +992,13 @@ int vidseg_gemm_profile_end(double* out) {
     out[0] = ms;
     out[1] = g_prof.flops;
     out[2] = (double)g_prof.launches;
+    return VS_OK;
+}
+
+// Per-kernel split of the last profiled region: out[k*3 + {0,1,2}] = {milliseconds, algorithmic FLOPs, launches} for
+// k = 0: k_gemm_dma (128x128), 1: k_gemm_tile big (256x320 / 256x256), 2: k_gemm_tile mid (128x320), 3: k_gemm_conv<256,64>.
+int vidseg_gemm_profile_kinds(double* out) {
+    for (int i = 0; i < 12; ++i) out[i] = g_kind_stats[i];
     return VS_OK;
 }
 

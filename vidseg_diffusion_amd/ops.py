@@ -47,6 +47,7 @@ _lib.register({
     "vidseg_add_rowvec_bf16": [_P, _P, _L, _I, _I, _I, _P, _P],
     "vidseg_gemm_profile_begin": [],
     "vidseg_gemm_profile_end": [_P],
+    "vidseg_gemm_profile_kinds": [_P],
 })
 
 BF16 = torch.bfloat16
@@ -321,6 +322,17 @@ def gemm_profile_end():
     out = (ctypes.c_double * 3)()
     call("vidseg_gemm_profile_end", out)
     return float(out[0]), float(out[1]), int(out[2])
+
+
+GEMM_KIND_NAMES = ("k_gemm_dma (128x128, LDS-DMA)", "k_gemm_tile<NJ,4,64,2> (256x320 / 256x256, LDS-DMA)",
+                   "k_gemm_tile<NJ,4,32,1> (128x320, LDS-DMA)", "k_gemm_conv<256,64>")
+
+
+def gemm_profile_kinds():
+    """Per-kernel split of the region closed by gemm_profile_end: list of (name, ms, flops, launches)."""
+    out = (ctypes.c_double * 12)()
+    call("vidseg_gemm_profile_kinds", out)
+    return [(GEMM_KIND_NAMES[k], float(out[3 * k]), float(out[3 * k + 1]), int(out[3 * k + 2])) for k in range(4)]
 
 
 # ----------------------------------------------------------------------------- video (SVD) operators
