@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--refine", action="store_true", help="also run Step 3b (correct_low_res_mask)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--narrow", action="store_true", help="debug: narrow-width UNet (NOT the benchmark config)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N=1 only: run each window's analysis after its own feature pass instead of concurrently with the next one's")
     ap.add_argument("--vae", action="store_true", help="also time the first-stage encode of one window (reported beside the metric)")
     ap.add_argument("--config", default="sd", choices=["sd", "svd"],
                     help="sd = BASELINE configs[1] (headline); svd = configs[2]: SVD 14x576x1024, t_start 17, is_refine_mask")
@@ -136,19 +138,43 @@ def main():
         return parallel.segment_windows_sharded(eng, lat, c, uc, noise=noise, num_masks=K_MASKS, num_steps=NUM_STEPS, t_start=T_START,
                                                 is_aggre_attn=True, is_refine_mask=args.refine, seed=17, rank=rank, world=world)
 
+    # N = 1: windows run through pipeline.WindowPipeline -- the analysis of step i (second HIP stream) overlaps the feature pass
+    # of step i+1; every step is still a complete window (K-means included) and all of them finish inside the timed region.
+    overlap = world == 1 and not args.no_overlap
+    if overlap:
+        from vidseg_diffusion_amd.pipeline import WindowPipeline
+        pipe = WindowPipeline(eng, chain=False, num_masks=K_MASKS, is_aggre_attn=True, is_refine_mask=args.refine)
+        step_no = [0]
+
+        def run_steps(n):
+            last = None
+            for _ in range(n):
+                step_no[0] += 1
+                FE.MaskStore.clear()
+                got = pipe.push(lat, c, uc, num_steps=NUM_STEPS, t_start=T_START, seed=17, noise=noise, keep_all_steps=False,
+                                exp_name=f"step{step_no[0] % 2}")
+                last = got if got is not None else last
+            got = pipe.flush()
+            return got if got is not None else last
+    else:
+        def run_steps(n):
+            last = None
+            for _ in range(n):
+                last = one_step()
+            return last
+
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
+    if args.warmup:
+        run_steps(args.warmup)
     barrier()
     ops.gemm_profile_begin()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        labels = one_step()
+    labels = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     k_ms, k_flops, k_launches = ops.gemm_profile_end()
@@ -185,7 +211,9 @@ def main():
                                    "(latent 14x4x64x64), 25-step schedule with t_start=22 (3 CFG UNet evals, batch 28), Q/K taps on decoder "
                                    "blocks 3-11, is_aggre_attn (blocks 6,7,8), K-means K=20 n_init=10 + 4-NN"
                                    + (", is_refine_mask" if args.refine else ""),
-                       "frames_per_gpu": F_WIN, "num_masks": K_MASKS, "unet_evals_per_step": 3, "parallelism": f"window-per-gpu x{world}"},
+                       "frames_per_gpu": F_WIN, "num_masks": K_MASKS, "unet_evals_per_step": 3, "parallelism": f"window-per-gpu x{world}",
+                       "overlap": "analysis of step i on a second HIP stream, concurrent with the feature pass of step i+1" if overlap
+                                  else "none (each window's analysis follows its own feature pass)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(achieved / 2500.0, 4), "traffic": traffic, "kernel": dom[0],
                          "launches_per_step": dom[3] // max(args.steps, 1),

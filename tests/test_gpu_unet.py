@@ -414,3 +414,49 @@ def test_c1_full_width_window_vs_oracle():
     print("C1 full-width mask IoU vs fp32 oracle", iou, "exact", exact)
     assert iou >= 0.90
     FE.FeatureStore.clear(); FE.MaskStore.clear()
+
+
+def test_overlapped_clip_equals_sequential(env):
+    """WindowPipeline (analysis of window w on a second stream while window w+1's feature pass runs) must give exactly the
+    sequential loop's masks: 3 windows of 4 frames incl. the re-anchored last one, refinement on."""
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import build_sd_engine, segment_clip
+    dev, g, net, sd = env
+    eng = build_sd_engine(net)
+    Ft = 10                                                        # windows [0,4) [4,8) [6,10)
+    lat = torch.from_numpy(synthetic.latent_clip(Ft, 16, 16, seed=7)).to(dev)
+    cc, ucc = synthetic.sd_conditioning(Ft, context_dim=64, seq=7, seed=3)
+    cc, ucc = torch.from_numpy(cc).to(dev), torch.from_numpy(ucc).to(dev)
+    noise_all = torch.randn(lat.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+
+    def run(overlap, tag):
+        FE.FeatureStore.clear(); FE.MaskStore.clear()
+        res = []
+        # per-window noise must not depend on the execution order: pass it explicitly
+        from vidseg_diffusion_amd.pipeline import WindowPipeline, WindowState, segment_window, window_slices
+        slices = window_slices(Ft, 4)
+        if overlap:
+            pipe = WindowPipeline(eng, num_masks=4, is_refine_mask=True)
+            for b, (s, e) in enumerate(slices):
+                prev = pipe.push(lat[s:e].contiguous(), {"crossattn": cc[s:e]}, {"crossattn": ucc[s:e]}, t_start=22, seed=17,
+                                 feature_folder="/nonexistent/ov" + tag, exp_name=f"w{b}", noise=noise_all[s:e].contiguous())
+                if prev is not None:
+                    res.append(prev)
+            res.append(pipe.flush())
+        else:
+            st = WindowState()
+            for b, (s, e) in enumerate(slices):
+                lab, st = segment_window(eng, lat[s:e].contiguous(), {"crossattn": cc[s:e]}, {"crossattn": ucc[s:e]}, num_masks=4,
+                                         is_refine_mask=True, t_start=22, seed=17, state=st, feature_folder="/nonexistent/ov" + tag,
+                                         exp_name=f"w{b}", noise=noise_all[s:e].contiguous())
+                res.append(lab)
+        return res
+
+    a, b = run(False, "s"), run(True, "p")
+    assert len(a) == len(b) == 3
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    out = segment_clip(eng, lat, lambda s, e: ({"crossattn": cc[s:e]}, {"crossattn": ucc[s:e]}), batch_size=4, num_masks=4, t_start=22,
+                       seed=17, feature_folder="/nonexistent/ovc")
+    assert [(s, e) for s, e, _ in out] == [(0, 4), (4, 8), (6, 10)]
+    FE.FeatureStore.clear(); FE.MaskStore.clear()

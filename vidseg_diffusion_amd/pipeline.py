@@ -115,21 +115,14 @@ def make_denoiser(engine: Engine, num_frames: int):
     return denoiser
 
 
-def segment_window(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, num_masks=20, num_steps=25, t_start=22,
-                   feature_timestep="24", is_aggre_attn=True, is_refine_mask=False, seed=17, state: WindowState = None,
-                   frame_names=None, feature_folder="features_outputs_VSPW", exp_name="exp", gt_mask_path=None, noise=None,
-                   keep_all_steps=True):
-    """One 14-frame window: latent [F,4,h,w] fp32 (VAE output * 0.18215) -> cluster-id masks int64 [F, h/2 * w/2].
-
-    Returns (labels [F, N] int64 numpy, state) -- `state` carries ref_mask/ref_feature_map/ref_unique_labels to the
-    next window exactly like the driver's loop variables."""
-    state = state or WindowState()
+def feature_pass(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, num_steps=25, t_start=22, feature_timestep="24", seed=17,
+                 feature_folder="features_outputs_VSPW", exp_name="exp", noise=None, keep_all_steps=True):
+    """Steps 1-2 of one window (sd_pipeline_vspw.py:255, 336-357): reseed, add_noise, the Euler steps of the UNet with the dump
+    callback.  Everything is enqueued on the current HIP stream; returns the handle `analyse_window` needs."""
     F, _, lh, lw = latent.shape
     seed_everything(seed)                                                           # SDP:255
     sampler = engine.sampler
-
     denoiser = make_denoiser(engine, F)
-
     x = sampler.add_noise(latent, cond=c, uc=uc, num_steps=num_steps, noise_level=t_start, noise=noise)   # Step 1, SDP:341
     want = int(feature_timestep)
 
@@ -139,11 +132,26 @@ def segment_window(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, n
 
     sampler(denoiser, x, cond=c, uc=uc, img_callback=callback, is_modulate=False, modulate_params=None, uc_list=None,
             t_start=t_start, is_latent_blending=False)                              # Step 2, SDP:357
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream())
+    return dict(F=F, fh=lh // 2, fw=lw // 2, t_start=t_start, feature_timestep=feature_timestep, seed=seed, feature_folder=feature_folder,
+                exp_name=exp_name, done=done)
+
+
+def analyse_window(engine: Engine, h: dict, *, num_masks=20, is_aggre_attn=True, is_refine_mask=False, state: WindowState = None,
+                   frame_names=None, gt_mask_path=None):
+    """Steps 3-3b of one window (sd_pipeline_vspw.py:365-405) on the dumps `feature_pass` left in the FeatureStore.  May run
+    on another stream than the feature pass (it first waits for the pass's completion event); numpy's global RandomState is
+    re-seeded like the window's seed_everything did -- nothing between that call and KMeans consumes it."""
+    state = state or WindowState()
+    torch.cuda.current_stream().wait_event(h["done"])
+    np.random.seed(h["seed"])
+    F, fh, fw, t_start, feature_timestep = h["F"], h["fh"], h["fw"], h["t_start"], h["feature_timestep"]
+    feature_folder, exp_name = h["feature_folder"], h["exp_name"]
     if is_aggre_attn:
         block_name = "output_block_8,output_block_7,output_block_6"                   # SDP:367-370 / SVP:351-354
     else:
         block_name = "output_block_8" if engine.video else "output_block_7"
-    fh, fw = lh // 2, lw // 2                                                       # H // (F*2), SDP:374-375
     unique_labels, ref_mask, ref_fm = FE.feature_extraction_main(
         "match_gt_mask", num_masks, t_start, block_name, exp_name, exp_name, "spatial_self_attn_q", fh, fw, feature_timestep,
         frame_name_list=frame_names, base_folder=feature_folder, num_frames=F, ref_mask=state.ref_mask,
@@ -161,15 +169,87 @@ def segment_window(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, n
     return np.asarray(ref_mask).reshape(F, fh * fw), state
 
 
-def segment_clip(engine, latents, c_fn, *, batch_size=14, **kw):
+def segment_window(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, num_masks=20, num_steps=25, t_start=22,
+                   feature_timestep="24", is_aggre_attn=True, is_refine_mask=False, seed=17, state: WindowState = None,
+                   frame_names=None, feature_folder="features_outputs_VSPW", exp_name="exp", gt_mask_path=None, noise=None,
+                   keep_all_steps=True):
+    """One 14-frame window: latent [F,4,h,w] fp32 (VAE output * 0.18215) -> cluster-id masks int64 [F, h/2 * w/2].
+
+    Returns (labels [F, N] int64 numpy, state) -- `state` carries ref_mask/ref_feature_map/ref_unique_labels to the
+    next window exactly like the driver's loop variables."""
+    h = feature_pass(engine, latent, c, uc, num_steps=num_steps, t_start=t_start, feature_timestep=feature_timestep, seed=seed,
+                     feature_folder=feature_folder, exp_name=exp_name, noise=noise, keep_all_steps=keep_all_steps)
+    return analyse_window(engine, h, num_masks=num_masks, is_aggre_attn=is_aggre_attn, is_refine_mask=is_refine_mask, state=state,
+                          frame_names=frame_names, gt_mask_path=gt_mask_path)
+
+
+class WindowPipeline:
+    """Software pipeline over windows: the UNet feature pass of window w+1 is enqueued on the caller's stream BEFORE the analysis
+    of window w runs on a second HIP stream, so the latency-bound K-means / 4-NN / tracking kernels (and their host polls) of
+    one window hide behind the MFMA-bound feature pass of the next.  Results are identical to the sequential loop: the
+    feature passes are independent, the analysis chain keeps its order (sd_pipeline_vspw.py:228-409).
+
+        pipe = WindowPipeline(engine, **analysis_kwargs)
+        for ...: out = pipe.push(latent, c, uc, **feature_kwargs)   # -> labels of the PREVIOUS window (None the first time)
+        last = pipe.flush()
+    """
+
+    def __init__(self, engine: Engine, chain=True, **analysis_kw):
+        """chain=False treats every pushed window as the first window of its own clip (K-means every time)."""
+        self.engine, self.analysis_kw, self.chain = engine, analysis_kw, chain
+        self.side = torch.cuda.Stream()
+        self.state = WindowState()
+        self.pending = None
+
+    def _analyse(self, h):
+        with torch.cuda.stream(self.side):
+            labels, state = analyse_window(self.engine, h, state=self.state if self.chain else WindowState(), **self.analysis_kw)
+        if self.chain:
+            self.state = state
+        FE.FeatureStore.clear(h["feature_folder"], h["exp_name"])                   # the window's dumps are no longer needed
+        return labels
+
+    def push(self, latent, c, uc, **feature_kw):
+        h = feature_pass(self.engine, latent, c, uc, **feature_kw)                   # enqueue first: the GPU never waits for the host
+        out = self._analyse(self.pending) if self.pending is not None else None
+        self.pending = h
+        return out
+
+    def flush(self):
+        out = self._analyse(self.pending) if self.pending is not None else None
+        self.pending = None
+        self.side.synchronize()
+        return out
+
+
+_FEATURE_KEYS = ("num_steps", "t_start", "feature_timestep", "seed", "feature_folder", "noise", "keep_all_steps")
+
+
+def segment_clip(engine, latents, c_fn, *, batch_size=14, overlap=True, exp_name="exp", **kw):
     """Whole clip: windows processed in order with the state chained (sd_pipeline_vspw.py:228-409).
-    `c_fn(start, end)` returns (c, uc) for a window.  Returns a list of (start, end, labels)."""
-    state = WindowState()
+    `c_fn(start, end)` returns (c, uc) for a window.  Returns a list of (start, end, labels).
+    overlap=True runs the windows through `WindowPipeline` (analysis of window w concurrent with the feature pass of window
+    w+1, identical results); the dumps of window b live under exp_name + f"_w{b}" while they are needed."""
+    fkw = {k: v for k, v in kw.items() if k in _FEATURE_KEYS}
+    akw = {k: v for k, v in kw.items() if k not in _FEATURE_KEYS}
+    slices = window_slices(latents.shape[0], batch_size)
     out = []
-    for (s, e) in window_slices(latents.shape[0], batch_size):
+    if not overlap:
+        state = WindowState()
+        for b, (s, e) in enumerate(slices):
+            c, uc = c_fn(s, e)
+            labels, state = segment_window(engine, latents[s:e].contiguous(), c, uc, state=state, exp_name=f"{exp_name}_w{b}", **kw)
+            out.append((s, e, labels))
+        return out
+    pipe = WindowPipeline(engine, **akw)
+    for b, (s, e) in enumerate(slices):
         c, uc = c_fn(s, e)
-        labels, state = segment_window(engine, latents[s:e].contiguous(), c, uc, state=state, **kw)
-        out.append((s, e, labels))
+        prev = pipe.push(latents[s:e].contiguous(), c, uc, exp_name=f"{exp_name}_w{b}", **fkw)
+        if prev is not None:
+            out.append((*slices[b - 1], prev))
+    last = pipe.flush()
+    if last is not None:
+        out.append((*slices[-1], last))
     return out
 
 
