@@ -86,7 +86,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--narrow", action="store_true", help="debug: narrow-width UNet (NOT the benchmark config)")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="N=1 only: run each window's analysis after its own feature pass instead of concurrently with the next one's")
+                    help="run each window's analysis after its own feature pass instead of concurrently with the next one's")
+    ap.add_argument("--overlap-multi", action="store_true",
+                    help="N>1: also overlap (parallel.ShardedPipeline: collectives on a second stream). Verified with 2 gloo ranks on one "
+                         "GPU; off by default until it has run over RCCL on a multi-GPU node")
     ap.add_argument("--vae", action="store_true", help="also time the first-stage encode of one window (reported beside the metric)")
     ap.add_argument("--config", default="sd", choices=["sd", "svd"],
                     help="sd = BASELINE configs[1] (headline); svd = configs[2]: SVD 14x576x1024, t_start 17, is_refine_mask")
@@ -156,6 +159,20 @@ def main():
                 last = got if got is not None else last
             got = pipe.flush()
             return got if got is not None else last
+    elif world > 1 and args.overlap_multi and not args.no_overlap:
+        spipe = parallel.ShardedPipeline(eng, rank, world, num_masks=K_MASKS, is_aggre_attn=True, is_refine_mask=args.refine)
+        step_no = [0]
+
+        def run_steps(n):
+            last = None
+            for _ in range(n):
+                step_no[0] += 1
+                FE.MaskStore.clear()
+                got = spipe.push(lat, c, uc, noise=noise, num_steps=NUM_STEPS, t_start=T_START, seed=17, exp_name=f"r{rank}s{step_no[0] % 2}")
+                last = got if got is not None else last
+            got = spipe.flush()
+            return got if got is not None else last
+        overlap = True
     else:
         def run_steps(n):
             last = None

@@ -41,6 +41,12 @@ def _worker(rank, world, port, q):
     lat, c, uc, noise = _inputs(rank, dev)
     labels = parallel.segment_windows_sharded(eng, lat, c, uc, noise=noise, num_masks=K, is_refine_mask=True, seed=17, rank=rank,
                                               world=world, feature_folder="/nonexistent/par", exp_name=f"r{rank}")
+    # the overlapped form: two steps through ShardedPipeline (step 2's feature pass queued before step 1's cross-window stage)
+    pipe = parallel.ShardedPipeline(eng, rank, world, num_masks=K, is_refine_mask=True)
+    assert pipe.push(lat, c, uc, noise=noise, seed=17, feature_folder="/nonexistent/par", exp_name=f"p{rank}a") is None
+    first = pipe.push(lat, c, uc, noise=noise, seed=17, feature_folder="/nonexistent/par", exp_name=f"p{rank}b")
+    second = pipe.flush()
+    assert np.array_equal(first, labels) and np.array_equal(second, labels), "overlapped sharded steps differ from the plain one"
     q.put((rank, labels))
     dist.barrier()
     dist.destroy_process_group()

@@ -87,31 +87,33 @@ def resolve_windows(feat: torch.Tensor, tracks: Optional[torch.Tensor], ops: Cha
     return torch.stack(out)
 
 
-def segment_windows_sharded(engine, latent, c, uc, *, noise=None, num_masks=20, num_steps=25, t_start=22, is_aggre_attn=True,
-                            is_refine_mask=False, seed=17, rank=0, world=1, feature_folder="features_outputs_VSPW", exp_name=None):
-    """Each rank segments its own window (`latent` is THIS rank's [F,4,h,w]); returns int64 labels:
-    world == 1 -> [F, N] (exactly pipeline.segment_window); world > 1 -> [world, F, N], same on every rank."""
-    from . import analysis as A
-    from . import feature_extraction as FE
-    from .pipeline import save_feature_maps, seed_everything, segment_window
+def sharded_feature_pass(engine, latent, c, uc, *, noise=None, num_steps=25, t_start=22, seed=17, rank=0,
+                         feature_folder="features_outputs_VSPW", exp_name=None):
+    """This rank's UNet feature pass (Steps 1-2), enqueued on the current stream; only the taps the cross-window stage reads
+    are kept (decoder blocks 6-8 at the last step).  Returns the handle for `sharded_resolve`."""
+    from .pipeline import make_denoiser, save_feature_maps, seed_everything
     exp_name = exp_name or f"rank{rank}"
-    if world == 1:
-        labels, _ = segment_window(engine, latent, c, uc, num_masks=num_masks, num_steps=num_steps, t_start=t_start,
-                                   is_aggre_attn=is_aggre_attn, is_refine_mask=is_refine_mask, seed=seed, noise=noise,
-                                   feature_folder=feature_folder, exp_name=exp_name, keep_all_steps=False)
-        return labels
     F, _, lh, lw = latent.shape
-    fh, fw = lh // 2, lw // 2
-    N = fh * fw
     seed_everything(seed)
-    from .pipeline import make_denoiser
     sampler = engine.sampler
     denoiser = make_denoiser(engine, F)
-
     x = sampler.add_noise(latent, cond=c, uc=uc, num_steps=num_steps, noise_level=t_start, noise=noise)
     sampler(denoiser, x, cond=c, uc=uc, t_start=t_start,
             img_callback=lambda xt, i: save_feature_maps(engine, feature_folder, exp_name, i, xt=xt, block_filter=(6, 7, 8)) if i == 24 else None)
-    store = FE.FeatureStore.folder(feature_folder, exp_name)
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream())
+    return dict(F=F, fh=lh // 2, fw=lw // 2, seed=seed, feature_folder=feature_folder, exp_name=exp_name, done=done)
+
+
+def sharded_resolve(engine, h, *, num_masks=20, is_aggre_attn=True, is_refine_mask=False, rank=0, world=1):
+    """Cross-window stage of one step on the current stream (may differ from the feature pass's): block aggregation, dense
+    tracking, the all-gather / top-4 search / label chain of `resolve_windows`.  Returns int64 [world, F, N]."""
+    from . import analysis as A
+    from . import feature_extraction as FE
+    torch.cuda.current_stream().wait_event(h["done"])
+    F, fh, fw, seed = h["F"], h["fh"], h["fw"], h["seed"]
+    N = fh * fw
+    store = FE.FeatureStore.folder(h["feature_folder"], h["exp_name"])
     names = ["output_block_8", "output_block_7", "output_block_6"] if is_aggre_attn else \
         (["output_block_8"] if engine.video else ["output_block_7"])
     blocks = [store[f"{n}_spatial_self_attn_q_time_24"] for n in names]
@@ -130,4 +132,50 @@ def segment_windows_sharded(engine, latent, c, uc, *, noise=None, num_masks=20, 
     ops = ChainOps(first_window_labels=first_window, knn_top4=A.knn_top4, vote4=A.vote4,
                    refine=(lambda t, l: A.trajectory_vote(t.contiguous(), l.contiguous(), fw)) if is_refine_mask else None)
     labels = resolve_windows(feat, tracks, ops, rank, world, F)
-    return labels.view(world, F, N).cpu().numpy().astype(np.int64)
+    out = labels.view(world, F, N).cpu().numpy().astype(np.int64)
+    FE.FeatureStore.clear(h["feature_folder"], h["exp_name"])
+    return out
+
+
+class ShardedPipeline:
+    """The multi-rank counterpart of pipeline.WindowPipeline: step i's cross-window stage (collectives included) runs on a second
+    HIP stream while step i+1's feature pass is already queued on the caller's stream.  Every rank pushes/flushes in the same
+    order, so the collectives of all ranks stay matched."""
+
+    def __init__(self, engine, rank, world, **resolve_kw):
+        self.engine, self.rank, self.world, self.resolve_kw = engine, rank, world, resolve_kw
+        self.side = torch.cuda.Stream()
+        self.pending = None
+
+    def _resolve(self, h):
+        with torch.cuda.stream(self.side):
+            return sharded_resolve(self.engine, h, rank=self.rank, world=self.world, **self.resolve_kw)
+
+    def push(self, latent, c, uc, **feature_kw):
+        h = sharded_feature_pass(self.engine, latent, c, uc, rank=self.rank, **feature_kw)
+        out = self._resolve(self.pending) if self.pending is not None else None
+        self.pending = h
+        return out
+
+    def flush(self):
+        out = self._resolve(self.pending) if self.pending is not None else None
+        self.pending = None
+        self.side.synchronize()
+        return out
+
+
+def segment_windows_sharded(engine, latent, c, uc, *, noise=None, num_masks=20, num_steps=25, t_start=22, is_aggre_attn=True,
+                            is_refine_mask=False, seed=17, rank=0, world=1, feature_folder="features_outputs_VSPW", exp_name=None):
+    """Each rank segments its own window (`latent` is THIS rank's [F,4,h,w]); returns int64 labels:
+    world == 1 -> [F, N] (exactly pipeline.segment_window); world > 1 -> [world, F, N], same on every rank."""
+    from .pipeline import segment_window
+    exp_name = exp_name or f"rank{rank}"
+    if world == 1:
+        labels, _ = segment_window(engine, latent, c, uc, num_masks=num_masks, num_steps=num_steps, t_start=t_start,
+                                   is_aggre_attn=is_aggre_attn, is_refine_mask=is_refine_mask, seed=seed, noise=noise,
+                                   feature_folder=feature_folder, exp_name=exp_name, keep_all_steps=False)
+        return labels
+    h = sharded_feature_pass(engine, latent, c, uc, noise=noise, num_steps=num_steps, t_start=t_start, seed=seed, rank=rank,
+                             feature_folder=feature_folder, exp_name=exp_name)
+    return sharded_resolve(engine, h, num_masks=num_masks, is_aggre_attn=is_aggre_attn, is_refine_mask=is_refine_mask, rank=rank,
+                           world=world)
