@@ -223,7 +223,7 @@ def main():
             "metric": "segmented frames/sec (14-frame 512^2 clip, 20 masks)",
             "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "f16" if ops.act_dtype() == torch.float16 else "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: SD 2.1 full-size UNet (865.9M params, random-init), 14-frame 512x512 window per GPU "
                                    "(latent 14x4x64x64), 25-step schedule with t_start=22 (3 CFG UNet evals, batch 28), Q/K taps on decoder "
                                    "blocks 3-11, is_aggre_attn (blocks 6,7,8), K-means K=20 n_init=10 + 4-NN"

@@ -33,6 +33,9 @@ typedef struct ihipStream_t* vidseg_stream_t; /* hipStream_t */
 
 int vidseg_version(void);
 const char* vidseg_last_error(void);
+/* 16-bit storage format of every `*_bf16` activation / weight argument below: 1 = IEEE fp16 (default build; the reference's
+ * CUDA autocast dtype), 0 = bfloat16 (-DVIDSEG_ACT_BF16).  The entry-point names keep their historical `bf16` suffix. */
+int vidseg_act_dtype(void);
 
 /* ------------------------------------------------------------------------------------------------------
  * Post-UNet analysis

@@ -16,7 +16,10 @@ import torch.nn.functional as F
 
 
 def _bf(x, on):
-    return x.bfloat16().float() if on else x
+    """Round where the HIP path stores 16-bit activations: on = "f16" (default build), True / "bf16", or falsy (pure fp32)."""
+    if not on:
+        return x
+    return x.half().float() if on == "f16" else x.bfloat16().float()
 
 
 class VAEEncoderOracle:

@@ -17,3 +17,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def act_mode():
+    """("f16" | "bf16", whole-network tolerance) of the library under test: the default fp16 build must stay within 4e-3
+    normalised rms of the fp32 reference (taps, UNet outputs, sampler trajectories), a -DVIDSEG_ACT_BF16 build within 4e-2."""
+    import torch
+    from vidseg_diffusion_amd import ops
+    return ("f16", 4e-3) if ops.act_dtype() == torch.float16 else ("bf16", 4e-2)

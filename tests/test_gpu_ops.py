@@ -37,9 +37,9 @@ def test_linear(dev, M, K, N):
     from vidseg_diffusion_amd import ops
     a, w, b = rnd((M, K), 1), rnd((N, K), 2, 0.05), rnd((N,), 3)
     res = rnd((M, N), 4)
-    out = ops.linear(a.bfloat16().to(dev), ops.pack_linear(w, dev), b.to(dev), residual=res.bfloat16().to(dev))
+    out = ops.linear(a.to(ops.act_dtype()).to(dev), ops.pack_linear(w, dev), b.to(dev), residual=res.to(ops.act_dtype()).to(dev))
     check(out, a @ w.T + b + res, "linear+bias+residual")
-    out32 = ops.linear(a.bfloat16().to(dev), ops.pack_linear(w, dev), b.to(dev), act=ops.ACT_SILU, out_f32=True)
+    out32 = ops.linear(a.to(ops.act_dtype()).to(dev), ops.pack_linear(w, dev), b.to(dev), act=ops.ACT_SILU, out_f32=True)
     ref = TF.silu(a @ w.T + b)
     assert (out32.cpu() - ref).abs().max() <= 1e-3 * ref.abs().max() + 1e-5
 
@@ -50,7 +50,7 @@ def test_linear_concat_rowvec_tap(dev):
     a0, a1 = rnd((B, HW, C0), 1), rnd((B, HW, C1), 2)
     w, bias, rv = rnd((N, C0 + C1), 3, 0.05), rnd((N,), 4), rnd((B, N), 5)
     tap = torch.empty((B, HW, 64), dtype=torch.float16, device=dev)
-    out = ops.linear(a0.bfloat16().to(dev), ops.pack_linear(w, dev), bias.to(dev), a1=a1.bfloat16().to(dev), rowvec=rv.to(dev),
+    out = ops.linear(a0.to(ops.act_dtype()).to(dev), ops.pack_linear(w, dev), bias.to(dev), a1=a1.to(ops.act_dtype()).to(dev), rowvec=rv.to(dev),
                      rows_per_sample=HW, tap=tap, tap_cols=64)
     ref = torch.cat([a0, a1], -1) @ w.T + bias + rv[:, None, :]
     check(out, ref, "linear concat+rowvec")
@@ -62,7 +62,7 @@ def test_geglu(dev, M, K, inner):
     from vidseg_diffusion_amd import ops
     a, w, b = rnd((M, K), 1), rnd((2 * inner, K), 2, 0.08), rnd((2 * inner,), 3, 0.5)
     wp, bp = ops.pack_geglu(w, b, dev)
-    out = ops.linear(a.bfloat16().to(dev), wp, bp, act=ops.ACT_GEGLU)
+    out = ops.linear(a.to(ops.act_dtype()).to(dev), wp, bp, act=ops.ACT_GEGLU)
     y = a @ w.T + b
     ref = y[:, :inner] * TF.gelu(y[:, inner:])
     check(out, ref, "GEGLU")
@@ -89,9 +89,9 @@ def test_conv3x3(dev, cfg):
     rv = rnd((B, Cout), 5)
     res = rnd(tuple(ref.permute(0, 2, 3, 1).shape), 6)
     ref = (ref + rv[:, :, None, None]).permute(0, 2, 3, 1) + res
-    out = ops.conv3x3(x0.bfloat16().to(dev), ops.pack_conv3x3(w, dev), b.to(dev),
-                      x1=x1.bfloat16().to(dev) if C1 else None, stride=cfg["stride"], up=cfg["up"], rowvec=rv.to(dev),
-                      residual=res.bfloat16().to(dev))
+    out = ops.conv3x3(x0.to(ops.act_dtype()).to(dev), ops.pack_conv3x3(w, dev), b.to(dev),
+                      x1=x1.to(ops.act_dtype()).to(dev) if C1 else None, stride=cfg["stride"], up=cfg["up"], rowvec=rv.to(dev),
+                      residual=res.to(ops.act_dtype()).to(dev))
     check(out, ref, f"conv3x3 {cfg}")
 
 
@@ -105,7 +105,7 @@ def test_conv_in_out(dev):
     x2 = rnd((2, 9, 7, 64), 4)
     w2, b2 = rnd((4, 64, 3, 3), 5, 0.05), rnd((4,), 6)
     ref2 = TF.conv2d(x2.permute(0, 3, 1, 2), w2, b2, padding=1)
-    out2 = ops.conv_out4(x2.bfloat16().to(dev), ops.pack_conv_out(w2, dev), b2.to(dev))
+    out2 = ops.conv_out4(x2.to(ops.act_dtype()).to(dev), ops.pack_conv_out(w2, dev), b2.to(dev))
     assert (out2.cpu() - ref2).abs().max() <= 1e-4 * ref2.abs().max() + 1e-5
 
 
@@ -121,7 +121,7 @@ def test_groupnorm(dev, B, HW, C0, C1, silu, eps):
     ref = TF.group_norm(x.permute(0, 2, 1), 32, g, bt, eps).permute(0, 2, 1)
     if silu:
         ref = TF.silu(ref)
-    out = ops.groupnorm(x0.bfloat16().to(dev), g.to(dev), bt.to(dev), x1=x1.bfloat16().to(dev) if C1 else None, eps=eps, silu=silu)
+    out = ops.groupnorm(x0.to(ops.act_dtype()).to(dev), g.to(dev), bt.to(dev), x1=x1.to(ops.act_dtype()).to(dev) if C1 else None, eps=eps, silu=silu)
     check(out, ref, "groupnorm")
 
 
@@ -129,7 +129,7 @@ def test_groupnorm(dev, B, HW, C0, C1, silu, eps):
 def test_layernorm(dev, M, C):
     from vidseg_diffusion_amd import ops
     x, g, b = (rnd((M, C), 1, 2.0) + 0.3).bfloat16().float(), rnd((C,), 2) * 0.2 + 1.0, rnd((C,), 3) * 0.2
-    out = ops.layernorm(x.bfloat16().to(dev), g.to(dev), b.to(dev))
+    out = ops.layernorm(x.to(ops.act_dtype()).to(dev), g.to(dev), b.to(dev))
     check(out, TF.layer_norm(x, (C,), g, b, 1e-5), "layernorm")
 
 
@@ -140,7 +140,7 @@ def test_attention(dev, B, H, Nq, Nk):
     q, k, v = rnd((B, Nq, C), 1), rnd((B, Nk, C), 2), rnd((B, Nk, C), 3)
     qh, kh, vh = (t.view(B, -1, H, 64).transpose(1, 2) for t in (q, k, v))
     ref = TF.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Nq, C)
-    out = ops.attention(q.bfloat16().to(dev), k.bfloat16().to(dev), v.bfloat16().to(dev), H)
+    out = ops.attention(q.to(ops.act_dtype()).to(dev), k.to(ops.act_dtype()).to(dev), v.to(ops.act_dtype()).to(dev), H)
     # P is rounded to bf16 before P.V: allow 2^-8 relative on top
     out = out.float().cpu()
     tol = (2.0 ** -7) * ref.abs() + 2e-3 * ref.abs().max()
@@ -152,7 +152,7 @@ def test_attention_fused_qkv_strides(dev):
     B, H, N = 2, 2, 128
     C = H * 64
     qkv = rnd((B, N, 3 * C), 1)
-    d = qkv.bfloat16().to(dev)
+    d = qkv.to(ops.act_dtype()).to(dev)
     out = ops.attention(d[..., :C], d[..., C:2 * C], d[..., 2 * C:], H)
     q, k, v = (qkv[..., i * C:(i + 1) * C].reshape(B, N, H, 64).transpose(1, 2) for i in range(3))
     ref = TF.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, C)

@@ -1,12 +1,13 @@
 """GPU parity of the SD UNet / sampler / one-window pipeline (HIP kernels behind the reference's plug-in API)
 against the reference-produced golden vectors and the oracle.
 
-Tolerance statement (floating point, bf16 MFMA path).  Each kernel alone is within 2^-8|ref| + 1e-3 max|ref| of an
-fp32 evaluation of the same bf16 inputs (tests/test_gpu_ops.py).  Through the whole ~60-layer network with
-random synthetic weights the bf16 *format* itself moves the output by ~1.5e-2 (rms, normalised) relative to the
-fp32 reference -- measured below by the oracle's bf16-rounding mode -- so the network-level requirement is:
-the HIP path deviates from the fp32 reference by no more than 1.5x what bf16 rounding alone does, and by
-< 3e-2 absolute (normalised rms)."""
+Tolerance statement (floating point, 16-bit MFMA path; fp16 activations by default like the reference's CUDA autocast, bf16
+with -DVIDSEG_ACT_BF16).  Each kernel alone is within 2^-8|ref| + 1e-3 max|ref| of an fp32 evaluation of the same 16-bit
+inputs (tests/test_gpu_ops.py).  Through the whole ~60-layer network with random synthetic weights the storage *format*
+itself moves the output relative to the fp32 reference (fp16: ~2e-3 normalised rms, bf16: ~1.5e-2) -- measured below by the
+oracle's rounding mode -- so the network-level requirement is: the HIP path deviates from the fp32 reference by no more
+than 1.5x what the format's rounding alone does (plus a small floor), and by less than `conftest.act_mode()`'s absolute bound
+(4e-3 for fp16, 4e-2 for bf16, normalised rms).  Masks: IoU >= 0.99 vs the all-fp32 oracle in the fp16 build."""
 import os
 
 import numpy as np
@@ -14,6 +15,7 @@ import pytest
 import torch
 
 from vidseg_diffusion_amd import synthetic
+from conftest import act_mode
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden", "unet_sd_narrow.npz")
@@ -45,9 +47,9 @@ def test_unet_forward_vs_reference(env):
     dev, g, net, sd = env
     x, t, ctx = (torch.from_numpy(g[k]) for k in ("fw_x", "fw_t", "fw_ctx"))
     out = net(x.to(dev), timesteps=t.to(dev), context=ctx.to(dev)).cpu().numpy()
-    fmt = nrms(UNetOracle(sd, round_bf16=True).forward(x, t, ctx).numpy(), g["fw_out"])      # what bf16 alone costs
+    fmt = nrms(UNetOracle(sd, round_bf16=act_mode()[0]).forward(x, t, ctx).numpy(), g["fw_out"])      # what bf16 alone costs
     err = nrms(out, g["fw_out"])
-    assert err < 3e-2 and err <= 1.5 * fmt, (err, fmt)
+    assert err < act_mode()[1] and err <= 1.5 * fmt + 1e-3, (err, fmt)
     for b in range(3, 12):                                                                     # reference dump protocol
         blk = net.output_blocks[b]
         assert len(blk) > 1 and "SpatialTransformer" in str(type(blk[1]))
@@ -57,7 +59,7 @@ def test_unet_forward_vs_reference(env):
                 ref = g[f"fw_output_block_{b}_spatial_{nm}_attn_{w}"].astype(np.float32)
                 got = getattr(a, w)
                 assert got.dtype == torch.float16 and tuple(got.shape) == ref.shape
-                assert nrms(got.float().cpu().numpy(), ref) < 3e-2, (b, nm, w)
+                assert nrms(got.float().cpu().numpy(), ref) < act_mode()[1], (b, nm, w)
     for b in range(0, 3):
         assert len(net.output_blocks[b]) == 1 or "SpatialTransformer" not in str(type(net.output_blocks[b][1]))
 
@@ -87,10 +89,10 @@ def test_sampler_steps_vs_reference(env):
     final = eng.sampler(denoiser, noised.clone(), cond=c, uc=uc, img_callback=cb, t_start=22)
     assert len(xs) == 3
     for i in range(3):
-        assert nrms(xs[i], g["sm_x_steps"][i]) < 3e-2, i
-    assert nrms(final.cpu().numpy(), g["sm_final"]) < 3e-2
+        assert nrms(xs[i], g["sm_x_steps"][i]) < act_mode()[1], i
+    assert nrms(final.cpu().numpy(), g["sm_final"]) < act_mode()[1]
     for b in (6, 7, 8):
-        assert nrms(taps[b], g[f"sm_q_block_{b}_time_24"].astype(np.float32)) < 3e-2
+        assert nrms(taps[b], g[f"sm_q_block_{b}_time_24"].astype(np.float32)) < act_mode()[1]
 
 
 def test_window_pipeline_vs_oracle(env):
@@ -127,7 +129,7 @@ def test_window_pipeline_vs_oracle(env):
     from tools_metrics import matched_iou
     iou, exact = matched_iou(labels, ref["labels"], K)
     print("pipeline mask IoU vs fp32 oracle", iou, "exact", exact)
-    assert iou >= 0.90
+    assert iou >= (0.99 if act_mode()[0] == "f16" else 0.90)
 
 
 def test_video_unet_forward_vs_reference():
@@ -145,10 +147,10 @@ def test_video_unet_forward_vs_reference():
     x, t, ctx, y = (torch.from_numpy(g[k]) for k in ("fw_x", "fw_t", "fw_ctx", "fw_y"))
     out = net(x.to(dev), timesteps=t.to(dev), context=ctx.to(dev), y=y.to(dev), num_video_frames=T,
               image_only_indicator=torch.zeros(2, T)).cpu().numpy()
-    fmt = nrms(UNetOracle(sd, round_bf16=True).forward(x, t, ctx, y=y, num_video_frames=T).numpy(), g["fw_out"])
+    fmt = nrms(UNetOracle(sd, round_bf16=act_mode()[0]).forward(x, t, ctx, y=y, num_video_frames=T).numpy(), g["fw_out"])
     err = nrms(out, g["fw_out"])
-    print("video unet nrms", err, "bf16 format", fmt)
-    assert err < 4e-2 and err <= 1.5 * fmt + 5e-3, (err, fmt)
+    print("video unet nrms", err, "16-bit format", fmt)
+    assert err < act_mode()[1] and err <= 1.5 * fmt + 5e-3, (err, fmt)
     for i in (3, 7, 8, 11):
         blk = net.output_blocks[i]
         assert "SpatialVideoTransformer" in str(type(blk[1]))
@@ -157,7 +159,7 @@ def test_video_unet_forward_vs_reference():
         for name, got in pairs:
             ref = g[f"fw_output_block_{i}_{name}"].astype(np.float32)
             assert tuple(got.shape) == ref.shape, (i, name, got.shape, ref.shape)
-            assert nrms(got.float().cpu().numpy(), ref) < 4e-2, (i, name)
+            assert nrms(got.float().cpu().numpy(), ref) < act_mode()[1], (i, name)
 
 
 def test_svd_sampler_steps_vs_reference():
@@ -192,9 +194,9 @@ def test_svd_sampler_steps_vs_reference():
     assert len(xs) == 8
     errs = [nrms(xs[i], g["sm_x_steps"][i]) for i in range(8)]
     print("svd step nrms", [round(e, 4) for e in errs])
-    assert max(errs) < 4e-2
-    assert nrms(taps["q8"], g["sm_q8"].astype(np.float32)) < 4e-2
-    assert nrms(taps["tq8"], g["sm_tq8"].astype(np.float32)) < 4e-2
+    assert max(errs) < act_mode()[1]
+    assert nrms(taps["q8"], g["sm_q8"].astype(np.float32)) < act_mode()[1]
+    assert nrms(taps["tq8"], g["sm_tq8"].astype(np.float32)) < act_mode()[1]
 
 
 def test_modulated_injected_pass_vs_reference(env):
@@ -220,7 +222,7 @@ def test_modulated_injected_pass_vs_reference(env):
 
     feat = eng.sampler(denoiser, noised.clone(), cond=c, uc=uc, t_start=22,
                        img_callback=lambda xt, i: save_feature_maps(eng, base, exp, i, xt=xt))
-    assert nrms(feat.cpu().numpy(), g["feat_final"]) < 3e-2
+    assert nrms(feat.cpu().numpy(), g["feat_final"]) < act_mode()[1]
     for tag, lam in (("pos", 50.0), ("neg", -50.0)):
         mp = {"feature_masks": [torch.from_numpy(m).to(dev) for m in g["masks"]], "modulate_block_idx": [7],
               "modulate_layer_type": ["spatial"], "modulate_attn_type": ["cross_attn"], "modulate_timestep": [22],
@@ -238,7 +240,7 @@ def test_modulated_injected_pass_vs_reference(env):
         assert len(xs) == ref.shape[0]
         errs = [nrms(xs[i], ref[i]) for i in range(len(xs))]
         print("modulated", tag, "step nrms", [round(e, 4) for e in errs])
-        assert max(errs) < 3e-2
+        assert max(errs) < act_mode()[1]
         # the modulation must actually have moved the sample the way the reference's did
         d_ref = g[f"mod_{tag}_final"] - g["feat_final"]
         d_got = final.cpu().numpy() - feat.cpu().numpy()
@@ -255,15 +257,15 @@ def test_inversion_vs_reference(env):
     x, lats = eng.sampler.inversion(lambda inp, s, cc, **k: eng.denoiser(eng.model, inp, s, cc), torch.from_numpy(g["sm_latent"]).to(dev),
                                     cond=c, uc=uc, num_steps=25)
     assert len(lats) == 26
-    assert nrms(lats[5].cpu().numpy(), g["inv_step5"]) < 3e-2
+    assert nrms(lats[5].cpu().numpy(), g["inv_step5"]) < act_mode()[1]
     # 24 network steps up to sigma = 14.6 with random weights amplify rounding chaotically: the bf16 FORMAT alone (oracle
     # in bf16-rounding mode) ends 14 % away from the fp32 reference; the HIP path must not be worse than that.
     from oracle.unet import UNetOracle, euler_inversion
     cc = torch.from_numpy(g["sm_c"])
-    xo, _ = euler_inversion(UNetOracle(sd, round_bf16=True), torch.from_numpy(g["sm_latent"]), cc, torch.zeros_like(cc))
+    xo, _ = euler_inversion(UNetOracle(sd, round_bf16=act_mode()[0]), torch.from_numpy(g["sm_latent"]), cc, torch.zeros_like(cc))
     fmt = nrms(xo.numpy(), g["inv_final"])
     err = nrms(x.cpu().numpy(), g["inv_final"])
-    print("inversion nrms", err, "bf16 format", fmt)
+    print("inversion nrms", err, "16-bit format", fmt)
     assert err <= 1.5 * fmt + 1e-2
 
 
@@ -296,7 +298,7 @@ def test_svd_modulated_injected_pass_vs_reference():
 
     feat = eng.sampler(denoiser, noised.clone(), cond=c, uc=uc, t_start=T0,
                        img_callback=lambda xt, i: save_feature_maps(eng, base, exp, i, xt=xt))
-    assert nrms(feat.cpu().numpy(), g["feat_final"]) < 4e-2
+    assert nrms(feat.cpu().numpy(), g["feat_final"]) < act_mode()[1]
     for tag in [k[4:-6] for k in g if k.startswith("mod_") and k.endswith("_final")]:
         lam = float(g[f"lam_{tag}"])
         mp = {"feature_masks": [torch.from_numpy(m).to(dev) for m in g["masks"]], "modulate_block_idx": [8],
@@ -319,7 +321,7 @@ def test_svd_modulated_injected_pass_vs_reference():
         d_got = final.cpu().numpy() - feat.cpu().numpy()
         print("svd modulated", tag, "lambda", lam, "step nrms", [round(e, 4) for e in errs], "delta nrms", round(nrms(d_got, d_ref), 4),
               "delta/ref", round(float(np.abs(d_ref).mean() / np.abs(g["feat_final"]).mean()), 4))
-        assert max(errs) < 4e-2
+        assert max(errs) < act_mode()[1]
         # the modulation must actually have moved the sample the way the reference's did (large-lambda cases dominate rounding)
         if abs(lam) >= 1000:
             assert nrms(d_got, d_ref) < 0.35, nrms(d_got, d_ref)
@@ -406,13 +408,13 @@ def test_c1_full_width_window_vs_oracle():
     for b in (6, 7, 8):
         e = nrms(taps[b].astype(np.float32), ref["q_taps"][b].astype(np.float32))
         print("C1 tap", b, "nrms", round(e, 4))
-        assert taps[b].shape == (2 * Fn, 256, 640) and e < 4e-2
+        assert taps[b].shape == (2 * Fn, 256, 640) and e < act_mode()[1]
     np.random.seed(17)
     _, lab_o, _ = OA.match_gt_mask(OA.aggregate_blocks([taps[8], taps[7], taps[6]]), K, np.random.mtrand._rand)
     assert np.array_equal(labels.reshape(-1), lab_o)
     iou, exact = matched_iou(labels, ref["labels"], K)
     print("C1 full-width mask IoU vs fp32 oracle", iou, "exact", exact)
-    assert iou >= 0.90
+    assert iou >= (0.99 if act_mode()[0] == "f16" else 0.90)
     FE.FeatureStore.clear(); FE.MaskStore.clear()
 
 

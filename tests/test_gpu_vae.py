@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from vidseg_diffusion_amd import synthetic
+from conftest import act_mode
 
 pytestmark = pytest.mark.gpu
 
@@ -24,12 +25,12 @@ def test_vae_encoder_vs_reference():
     net.load_state_dict(sd)
     x = torch.from_numpy(g["x"]).to(dev)
     mom = net.moments(x).permute(0, 3, 1, 2).cpu().numpy()
-    fmt = nrms(VAEEncoderOracle(sd, round_bf16=True).moments(torch.from_numpy(g["x"])).numpy(), g["moments"])
+    fmt = nrms(VAEEncoderOracle(sd, round_bf16=act_mode()[0]).moments(torch.from_numpy(g["x"])).numpy(), g["moments"])
     err = nrms(mom, g["moments"])
-    print("vae moments nrms", err, "bf16 format", fmt)
-    assert err < 3e-2 and err <= 1.5 * fmt + 5e-3, (err, fmt)
+    print("vae moments nrms", err, "16-bit format", fmt)
+    assert err < act_mode()[1] and err <= 1.5 * fmt + 5e-3, (err, fmt)
     z = encode_first_stage(net, x, 0.18215, noise=torch.from_numpy(g["noise"]))
-    assert z.shape == (2, 4, 8, 8) and nrms(z.cpu().numpy(), g["z"]) < 3e-2
+    assert z.shape == (2, 4, 8, 8) and nrms(z.cpu().numpy(), g["z"]) < act_mode()[1]
     # default noise path = host torch.randn under the caller's seed, like posterior.sample()
     torch.manual_seed(11)
     z2 = encode_first_stage(net, x, 0.18215)
@@ -40,11 +41,11 @@ def test_asymmetric_downsample_and_softmax_ops():
     from vidseg_diffusion_amd import ops
     dev = torch.device("cuda:0")
     gen = torch.Generator().manual_seed(4)
-    x = torch.randn(2, 10, 12, 64, generator=gen).bfloat16()
+    x = torch.randn(2, 10, 12, 64, generator=gen).bfloat16().float()          # representable in bf16 and fp16
     w = (torch.randn(64, 64, 3, 3, generator=gen) * 0.05)
     b = torch.randn(64, generator=gen)
     ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x.float().permute(0, 3, 1, 2), (0, 1, 0, 1)), w.bfloat16().float(), b, stride=2)
-    out, out32 = ops.conv3x3(x.to(dev), ops.pack_conv3x3(w, dev), b.to(dev), stride=2, pad=0, want_f32=True)
+    out, out32 = ops.conv3x3(x.to(ops.act_dtype()).to(dev), ops.pack_conv3x3(w, dev), b.to(dev), stride=2, pad=0, want_f32=True)
     got = out32.permute(0, 3, 1, 2).cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max() <= 2e-3 * ref.abs().max()

@@ -13,8 +13,8 @@ def bench(fn, flops, name, iters=10):
 B = 28
 for (N, H, Nk) in [(4096, 5, 4096), (1024, 10, 1024), (256, 20, 256), (64, 20, 64), (4096, 5, 77), (1024, 10, 77)]:
     C = H * 64
-    qkv = torch.randn(B, N, 3 * C, device=dev).bfloat16()
-    kv = torch.randn(B, Nk, 2 * C, device=dev).bfloat16()
+    qkv = torch.randn(B, N, 3 * C, device=dev).to(ops.act_dtype())
+    kv = torch.randn(B, Nk, 2 * C, device=dev).to(ops.act_dtype())
     if Nk == N:
         bench(lambda: ops.attention(qkv[..., :C], qkv[..., C:2*C], qkv[..., 2*C:], H), 4 * B * H * N * Nk * 64, f"self N{N} H{H}")
     else:

@@ -11,7 +11,7 @@ net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dic
 net.pack(dev)
 x = torch.randn(28, 64, 64, 4, device=dev)
 t = torch.full((28,), 958.0, device=dev)
-ctx = torch.randn(28, 77, 1024, device=dev).bfloat16()
+ctx = torch.randn(28, 77, 1024, device=dev).to(ops.act_dtype())
 for _ in range(2): net.forward_nhwc(x, t, ctx)
 torch.cuda.synchronize()
 for rep in range(3):

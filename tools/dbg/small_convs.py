@@ -14,5 +14,5 @@ for (B, H, W, Cin, Cout) in [(28, 64, 64, 4, 320), (28, 72, 128, 8, 320), (14, 5
     x = torch.randn(B, H, W, Cin, device=dev); w = ops.pack_conv_in(torch.randn(Cout, Cin, 3, 3) * 0.05, dev); b = torch.zeros(Cout, device=dev)
     bench(lambda: ops.conv_in(x, w, b), f"conv_in B{B} {H}x{W} {Cin}->{Cout}", B * H * W * (Cin * 4 + Cout * 2))
 for (B, H, W, Cin) in [(28, 64, 64, 320), (28, 72, 128, 320)]:
-    x = torch.randn(B, H, W, Cin, device=dev).bfloat16(); w = ops.pack_conv_out(torch.randn(4, Cin, 3, 3) * 0.05, dev); b = torch.zeros(4, device=dev)
+    x = torch.randn(B, H, W, Cin, device=dev).to(ops.act_dtype()); w = ops.pack_conv_out(torch.randn(4, Cin, 3, 3) * 0.05, dev); b = torch.zeros(4, device=dev)
     bench(lambda: ops.conv_out4(x, w, b), f"conv_out4 B{B} {H}x{W} {Cin}->4", B * H * W * (Cin * 2 + 16))

@@ -30,7 +30,7 @@ if len(sys.argv) > 1:
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     t0 = time.time(); sd = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, 1234).items()}; print("fill", time.time() - t0)
     net.load_state_dict(sd); t0 = time.time(); net.pack(dev); torch.cuda.synchronize(); print("pack", time.time() - t0)
-    x = torch.randn(2 * F, 64, 64, 4, device=dev); tt = torch.full((2 * F,), 500.0, device=dev); ctx = torch.randn(2 * F, 77, 1024, device=dev).bfloat16()
+    x = torch.randn(2 * F, 64, 64, 4, device=dev); tt = torch.full((2 * F,), 500.0, device=dev); ctx = torch.randn(2 * F, 77, 1024, device=dev).to(ops.act_dtype())
     for it in range(3):
         torch.cuda.synchronize(); t0 = time.time()
         o = net.forward_nhwc(x, tt, ctx); torch.cuda.synchronize(); print("full fwd ms", (time.time() - t0) * 1e3, float(o.abs().mean()))

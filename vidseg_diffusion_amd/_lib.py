@@ -72,13 +72,20 @@ def lib():
         l = ctypes.CDLL(LIB_PATH)
         l.vidseg_version.restype = _I
         l.vidseg_last_error.restype = ctypes.c_char_p
+        l.vidseg_act_dtype.restype = _I
         _bind(l, _SIGS)
         _lib = l
     return _lib
 
 
 def exported_symbols():
-    return ["vidseg_version", "vidseg_last_error"] + sorted(_SIGS)
+    return ["vidseg_version", "vidseg_last_error", "vidseg_act_dtype"] + sorted(_SIGS)
+
+
+def act_dtype():
+    """torch dtype of the UNet path's activations / packed weights as the library was built: float16 (default, the
+    reference's CUDA-autocast dtype) or bfloat16 (-DVIDSEG_ACT_BF16)."""
+    return torch.float16 if lib().vidseg_act_dtype() == 1 else torch.bfloat16
 
 
 def stream() -> int:

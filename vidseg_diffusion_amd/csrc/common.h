@@ -36,19 +36,43 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef unsigned short bf16_t;   // raw bf16 bits
+// Activation / weight storage format of the UNet path: IEEE fp16 by default -- what the reference computes in under CUDA
+// autocast (11 significand bits; the dumped Q/K "attention maps" are fp16 anyway) -- or bf16 when built with
+// -DVIDSEG_ACT_BF16.  Both are 16-bit and feed the same-rate MFMA (v_mfma_f32_32x32x16_{f16,bf16}); the kernels only touch
+// the format through the four helpers below, so `bf16_t` simply means "raw 16-bit activation bits".
+typedef unsigned short bf16_t;
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+typedef __attribute__((ext_vector_type(2))) float vs_f32x2;
+typedef __attribute__((ext_vector_type(8))) short vs_s16x8;
+#ifdef VIDSEG_ACT_BF16
+#define VIDSEG_ACT_IS_F16 0
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {       // round-to-nearest-even: v_cvt_pk_bf16_f32 on gfx950
     return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 typedef __attribute__((ext_vector_type(2))) __bf16 vs_bf16x2;
-typedef __attribute__((ext_vector_type(2))) float vs_f32x2;
 __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {   // one v_cvt_pk_bf16_f32
     return __builtin_bit_cast(unsigned, __builtin_convertvector(vs_f32x2{lo, hi}, vs_bf16x2));
 }
+__device__ __forceinline__ f32x16 mfma_32x32x16(vs_s16x8 a, vs_s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+#else
+#define VIDSEG_ACT_IS_F16 1
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {       // round-to-nearest-even v_cvt_f16_f32
+    return __builtin_bit_cast(bf16_t, (_Float16)f);
+}
+typedef __attribute__((ext_vector_type(2))) _Float16 vs_f16x2;
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {   // RNE pair conversion
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(vs_f32x2{lo, hi}, vs_f16x2));
+}
+__device__ __forceinline__ f32x16 mfma_32x32x16(vs_s16x8 a, vs_s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+#endif
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll

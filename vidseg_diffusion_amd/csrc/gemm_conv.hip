@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_conv(GemmParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_32x32x16(fa[i], fb[j], acc[i][j]);
         }
     };
     // Pipeline: chunk k is computed from LDS buffer k&1 while chunk k+1 is in flight into registers (issued before the
@@ -542,7 +542,7 @@ __global__ void __launch_bounds__(256, NST == 2 ? 4 : 3) k_gemm_dma(GemmParams p
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_32x32x16(fa[i], fb[j], acc[i][j]);
         }
     };
     const int nk = ks_end - ks_begin;
@@ -742,7 +742,7 @@ __global__ void __launch_bounds__(WM * 128, MI == 1 ? 4 : (WM == 4 ? 1 : 2)) k_g
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(B + j * 32 * RB + co);
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb, acc[0][j], 0, 0, 0);
+                    acc[0][j] = mfma_32x32x16(fa[0], fb, acc[0][j]);
                 }
             } else {
                 bf16x8_t fb[NJ];
@@ -752,7 +752,7 @@ __global__ void __launch_bounds__(WM * 128, MI == 1 ? 4 : (WM == 4 ? 1 : 2)) k_g
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma_32x32x16(fa[i], fb[j], acc[i][j]);
             }
         }
     };

@@ -266,10 +266,10 @@ __global__ void __launch_bounds__(256, 3) k_attention(const bf16_t* __restrict__
                 const int ch = s * 2 + hi;
                 const bf16x8_t fk = *reinterpret_cast<const bf16x8_t*>(sK + r * 128 + ((ch ^ (r & 7)) << 4));
                 if (s == 0)                                            // C = inline 0: no accumulator initialisation moves
-                    sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[s], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
-                                                                                       0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    sacc[j] = mfma_32x32x16(fk, fq[s], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                                                                       0.f, 0.f, 0.f, 0.f, 0.f});
                 else
-                    sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[s], sacc[j], 0, 0, 0);
+                    sacc[j] = mfma_32x32x16(fk, fq[s], sacc[j]);
             }
         }
         // online softmax for this lane's query; key index of sacc[j][r] = k0 + j*32 + (r&3) + 8*(r>>2) + 4*hi.
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(256, 3) k_attention(const bf16_t* __restrict__
                     const u32x2 hi2 = *reinterpret_cast<const u32x2*>(vr + 8);
                     u32x4 pv = {lo[0], lo[1], hi2[0], hi2[1]};
                     const bf16x8_t fv = *reinterpret_cast<bf16x8_t*>(&pv);
-                    oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv, fp, oacc[i], 0, 0, 0);
+                    oacc[i] = mfma_32x32x16(fv, fp, oacc[i]);
                 }
             }
         if (t + 1 < ntiles) stage_store((t + 1) & 1);

@@ -50,7 +50,19 @@ _lib.register({
     "vidseg_gemm_profile_kinds": [_P],
 })
 
-BF16 = torch.bfloat16
+
+
+def act_dtype():
+    """Storage dtype of activations and packed weights (float16 unless the library was built with -DVIDSEG_ACT_BF16)."""
+    return _lib.act_dtype()
+
+
+def __getattr__(name):                                      # ops.ACT / ops.BF16 (historical name) resolve lazily: the .so decides
+    if name in ("ACT", "BF16"):
+        return _lib.act_dtype()
+    raise AttributeError(name)
+
+
 F32 = torch.float32
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 
@@ -58,13 +70,13 @@ ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 # ----------------------------------------------------------------------------- weight packing
 def pack_linear(weight: torch.Tensor, device) -> torch.Tensor:
     """nn.Linear weight [N, K] -> bf16 [N, K] (already the K-contiguous 'B^T' layout MFMA wants)."""
-    return weight.detach().to(device=device, dtype=BF16).contiguous()
+    return weight.detach().to(device=device, dtype=act_dtype()).contiguous()
 
 
 def pack_conv3x3(weight: torch.Tensor, device) -> torch.Tensor:
     """Conv2d weight [Cout, Cin, 3, 3] -> bf16 [Cout, (kh*3+kw)*Cin + c] for the NHWC implicit GEMM."""
     co, ci, kh, kw = weight.shape
-    return weight.detach().permute(0, 2, 3, 1).reshape(co, kh * kw * ci).to(device=device, dtype=BF16).contiguous()
+    return weight.detach().permute(0, 2, 3, 1).reshape(co, kh * kw * ci).to(device=device, dtype=act_dtype()).contiguous()
 
 
 def pack_conv_in(weight: torch.Tensor, device) -> torch.Tensor:
@@ -74,7 +86,7 @@ def pack_conv_in(weight: torch.Tensor, device) -> torch.Tensor:
 
 def pack_conv_out(weight: torch.Tensor, device) -> torch.Tensor:
     """Conv2d weight [4, Cin, 3, 3] -> bf16 [4, 3, 3, Cin]."""
-    return weight.detach().permute(0, 2, 3, 1).to(device=device, dtype=BF16).contiguous()
+    return weight.detach().permute(0, 2, 3, 1).to(device=device, dtype=act_dtype()).contiguous()
 
 
 def pack_geglu(weight: torch.Tensor, bias: torch.Tensor, device):
@@ -86,7 +98,7 @@ def pack_geglu(weight: torch.Tensor, bias: torch.Tensor, device):
     assert inner % 32 == 0
     w = weight.detach().view(2, inner // 32, 32, K).permute(1, 0, 2, 3).reshape(two_inner, K)
     b = bias.detach().view(2, inner // 32, 32).permute(1, 0, 2).reshape(two_inner)
-    return w.to(device=device, dtype=BF16).contiguous(), b.to(device=device, dtype=F32).contiguous()
+    return w.to(device=device, dtype=act_dtype()).contiguous(), b.to(device=device, dtype=F32).contiguous()
 
 
 def f32(t: torch.Tensor, device) -> torch.Tensor:
@@ -103,7 +115,7 @@ def linear(a, w, bias=None, *, a1=None, rowvec=None, rows_per_sample=0, residual
     M = a.numel() // C0
     N = w.shape[0]
     n_out = N // 2 if act == ACT_GEGLU else N
-    out = torch.empty(a.shape[:-1] + (n_out,), dtype=F32 if out_f32 else BF16, device=a.device)
+    out = torch.empty(a.shape[:-1] + (n_out,), dtype=F32 if out_f32 else act_dtype(), device=a.device)
     call("vidseg_linear_bf16", ptr(a), ptr(a1), C0, C1, M, ptr(w), N, ptr(bias), ptr(rowvec),
          rowvec.stride(0) if rowvec is not None else 0, rows_per_sample, ptr(residual),
          residual.shape[-1] if residual is not None else 0,
@@ -122,7 +134,7 @@ def conv3x3(x0, w, bias, *, x1=None, stride=1, up=1, rowvec=None, residual=None,
     Cout = w.shape[0]
     Ho = (H * up + 2 - 3) // stride + 1
     Wo = (W * up + 2 - 3) // stride + 1
-    out = torch.empty((B, Ho, Wo, Cout), dtype=BF16, device=x0.device)
+    out = torch.empty((B, Ho, Wo, Cout), dtype=act_dtype(), device=x0.device)
     out32 = torch.empty((B, Ho, Wo, Cout), dtype=F32, device=x0.device) if want_f32 else None
     call("vidseg_conv3x3_bf16", ptr(x0), ptr(x1), C0, C1, B, H, W, stride, up, ptr(w), Cout, ptr(bias), ptr(rowvec),
          rowvec.stride(0) if rowvec is not None else 0, ptr(residual), ptr(out), pad, ptr(out32), stream())
@@ -132,7 +144,7 @@ def conv3x3(x0, w, bias, *, x1=None, stride=1, up=1, rowvec=None, residual=None,
 def softmax_rows(x_f32, scale):
     """softmax(scale * x) over the last dim of an fp32 matrix -> bf16 (first-stage mid attention)."""
     cols = x_f32.shape[-1]
-    out = torch.empty(x_f32.shape, dtype=BF16, device=x_f32.device)
+    out = torch.empty(x_f32.shape, dtype=act_dtype(), device=x_f32.device)
     call("vidseg_softmax_rows_bf16", ptr(x_f32), x_f32.numel() // cols, cols, float(scale), ptr(out), stream())
     return out
 
@@ -149,7 +161,7 @@ def conv_in(x_nhwc_f32, w, bias):
     """Input conv (openaimodel.py:638-644): fp32 NHWC [B,H,W,4|8] -> bf16 NHWC [B,H,W,Cout]."""
     B, H, W, Cin = x_nhwc_f32.shape
     Cout = w.shape[-1]
-    out = torch.empty((B, H, W, Cout), dtype=BF16, device=x_nhwc_f32.device)
+    out = torch.empty((B, H, W, Cout), dtype=act_dtype(), device=x_nhwc_f32.device)
     call("vidseg_conv_in", ptr(x_nhwc_f32), ptr(w), ptr(bias), B, H, W, Cin, Cout, ptr(out), stream())
     return out
 
@@ -195,7 +207,7 @@ def groupnorm(x0, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True):
         ws.part = torch.empty(need, dtype=F32, device=x0.device)
     if B * 2 * (C0 + C1) > ws.stats.numel():
         ws.stats = torch.empty(B * 2 * (C0 + C1), dtype=F32, device=x0.device)
-    out = torch.empty(x0.shape[:-1] + (C0 + C1,), dtype=BF16, device=x0.device)
+    out = torch.empty(x0.shape[:-1] + (C0 + C1,), dtype=act_dtype(), device=x0.device)
     call("vidseg_groupnorm_nhwc_bf16", ptr(x0), ptr(x1), C0, C1, B, HW, groups, ptr(gamma), ptr(beta), eps, int(silu),
          ptr(ws.part), ws.part.numel(), ptr(ws.stats), ws.stats.numel(), ptr(out), stream())
     return out
@@ -214,14 +226,14 @@ def attention(q, k, v, heads, *, q_ld=None, k_ld=None, v_ld=None, Nq=None, Nk=No
     B = q.shape[0] if B is None else B
     Nq = q.shape[1] if Nq is None else Nq
     Nk = k.shape[1] if Nk is None else Nk
-    out = torch.empty((B, Nq, heads * 64), dtype=BF16, device=q.device)
+    out = torch.empty((B, Nq, heads * 64), dtype=act_dtype(), device=q.device)
     call("vidseg_attention_bf16", q.data_ptr(), q_ld or q.stride(1), k.data_ptr(), k_ld or k.stride(1), v.data_ptr(),
          v_ld or v.stride(1), ptr(out), heads * 64, B, heads, Nq, Nk, 64, stream())
     return out
 
 
 def timestep_embedding(t, dim, max_period=10000.0):
-    out = torch.empty((t.shape[0], dim), dtype=BF16, device=t.device)
+    out = torch.empty((t.shape[0], dim), dtype=act_dtype(), device=t.device)
     call("vidseg_timestep_embedding", ptr(t), t.shape[0], dim, float(max_period), ptr(out), stream())
     return out
 
@@ -233,14 +245,14 @@ def silu(x):
 
 
 def f16_to_bf16(x):
-    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    out = torch.empty(x.shape, dtype=act_dtype(), device=x.device)
     xc = x.contiguous()
     call("vidseg_f16_to_bf16", ptr(xc), xc.numel(), ptr(out), stream())
     return out
 
 
 def to_bf16(x):
-    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    out = torch.empty(x.shape, dtype=act_dtype(), device=x.device)
     call("vidseg_f32_to_bf16", ptr(x), x.numel(), ptr(out), stream())
     return out
 
@@ -339,7 +351,7 @@ def gemm_profile_kinds():
 def pack_conv_temporal3(weight: torch.Tensor, device) -> torch.Tensor:
     """Conv3d weight [Cout, Cin, 3, 1, 1] -> bf16 [Cout, dt*Cin + c]."""
     co, ci = weight.shape[:2]
-    return weight.detach().reshape(co, ci, 3).permute(0, 2, 1).reshape(co, 3 * ci).to(device=device, dtype=BF16).contiguous()
+    return weight.detach().reshape(co, ci, 3).permute(0, 2, 1).reshape(co, 3 * ci).to(device=device, dtype=act_dtype()).contiguous()
 
 
 def conv_temporal3(x, w, bias, T, *, rowvec=None, residual=None):
@@ -347,7 +359,7 @@ def conv_temporal3(x, w, bias, T, *, rowvec=None, residual=None):
     workspace(x.device)
     BT, H, W, C = x.shape
     Cout = w.shape[0]
-    out = torch.empty((BT, H, W, Cout), dtype=BF16, device=x.device)
+    out = torch.empty((BT, H, W, Cout), dtype=act_dtype(), device=x.device)
     call("vidseg_conv_temporal3_bf16", ptr(x), C, BT, H * W, T, ptr(w), Cout, ptr(bias), ptr(rowvec),
          rowvec.stride(0) if rowvec is not None else 0, ptr(residual), ptr(out), stream())
     return out
@@ -359,7 +371,7 @@ def linear_temporal_tap(a, w, T, S, tap, tap2, tap_cols):
     C0 = a.shape[-1]
     M = a.numel() // C0
     N = w.shape[0]
-    out = torch.empty(a.shape[:-1] + (N,), dtype=BF16, device=a.device)
+    out = torch.empty(a.shape[:-1] + (N,), dtype=act_dtype(), device=a.device)
     call("vidseg_linear_bf16_ttap", ptr(a), M, C0, ptr(w), N, ptr(out), N, ptr(tap), ptr(tap2), tap_cols,
          tap.shape[-1] if tap is not None else 0, T if tap is not None else 0, S, stream())
     return out
@@ -367,7 +379,7 @@ def linear_temporal_tap(a, w, T, S, tap, tap2, tap_cols):
 
 def temporal_attention(q, k, v, heads, Bv, T, S):
     """Attention across the T frames of every (sample, location); q/k/v rows in spatial order (b t) s."""
-    out = torch.empty((Bv * T, S, heads * 64), dtype=BF16, device=q.device)
+    out = torch.empty((Bv * T, S, heads * 64), dtype=act_dtype(), device=q.device)
     call("vidseg_temporal_attention_bf16", q.data_ptr(), q.stride(-2), k.data_ptr(), k.stride(-2), v.data_ptr(), v.stride(-2),
          ptr(out), heads * 64, Bv, T, S, heads, 64, stream())
     return out

@@ -451,7 +451,7 @@ class UNetModel(nn.Module):
         t_emb = ops.timestep_embedding(timesteps.float(), self.model_channels)                         # DU:209-233
         emb = ops.linear(ops.linear(t_emb, self.te_w1, self.te_b1, act=ops.ACT_SILU), self.te_w2, self.te_b2)
         if self.num_classes is not None:
-            yb = y if y.dtype == torch.bfloat16 else ops.to_bf16(y.float().contiguous())
+            yb = y if y.dtype == ops.act_dtype() else ops.to_bf16(y.float().contiguous())
             emb = ops.linear(ops.linear(yb, self.le_w1, self.le_b1, act=ops.ACT_SILU), self.le_w2, self.le_b2, residual=emb)
         return emb
 
@@ -503,5 +503,5 @@ class UNetModel(nn.Module):
         if not x.is_cuda:
             raise VidsegError("UNetModel runs on a HIP device only (no CPU fallback)")
         xn = x.float().permute(0, 2, 3, 1).contiguous()
-        ctx = context if context.dtype == torch.bfloat16 else ops.to_bf16(context.float().contiguous())
+        ctx = context if context.dtype == ops.act_dtype() else ops.to_bf16(context.float().contiguous())
         return self.forward_nhwc(xn, timesteps, ctx, y, is_modulate_step, is_injected_step, modulate_params)

@@ -100,7 +100,7 @@ class AttnBlock(nn.Module):
         N = H * W
         t = ops.groupnorm(x, self.g, self.b, eps=1e-6, silu=False).view(B, N, C)
         qkv = ops.linear(t, self.w_qkv, self.b_qkv)                                   # [B, N, 3C]
-        att = torch.empty((B, N, C), dtype=torch.bfloat16, device=x.device)
+        att = torch.empty((B, N, C), dtype=ops.act_dtype(), device=x.device)
         for b in range(B):                                                             # one frame at a time: N x N fp32 logits
             q = qkv[b, :, :C].contiguous()
             k = qkv[b, :, C:2 * C].contiguous()

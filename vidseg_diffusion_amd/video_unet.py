@@ -370,5 +370,5 @@ class VideoUNet(UNetModel):
         if not x.is_cuda:
             raise VidsegError("VideoUNet runs on a HIP device only (no CPU fallback)")
         xn = x.float().permute(0, 2, 3, 1).contiguous()
-        ctx = context if context.dtype == torch.bfloat16 else ops.to_bf16(context.float().contiguous())
+        ctx = context if context.dtype == ops.act_dtype() else ops.to_bf16(context.float().contiguous())
         return self.forward_nhwc(xn, timesteps, ctx, y, num_video_frames, is_modulate_step, is_injected_step, modulate_params)
