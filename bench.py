@@ -18,6 +18,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 (MI355X_MICROARCH.md); traffic = PMC bytes per launch of that kernel (profiles/r01_traffic.json).
                 `family` = the same figures over ALL conv/linear launches (three kernels share the work).
   cpu_baseline  the oracle ("port") timed on this box's host cores on a bounded sample (see `sample`).
+  mask_iou_vs_oracle  the metric's second half: HIP masks vs the all-fp32 oracle's on BASELINE configs[0] at full UNet width
+                (the case the CPU finishes in seconds), IoU up to a label permutation.
 """
 import argparse
 import json
@@ -75,6 +77,36 @@ def cpu_baseline(sd_cpu, cfg):
     return {"value": round(F_WIN / t_window, 5), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle fp32 on host: 1 full-size UNet eval of 1 frame (CFG batch 2, {t_unet:.1f}s) + full 14x32x32x640 K=20 "
                       f"analysis ({t_an:.1f}s); window time = 3*14*t_unet + t_analysis = {t_window:.0f}s"}
+
+
+def mask_iou_check(eng, sd_cpu, cfg, dev):
+    """The metric's second half, on a case the CPU can finish in seconds: BASELINE configs[0] (4 frames at 256x256, K = 5, one
+    step) at FULL UNet width -- HIP pipeline vs the all-fp32 oracle, IoU up to a label permutation (tests/tools_metrics.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import pipeline as OP
+    from oracle.unet import UNetOracle
+    from tools_metrics import matched_iou
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd import synthetic
+    from vidseg_diffusion_amd.pipeline import segment_window
+    Fn, K, T0 = 4, 5, 24
+    lat = synthetic.latent_clip(Fn, 32, 32, seed=1)
+    c, ucn = synthetic.sd_conditioning(Fn, context_dim=cfg["context_dim"], seq=77, seed=1)
+    noise = torch.from_numpy(np.random.Generator(np.random.PCG64(9)).standard_normal(lat.shape).astype(np.float32))
+    t0 = time.time()
+    ref = OP.segment_window(UNetOracle(sd_cpu), torch.from_numpy(lat), torch.from_numpy(c), torch.from_numpy(ucn), noise, num_masks=K,
+                            t_start=T0, seed=17)
+    t_cpu = time.time() - t0
+    FE.FeatureStore.clear()
+    FE.MaskStore.clear()
+    labels, _ = segment_window(eng, torch.from_numpy(lat).to(dev), {"crossattn": torch.from_numpy(c).to(dev)},
+                               {"crossattn": torch.from_numpy(ucn).to(dev)}, num_masks=K, t_start=T0, seed=17, noise=noise.to(dev),
+                               feature_folder="/nonexistent/bench_iou", exp_name="c1")
+    FE.FeatureStore.clear()
+    FE.MaskStore.clear()
+    iou, exact = matched_iou(labels, ref["labels"], K)
+    return {"iou": round(float(iou), 4), "identical_fraction": round(float(exact), 4),
+            "case": f"BASELINE configs[0] at full width: 4x256x256, K=5, 1 step; fp32 oracle took {t_cpu:.1f}s on the host"}
 
 
 def main():
@@ -270,6 +302,7 @@ def main():
                                   "image": [ih, iw], "note": "AutoencoderKL.encode, synthetic weights; excluded from `value`"}
         if not args.no_cpu_baseline and not args.narrow and not svd:
             out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg)
+            out["mask_iou_vs_oracle"] = mask_iou_check(eng, sd_cpu, cfg, dev)
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
