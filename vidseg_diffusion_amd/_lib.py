@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvidseg_hip.so")
+# fp16 activations by default; VIDSEG_ACT=bf16 selects the bfloat16 build of the same sources (see csrc/common.h)
+LIB_PATH = os.path.join(_HERE, "libvidseg_hip_bf16.so" if os.environ.get("VIDSEG_ACT", "f16").lower() == "bf16" else "libvidseg_hip.so")
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
