@@ -300,7 +300,7 @@ def main():
             torch.cuda.synchronize()
             out["first_stage"] = {"encode_ms_per_window": round(1e3 * (time.perf_counter() - tv) / 3, 2), "frames": F_WIN,
                                   "image": [ih, iw], "note": "AutoencoderKL.encode, synthetic weights; excluded from `value`"}
-        if not args.no_cpu_baseline and not args.narrow and not svd:
+        if not args.no_cpu_baseline and not args.narrow and not svd and world == 1:     # host-side legs: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg)
             out["mask_iou_vs_oracle"] = mask_iou_check(eng, sd_cpu, cfg, dev)
         print(json.dumps(out))
