@@ -133,7 +133,8 @@ def test_layernorm(dev, M, C):
     check(out, TF.layer_norm(x, (C,), g, b, 1e-5), "layernorm")
 
 
-@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 1, 64, 64), (2, 2, 256, 256), (3, 5, 100, 77), (1, 4, 16, 16), (2, 2, 4, 4), (1, 5, 1024, 1024)])
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 1, 64, 64), (2, 2, 256, 256), (3, 5, 100, 77), (1, 4, 16, 16), (2, 2, 4, 4), (1, 5, 1024, 1024),
+                                        (1, 2, 2304, 2304), (1, 1, 2100, 2048)])     # >= 2048 queries: the 64-queries-per-wave kernel
 def test_attention(dev, B, H, Nq, Nk):
     from vidseg_diffusion_amd import ops
     C = H * 64

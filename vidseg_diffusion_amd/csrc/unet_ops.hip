@@ -2,6 +2,7 @@
 // two-source channel concat, LayerNorm, flash-style attention (head dim 64, MFMA), timestep embedding,
 // and the sampler's small elementwise steps.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -353,6 +354,180 @@ __global__ void __launch_bounds__(256, 3) k_attention(const bf16_t* __restrict__
     }
 }
 
+// Two query blocks per wave (64 queries): every K / V fragment read from LDS feeds two MFMAs -- half the LDS traffic per
+// flop of k_attention, at twice the accumulator registers (occupancy 2).
+template <bool RAGGED>
+__global__ void __launch_bounds__(256, 2) k_attention2(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                                                   const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo, int Nq,
+                                                   int Nk, int H, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) char sK2[2][64 * 128];          // K tile [key][d], 16-B slot XOR swizzle, double buffered
+    __shared__ __attribute__((aligned(16))) bf16_t sVt2[2][64 * VT_LD];     // V tile transposed [d][key]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int q0 = blockIdx.x * 256 + wave * 64;
+    const bf16_t* qp = q + (long long)b * Nq * ldq + h * 64;
+    const bf16_t* kp = k + (long long)b * Nk * ldk + h * 64;
+    const bf16_t* vp = v + (long long)b * Nk * ldv + h * 64;
+
+    // Q^T as the MFMA B operand: lane holds query (q0 + l31), d = s*16 + hi*8 .. +8
+    bf16x8_t fq[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = min(q0 + qb * 32 + l31, Nq - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fq[qb][s] = *reinterpret_cast<const bf16x8_t*>(qp + (long long)qi * ldq + s * 16 + hi * 8);
+    }
+    f32x16 oacc[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qb][i][r] = 0.f;
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+    const int ntiles = (Nk + 63) / 64;
+    // K/V staging: global -> registers one tile ahead (issued before the MFMAs of the current tile), registers -> LDS
+    // (K row-major swizzled, V transposed) after them; one barrier per tile.
+    u32x4 rk[2];
+    bf16x8_t rv[2];
+    const int st_ch = tid & 7;
+    auto stage_load = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = min(t * 64 + (tid >> 3) + 32 * i, Nk - 1);
+            rk[i] = *reinterpret_cast<const u32x4*>(kp + (long long)key * ldk + st_ch * 8);
+            rv[i] = *reinterpret_cast<const bf16x8_t*>(vp + (long long)key * ldv + st_ch * 8);
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (tid >> 3) + 32 * i;
+            *reinterpret_cast<u32x4*>(sK2[buf] + r * 128 + ((st_ch ^ (r & 7)) << 4)) = rk[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sVt2[buf][(st_ch * 8 + e) * VT_LD + r] = (bf16_t)rv[i][e];
+        }
+    };
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * 64;
+        const char* sK = sK2[t & 1];
+        const bf16_t* sVt = sVt2[t & 1];
+        if (t + 1 < ntiles) stage_load(t + 1);
+        // S^T[j] : rows = keys j*32 + .., cols = queries
+        f32x16 sacc[2][2];                                             // [query block][key block j]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = j * 32 + l31;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int ch = s * 2 + hi;
+                const bf16x8_t fk = *reinterpret_cast<const bf16x8_t*>(sK + r * 128 + ((ch ^ (r & 7)) << 4));
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    if (s == 0)
+                        sacc[qb][j] = mfma_32x32x16(fk, fq[qb][s], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                                                         0.f, 0.f});
+                    else
+                        sacc[qb][j] = mfma_32x32x16(fk, fq[qb][s], sacc[qb][j]);
+                }
+            }
+        }
+        unsigned pk[2][2][8];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+        // online softmax for this lane's query; key index of sacc[qb][j][r] = k0 + j*32 + (r&3) + 8*(r>>2) + 4*hi.
+            // VALU budget matters as much as MFMA here: max on raw scores, scale folded into one fma per element,
+            // masking only on the ragged last tile, O rescale skipped when no lane's running max moved.
+            if (RAGGED && k0 + 64 > Nk) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = k0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (key >= Nk) sacc[qb][j][r] = -INFINITY;
+                    }
+            }
+            float mx = sacc[qb][0][0];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qb][j][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
+            const float m_new = fmaxf(m_run[qb], mx);
+            vs_f32x2 psum2 = {0.f, 0.f};
+            const vs_f32x2 sc2 = {scale_log2e, scale_log2e}, mn2 = {-m_new, -m_new};
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const vs_f32x2 a = vs_f32x2{sacc[qb][j][r], sacc[qb][j][r + 1]} * sc2 + mn2;        // v_pk_fma_f32
+                    const vs_f32x2 p = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                    psum2 += p;                                                               // v_pk_add_f32
+                    pk[qb][j][r >> 1] = pack2_bf16(p[0], p[1]);
+                }
+            float psum = psum2[0] + psum2[1];
+            psum += __shfl_xor(psum, 32, 64);
+            if (__any(m_new != m_run[qb])) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[qb][i][r] *= alpha;
+                m_run[qb] = m_new;
+            }
+            l_run[qb] += psum;
+
+        }
+        // O^T[qb][i] += V^T[d-block i] P^T[qb] : each V fragment is read once and used for both query blocks
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int kb = j * 32 + s * 16 + 4 * hi;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bf16_t* vr = sVt + (i * 32 + l31) * VT_LD + kb;
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(vr);
+                    const u32x2 hi2 = *reinterpret_cast<const u32x2*>(vr + 8);
+                    u32x4 pv = {lo[0], lo[1], hi2[0], hi2[1]};
+                    const bf16x8_t fv = *reinterpret_cast<bf16x8_t*>(&pv);
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) {
+                        u32x4 pw = {pk[qb][j][s * 4 + 0], pk[qb][j][s * 4 + 1], pk[qb][j][s * 4 + 2], pk[qb][j][s * 4 + 3]};
+                        const bf16x8_t fp = *reinterpret_cast<bf16x8_t*>(&pw);
+                        oacc[qb][i] = mfma_32x32x16(fv, fp, oacc[qb][i]);
+                    }
+                }
+            }
+        if (t + 1 < ntiles) stage_store((t + 1) & 1);
+        __syncthreads();
+    }
+    // write O: lane owns query q0 + l31; oacc[i][r] is d = i*32 + (r&3) + 8*(r>>2) + 4*hi
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+    const int qi = q0 + qb * 32 + l31;
+    if (qi < Nq) {
+        const float inv = 1.0f / l_run[qb];
+        bf16_t* op = o + ((long long)b * Nq + qi) * ldo + h * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned w0 = (unsigned)f32_to_bf16(oacc[qb][i][g * 4 + 0] * inv) | ((unsigned)f32_to_bf16(oacc[qb][i][g * 4 + 1] * inv) << 16);
+                unsigned w1 = (unsigned)f32_to_bf16(oacc[qb][i][g * 4 + 2] * inv) | ((unsigned)f32_to_bf16(oacc[qb][i][g * 4 + 3] * inv) << 16);
+                u32x2 pk = {w0, w1};
+                *reinterpret_cast<u32x2*>(op + i * 32 + 8 * g + 4 * hi) = pk;
+            }
+    }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // timestep_embedding (sgm/modules/diffusionmodules/util.py:209-233): [cos(t f_i) | sin(t f_i)], bf16 out
 // ---------------------------------------------------------------------------------------------
@@ -682,7 +857,13 @@ int vidseg_attention_bf16(const void* q, int ldq, const void* k, int ldk, const 
     VS_REQUIRE(head_dim == 64, "attention: head_dim=%d (only 64 is on the path)", head_dim);
     VS_REQUIRE(Nq > 0 && Nk > 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attention: bad sizes/strides");
     const float scale_log2e = 0.125f * 1.44269504088896340736f;           // dim_head ** -0.5 * log2(e)
-    if (Nk % 64 == 0)
+    // 64 queries per wave for long sequences (measured: 4096 tokens 1034 -> 947 us, 1024 tokens unchanged); VIDSEG_ATTN2=0 disables
+    static int attn2 = -1;
+    if (attn2 < 0) { const char* e = getenv("VIDSEG_ATTN2"); attn2 = e ? atoi(e) : 1; }
+    if (attn2 && Nk % 64 == 0 && Nq >= 2048)
+        k_attention2<false><<<dim3((Nq + 255) / 256, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
+                                                                            (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
+    else if (Nk % 64 == 0)
         k_attention<false><<<dim3((Nq + 127) / 128, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
                                                                            (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
     else
