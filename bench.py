@@ -12,7 +12,7 @@ starts (VAE + conditioner excluded).  N > 1: one window per GP
 vidseg_diffusion_amd/parallel.py for the exchange.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      the single kernel with the most time in the timed region (normally k_gemm_tile<NJ,4,64,2>, the 256x320 /
+  roofline      the single kernel with the most time in the timed region (normally k_gemm_ph<NJ>, the phased 256x320 /
                 256x256 LDS-DMA implicit-GEMM tile): achieved = algorithmic FLOPs (2*M*N*K per launch) / HIP-event time of its
                 launches, recorded on the launch stream inside the timed region; peak = 2500 TFLOP/s dense bf16
                 (MI355X_MICROARCH.md); traffic = PMC bytes per launch of that kernel (profiles/r01_traffic.json).
@@ -246,7 +246,7 @@ def main():
         dom = max(kinds, key=lambda r: r[1])                                  # the single kernel with the most time in the region
         if traffic is not None:                                               # PMC pass: per-launch bytes of that kernel if recorded
             for kname, rec in tj.get("per_kernel", {}).items():
-                if ("k_gemm_tile<5, 4, 64" in kname and dom[0].startswith("k_gemm_tile<NJ,4,64")) or \
+                if ("k_gemm_ph<5>" in kname and dom[0].startswith("k_gemm_ph")) or \
                         ("k_gemm_dma<2>" in kname and dom[0].startswith("k_gemm_dma")):
                     traffic = rec["traffic_bytes_per_launch"]
                     break

@@ -768,6 +768,255 @@ __global__ void __launch_bounds__(WM * 128, MI == 1 ? 4 : (WM == 4 ? 1 : 2)) k_g
     gemm_epilogue<NJ, MI>(p, acc, smem, m0 + wm * (MI * 32), n0 + wn * (NJ * 32), lane, wave, split);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Phased big tile: the same 256 x (NJ*64) block / 64 x (NJ*32) wave tile as k_gemm_tile<NJ,4,64>, but the K-tile is worked
+// off in NJ phases (phase j = column block j of the wave tile over the full BK = 64: 8 MFMAs, 256 cycles) and the two halves
+// of the workgroup (waves 0-3 / 4-7, one of each per SIMD) run one barrier apart, so while one half feeds the matrix
+// pipe the other reads LDS and issues the LDS-DMA of a later tile.  Two LDS buffers, restaged region by region:
+//   group G0(u) = A rows 0-127 + B block 0, G1(u) = A rows 128-255 + B block 1, Gg(u) = B block g  (tile u)
+//   Gg(u) is issued in the read section of phase (u-2, g+2) [A and B block g of tile u-2 were last read in phases (u-2, 0) and
+//   (u-2, g); two phases later every wave of both halves has retired those reads], i.e. 5-7 phases before its first use.
+// Waits are counted (loads retire in order): before phase q's first barrier each wave waits until at most VM(q+1) of its own
+// loads are outstanding, which covers everything phase q+1 reads; the barrier publishes it to the other waves.  Tiles beyond the
+// K range are staged with out-of-range buffer offsets (zeros, no memory traffic) so the counts stay uniform.
+// ---------------------------------------------------------------------------------------------
+#ifndef PH_EXP
+#define PH_EXP 0
+#endif
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NJ>
+__global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = NJ * 64, RB = 128;
+    constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB;              // LDS map: A[0] A[1] B[0] B[1] (ds offsets stay within 16 bits)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: DMA destinations and piece rows live in SGPRs
+    const int wm = wave >> 1, wn = wave & 1, grp = wave >> 2;
+    const long long tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const long long nwg = tiles_m * tiles_n;
+    const int split = p.ksplit > 1 ? (int)(blockIdx.x / nwg) : 0;
+    long long bid = p.ksplit > 1 ? (long long)(blockIdx.x % nwg) : (long long)blockIdx.x;
+    {
+        const long long q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long long tm = bid / tiles_n;
+    const int tn = (int)(bid % tiles_n);
+    const long long m0 = tm * BM;
+    const int n0 = tn * BN;
+
+    constexpr unsigned OOB = 0xF0000000u;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w), 0, (int)((long long)p.N * p.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x0), 0, (int)p.x0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x1 ? p.x1 : p.x0), 0, (int)p.x1_bytes, 0x00020000);
+
+    // staging: a DMA piece is 8 rows x 128 B; lane l -> row l/8, 16-byte chunk l%8.  A set s4 = (half h = s4>>1, i = s4&1) is
+    // piece wave + 8i of rows h*128..; B block g is 64 rows (32 of each column half of the wave grid), piece = wave.  Every
+    // staged row of this lane has the same (row>>1)&7, so one swizzled chunk offset serves all of them.
+    const int Cin = p.C0 + p.C1;
+    const int HWo = p.Hout * p.Wout;
+    const int upsh = p.up - 1;
+    const int Hup = p.Hin << upsh, Wup = p.Win << upsh;
+    const int lrow = lane >> 3, lch = lane & 7;
+    const unsigned swz16 = (unsigned)((lch ^ (((wave & 1) << 2) | (lrow >> 1))) << 4);
+    // One branch-free address form for the three A operands: pixel = base + ((ih0 + kh) >> upsh) * wmul + ((iw0 + kw) >> upsh),
+    // valid iff 0 <= ih0 + kh < hb and 0 <= iw0 + kw < wb.  3x3 conv: (kh, kw) = tap; temporal 3-tap conv: the "row" is the frame
+    // index (kh = tap, wmul = Hout*Wout, hb = T); linear: one tap, ih0 = iw0 = 0.  Rows past M carry ih0 = -0x4000.
+    const int hb = p.ksize == 1 ? 1 : (p.tmode ? p.T : Hup), wb = (p.ksize == 1 || p.tmode) ? 1 : Wup;
+    const int wmul = p.tmode ? HWo : p.Win;
+    // a_base is needed only when the tap changes: it lives in LDS behind the tile buffers (a scratch spill there would drain vmcnt)
+    int a_base[4], a_hw[4];                                            // a_hw = (ih0 + 0x4000) << 16 | (iw0 + 0x4000)
+    int4* a_base_lds = reinterpret_cast<int4*>(smem + 2 * (A_BYTES + B_BYTES)) + tid;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int r = (s4 >> 1) * 128 + (wave + 8 * (s4 & 1)) * 8 + lrow;
+        const long long m = m0 + r;
+        const bool ok = m < p.M;
+        const int mm = ok ? (int)m : 0;
+        int ih0 = 0, iw0 = 0;
+        if (p.ksize == 1) {
+            a_base[s4] = mm;
+        } else if (p.tmode) {
+            const int t = (mm / HWo) % p.T;
+            a_base[s4] = mm - t * HWo;
+            ih0 = t - 1;
+        } else {
+            const int b = mm / HWo, rem = mm - b * HWo;
+            const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
+            a_base[s4] = b * p.Hin * p.Win;
+            ih0 = oh * p.stride - p.pad;
+            iw0 = ow * p.stride - p.pad;
+        }
+        if (!ok) ih0 = -0x4000;
+        a_hw[s4] = ((ih0 + 0x4000) << 16) | (iw0 + 0x4000);
+    }
+    *a_base_lds = make_int4(a_base[0], a_base[1], a_base[2], a_base[3]);
+    const int b_r0 = (wave >> 2) * (NJ * 32) + (wave & 3) * 8;              // first row of this wave's piece inside B block 0
+    const int b_n = n0 + b_r0 + lrow;                                        // + g*32: the weight row this lane stages for block g
+    const unsigned b_off0 = (unsigned)((long long)b_n * p.K * 2) + swz16;
+    const unsigned b_gstep = (unsigned)p.K * 64u;                            // 32 weight rows
+    const int nk_all = p.K / 64;
+    const int ks_begin = p.ksplit > 1 ? (int)((long long)nk_all * split / p.ksplit) : 0;
+    const int ks_end = p.ksplit > 1 ? (int)((long long)nk_all * (split + 1) / p.ksplit) : nk_all;
+    const int nk = ks_end - ks_begin;
+    int ld_tap = (ks_begin * 64) / Cin, ld_c0 = (ks_begin * 64) % Cin;
+    // A byte offsets of the four staged rows for the (tap, source) the cursor is in; refreshed only when the cursor enters a
+    // new tap or crosses from x0 to x1 (every Cin/64 .. C0/64 tiles), so the read sections stay short
+    unsigned a_off[4];
+    unsigned a_cbyte = 0;
+    bool a_second = false, a_first = true;
+    auto a_prepare = [&]() {
+        if (a_first || ld_c0 == 0 || ld_c0 == p.C0) {
+            a_first = false;
+            a_second = ld_c0 >= p.C0;
+            const int Cs = a_second ? p.C1 : p.C0;
+            const int t3 = ld_tap / 3;
+            const int kh = p.tmode ? ld_tap : t3, kw = p.tmode ? 0 : ld_tap - t3 * 3;
+            const int4 ab4 = *a_base_lds;
+            const int ab[4] = {ab4.x, ab4.y, ab4.z, ab4.w};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int ih = (a_hw[s4] >> 16) - 0x4000 + kh, iw = (a_hw[s4] & 0xFFFF) - 0x4000 + kw;
+                const bool ok = (unsigned)ih < (unsigned)hb && (unsigned)iw < (unsigned)wb;
+                const int pix = ab[s4] + (ih >> upsh) * wmul + (iw >> upsh);
+                a_off[s4] = ok ? (unsigned)(pix * Cs) * 2u + swz16 : OOB;
+            }
+        }
+        a_cbyte = (unsigned)(a_second ? ld_c0 - p.C0 : ld_c0) * 2u;
+        ld_c0 += 64;
+        if (ld_c0 >= Cin) {
+            ld_c0 = 0;
+            ld_tap++;
+        }
+    };
+    // stage group g of tile u into buffer buf (groups of one tile are staged in order g = 0, 1, ..)
+    auto stage = [&](int g, int u, int buf) {
+#if PH_EXP & 16
+        const bool live = u < 2;
+#else
+        const bool live = u < nk;
+#endif
+        if (g == 0) a_prepare();
+        if (g < 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                char* dst = smem + buf * A_BYTES + (g * 128 + (wave + 8 * i) * 8) * RB;
+                const unsigned off = live ? a_off[g * 2 + i] + a_cbyte : OOB;
+                if (a_second)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+            }
+        }
+        char* dst = smem + 2 * A_BYTES + buf * B_BYTES + (b_r0 + g * 32) * RB;
+        const unsigned off = (live && b_n + g * 32 < p.N) ? b_off0 + (unsigned)g * b_gstep + (unsigned)(ks_begin + u) * 128u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+    };
+
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int sw = lds_swz<64>(l31);
+    const int arow = (wm * 64 + l31) * RB, brow = 2 * A_BYTES + (wn * (NJ * 32) + l31) * RB;
+
+    // prologue: everything the steady state would have issued before phase (0, 0)
+#pragma unroll
+    for (int g = 0; g < NJ; ++g) stage(g, 0, 0);
+#pragma unroll
+    for (int g = 0; g + 2 < NJ; ++g) stage(g, 1, 1);
+    constexpr int CNT_ALL = 2 * (NJ + 4);
+    // loads of the groups staged at phase positions j', j'+1, j'+2 (and 0..3 for j' = 0) are the only ones that may still fly
+    constexpr auto cnt = [](int pos) { return (pos == 2 || pos == 3) ? 3 : 1; };
+    wait_vmcnt<CNT_ALL - 8>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+
+    bf16x8_t fa[2][4];
+    auto tile = [&](int t, int buf) {
+        const char* A = smem + buf * A_BYTES + arow;
+        const char* B = smem + buf * B_BYTES + brow;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            // ---- read section
+            bf16x8_t fb[4];
+#if PH_EXP & 1                                                 // experiment: no LDS reads in the loop (wrong results)
+            if (t == 0) {
+#endif
+            if (j == 0 && (!(PH_EXP & 32) || t == 0)) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fa[i][s] = *reinterpret_cast<const bf16x8_t*>(A + i * 32 * RB + (((s * 2 + hi) ^ sw) << 4));
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fb[s] = *reinterpret_cast<const bf16x8_t*>(B + j * 32 * RB + (((s * 2 + hi) ^ sw) << 4));
+#if PH_EXP & 1
+            }
+#endif
+#if PH_EXP & 2                                                 // experiment: no DMA in the loop (wrong results)
+            if (t < 0) {
+#endif
+            if (j >= 2)
+                stage(j - 2, t + 2, buf);
+            else
+                stage(j - 2 + NJ, t + 1, buf ^ 1);
+#if PH_EXP & 2
+            }
+#endif
+            // counted wait for what phase j+1 reads
+            const int jn = (j + 1) % NJ;
+#if PH_EXP & 4
+            if (false) {
+            } else if (t < 0)
+#else
+            if (jn == 0)
+#endif
+                wait_vmcnt<CNT_ALL - 8>();
+            else if (cnt(jn) + cnt((jn + 1) % NJ) + cnt((jn + 2) % NJ) == 7)
+                wait_vmcnt<CNT_ALL - 7>();
+            else if (cnt(jn) + cnt((jn + 1) % NJ) + cnt((jn + 2) % NJ) == 5)
+                wait_vmcnt<CNT_ALL - 5>();
+            else
+                wait_vmcnt<CNT_ALL - 3>();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- matrix section
+#if !(PH_EXP & 8)
+            __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][j] = mfma_32x32x16(fa[i][s], fb[s], acc[i][j]);
+#if !(PH_EXP & 8)
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int t = 0; t < nk; t += 2) {
+        tile(t, 0);
+        if (t + 1 < nk) tile(t + 1, 1);
+    }
+    wait_vmcnt<0>();
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    gemm_epilogue<NJ, 2>(p, acc, smem, m0 + wm * 64, n0 + wn * (NJ * 32), lane, wave, split);
+}
+
 // Split-K finish: sum the fp32 partials in split order (deterministic), then the same epilogue as above.
 __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
     const long long i8 = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1042,7 +1291,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         k_gemm_conv<256, 64><<<dim3((unsigned)tiles), 256, 2 * (256 + 64) * BK * 2, st>>>(p);
     } else {
         const int nk = p.K / BK;
-        static int nosplit = -1, use_dma = -1, big_mode = -1, mid_mode = -1;
+        static int nosplit = -1, use_dma = -1, big_mode = -1, mid_mode = -1, ph_mode = 0;
         constexpr int MID_LDS = 8 * 32 * 68 * 4;               // epilogue staging of 8 waves (69.6 KiB) > 2 x (128+320) x 64 B
         if (nosplit < 0) {
             const char* e = getenv("VIDSEG_NO_SPLITK");
@@ -1059,6 +1308,10 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)k_gemm_tile<5, 4, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS);
             (void)hipFuncSetAttribute((const void*)k_gemm_tile<4, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
             (void)hipFuncSetAttribute((const void*)k_gemm_tile<5, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
+            e = getenv("VIDSEG_GEMM_PH");                        // phased big tile (k_gemm_ph)
+            ph_mode = e ? atoi(e) : 1;
+            (void)hipFuncSetAttribute((const void*)k_gemm_ph<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128 + 8192);
+            (void)hipFuncSetAttribute((const void*)k_gemm_ph<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128 + 8192);
         }
         // Blocks run in rounds over the resident slots, so the last round's fill decides the efficiency.  Pick the K
         // split that maximises fill / (1 + cost of writing+reading the fp32 partials); deterministic finish kernel.
@@ -1099,7 +1352,11 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         if (big) {
             p.ksplit = S;
             p.ws = S > 1 ? g_ws : nullptr;
-            if (NJ == 5)
+            if (ph_mode && NJ == 5)
+                k_gemm_ph<5><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 320) * 128 + 8192, st>>>(p);
+            else if (ph_mode)
+                k_gemm_ph<4><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 256) * 128 + 8192, st>>>(p);
+            else if (NJ == 5)
                 k_gemm_tile<5, 4, 64><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 320) * 128, st>>>(p);
             else
                 k_gemm_tile<4, 4, 64><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 256) * 128, st>>>(p);

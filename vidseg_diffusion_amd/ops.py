@@ -336,7 +336,7 @@ def gemm_profile_end():
     return float(out[0]), float(out[1]), int(out[2])
 
 
-GEMM_KIND_NAMES = ("k_gemm_dma (128x128, LDS-DMA)", "k_gemm_tile<NJ,4,64,2> (256x320 / 256x256, LDS-DMA)",
+GEMM_KIND_NAMES = ("k_gemm_dma (128x128, LDS-DMA)", "k_gemm_ph<NJ> (256x320 / 256x256, LDS-DMA, phased)",
                    "k_gemm_tile<NJ,4,32,1> (128x320, LDS-DMA)", "k_gemm_conv<256,64>")
 
 
