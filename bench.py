@@ -125,7 +125,14 @@ def main():
     ap.add_argument("--vae", action="store_true", help="also time the first-stage encode of one window (reported beside the metric)")
     ap.add_argument("--config", default="sd", choices=["sd", "svd"],
                     help="sd = BASELINE configs[1] (headline); svd = configs[2]: SVD 14x576x1024, t_start 17, is_refine_mask")
+    ap.add_argument("--fp8-attn", action="store_true",
+                    help="BASELINE configs[4]: e4m3 attention (q, k, v, P) on the long spatial self-attentions; reports the masks' agreement "
+                         "with the 16-bit path of the same build")
+    ap.add_argument("--masks", type=int, default=None, help="number of masks K (default 20; configs[4] uses 50)")
     args = ap.parse_args()
+    global K_MASKS
+    if args.masks:
+        K_MASKS = args.masks
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -144,6 +151,7 @@ def main():
     from vidseg_diffusion_amd.unet import UNetModel
 
     svd = args.config == "svd"
+    ops.set_attention_fp8(args.fp8_attn)
     global T_START
     if svd:
         from vidseg_diffusion_amd.video_unet import VideoUNet
@@ -281,6 +289,19 @@ def main():
                                          "window per GPU (latent 14x4x72x128), t_start=17 (8 CFG UNet evals, batch 28), spatial+temporal taps, "
                                          "is_aggre_attn, K-means K=20 + 4-NN, is_refine_mask (dense tracking + vote)")
             out["config"]["unet_evals_per_step"] = 8
+        if args.masks:
+            out["metric"] = out["metric"].replace("20 masks", f"{K_MASKS} masks")
+            out["config"]["workload"] = out["config"]["workload"].replace("K=20", f"K={K_MASKS}")
+        if args.fp8_attn:                                                # outside the timed region: the same window on the 16-bit kernels
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from tools_metrics import matched_iou
+            ops.set_attention_fp8(False)
+            ref_labels = one_step()
+            ops.set_attention_fp8(True)
+            iou, exact = matched_iou(np.asarray(labels).reshape(-1), np.asarray(ref_labels).reshape(-1), K_MASKS)
+            out["dtype"] += " + e4m3 attention (q, k, v, P; >= 1024 keys)"
+            out["config"]["workload"] += "; BASELINE configs[4] attention path: OCP e4m3 MFMA on the spatial self-attentions"
+            out["fp8_vs_16bit_masks"] = {"iou": round(float(iou), 4), "identical_fraction": round(float(exact), 4)}
         if args.vae:                                                     # outside the timed region, never part of `value`
             from vidseg_diffusion_amd.vae import AutoencoderKL, encode_first_stage
             dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],

@@ -154,6 +154,12 @@ int vidseg_layernorm_bf16(const void* x, long long M, int C, const float* gamma,
 /* ATT:352-356 F.scaled_dot_product_attention per 64-wide head; q/k/v/o are column slices with leading dims. */
 int vidseg_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B,
                           int H, int Nq, int Nk, int head_dim, vidseg_stream_t stream);
+/* BASELINE configs[4] (fp8 attention path): the same operator (ATT:352-356) with q, k, v and the probabilities in OCP e4m3
+ * (v_mfma_f32_32x32x16_fp8_fp8), fp32 softmax/accumulation, output in the activation dtype; strides in bytes = elements.
+ * vidseg_quant_fp8: saturating round-to-nearest-even conversion of n activations (n % 8 == 0) to e4m3 bytes. */
+int vidseg_quant_fp8(const void* x, long long n, void* out_fp8, vidseg_stream_t stream);
+int vidseg_attention_fp8(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int H,
+                         int Nq, int Nk, int head_dim, vidseg_stream_t stream);
 /* SVD (video) operators -- video_model.py:15-89 VideoResBlock, video_attention.py:18-489 */
 /* Conv3d kernel [3,1,1], padding [1,0,0] over frames; x NHWC [(b t)][HW][C], w [Cout][dt*Cin+c] (video_model.py:45-58) */
 int vidseg_conv_temporal3_bf16(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,

@@ -160,6 +160,48 @@ def test_attention_fused_qkv_strides(dev):
     assert ((out.float().cpu() - ref).abs() <= (2.0 ** -7) * ref.abs() + 2e-3 * ref.abs().max()).all()
 
 
+def test_quant_fp8(dev):
+    """e4m3 conversion = torch's round-to-nearest-even float8_e4m3fn of the clamped value, byte for byte."""
+    from vidseg_diffusion_amd import ops
+    x = torch.cat([rnd((4096,), 1, 3.0), rnd((2048,), 2, 0.01), rnd((1024,), 3, 300.0), torch.tensor([0.0, -0.0, 448.0, -448.0, 1000.0, -6e4, 2.0 ** -9, 2.0 ** -10])])
+    x = x.to(ops.act_dtype())
+    out = ops.quant_fp8(x.to(dev)).cpu()
+    ref = x.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(out, ref), f"{(out != ref).sum().item()} of {out.numel()} bytes differ"
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 1, 64, 64), (2, 2, 256, 256), (3, 5, 100, 77), (1, 4, 16, 16), (1, 5, 1024, 1024), (1, 2, 2304, 2304)])
+def test_attention_fp8(dev, B, H, Nq, Nk):
+    """BASELINE configs[4]: q, k, v and P in e4m3.  Reference = fp32 attention on the SAME quantised q, k, v (dequantised on the
+    host); what remains is the e4m3 rounding of the probabilities (2^-4 relative per term, averaged over the keys)."""
+    from vidseg_diffusion_amd import ops
+    C = H * 64
+    q, k, v = (rnd(s, i).to(ops.act_dtype()).to(dev) for i, s in ((1, (B, Nq, C)), (2, (B, Nk, C)), (3, (B, Nk, C))))
+    out = ops.attention(q, k, v, H, fp8=True).float().cpu()
+    qd, kd, vd = (ops.quant_fp8(t).cpu().view(torch.float8_e4m3fn).float() for t in (q, k, v))
+    qh, kh, vh = (t.view(B, -1, H, 64).transpose(1, 2) for t in (qd, kd, vd))
+    ref = TF.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Nq, C)
+    err = (out - ref).abs()
+    assert (err <= (2.0 ** -4) * ref.abs() + 4e-2 * ref.abs().max()).all(), f"fp8 attention max err {err.max():.4g} (max ref {ref.abs().max():.4g})"
+    rel = (err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    assert rel <= 3e-2, f"fp8 attention rms error {rel:.4g}"
+    # and it stays close to the 16-bit kernel on the unquantised inputs (e4m3 inputs: 2^-4 relative)
+    full = ops.attention(q, k, v, H, fp8=False).float().cpu()
+    assert (out - full).pow(2).mean().sqrt() <= 0.08 * full.pow(2).mean().sqrt() + 1e-3
+
+
+def test_attention_fp8_fused_qkv(dev):
+    from vidseg_diffusion_amd import ops
+    B, H, N = 2, 2, 192
+    C = H * 64
+    d = rnd((B, N, 3 * C), 1).to(ops.act_dtype()).to(dev)
+    out = ops.attention(d[..., :C], d[..., C:2 * C], d[..., 2 * C:], H, fp8=True).float().cpu()
+    dq = ops.quant_fp8(d).cpu().view(torch.float8_e4m3fn).float()
+    q, k, v = (dq[..., i * C:(i + 1) * C].reshape(B, N, H, 64).transpose(1, 2) for i in range(3))
+    ref = TF.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, C)
+    assert ((out - ref).abs() <= (2.0 ** -4) * ref.abs() + 4e-2 * ref.abs().max()).all()
+
+
 def test_timestep_embedding(dev):
     from vidseg_diffusion_amd import ops
     t = torch.tensor([0.0, 1.0, 500.0, 999.0])

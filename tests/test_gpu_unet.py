@@ -462,3 +462,24 @@ def test_overlapped_clip_equals_sequential(env):
                        seed=17, feature_folder="/nonexistent/ovc")
     assert [(s, e) for s, e, _ in out] == [(0, 4), (4, 8), (6, 10)]
     FE.FeatureStore.clear(); FE.MaskStore.clear()
+
+
+def test_fp8_attention_path(env):
+    """BASELINE configs[4]: every spatial attention of the UNet on the e4m3 kernel.  There is no reference for an fp8 path; the bar
+    is closeness to the 16-bit path of the same build: UNet output and decoder Q taps within 5e-2 normalised rms (e4m3 keeps
+    3 mantissa bits: 2^-4 relative per operand, averaged over 64-wide dot products and the softmax)."""
+    from vidseg_diffusion_amd import ops
+    dev, g, net, sd = env
+    x, t, ctx = (torch.from_numpy(g[k]).to(dev) for k in ("fw_x", "fw_t", "fw_ctx"))
+    base = net(x, timesteps=t, context=ctx).cpu().numpy()
+    taps = {b: net.output_blocks[b][1].transformer_blocks[0].attn1.q.float().cpu().numpy() for b in (6, 7, 8)}
+    prev = ops.set_attention_fp8(True, min_keys=0)
+    try:
+        out = net(x, timesteps=t, context=ctx).cpu().numpy()
+        taps8 = {b: net.output_blocks[b][1].transformer_blocks[0].attn1.q.float().cpu().numpy() for b in (6, 7, 8)}
+    finally:
+        ops.set_attention_fp8(prev)
+    assert not np.array_equal(out, base), "the fp8 switch did not change the attention kernel"
+    assert nrms(out, base) < 5e-2, nrms(out, base)
+    for b in taps:
+        assert nrms(taps8[b], taps[b]) < 5e-2, (b, nrms(taps8[b], taps[b]))

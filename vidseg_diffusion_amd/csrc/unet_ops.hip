@@ -354,6 +354,175 @@ __global__ void __launch_bounds__(256, 3) k_attention(const bf16_t* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// FP8 attention (BASELINE configs[4]): Q, K, V and the probabilities P in OCP e4m3, fp32 accumulation and softmax,
+// fp16/bf16 output.  Same schedule as k_attention (32 queries per wave, S^T = K Q^T so the softmax statistics are
+// lane-local); v_mfma_f32_32x32x16_fp8_fp8 has the k mapping of the 16-bit form (lane: 8 consecutive k at 8*hi), so the
+// fragments are 8 bytes instead of 16: half the global and LDS bytes per flop.  Inputs are quantised once per call by
+// k_quant_fp8 (saturating round-to-nearest-even, v_cvt_pk_fp8_f32); P is scaled by 2^8 before rounding (see below).
+// ---------------------------------------------------------------------------------------------
+#define VT8_LD 68  // Vt[d][key] row stride in bytes: 17 dwords, conflict-free ds_read_b32 across d rows
+
+__global__ void __launch_bounds__(256) k_quant_fp8(const bf16_t* __restrict__ x, long long n8, unsigned char* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(x + i * 8);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(bf16_to_f32((bf16_t)v[e]), -448.f), 448.f);
+    int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+    int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+    *reinterpret_cast<u32x2*>(out + i * 8) = u32x2{(unsigned)w0, (unsigned)w1};
+}
+
+template <bool RAGGED>
+__global__ void __launch_bounds__(256, 3) k_attention_fp8(const unsigned char* __restrict__ q, int ldq, const unsigned char* __restrict__ k,
+                                                       int ldk, const unsigned char* __restrict__ v, int ldv, bf16_t* __restrict__ o,
+                                                       int ldo, int Nq, int Nk, int H, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) unsigned char sK2[2][64 * 64];        // K tile [key][d] bytes, 8-B slot XOR swizzle
+    __shared__ __attribute__((aligned(16))) unsigned char sVt2[2][64 * VT8_LD];   // V tile transposed [d][key]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const unsigned char* qp = q + (long long)b * Nq * ldq + h * 64;
+    const unsigned char* kp = k + (long long)b * Nk * ldk + h * 64;
+    const unsigned char* vp = v + (long long)b * Nk * ldv + h * 64;
+
+    long fq[4];                                             // Q^T as the B operand: query q0 + l31, d = s*16 + hi*8 .. +8
+    {
+        const int qi = min(q0 + l31, Nq - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fq[s] = *reinterpret_cast<const long*>(qp + (long long)qi * ldq + s * 16 + hi * 8);
+    }
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (Nk + 63) / 64;
+    // staging: thread -> (key = tid>>2, 16-byte chunk tid&3) of the 64 x 64-byte K and V tiles, one tile ahead in registers
+    u32x4 rk, rv;
+    const int st_key = tid >> 2, st_ch = tid & 3;
+    auto stage_load = [&](int t) {
+        const int key = min(t * 64 + st_key, Nk - 1);
+        rk = *reinterpret_cast<const u32x4*>(kp + (long long)key * ldk + st_ch * 16);
+        rv = *reinterpret_cast<const u32x4*>(vp + (long long)key * ldv + st_ch * 16);
+    };
+    auto stage_store = [&](int buf) {
+        const int sw = (st_key >> 2) & 7;
+        *reinterpret_cast<u32x2*>(sK2[buf] + st_key * 64 + (((st_ch * 2) ^ sw) << 3)) = u32x2{rk[0], rk[1]};
+        *reinterpret_cast<u32x2*>(sK2[buf] + st_key * 64 + (((st_ch * 2 + 1) ^ sw) << 3)) = u32x2{rk[2], rk[3]};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sVt2[buf][(st_ch * 16 + e) * VT8_LD + st_key] = (unsigned char)(rv[e >> 2] >> (8 * (e & 3)));
+    };
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * 64;
+        const unsigned char* sK = sK2[t & 1];
+        const unsigned char* sVt = sVt2[t & 1];
+        if (t + 1 < ntiles) stage_load(t + 1);
+        f32x16 sacc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = j * 32 + l31;
+            const int sw = (r >> 2) & 7;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const long fk = *reinterpret_cast<const long*>(sK + r * 64 + (((s * 2 + hi) ^ sw) << 3));
+                if (s == 0)
+                    sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(fk, fq[s], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                                                                          0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                else
+                    sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(fk, fq[s], sacc[j], 0, 0, 0);
+            }
+        }
+        if (RAGGED && k0 + 64 > Nk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= Nk) sacc[j][r] = -INFINITY;
+                }
+        }
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
+        const float m_new = fmaxf(m_run, mx);
+        vs_f32x2 psum2 = {0.f, 0.f};
+        // P is carried as 2^8 p (<= 256 < 448): e4m3 is normal down to 2^-6, so probabilities keep 3 mantissa bits down to
+        // 2^-14 of the row maximum instead of 2^-6; l_run carries the same factor, so O / l is unchanged
+        const vs_f32x2 sc2 = {scale_log2e, scale_log2e}, mn2 = {8.f - m_new, 8.f - m_new};
+        unsigned pk[2][4];                                  // 4 fp8 probabilities per word, accumulator order
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const vs_f32x2 a0 = vs_f32x2{sacc[j][g * 4 + 0], sacc[j][g * 4 + 1]} * sc2 + mn2;
+                const vs_f32x2 a1 = vs_f32x2{sacc[j][g * 4 + 2], sacc[j][g * 4 + 3]} * sc2 + mn2;
+                const vs_f32x2 p0 = {__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
+                const vs_f32x2 p1 = {__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
+                psum2 += p0;
+                psum2 += p1;
+                int w = __builtin_amdgcn_cvt_pk_fp8_f32(p0[0], p0[1], 0, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(p1[0], p1[1], w, true);
+                pk[j][g] = (unsigned)w;
+            }
+        float psum = psum2[0] + psum2[1];
+        psum += __shfl_xor(psum, 32, 64);
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            m_run = m_new;
+        }
+        l_run += psum;
+        // O^T[i] += V^T[d-block i] P^T : k-slices of 16 keys, lane's 8 k-slots = keys base + {0..3, 8..11} + 4*hi
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const u32x2 pw = {pk[j][s * 2 + 0], pk[j][s * 2 + 1]};
+                const long fp = *reinterpret_cast<const long*>(&pw);
+                const int kb = j * 32 + s * 16 + 4 * hi;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned char* vr = sVt + (i * 32 + l31) * VT8_LD + kb;
+                    const u32x2 pv = {*reinterpret_cast<const unsigned*>(vr), *reinterpret_cast<const unsigned*>(vr + 8)};
+                    oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(*reinterpret_cast<const long*>(&pv), fp, oacc[i], 0, 0, 0);
+                }
+            }
+        if (t + 1 < ntiles) stage_store((t + 1) & 1);
+        __syncthreads();
+    }
+    const int qi = q0 + l31;
+    if (qi < Nq) {
+        const float inv = 1.0f / l_run;
+        bf16_t* op = o + ((long long)b * Nq + qi) * ldo + h * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned w0 = (unsigned)f32_to_bf16(oacc[i][g * 4 + 0] * inv) | ((unsigned)f32_to_bf16(oacc[i][g * 4 + 1] * inv) << 16);
+                unsigned w1 = (unsigned)f32_to_bf16(oacc[i][g * 4 + 2] * inv) | ((unsigned)f32_to_bf16(oacc[i][g * 4 + 3] * inv) << 16);
+                *reinterpret_cast<u32x2*>(op + i * 32 + 8 * g + 4 * hi) = u32x2{w0, w1};
+            }
+    }
+}
+
 // Two query blocks per wave (64 queries): every K / V fragment read from LDS feeds two MFMAs -- half the LDS traffic per
 // flop of k_attention, at twice the accumulator registers (occupancy 2).
 template <bool RAGGED>
@@ -870,6 +1039,29 @@ int vidseg_attention_bf16(const void* q, int ldq, const void* k, int ldk, const 
         k_attention<true><<<dim3((Nq + 127) / 128, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
                                                                           (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
     VS_CHECK_LAUNCH("attention");
+    return VS_OK;
+}
+
+int vidseg_quant_fp8(const void* x, long long n, void* out_fp8, hipStream_t st) {
+    VS_REQUIRE(n % 8 == 0, "quant_fp8: n=%lld must be a multiple of 8", n);
+    if (n == 0) return VS_OK;
+    k_quant_fp8<<<dim3((unsigned)((n / 8 + 255) / 256)), 256, 0, st>>>((const bf16_t*)x, n / 8, (unsigned char*)out_fp8);
+    VS_CHECK_LAUNCH("quant_fp8");
+    return VS_OK;
+}
+
+int vidseg_attention_fp8(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int H, int Nq,
+                         int Nk, int head_dim, hipStream_t st) {
+    VS_REQUIRE(head_dim == 64, "attention_fp8: head_dim=%d (only 64 is on the path)", head_dim);
+    VS_REQUIRE(Nq > 0 && Nk > 0 && ldq % 16 == 0 && ldk % 16 == 0 && ldv % 16 == 0 && ldo % 4 == 0, "attention_fp8: bad sizes/strides");
+    const float scale_log2e = 0.125f * 1.44269504088896340736f;
+    if (Nk % 64 == 0)
+        k_attention_fp8<false><<<dim3((Nq + 127) / 128, B * H), 256, 0, st>>>((const unsigned char*)q, ldq, (const unsigned char*)k, ldk,
+                                                                               (const unsigned char*)v, ldv, (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
+    else
+        k_attention_fp8<true><<<dim3((Nq + 127) / 128, B * H), 256, 0, st>>>((const unsigned char*)q, ldq, (const unsigned char*)k, ldk,
+                                                                              (const unsigned char*)v, ldv, (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
+    VS_CHECK_LAUNCH("attention_fp8");
     return VS_OK;
 }
 

@@ -7,6 +7,7 @@ torch's current HIP stream and returns the output tensor it allocated.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -25,6 +26,8 @@ _lib.register({
     "vidseg_groupnorm_nhwc_bf16": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _I, _P, _P],
     "vidseg_layernorm_bf16": [_P, _L, _I, _P, _P, _F, _P, _P],
     "vidseg_attention_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vidseg_attention_fp8": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vidseg_quant_fp8": [_P, _L, _P, _P],
     "vidseg_timestep_embedding": [_P, _I, _I, _F, _P, _P],
     "vidseg_silu_bf16": [_P, _L, _P, _P],
     "vidseg_f32_to_bf16": [_P, _L, _P, _P],
@@ -220,13 +223,47 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return out
 
 
-def attention(q, k, v, heads, *, q_ld=None, k_ld=None, v_ld=None, Nq=None, Nk=None, B=None):
+_ATTN_FP8 = os.environ.get("VIDSEG_ATTN_FP8", "0") == "1"
+_ATTN_FP8_MIN_KEYS = 1024       # the one-off quantisation pays from here on (measured: 1024 keys break even, 4096 keys -18 %)
+
+
+def set_attention_fp8(on, min_keys=1024):
+    """Route the 64-wide-head attention (spatial self/cross attention of both UNets) with at least `min_keys` keys through the
+    OCP-e4m3 kernel (BASELINE configs[4]); also selectable with VIDSEG_ATTN_FP8=1.  Returns the previous on/off setting."""
+    global _ATTN_FP8, _ATTN_FP8_MIN_KEYS
+    prev, _ATTN_FP8, _ATTN_FP8_MIN_KEYS = _ATTN_FP8, bool(on), int(min_keys)
+    return prev
+
+
+def quant_fp8(x):
+    """fp16/bf16 -> OCP e4m3 bytes (saturating, round to nearest even); same shape, contiguous."""
+    assert x.is_contiguous() and x.dtype == act_dtype()
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    call("vidseg_quant_fp8", ptr(x), x.numel(), ptr(out), stream())
+    return out
+
+
+def attention(q, k, v, heads, *, q_ld=None, k_ld=None, v_ld=None, Nq=None, Nk=None, B=None, fp8=None):
     """softmax(q k^T / 8) v per 64-wide head.  q/k/v may be column slices of wider row-major buffers
-    (pass the data pointers' leading dimensions)."""
+    (pass the data pointers' leading dimensions).  fp8: quantise q, k, v (whole underlying buffers, once each) to e4m3
+    and run the fp8 MFMA kernel; the output stays in the activation dtype."""
     B = q.shape[0] if B is None else B
     Nq = q.shape[1] if Nq is None else Nq
     Nk = k.shape[1] if Nk is None else Nk
     out = torch.empty((B, Nq, heads * 64), dtype=act_dtype(), device=q.device)
+    if (_ATTN_FP8 and Nk >= _ATTN_FP8_MIN_KEYS) if fp8 is None else fp8:
+        done = {}
+
+        def q8(t):                                   # pointer of t's first element inside the quantised copy of its base buffer
+            base = t._base if t._base is not None else t
+            if base.data_ptr() not in done:
+                done[base.data_ptr()] = quant_fp8(base if base.is_contiguous() else base.contiguous())
+            return done[base.data_ptr()].data_ptr() + (t.data_ptr() - base.data_ptr()) // 2, done[base.data_ptr()]
+
+        (pq, _kq), (pk, _kk), (pv, _kv) = q8(q), q8(k), q8(v)
+        call("vidseg_attention_fp8", pq, q_ld or q.stride(1), pk, k_ld or k.stride(1), pv, v_ld or v.stride(1), ptr(out), heads * 64,
+             B, heads, Nq, Nk, 64, stream())
+        return out
     call("vidseg_attention_bf16", q.data_ptr(), q_ld or q.stride(1), k.data_ptr(), k_ld or k.stride(1), v.data_ptr(),
          v_ld or v.stride(1), ptr(out), heads * 64, B, heads, Nq, Nk, 64, stream())
     return out
