@@ -13,7 +13,7 @@ import json
 import sqlite3
 import sys
 
-FAMILY = ("k_gemm_tile", "k_gemm_dma", "k_gemm_conv")
+FAMILY = ("k_gemm_tile", "k_gemm_dma", "k_gemm_conv", "k_gemm_ph")
 
 
 def per_kernel(db_path, counter):
