@@ -128,7 +128,8 @@ int vidseg_linear_bf16(const void* a0, const void* a1, int C0, int C1, long long
  * Upsample = nearest x2 folded into the addressing) over the channel concat of x0 and x1 (skip connection,
  * OAI:912), + bias + per-sample emb vector (OAI:353-365) + residual (OAI:369).  pad = 1, or 0 for the first stage's
  * (0,1,0,1)-padded stride-2 Downsample (sgm/modules/diffusionmodules/model.py:84-91); out_f32 (optional) receives an fp32
- * copy of the result (the VAE's conv_out moments). */
+ * copy of the result (the VAE's conv_out moments).  Weight layout: [Cout][c/64][kh*3+kw][c%64] (channel-chunk-major K order:
+ * the 9 taps of a 64-channel chunk are consecutive K-tiles; C0 and C1 are multiples of 64). */
 int vidseg_conv3x3_bf16(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up,
                         const void* w, int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual,
                         void* out, int pad, float* out_f32 /*opt*/, vidseg_stream_t stream);
@@ -161,7 +162,7 @@ int vidseg_quant_fp8(const void* x, long long n, void* out_fp8, vidseg_stream_t 
 int vidseg_attention_fp8(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int H,
                          int Nq, int Nk, int head_dim, vidseg_stream_t stream);
 /* SVD (video) operators -- video_model.py:15-89 VideoResBlock, video_attention.py:18-489 */
-/* Conv3d kernel [3,1,1], padding [1,0,0] over frames; x NHWC [(b t)][HW][C], w [Cout][dt*Cin+c] (video_model.py:45-58) */
+/* Conv3d kernel [3,1,1], padding [1,0,0] over frames; x NHWC [(b t)][HW][C], w [Cout][c/64][dt][c%64] (video_model.py:45-58) */
 int vidseg_conv_temporal3_bf16(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
                                const float* rowvec, int rv_stride, const void* residual, void* out, vidseg_stream_t stream);
 /* bias-free projection with fp16 taps in the reference's temporal layout [(b s), t, c] (video_attention.py:152, ATT:330) */

@@ -49,6 +49,48 @@ struct GemmParams {
     int tap_T, tap_S;        // >0: taps are written in the reference's temporal layout [(b s), t, c] (row permutation)
     const float* rowadd;     // per-row scalar added to every column before the residual (attention-output modulation
                              // lambda*mask[:,None], attention.py:646-663, 697-719) or nullptr
+    int gn;                  // tile columns per panel of the launch order (panel_tile)
+    int taps, kchunk;        // K order of a conv weight row: k = (c / kchunk) * taps * kchunk + tap * kchunk + c % kchunk.
+                             // kchunk = 64 (channel-chunk major: the taps of one 64-channel chunk are consecutive K-tiles, so the
+                             // 9 shifted reads of an input pixel's 128-byte line are one K-tile apart and hit L1/L2 instead of
+                             // going back to memory 9 times) when Cin and C0 are multiples of 64, else kchunk = Cin (tap major)
+};
+
+// Tile order inside an XCD's contiguous chunk of logical ids: panels of gn tile columns, row-major inside a panel, so the tiles
+// resident together on an XCD form a (resident/gn) x gn block and share A slabs along rows and W slabs along columns through
+// that XCD's L2 (gn = tiles_n is plain row-major; the host picks gn to minimise rows*A_slab + gn*W_slab, see launch_gemm).
+__device__ __forceinline__ void panel_tile(long long bid, long long tiles_m, int tiles_n, int gn, long long& tm, int& tn) {
+    const long long per = tiles_m * gn;
+    const int npan = (tiles_n + gn - 1) / gn;
+    const int panel = (int)min((long long)(npan - 1), bid / per);
+    const int pn0 = panel * gn;
+    const int w = min(gn, tiles_n - pn0);
+    const long long within = bid - panel * per;
+    tm = within / w;
+    tn = pn0 + (int)(within % w);
+}
+
+// position of the next K-tile in that order: chunk base channel cq, tap, offset inside the chunk
+struct KCursor {
+    int cq, tap, sub;
+    __device__ __forceinline__ void init(int k, int taps, int kchunk) {
+        const int per = taps * kchunk;
+        cq = (k / per) * kchunk;
+        const int rem = k % per;
+        tap = rem / kchunk;
+        sub = rem % kchunk;
+    }
+    __device__ __forceinline__ int c0() const { return cq + sub; }
+    __device__ __forceinline__ void advance(int bk, int taps, int kchunk) {
+        sub += bk;
+        if (sub >= kchunk) {
+            sub = 0;
+            if (++tap == taps) {
+                tap = 0;
+                cq += kchunk;
+            }
+        }
+    }
 };
 
 #define BK 64
@@ -205,12 +247,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_conv(GemmParams p) {
     const long long tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = (p.N + BN - 1) / BN;
     const long long nwg = tiles_m * tiles_n;
-    const int split = p.ksplit > 1 ? (int)(blockIdx.x / nwg) : 0;
-    long long bid = p.ksplit > 1 ? (long long)(blockIdx.x % nwg) : (long long)blockIdx.x;
+    // blocks go to XCDs round-robin by blockIdx; give each XCD one contiguous chunk of the (split, tile) space, so a K split's
+    // tiles (which share that split's slice of W and of A's channels) meet in one L2
+    long long bid = blockIdx.x;
     {
-        const long long q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        const long long tot = nwg * max(p.ksplit, 1);
+        const long long q = tot / 8, r = tot % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int split = (int)(bid / nwg);
+    bid -= split * nwg;
     // `bid` is a position in a chunk that stays on one XCD (private 4 MB L2).  Default order: N-tile fastest, so the
     // tiles resident together share activation (A) rows.  For linears whose weight matrix is far larger than L2
     // (GEGLU projections, 6-26 MB) the order is flipped inside bands of ~tiles_m/8 M-tiles: N-tile outer, M-tile
@@ -269,7 +315,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_conv(GemmParams p) {
     const int ks_begin = p.ksplit > 1 ? (int)((long long)nk_all * split / p.ksplit) : 0;
     const int ks_end = p.ksplit > 1 ? (int)((long long)nk_all * (split + 1) / p.ksplit) : nk_all;
     int ld_k = ks_begin * BK;
-    int ld_tap = (ks_begin * BK) / Cin, ld_c0 = (ks_begin * BK) % Cin;   // K cursor of the next load (tap-major, then channel chunk)
+    KCursor cur;
+    cur.init(ld_k, p.taps, p.kchunk);
     const char* wbase = reinterpret_cast<const char*>(p.w);
     unsigned b_off[BR];
 #pragma unroll
@@ -279,10 +326,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm_conv(GemmParams p) {
     const char* a_src = reinterpret_cast<const char*>(p.x0);
     bool first_load = true;
     auto load_regs = [&](u32x4 (&ra)[AR], u32x4 (&rb)[BR]) {
-        const int tap = ld_tap, c0 = ld_c0;            // uniform
+        const int tap = cur.tap, c0 = cur.c0();        // uniform
         const int k0 = ld_k;
         // the pixel each A row reads changes only when the tap or the concat source changes (uniform branch)
-        if (first_load || c0 == 0 || c0 == p.C0) {
+        if (first_load || cur.sub == 0 || c0 == p.C0) {
             first_load = false;
             const bool second = c0 >= p.C0;
             a_src = reinterpret_cast<const char*>(second ? p.x1 : p.x0);
@@ -309,11 +356,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_conv(GemmParams p) {
         }
         const unsigned cbyte = (unsigned)(c0 >= p.C0 ? c0 - p.C0 : c0) * 2u;
         ld_k += BK;
-        ld_c0 += BK;
-        if (ld_c0 >= Cin) {
-            ld_c0 = 0;
-            ld_tap++;
-        }
+        cur.advance(BK, p.taps, p.kchunk);
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             u32x4 v = {0u, 0u, 0u, 0u};
@@ -412,14 +455,19 @@ __global__ void __launch_bounds__(256, NST == 2 ? 4 : 3) k_gemm_dma(GemmParams p
     const long long tiles_m = (p.M + 127) / 128;
     const int tiles_n = (p.N + 127) / 128;
     const long long nwg = tiles_m * tiles_n;
-    const int split = p.ksplit > 1 ? (int)(blockIdx.x / nwg) : 0;
-    long long bid = p.ksplit > 1 ? (long long)(blockIdx.x % nwg) : (long long)blockIdx.x;
+    // blocks go to XCDs round-robin by blockIdx; give each XCD one contiguous chunk of the (split, tile) space, so a K split's
+    // tiles (which share that split's slice of W and of A's channels) meet in one L2
+    long long bid = blockIdx.x;
     {
-        const long long q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        const long long tot = nwg * max(p.ksplit, 1);
+        const long long q = tot / 8, r = tot % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const long long tm = bid / tiles_n;
-    const int tn = (int)(bid % tiles_n);
+    const int split = (int)(bid / nwg);
+    bid -= split * nwg;
+    long long tm;
+    int tn;
+    panel_tile(bid, tiles_m, tiles_n, p.gn, tm, tn);
     const long long m0 = tm * 128;
     const int n0 = tn * 128;
 
@@ -465,12 +513,13 @@ __global__ void __launch_bounds__(256, NST == 2 ? 4 : 3) k_gemm_dma(GemmParams p
     const int ks_begin = p.ksplit > 1 ? (int)((long long)nk_all * split / p.ksplit) : 0;
     const int ks_end = p.ksplit > 1 ? (int)((long long)nk_all * (split + 1) / p.ksplit) : nk_all;
     int ld_k = ks_begin * DK;
-    int ld_tap = ld_k / Cin, ld_c0 = ld_k % Cin;
+    KCursor cur;
+    cur.init(ld_k, p.taps, p.kchunk);
     unsigned a_off[2] = {OOB, OOB};
     bool a_second = false, first = true;
     auto issue = [&](int buf) {
-        const int tap = ld_tap, c0 = ld_c0, k0 = ld_k;
-        if (first || c0 == 0 || c0 == p.C0) {
+        const int tap = cur.tap, c0 = cur.c0(), k0 = ld_k;
+        if (first || cur.sub == 0 || c0 == p.C0) {
             first = false;
             a_second = c0 >= p.C0;
             const int Cs = a_second ? p.C1 : p.C0;
@@ -495,11 +544,7 @@ __global__ void __launch_bounds__(256, NST == 2 ? 4 : 3) k_gemm_dma(GemmParams p
         }
         const unsigned cbyte = (unsigned)(c0 >= p.C0 ? c0 - p.C0 : c0) * 2u;
         ld_k += DK;
-        ld_c0 += DK;
-        if (ld_c0 >= Cin) {
-            ld_c0 = 0;
-            ld_tap++;
-        }
+        cur.advance(DK, p.taps, p.kchunk);
         char* A = smem + buf * BUF;
         char* B = A + TILE;
 #pragma unroll
@@ -608,14 +653,19 @@ __global__ void __launch_bounds__(WM * 128, MI == 1 ? 4 : (WM == 4 ? 1 : 2)) k_g
     const long long tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = (p.N + BN - 1) / BN;
     const long long nwg = tiles_m * tiles_n;
-    const int split = p.ksplit > 1 ? (int)(blockIdx.x / nwg) : 0;
-    long long bid = p.ksplit > 1 ? (long long)(blockIdx.x % nwg) : (long long)blockIdx.x;
+    // blocks go to XCDs round-robin by blockIdx; give each XCD one contiguous chunk of the (split, tile) space, so a K split's
+    // tiles (which share that split's slice of W and of A's channels) meet in one L2
+    long long bid = blockIdx.x;
     {
-        const long long q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        const long long tot = nwg * max(p.ksplit, 1);
+        const long long q = tot / 8, r = tot % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const long long tm = bid / tiles_n;
-    const int tn = (int)(bid % tiles_n);
+    const int split = (int)(bid / nwg);
+    bid -= split * nwg;
+    long long tm;
+    int tn;
+    panel_tile(bid, tiles_m, tiles_n, p.gn, tm, tn);
     const long long m0 = tm * BM;
     const int n0 = tn * BN;
 
@@ -664,14 +714,15 @@ __global__ void __launch_bounds__(WM * 128, MI == 1 ? 4 : (WM == 4 ? 1 : 2)) k_g
     const int ks_begin = p.ksplit > 1 ? (int)((long long)nk_all * split / p.ksplit) : 0;
     const int ks_end = p.ksplit > 1 ? (int)((long long)nk_all * (split + 1) / p.ksplit) : nk_all;
     int ld_k = ks_begin * BKT;
-    int ld_tap = ld_k / Cin, ld_c0 = ld_k % Cin;
+    KCursor cur;
+    cur.init(ld_k, p.taps, p.kchunk);
     unsigned a_off[APW];
 #pragma unroll
     for (int i = 0; i < APW; ++i) a_off[i] = OOB;
     bool a_second = false, first = true;
     auto issue = [&](int buf) {
-        const int tap = ld_tap, c0 = ld_c0, k0 = ld_k;
-        if (first || c0 == 0 || c0 == p.C0) {
+        const int tap = cur.tap, c0 = cur.c0(), k0 = ld_k;
+        if (first || cur.sub == 0 || c0 == p.C0) {
             first = false;
             a_second = c0 >= p.C0;
             const int Cs = a_second ? p.C1 : p.C0;
@@ -697,11 +748,7 @@ __global__ void __launch_bounds__(WM * 128, MI == 1 ? 4 : (WM == 4 ? 1 : 2)) k_g
         }
         const unsigned cbyte = (unsigned)(c0 >= p.C0 ? c0 - p.C0 : c0) * 2u;
         ld_k += BKT;
-        ld_c0 += BKT;
-        if (ld_c0 >= Cin) {
-            ld_c0 = 0;
-            ld_tap++;
-        }
+        cur.advance(BKT, p.taps, p.kchunk);
         char* A = smem + buf * BUF + wave * 1024;
         char* B = smem + buf * BUF + A_BYTES + wave * 1024;
 #pragma unroll
@@ -799,14 +846,19 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
     const long long tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = (p.N + BN - 1) / BN;
     const long long nwg = tiles_m * tiles_n;
-    const int split = p.ksplit > 1 ? (int)(blockIdx.x / nwg) : 0;
-    long long bid = p.ksplit > 1 ? (long long)(blockIdx.x % nwg) : (long long)blockIdx.x;
+    // blocks go to XCDs round-robin by blockIdx; give each XCD one contiguous chunk of the (split, tile) space, so a K split's
+    // tiles (which share that split's slice of W and of A's channels) meet in one L2
+    long long bid = blockIdx.x;
     {
-        const long long q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        const long long tot = nwg * max(p.ksplit, 1);
+        const long long q = tot / 8, r = tot % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const long long tm = bid / tiles_n;
-    const int tn = (int)(bid % tiles_n);
+    const int split = (int)(bid / nwg);
+    bid -= split * nwg;
+    long long tm;
+    int tn;
+    panel_tile(bid, tiles_m, tiles_n, p.gn, tm, tn);
     const long long m0 = tm * BM;
     const int n0 = tn * BN;
 
@@ -829,9 +881,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
     // index (kh = tap, wmul = Hout*Wout, hb = T); linear: one tap, ih0 = iw0 = 0.  Rows past M carry ih0 = -0x4000.
     const int hb = p.ksize == 1 ? 1 : (p.tmode ? p.T : Hup), wb = (p.ksize == 1 || p.tmode) ? 1 : Wup;
     const int wmul = p.tmode ? HWo : p.Win;
-    // a_base is needed only when the tap changes: it lives in LDS behind the tile buffers (a scratch spill there would drain vmcnt)
     int a_base[4], a_hw[4];                                            // a_hw = (ih0 + 0x4000) << 16 | (iw0 + 0x4000)
-    int4* a_base_lds = reinterpret_cast<int4*>(smem + 2 * (A_BYTES + B_BYTES)) + tid;
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
         const int r = (s4 >> 1) * 128 + (wave + 8 * (s4 & 1)) * 8 + lrow;
@@ -855,7 +905,6 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
         if (!ok) ih0 = -0x4000;
         a_hw[s4] = ((ih0 + 0x4000) << 16) | (iw0 + 0x4000);
     }
-    *a_base_lds = make_int4(a_base[0], a_base[1], a_base[2], a_base[3]);
     const int b_r0 = (wave >> 2) * (NJ * 32) + (wave & 3) * 8;              // first row of this wave's piece inside B block 0
     const int b_n = n0 + b_r0 + lrow;                                        // + g*32: the weight row this lane stages for block g
     const unsigned b_off0 = (unsigned)((long long)b_n * p.K * 2) + swz16;
@@ -864,49 +913,39 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
     const int ks_begin = p.ksplit > 1 ? (int)((long long)nk_all * split / p.ksplit) : 0;
     const int ks_end = p.ksplit > 1 ? (int)((long long)nk_all * (split + 1) / p.ksplit) : nk_all;
     const int nk = ks_end - ks_begin;
-    int ld_tap = (ks_begin * 64) / Cin, ld_c0 = (ks_begin * 64) % Cin;
-    // A byte offsets of the four staged rows for the (tap, source) the cursor is in; refreshed only when the cursor enters a
-    // new tap or crosses from x0 to x1 (every Cin/64 .. C0/64 tiles), so the read sections stay short
-    unsigned a_off[4];
-    unsigned a_cbyte = 0;
-    bool a_second = false, a_first = true;
-    auto a_prepare = [&]() {
-        if (a_first || ld_c0 == 0 || ld_c0 == p.C0) {
-            a_first = false;
-            a_second = ld_c0 >= p.C0;
-            const int Cs = a_second ? p.C1 : p.C0;
-            const int t3 = ld_tap / 3;
-            const int kh = p.tmode ? ld_tap : t3, kw = p.tmode ? 0 : ld_tap - t3 * 3;
-            const int4 ab4 = *a_base_lds;
-            const int ab[4] = {ab4.x, ab4.y, ab4.z, ab4.w};
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int ih = (a_hw[s4] >> 16) - 0x4000 + kh, iw = (a_hw[s4] & 0xFFFF) - 0x4000 + kw;
-                const bool ok = (unsigned)ih < (unsigned)hb && (unsigned)iw < (unsigned)wb;
-                const int pix = ab[s4] + (ih >> upsh) * wmul + (iw >> upsh);
-                a_off[s4] = ok ? (unsigned)(pix * Cs) * 2u + swz16 : OOB;
-            }
-        }
-        a_cbyte = (unsigned)(a_second ? ld_c0 - p.C0 : ld_c0) * 2u;
-        ld_c0 += 64;
-        if (ld_c0 >= Cin) {
-            ld_c0 = 0;
-            ld_tap++;
-        }
-    };
-    // stage group g of tile u into buffer buf (groups of one tile are staged in order g = 0, 1, ..)
+    // A addressing: with the chunk-major K order the tap changes every K-tile, so the two rows a stage call loads are addressed
+    // from (a_base, a_hw) on the spot (about 10 VALU ops per row, inside the read section that runs under the other half's MFMAs);
+    // the tile-uniform part (tap -> kh, kw; source; channel offset) is scalar
+    KCursor cur;
+    cur.init(ks_begin * 64, p.taps, p.kchunk);
+    int t_kh = 0, t_kw = 0, t_Cs = 0, t_cc = 0;
+    bool a_second = false;
+    // stage group g of tile u into buffer buf (groups of one tile are staged in order g = 0, 1, ..; the cursor moves after G1)
     auto stage = [&](int g, int u, int buf) {
 #if PH_EXP & 16
         const bool live = u < 2;
 #else
         const bool live = u < nk;
 #endif
-        if (g == 0) a_prepare();
+        if (g == 0) {
+            const int c0 = cur.c0();
+            a_second = c0 >= p.C0;
+            t_Cs = a_second ? p.C1 : p.C0;
+            t_cc = a_second ? c0 - p.C0 : c0;
+            const int t3 = cur.tap / 3;
+            t_kh = p.tmode ? cur.tap : t3;
+            t_kw = p.tmode ? 0 : cur.tap - t3 * 3;
+            cur.advance(64, p.taps, p.kchunk);
+        }
         if (g < 2) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                const int s4 = g * 2 + i;
                 char* dst = smem + buf * A_BYTES + (g * 128 + (wave + 8 * i) * 8) * RB;
-                const unsigned off = live ? a_off[g * 2 + i] + a_cbyte : OOB;
+                const int ih = (a_hw[s4] >> 16) - 0x4000 + t_kh, iw = (a_hw[s4] & 0xFFFF) - 0x4000 + t_kw;
+                const bool ok = live && (unsigned)ih < (unsigned)hb && (unsigned)iw < (unsigned)wb;
+                const int pix = a_base[s4] + (ih >> upsh) * wmul + (iw >> upsh);
+                const unsigned off = ok ? (unsigned)(pix * t_Cs + t_cc) * 2u + swz16 : OOB;
                 if (a_second)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
                 else
@@ -1265,6 +1304,8 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     VS_REQUIRE(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
     VS_REQUIRE(p.C0 % BK == 0 && p.C1 % BK == 0, "gemm: source channels (%d,%d) must be multiples of %d", p.C0, p.C1, BK);
     VS_REQUIRE(p.M > 0 && p.N > 0, "gemm: empty problem");
+    p.taps = p.ksize == 1 ? 1 : (p.tmode ? 3 : 9);
+    p.kchunk = p.ksize == 1 ? p.C0 + p.C1 : 64;                          // conv weights are packed chunk-major (see GemmParams)
     VS_REQUIRE(p.N % 8 == 0 && p.ldo % 8 == 0 && (!p.residual || p.ldr % 8 == 0) && (!p.tap || (p.tap_ld % 8 == 0 && p.tap_cols % 8 == 0)),
                "gemm: N=%d ldo=%d ldr=%d tap_ld=%d must be multiples of 8 (16-byte epilogue)", p.N, p.ldo, p.ldr, p.tap_ld);
     static bool attr = false;
@@ -1310,8 +1351,8 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)k_gemm_tile<5, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
             e = getenv("VIDSEG_GEMM_PH");                        // phased big tile (k_gemm_ph)
             ph_mode = e ? atoi(e) : 1;
-            (void)hipFuncSetAttribute((const void*)k_gemm_ph<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128 + 8192);
-            (void)hipFuncSetAttribute((const void*)k_gemm_ph<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128 + 8192);
+            (void)hipFuncSetAttribute((const void*)k_gemm_ph<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
+            (void)hipFuncSetAttribute((const void*)k_gemm_ph<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
         }
         // Blocks run in rounds over the resident slots, so the last round's fill decides the efficiency.  Pick the K
         // split that maximises fill / (1 + cost of writing+reading the fp32 partials); deterministic finish kernel.
@@ -1349,13 +1390,33 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             // unoverlapped prologue/epilogue (one block per CU) and the grid fills the chip
             big = big_mode == 2 || (fill >= 0.70 && p.K >= 960 && (S == 1 || p.K / S >= 1440));
         }
+        // panel width of the tile order: the `res` tiles resident on one XCD read (res/gn) A slabs and gn W slabs per pass
+        static int panel_mode = -1;
+        if (panel_mode < 0) { const char* e = getenv("VIDSEG_GEMM_PANEL"); panel_mode = e ? atoi(e) : 1; }
+        auto pick_gn = [&](int bm, int bn, int res, int split) {
+            const int tn_all = (p.N + bn - 1) / bn;
+            if (!panel_mode) return tn_all;
+            const double a_slab = (double)bm * (p.K / p.taps) * (p.stride * p.stride) / (double)(p.up * p.up);   // input bytes/2 behind a tile row
+            const double w_slab = (double)bn * p.K / split;
+            int best = tn_all;
+            double bc = 1e300;
+            for (int g = 1; g <= tn_all; ++g) {
+                const double c = (double)((res + g - 1) / g) * a_slab + (double)g * w_slab;
+                if (c < bc * 0.999) {
+                    bc = c;
+                    best = g;
+                }
+            }
+            return best;
+        };
         if (big) {
             p.ksplit = S;
             p.ws = S > 1 ? g_ws : nullptr;
+            p.gn = pick_gn(256, NJ * 64, 32, S);
             if (ph_mode && NJ == 5)
-                k_gemm_ph<5><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 320) * 128 + 8192, st>>>(p);
+                k_gemm_ph<5><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 320) * 128, st>>>(p);
             else if (ph_mode)
-                k_gemm_ph<4><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 256) * 128 + 8192, st>>>(p);
+                k_gemm_ph<4><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 256) * 128, st>>>(p);
             else if (NJ == 5)
                 k_gemm_tile<5, 4, 64><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 320) * 128, st>>>(p);
             else
@@ -1364,6 +1425,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         } else if (mid_mode && p.M >= 128 && (mid_mode == 2 || mid_ok)) {
             p.ksplit = 1;
             p.ws = nullptr;
+            p.gn = pick_gn(128, NJ * 64, 64, 1);
             if (NJ == 5)
                 k_gemm_tile<5, 4, 32, 1><<<dim3((unsigned)tiles_mid), 512, MID_LDS, st>>>(p);
             else
@@ -1373,6 +1435,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             S = pick_split(tiles, 512);
             p.ksplit = S;
             p.ws = S > 1 ? g_ws : nullptr;
+            p.gn = pick_gn(128, 128, 128, S);
             // grids that do not fill the 4 x 256 block slots gain from two K-steps in flight per block (measured -10..-20 %);
             // full grids prefer the fourth resident block (VIDSEG_GEMM_DMA=3 forces the 3-stage variant everywhere)
             if (use_dma == 3 || (use_dma == 1 && tiles * S <= 512 && p.act != 2))
@@ -1462,7 +1525,7 @@ int vidseg_linear_bf16_ttap(const void* a0, long long M, int C0, const void* w, 
 }
 
 // Conv3d with kernel [3,1,1], padding [1,0,0] over frames (video_model.py:45-58): x NHWC bf16 [(b t)][HW][C],
-// w packed [Cout][dt*Cin + c], + bias + per-sample emb vector + residual.
+// w packed [Cout][c/64][dt][c%64] (chunk-major K order, see GemmParams), + bias + per-sample emb vector + residual.
 int vidseg_conv_temporal3_bf16(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
                                const float* rowvec, int rv_stride, const void* residual, void* out, hipStream_t st) {
     VS_REQUIRE(T >= 1 && BT % T == 0, "conv_temporal3: BT=%d T=%d", BT, T);
@@ -1492,7 +1555,7 @@ int vidseg_conv_temporal3_bf16(const void* x, int C, int BT, int HW, int T, cons
     return launch_gemm(p, st);
 }
 
-// 3x3 convolution, padding 1, NHWC bf16 activations, weight packed [Cout][(kh*3+kw)*Cin + c].
+// 3x3 convolution, padding 1, NHWC bf16 activations, weight packed [Cout][c/64][kh*3+kw][c%64] (chunk-major K order).
 int vidseg_conv3x3_bf16(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up, const void* w,
                         int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual, void* out,
                         int pad, float* out_f32, hipStream_t st) {

@@ -77,9 +77,12 @@ def pack_linear(weight: torch.Tensor, device) -> torch.Tensor:
 
 
 def pack_conv3x3(weight: torch.Tensor, device) -> torch.Tensor:
-    """Conv2d weight [Cout, Cin, 3, 3] -> bf16 [Cout, (kh*3+kw)*Cin + c] for the NHWC implicit GEMM."""
+    """Conv2d weight [Cout, Cin, 3, 3] -> bf16 [Cout, c//64, kh*3+kw, c%64] flattened: the NHWC implicit GEMM walks K chunk-major
+    (the 9 taps of one 64-channel chunk are consecutive K-tiles, so the shifted re-reads of an input line hit L1/L2)."""
     co, ci, kh, kw = weight.shape
-    return weight.detach().permute(0, 2, 3, 1).reshape(co, kh * kw * ci).to(device=device, dtype=act_dtype()).contiguous()
+    assert ci % 64 == 0, "conv3x3: Cin must be a multiple of 64"
+    w = weight.detach().reshape(co, ci // 64, 64, kh * kw).permute(0, 1, 3, 2)
+    return w.reshape(co, kh * kw * ci).to(device=device, dtype=act_dtype()).contiguous()
 
 
 def pack_conv_in(weight: torch.Tensor, device) -> torch.Tensor:
@@ -386,9 +389,11 @@ def gemm_profile_kinds():
 
 # ----------------------------------------------------------------------------- video (SVD) operators
 def pack_conv_temporal3(weight: torch.Tensor, device) -> torch.Tensor:
-    """Conv3d weight [Cout, Cin, 3, 1, 1] -> bf16 [Cout, dt*Cin + c]."""
+    """Conv3d weight [Cout, Cin, 3, 1, 1] -> bf16 [Cout, c//64, dt, c%64] flattened (same chunk-major K order as pack_conv3x3)."""
     co, ci = weight.shape[:2]
-    return weight.detach().reshape(co, ci, 3).permute(0, 2, 1).reshape(co, 3 * ci).to(device=device, dtype=act_dtype()).contiguous()
+    assert ci % 64 == 0, "conv_temporal3: Cin must be a multiple of 64"
+    w = weight.detach().reshape(co, ci // 64, 64, 3).permute(0, 1, 3, 2)
+    return w.reshape(co, 3 * ci).to(device=device, dtype=act_dtype()).contiguous()
 
 
 def conv_temporal3(x, w, bias, T, *, rowvec=None, residual=None):
