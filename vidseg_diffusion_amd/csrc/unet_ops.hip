@@ -188,6 +188,18 @@ __global__ void __launch_bounds__(256) k_layernorm(const bf16_t* __restrict__ x,
     }
 }
 
+// Blocks reach the 8 XCDs round-robin by linear block id; give every XCD one contiguous chunk of the (head, query block) space so
+// the query blocks of a (sample, head) share its K/V through one L2 instead of fetching it on all eight.
+__device__ __forceinline__ void attn_block(int& bh, int& qb) {
+    const int gx = gridDim.x;
+    const long long tot = (long long)gx * gridDim.y;
+    const long long lin = (long long)blockIdx.y * gx + blockIdx.x;
+    const long long q = tot / 8, r = tot % 8, xcd = lin % 8, idx = lin / 8;
+    const long long id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bh = (int)(id / gx);
+    qb = (int)(id % gx);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Attention, head dim 64 (sgm/modules/attention.py:352-356: softmax(q k^T / sqrt(64)) v per head).
 // q: [B][Nq][*] rows with stride ldq, head h at column h*64; likewise k, v (stride ldk / ldv), out stride ldo.
@@ -206,8 +218,10 @@ __global__ void __launch_bounds__(256, 3) k_attention(const bf16_t* __restrict__
     __shared__ __attribute__((aligned(16))) bf16_t sVt2[2][64 * VT_LD];     // V tile transposed [d][key]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int bh = blockIdx.y, b = bh / H, h = bh % H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    int bh, qb;
+    attn_block(bh, qb);
+    const int b = bh / H, h = bh % H;
+    const int q0 = qb * 128 + wave * 32;
     const bf16_t* qp = q + (long long)b * Nq * ldq + h * 64;
     const bf16_t* kp = k + (long long)b * Nk * ldk + h * 64;
     const bf16_t* vp = v + (long long)b * Nk * ldv + h * 64;
@@ -385,8 +399,10 @@ __global__ void __launch_bounds__(256, 3) k_attention_fp8(const unsigned char* _
     __shared__ __attribute__((aligned(16))) unsigned char sVt2[2][64 * VT8_LD];   // V tile transposed [d][key]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int bh = blockIdx.y, b = bh / H, h = bh % H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    int bh, qb;
+    attn_block(bh, qb);
+    const int b = bh / H, h = bh % H;
+    const int q0 = qb * 128 + wave * 32;
     const unsigned char* qp = q + (long long)b * Nq * ldq + h * 64;
     const unsigned char* kp = k + (long long)b * Nk * ldk + h * 64;
     const unsigned char* vp = v + (long long)b * Nk * ldv + h * 64;
@@ -533,8 +549,10 @@ __global__ void __launch_bounds__(256, 2) k_attention2(const bf16_t* __restrict_
     __shared__ __attribute__((aligned(16))) bf16_t sVt2[2][64 * VT_LD];     // V tile transposed [d][key]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int bh = blockIdx.y, b = bh / H, h = bh % H;
-    const int q0 = blockIdx.x * 256 + wave * 64;
+    int bh, qb;
+    attn_block(bh, qb);
+    const int b = bh / H, h = bh % H;
+    const int q0 = qb * 256 + wave * 64;
     const bf16_t* qp = q + (long long)b * Nq * ldq + h * 64;
     const bf16_t* kp = k + (long long)b * Nk * ldk + h * 64;
     const bf16_t* vp = v + (long long)b * Nk * ldv + h * 64;
