@@ -319,8 +319,19 @@ def main():
             for _ in range(3):
                 encode_first_stage(vae, frames, 0.18215, noise=nz)
             torch.cuda.synchronize()
-            out["first_stage"] = {"encode_ms_per_window": round(1e3 * (time.perf_counter() - tv) / 3, 2), "frames": F_WIN,
-                                  "image": [ih, iw], "note": "AutoencoderKL.encode, synthetic weights; excluded from `value`"}
+            enc_ms = 1e3 * (time.perf_counter() - tv) / 3
+            from vidseg_diffusion_amd.vae import decode_first_stage
+            zz = encode_first_stage(vae, frames, 0.18215, noise=nz)
+            for _ in range(2):
+                decode_first_stage(vae, zz, 0.18215)
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(3):
+                decode_first_stage(vae, zz, 0.18215)
+            torch.cuda.synchronize()
+            out["first_stage"] = {"encode_ms_per_window": round(enc_ms, 2), "decode_ms_per_window": round(1e3 * (time.perf_counter() - tv) / 3, 2),
+                                  "frames": F_WIN, "image": [ih, iw],
+                                  "note": "AutoencoderKL.encode / .decode (SD image decoder), synthetic weights; excluded from `value`"}
         if not args.no_cpu_baseline and not args.narrow and not svd and world == 1:     # host-side legs: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg)
             out["mask_iou_vs_oracle"] = mask_iou_check(eng, sd_cpu, cfg, dev)

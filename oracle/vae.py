@@ -1,12 +1,17 @@
-"""Oracle (CPU restatement) of the first stage's encode side -- test infrastructure only.
+"""Oracle (CPU restatement) of the first stage (encode and decode) -- test infrastructure only.
 
     sgm/modules/diffusionmodules/model.py:487-600  Encoder.forward (ResnetBlock :94-151, Downsample :72-91, AttnBlock :161-202)
     sgm/models/autoencoder.py:469-489              AutoencodingEngineLegacy.encode (quant_conv, regularizer)
     sgm/modules/distributions/distributions.py:24-41  DiagonalGaussianDistribution (clamp, std, sample)
     sgm/models/diffusion.py:138-151                encode_first_stage (* scale_factor)
 
-Functional torch-CPU fp32, driven by the reference's state-dict keys.  Pinned by tests/golden/vae_encoder_narrow.npz
-(tools/gen_golden_vae.py runs the reference's own Encoder / DiagonalGaussianDistribution).
+    sgm/modules/diffusionmodules/model.py:604-748  Decoder.forward (Upsample :58-71)
+    sgm/models/autoencoder.py:490-506              decode (post_quant_conv -> decoder)
+    sgm/models/diffusion.py:117-136                decode_first_stage (z / scale_factor)
+
+Functional torch-CPU fp32, driven by the reference's state-dict keys.  Pinned by tests/golden/vae_encoder_narrow.npz and
+tests/golden/vae_decoder_narrow.npz (tools/gen_golden_vae.py runs the reference's own Encoder / Decoder /
+DiagonalGaussianDistribution).
 `round_bf16=True` rounds activations where the HIP path stores bf16 (format-error yardstick for the GPU tests).
 """
 from __future__ import annotations
@@ -81,3 +86,27 @@ class VAEEncoderOracle:
         mean, logvar = torch.chunk(mom, 2, dim=1)
         std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
         return scale_factor * (mean + std * noise)
+
+
+class VAEDecoderOracle(VAEEncoderOracle):
+    """decoder.* / post_quant_conv.* keys; same block restatements as the encoder."""
+
+    def decode(self, z, scale_factor=1.0):
+        """z [B, embed, h, w] (already divided by nothing: scale_factor is applied here like decode_first_stage) -> [B, 3, 8h, 8w]."""
+        h = self.conv(z * (1.0 / scale_factor), "post_quant_conv", pad=0)
+        h = _bf(self.conv(h, "decoder.conv_in"), self.rb)
+        h = self.resnet(h, "decoder.mid.block_1")
+        h = self.attn(h, "decoder.mid.attn_1")
+        h = self.resnet(h, "decoder.mid.block_2")
+        lvl = 0
+        while self.has(f"decoder.up.{lvl + 1}."):
+            lvl += 1
+        for i in range(lvl, -1, -1):
+            j = 0
+            while self.has(f"decoder.up.{i}.block.{j}."):
+                h = self.resnet(h, f"decoder.up.{i}.block.{j}")
+                j += 1
+            if self.has(f"decoder.up.{i}.upsample."):
+                h = _bf(self.conv(F.interpolate(h, scale_factor=2.0, mode="nearest"), f"decoder.up.{i}.upsample.conv"), self.rb)
+        h = _bf(self.swish(self.gn(h, "decoder.norm_out")), self.rb)
+        return self.conv(h, "decoder.conv_out")

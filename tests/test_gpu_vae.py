@@ -37,6 +37,30 @@ def test_vae_encoder_vs_reference():
     assert torch.equal(z2, z)
 
 
+def test_vae_decoder_vs_reference():
+    """AutoencoderKL.decode behind decode_first_stage vs the reference's Decoder(post_quant_conv(z / scale)) golden."""
+    from oracle.vae import VAEDecoderOracle
+    from tests.test_oracle_vae import narrow_decoder_state_dict
+    from vidseg_diffusion_amd._lib import VidsegError
+    from vidseg_diffusion_amd.vae import decode_first_stage
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vae_decoder_narrow.npz"))
+    net, shapes, sd = narrow_decoder_state_dict(g["pq_bias"])
+    net.load_state_dict(sd)
+    with pytest.raises(VidsegError):
+        net.moments(torch.zeros(1, 3, 64, 64, device=dev))          # no encoder weights in this state dict
+    z = torch.from_numpy(g["z"]).to(dev)
+    out = decode_first_stage(net, z, 0.18215).cpu().numpy()
+    assert out.shape == g["out"].shape
+    fmt = nrms(VAEDecoderOracle(sd, round_bf16=act_mode()[0]).decode(torch.from_numpy(g["z"]), 0.18215).numpy(), g["out"])
+    err = nrms(out, g["out"])
+    print("vae decoder nrms", err, "16-bit format", fmt)
+    assert err < act_mode()[1] and err <= 1.5 * fmt + 5e-3, (err, fmt)
+    # chunked decode (en_and_decode_n_samples_a_time = 1) gives the same frames
+    out1 = decode_first_stage(net, z, 0.18215, n_samples=1).cpu().numpy()
+    assert np.array_equal(out1, out)
+
+
 def test_asymmetric_downsample_and_softmax_ops():
     from vidseg_diffusion_amd import ops
     dev = torch.device("cuda:0")

@@ -43,5 +43,31 @@ def main():
           "logvar range", float(mom[:, 4:].min()), float(mom[:, 4:].max()))
 
 
+def main_decoder():
+    """tests/golden/vae_decoder_narrow.npz: the reference's Decoder behind post_quant_conv (autoencoder.py:490-506)."""
+    import_reference()
+    from sgm.modules.diffusionmodules.model import Decoder
+    torch.set_grad_enabled(False)
+    dec = Decoder(**VAE_NARROW).eval()
+    pq = torch.nn.Conv2d(4, 4, 1)
+    shapes = {"decoder." + k: tuple(v.shape) for k, v in dec.state_dict().items()}
+    shapes.update({"post_quant_conv." + k: tuple(v.shape) for k, v in pq.state_dict().items()})
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=1357, gain=1.0).items()}
+    # biases are zero in the synthetic filler; give post_quant_conv one so the padding interaction of the folded conv is exercised
+    sd["post_quant_conv.bias"] = torch.tensor([0.3, -0.2, 0.1, 0.25])
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")})
+    pq.load_state_dict({k[len("post_quant_conv."):]: v for k, v in sd.items() if k.startswith("post_quant_conv.")})
+    g = np.random.Generator(np.random.PCG64(78))
+    z = (g.standard_normal((2, 4, 8, 8)).astype(np.float32) * 0.18215 * 4)
+    out = dec(pq(torch.from_numpy(z) / 0.18215))
+    rec = dict(z=z, out=out.numpy(), pq_bias=sd["post_quant_conv.bias"].numpy(), state_dict_signature=synthetic.state_dict_signature(shapes))
+    path = os.path.join(ROOT, "tests", "golden", "vae_decoder_narrow.npz")
+    np.savez_compressed(path, **rec)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; out absmax", float(np.abs(rec["out"]).max()), "rms", float(out.pow(2).mean().sqrt()))
+
+
 if __name__ == "__main__":
-    main()
+    if "--decoder" in sys.argv:
+        main_decoder()
+    else:
+        main()

@@ -1,4 +1,4 @@
-"""First stage, encode side: `AutoencoderKL.encode` of the reference on MI355X.
+"""First stage: `AutoencoderKL.encode` and `.decode` of the reference on MI355X.
 
     sgm/models/autoencoder.py:437-522   AutoencodingEngineLegacy / AutoencoderKL: encoder -> quant_conv -> regularizer
     sgm/modules/diffusionmodules/model.py:84-91 (Downsample), 94-151 (ResnetBlock), 161-202 (AttnBlock),
@@ -11,7 +11,12 @@ Same constructor kwargs and state-dict keys as the reference (`encoder.*`, `quan
 same kernels as the UNet: k_conv_in (Cin = 3), implicit-GEMM 3x3 convs (the (0,1,0,1)-padded stride-2 Downsample is the
 `pad=0` form), GroupNorm(eps 1e-6)+swish, 1x1 convs as linears.  The one single-head attention of dim `block_in` (512)
 over H/8*W/8 tokens runs per frame as GEMM (fp32 logits) -> row softmax -> GEMM.  `quant_conv` (1x1, 8 -> 8) is folded
-into `conv_out`'s weights at pack time (exact algebra: W' = Wq Wc, b' = Wq bc + bq).  The decoder is not built.
+into `conv_out`'s weights at pack time (exact algebra: W' = Wq Wc, b' = Wq bc + bq).
+
+Decode side (model.py:604-748 Decoder, :58-71 Upsample; autoencoder.py:490-506 decode; diffusion.py:117-136
+decode_first_stage): `post_quant_conv` (1x1, embed -> z) is folded into the decoder's `conv_in` (z = 4 input channels: the
+UNet's small-Cin kernel), the nearest-2x Upsample is folded into its conv's addressing (`up=2`), `conv_out` (128 -> 3) runs on
+the UNet's 4-output-channel kernel with a zero fourth filter.  The SVD `VideoDecoder` (temporal_ae.py) is not built.
 """
 from __future__ import annotations
 
@@ -41,6 +46,22 @@ class Downsample(nn.Module):
 
     def run(self, x):
         return ops.conv3x3(x, self.w, self.b, stride=2, pad=0)
+
+
+class Upsample(nn.Module):
+    """model.py:58-71 with_conv=True: nearest x2, then 3x3 conv (one kernel: the upsample is an address shift)."""
+
+    def __init__(self, in_channels, with_conv=True):
+        super().__init__()
+        if not with_conv:
+            raise NotImplementedError("Upsample(with_conv=False) is not on the path")
+        self.conv = _meta(nn.Conv2d, in_channels, in_channels, 3, stride=1, padding=1)
+
+    def pack(self, dev):
+        self.w, self.b = ops.pack_conv3x3(self.conv.weight, dev), ops.f32(self.conv.bias, dev)
+
+    def run(self, x):
+        return ops.conv3x3(x, self.w, self.b, up=2)
 
 
 class ResnetBlock(nn.Module):
@@ -153,8 +174,43 @@ class Encoder(nn.Module):
         self.conv_out = _meta(nn.Conv2d, block_in, 2 * z_channels if double_z else z_channels, 3, padding=1)
 
 
+class Decoder(nn.Module):
+    """model.py:604-748 (attn_resolutions = [], attn_type "vanilla", no tanh_out / give_pre_end)."""
+
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions=(), dropout=0.0, resamp_with_conv=True,
+                 in_channels, resolution, z_channels, give_pre_end=False, tanh_out=False, use_linear_attn=False,
+                 attn_type="vanilla", **ignore_kwargs):
+        super().__init__()
+        if list(attn_resolutions) or use_linear_attn or give_pre_end or tanh_out or attn_type not in ("vanilla", "vanilla-xformers"):
+            raise NotImplementedError("Decoder: only the AutoencoderKL configuration is on the path")
+        if ch % 64 != 0 or out_ch > 4:
+            raise NotImplementedError("Decoder: ch must be a multiple of 64 and out_ch <= 4")
+        self.ch, self.num_resolutions, self.num_res_blocks, self.out_ch = ch, len(ch_mult), num_res_blocks, out_ch
+        block_in = ch * ch_mult[self.num_resolutions - 1]
+        self.conv_in = _meta(nn.Conv2d, z_channels, block_in, 3, padding=1)
+        self.mid = _Level()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, dropout=dropout)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, dropout=dropout)
+        ups = []
+        for i_level in reversed(range(self.num_resolutions)):
+            block_out = ch * ch_mult[i_level]
+            level = _Level()
+            level.block = nn.ModuleList()
+            level.attn = nn.ModuleList()
+            for _ in range(num_res_blocks + 1):
+                level.block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, dropout=dropout))
+                block_in = block_out
+            if i_level != 0:
+                level.upsample = Upsample(block_in, resamp_with_conv)
+            ups.insert(0, level)                                     # `up.0` is the full-resolution level, like the reference
+        self.up = nn.ModuleList(ups)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = _meta(nn.Conv2d, block_in, out_ch, 3, padding=1)
+
+
 class AutoencoderKL(nn.Module):
-    """sgm/models/autoencoder.py:508-522 (+ :437-506), encode side, with DiagonalGaussianRegularizer(sample=True)."""
+    """sgm/models/autoencoder.py:508-522 (+ :437-506) with DiagonalGaussianRegularizer(sample=True)."""
 
     def __init__(self, embed_dim=4, ddconfig=None, lossconfig=None, loss_config=None, monitor=None, ckpt_path=None,
                  ckpt_engine=None, max_batch_size=None, **ignored):
@@ -162,6 +218,8 @@ class AutoencoderKL(nn.Module):
         if ddconfig is None:
             raise ValueError("AutoencoderKL needs ddconfig")
         self.encoder = Encoder(**ddconfig)
+        self.decoder = Decoder(**ddconfig)
+        self.post_quant_conv = _meta(nn.Conv2d, embed_dim, ddconfig["z_channels"], 1)
         zc = (1 + bool(ddconfig.get("double_z", True))) * ddconfig["z_channels"]
         self.quant_conv = _meta(nn.Conv2d, zc, (1 + bool(ddconfig.get("double_z", True))) * embed_dim, 1)
         self.embed_dim = embed_dim
@@ -170,11 +228,17 @@ class AutoencoderKL(nn.Module):
 
     # ------------------------------------------------------------------ packing
     def load_state_dict(self, state_dict, strict=False, assign=True):
-        own = {k: v for k, v in state_dict.items() if k.startswith("encoder.") or k.startswith("quant_conv.")}
+        own = {k: v for k, v in state_dict.items() if k.split(".")[0] in ("encoder", "quant_conv", "decoder", "post_quant_conv")}
+        self._packed_on = None
         return super().load_state_dict(own, strict=strict, assign=True)
 
     def pack(self, dev):
+        self._pack_decoder(dev)
+        self._packed_on = dev
         e = self.encoder
+        self._enc_ready = not any(t.is_meta for t in list(e.parameters()) + list(self.quant_conv.parameters()))
+        if not self._enc_ready:                                       # decoder-only state dict
+            return
         self.cin_w, self.cin_b = ops.pack_conv_in(e.conv_in.weight, dev), ops.f32(e.conv_in.bias, dev)
         for level in e.down:
             for blk in level.block:
@@ -196,7 +260,40 @@ class AutoencoderKL(nn.Module):
             wf = torch.cat([wf, wf.new_zeros((pad,) + tuple(wf.shape[1:]))], 0)
             bf = torch.cat([bf, bf.new_zeros(pad)], 0)
         self.out_w, self.out_b = ops.pack_conv3x3(wf.float(), dev), ops.f32(bf.float(), dev)
-        self._packed_on = dev
+
+    def _pack_decoder(self, dev):
+        d = self.decoder
+        self._dec_ready = not any(t.is_meta for t in list(d.parameters()) + list(self.post_quant_conv.parameters()))
+        if not self._dec_ready:                                       # encoder-only checkpoint
+            return
+        # post_quant_conv (1x1, embed -> z) then conv_in (3x3, z -> C): W'[o,e,kh,kw] = sum_z Wc[o,z,kh,kw] Wp[z,e]; the bias of
+        # the 1x1 passes through the 3x3's zero padding only where the tap is inside the image, so it stays a separate input
+        # channel: a constant-one plane appended to z carries it exactly (Cin = embed + 1 <= 8)
+        wp = self.post_quant_conv.weight.detach().double().reshape(self.post_quant_conv.weight.shape[0], -1)      # [z, e]
+        wc = d.conv_in.weight.detach().double()                                                                     # [C, z, 3, 3]
+        w_e = torch.einsum("ozkl,ze->oekl", wc, wp)
+        w_one = torch.einsum("ozkl,z->okl", wc, self.post_quant_conv.bias.detach().double()).unsqueeze(1)
+        wf = torch.cat([w_e, w_one], 1)                                                                             # [C, e+1, 3, 3]
+        self.dec_cin = wf.shape[1]
+        pad = (4 if self.dec_cin <= 4 else 8) - self.dec_cin
+        if pad < 0:
+            raise NotImplementedError("Decoder: embed_dim + 1 must be <= 8")
+        wf = torch.cat([wf, wf.new_zeros((wf.shape[0], pad, 3, 3))], 1)
+        self.dec_cin_pad = wf.shape[1]
+        self.din_w, self.din_b = ops.pack_conv_in(wf.float(), dev), ops.f32(d.conv_in.bias, dev)
+        for m in (d.mid.block_1, d.mid.attn_1, d.mid.block_2):
+            m.pack(dev)
+        for level in d.up:
+            for blk in level.block:
+                blk.pack(dev)
+            if hasattr(level, "upsample"):
+                level.upsample.pack(dev)
+        self.dno_g, self.dno_b = ops.f32(d.norm_out.weight, dev), ops.f32(d.norm_out.bias, dev)
+        wo, bo = d.conv_out.weight.detach(), d.conv_out.bias.detach()
+        if wo.shape[0] < 4:                                            # the 4-output-channel kernel: zero filters for the rest
+            wo = torch.cat([wo, wo.new_zeros((4 - wo.shape[0],) + tuple(wo.shape[1:]))], 0)
+            bo = torch.cat([bo, bo.new_zeros(4 - bo.shape[0])], 0)
+        self.dout_w, self.dout_b = ops.pack_conv_out(wo, dev), ops.f32(bo, dev)
 
     # ------------------------------------------------------------------ forward
     def moments(self, x):
@@ -205,6 +302,8 @@ class AutoencoderKL(nn.Module):
             raise VidsegError("AutoencoderKL runs on a HIP device only (no CPU fallback)")
         if self._packed_on is None:
             self.pack(x.device)
+        if not self._enc_ready:
+            raise VidsegError("AutoencoderKL.encode: the loaded state dict has no encoder.* / quant_conv.* weights")
         e = self.encoder
         h = ops.conv_in(x.float().permute(0, 2, 3, 1).contiguous(), self.cin_w, self.cin_b)
         for level in e.down:
@@ -232,8 +331,37 @@ class AutoencoderKL(nn.Module):
         z = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
         return (z, {}) if return_reg_log else z
 
-    def decode(self, z, **kw):
-        raise NotImplementedError("the first-stage decoder is not built (SURVEY.md §8(f) rank 1/2)")
+    def _decode_batch(self, z):
+        d = self.decoder
+        B, E, h, w = z.shape
+        zin = torch.zeros((B, h, w, self.dec_cin_pad), dtype=torch.float32, device=z.device)
+        zin[..., :E] = z.float().permute(0, 2, 3, 1)
+        zin[..., E] = 1.0                                              # carries post_quant_conv's bias through the 3x3's padding
+        x = ops.conv_in(zin, self.din_w, self.din_b)
+        x = d.mid.block_1.run(x)
+        x = d.mid.attn_1.run(x)
+        x = d.mid.block_2.run(x)
+        for i_level in reversed(range(d.num_resolutions)):
+            level = d.up[i_level]
+            for blk in level.block:
+                x = blk.run(x)
+            if hasattr(level, "upsample"):
+                x = level.upsample.run(x)
+        x = ops.groupnorm(x, self.dno_g, self.dno_b, eps=1e-6, silu=True)
+        return ops.conv_out4(x, self.dout_w, self.dout_b)[:, :d.out_ch]
+
+    def decode(self, z, **decoder_kwargs):
+        """autoencoder.py:490-506: post_quant_conv -> decoder, `max_batch_size` frames at a time.  z: fp32 NCHW [B, embed, h, w]
+        on the device -> fp32 NCHW [B, out_ch, 8h, 8w]."""
+        if not z.is_cuda:
+            raise VidsegError("AutoencoderKL runs on a HIP device only (no CPU fallback)")
+        if self._packed_on is None:
+            self.pack(z.device)
+        if not self._dec_ready:
+            raise VidsegError("AutoencoderKL.decode: the loaded state dict has no decoder.* / post_quant_conv.* weights")
+        bs = self.max_batch_size or z.shape[0]
+        outs = [self._decode_batch(z[i:i + bs]) for i in range(0, z.shape[0], bs)]
+        return torch.cat(outs, 0) if len(outs) > 1 else outs[0].contiguous()
 
 
 def encode_first_stage(first_stage_model: AutoencoderKL, x, scale_factor=0.18215, n_samples=None, noise=None):
@@ -241,4 +369,12 @@ def encode_first_stage(first_stage_model: AutoencoderKL, x, scale_factor=0.18215
     n = n_samples or x.shape[0]
     outs = [first_stage_model.encode(x[i:i + n], noise=None if noise is None else noise[i:i + n], scale=scale_factor)
             for i in range(0, x.shape[0], n)]
+    return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+
+
+def decode_first_stage(first_stage_model: AutoencoderKL, z, scale_factor=0.18215, n_samples=None):
+    """sgm/models/diffusion.py:117-136: z / scale_factor, decoded `n_samples` (en_and_decode_n_samples_a_time) at a time."""
+    z = z.float() * (1.0 / scale_factor)
+    n = n_samples or z.shape[0]
+    outs = [first_stage_model.decode(z[i:i + n]) for i in range(0, z.shape[0], n)]
     return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
