@@ -539,6 +539,157 @@ __global__ void __launch_bounds__(256, 3) k_attention_fp8(const unsigned char* _
     }
 }
 
+// The same attention on the block-scaled instruction v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 operands, unit E8M0 scales): K = 64
+// per instruction at twice the 16-bit rate, so S^T of a 64-key tile is two MFMAs (d = 64 is one K) and O^T += V^T P^T two more,
+// instead of sixteen 32x32x16 ones.  Operand layout (checked on the device by tools/dbg/ubench/mx_layout.hip): lane l holds row
+// l & 31 and the 32 contiguous k of block l >> 5.  After S^T a lane owns the keys with bit 2 == hi of BOTH 32-key blocks; one
+// lane <-> lane+32 exchange of four words gives it all 32 keys of block hi, in natural order, which is how V^T is read.
+#define VT8M_LD 80   // Vt[d][key] row stride in bytes: 5 x 16, conflict-free ds_read_b128 across d rows
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+
+template <bool RAGGED>
+__global__ void __launch_bounds__(256, 3) k_attention_mx8(const unsigned char* __restrict__ q, int ldq, const unsigned char* __restrict__ k,
+                                                       int ldk, const unsigned char* __restrict__ v, int ldv, bf16_t* __restrict__ o,
+                                                       int ldo, int Nq, int Nk, int H, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) unsigned char sK2[2][64 * 64];        // K tile [key][d], 16-B slot ^ ((key>>2)&3)
+    __shared__ __attribute__((aligned(16))) unsigned char sVt2[2][64 * VT8M_LD];  // V tile transposed [d][key]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int bh, qb;
+    attn_block(bh, qb);
+    const int b = bh / H, h = bh % H;
+    const int q0 = qb * 128 + wave * 32;
+    const unsigned char* qp = q + (long long)b * Nq * ldq + h * 64;
+    const unsigned char* kp = k + (long long)b * Nk * ldk + h * 64;
+    const unsigned char* vp = v + (long long)b * Nk * ldv + h * 64;
+    constexpr int ONE = 0x7f7f7f7f;                         // E8M0 127 = 2^0 in every byte
+
+    v8i_t fq;                                               // Q^T as the B operand: query q0 + l31, d = 32*hi .. +32
+    {
+        const int qi = min(q0 + l31, Nq - 1);
+        const u32x4 a = *reinterpret_cast<const u32x4*>(qp + (long long)qi * ldq + hi * 32);
+        const u32x4 c = *reinterpret_cast<const u32x4*>(qp + (long long)qi * ldq + hi * 32 + 16);
+        fq = v8i_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
+    }
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (Nk + 63) / 64;
+    u32x4 rk, rv;
+    const int st_key = tid >> 2, st_ch = tid & 3;
+    auto stage_load = [&](int t) {
+        const int key = min(t * 64 + st_key, Nk - 1);
+        rk = *reinterpret_cast<const u32x4*>(kp + (long long)key * ldk + st_ch * 16);
+        rv = *reinterpret_cast<const u32x4*>(vp + (long long)key * ldv + st_ch * 16);
+    };
+    auto stage_store = [&](int buf) {
+        *reinterpret_cast<u32x4*>(sK2[buf] + st_key * 64 + ((st_ch ^ ((st_key >> 2) & 3)) << 4)) = rk;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sVt2[buf][(st_ch * 16 + e) * VT8M_LD + st_key] = (unsigned char)(rv[e >> 2] >> (8 * (e & 3)));
+    };
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * 64;
+        const unsigned char* sK = sK2[t & 1];
+        const unsigned char* sVt = sVt2[t & 1];
+        if (t + 1 < ntiles) stage_load(t + 1);
+        f32x16 sacc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = j * 32 + l31;
+            const int sw = (r >> 2) & 3;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(sK + r * 64 + (((2 * hi) ^ sw) << 4));
+            const u32x4 c = *reinterpret_cast<const u32x4*>(sK + r * 64 + (((2 * hi + 1) ^ sw) << 4));
+            const v8i_t fk = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
+            sacc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fk, fq, zero16, 0, 0, 0, ONE, 0, ONE);
+        }
+        if (RAGGED && k0 + 64 > Nk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= Nk) sacc[j][r] = -INFINITY;
+                }
+        }
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
+        const float m_new = fmaxf(m_run, mx);
+        vs_f32x2 psum2 = {0.f, 0.f};
+        const vs_f32x2 sc2 = {scale_log2e, scale_log2e}, mn2 = {8.f - m_new, 8.f - m_new};     // P carried as 2^8 p (see k_attention_fp8)
+        unsigned pk[2][4];                                  // word g of block j: keys j*32 + 8g + 4hi + 0..3
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const vs_f32x2 a0 = vs_f32x2{sacc[j][g * 4 + 0], sacc[j][g * 4 + 1]} * sc2 + mn2;
+                const vs_f32x2 a1 = vs_f32x2{sacc[j][g * 4 + 2], sacc[j][g * 4 + 3]} * sc2 + mn2;
+                const vs_f32x2 p0 = {__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
+                const vs_f32x2 p1 = {__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
+                psum2 += p0;
+                psum2 += p1;
+                int w = __builtin_amdgcn_cvt_pk_fp8_f32(p0[0], p0[1], 0, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(p1[0], p1[1], w, true);
+                pk[j][g] = (unsigned)w;
+            }
+        float psum = psum2[0] + psum2[1];
+        psum += __shfl_xor(psum, 32, 64);
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            m_run = m_new;
+        }
+        l_run += psum;
+        // this lane keeps block `hi`: its own words are the keys with bit 2 == hi, the partner's the others
+        v8i_t fp;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const unsigned own = hi ? pk[1][g] : pk[0][g];
+            const unsigned got = (unsigned)__shfl_xor((int)(hi ? pk[0][g] : pk[1][g]), 32, 64);
+            fp[2 * g] = (int)(hi ? got : own);
+            fp[2 * g + 1] = (int)(hi ? own : got);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned char* vr = sVt + (i * 32 + l31) * VT8M_LD + hi * 32;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(vr);
+            const u32x4 c = *reinterpret_cast<const u32x4*>(vr + 16);
+            const v8i_t fv = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
+            oacc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fv, fp, oacc[i], 0, 0, 0, ONE, 0, ONE);
+        }
+        if (t + 1 < ntiles) stage_store((t + 1) & 1);
+        __syncthreads();
+    }
+    const int qi = q0 + l31;
+    if (qi < Nq) {
+        const float inv = 1.0f / l_run;
+        bf16_t* op = o + ((long long)b * Nq + qi) * ldo + h * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned w0 = (unsigned)f32_to_bf16(oacc[i][g * 4 + 0] * inv) | ((unsigned)f32_to_bf16(oacc[i][g * 4 + 1] * inv) << 16);
+                unsigned w1 = (unsigned)f32_to_bf16(oacc[i][g * 4 + 2] * inv) | ((unsigned)f32_to_bf16(oacc[i][g * 4 + 3] * inv) << 16);
+                *reinterpret_cast<u32x2*>(op + i * 32 + 8 * g + 4 * hi) = u32x2{w0, w1};
+            }
+    }
+}
+
 // Two query blocks per wave (64 queries): every K / V fragment read from LDS feeds two MFMAs -- half the LDS traffic per
 // flop of k_attention, at twice the accumulator registers (occupancy 2).
 template <bool RAGGED>
@@ -1073,7 +1224,15 @@ int vidseg_attention_fp8(const void* q, int ldq, const void* k, int ldk, const v
     VS_REQUIRE(head_dim == 64, "attention_fp8: head_dim=%d (only 64 is on the path)", head_dim);
     VS_REQUIRE(Nq > 0 && Nk > 0 && ldq % 16 == 0 && ldk % 16 == 0 && ldv % 16 == 0 && ldo % 4 == 0, "attention_fp8: bad sizes/strides");
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
-    if (Nk % 64 == 0)
+    static int mx = -1;                                   // block-scaled 32x32x64 instruction (default) or plain 32x32x16 fp8
+    if (mx < 0) { const char* e = getenv("VIDSEG_ATTN_MX"); mx = e ? atoi(e) : 1; }
+    if (mx && Nk % 64 == 0)
+        k_attention_mx8<false><<<dim3((Nq + 127) / 128, B * H), 256, 0, st>>>((const unsigned char*)q, ldq, (const unsigned char*)k, ldk,
+                                                                               (const unsigned char*)v, ldv, (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
+    else if (mx)
+        k_attention_mx8<true><<<dim3((Nq + 127) / 128, B * H), 256, 0, st>>>((const unsigned char*)q, ldq, (const unsigned char*)k, ldk,
+                                                                              (const unsigned char*)v, ldv, (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
+    else if (Nk % 64 == 0)
         k_attention_fp8<false><<<dim3((Nq + 127) / 128, B * H), 256, 0, st>>>((const unsigned char*)q, ldq, (const unsigned char*)k, ldk,
                                                                                (const unsigned char*)v, ldv, (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
     else
