@@ -161,6 +161,17 @@ int vidseg_attention_bf16(const void* q, int ldq, const void* k, int ldk, const 
 int vidseg_quant_fp8(const void* x, long long n, void* out_fp8, vidseg_stream_t stream);
 int vidseg_attention_fp8(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int H,
                          int Nq, int Nk, int head_dim, vidseg_stream_t stream);
+/* Step 5 (scripts/sampling/process_output.py) on decoded frames resident in HBM.
+ * vidseg_seg_difference: compute_difference (PO:8-29) for one mask: pos/neg fp32 NCHW [F][3][H][W] decoded frames -> uint8 frames
+ *   (SDP:152-168: clamp((x+1)/2,0,1)*255 truncated), wrapped-uint8 channel distance (PO:13), 5x5 Gaussian sigma 3 with reflect-101
+ *   borders (PO:15), "L" image (clip + truncate, PO:18) in out_u8 [F][H][W] and its per-frame maximum in fmax_u32 [F].  The
+ *   reference's JPEG save / re-load of that image (PO:19, 119) is NOT reproduced (lossy codec).
+ * vidseg_seg_argmax: get_seg_map_main (PO:119-161): maps_u8 [K][F][H][W] / (max_u32[K][F] + 1e-5), optional
+ *   filter_difference_map (PO:31-40) with weight_u8 [K][F][H][W] (the label's mask image resized to the frame, 0..255) and
+ *   filter_s, arg-max over the K masks (first maximum), seg_u8 [F][H][W] = labels[arg]. */
+int vidseg_seg_difference(const float* pos, const float* neg, int F, int H, int W, void* out_u8, void* fmax_u32, vidseg_stream_t stream);
+int vidseg_seg_argmax(const void* maps_u8, const void* max_u32, const void* weight_u8, double filter_s, const int* labels, int K, int F,
+                      int H, int W, void* seg_u8, vidseg_stream_t stream);
 /* SVD (video) operators -- video_model.py:15-89 VideoResBlock, video_attention.py:18-489 */
 /* Conv3d kernel [3,1,1], padding [1,0,0] over frames; x NHWC [(b t)][HW][C], w [Cout][c/64][dt][c%64] (video_model.py:45-58) */
 int vidseg_conv_temporal3_bf16(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,

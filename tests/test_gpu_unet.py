@@ -374,6 +374,25 @@ def test_modulation_sweep_step4(env):
     ref = eng.sampler(make_denoiser(eng, Fn), x0.clone(), cond=c, uc=uc, is_modulate=True, modulate_params=mp, t_start=22,
                       is_latent_blending=True, feature_height=8, feature_width=8)
     assert torch.equal(ref, a)
+    # Steps 4-5 in one call: sweep -> decode_first_stage -> difference maps -> arg-max, against the oracle's Step 5 on the device's
+    # own decoded frames (narrow first stage with the golden's decoder weights)
+    from oracle import process_output as OPO
+    from tests.test_oracle_vae import narrow_decoder_state_dict
+    from vidseg_diffusion_amd.pipeline import segmentation_map_window
+    from vidseg_diffusion_amd.vae import decode_first_stage
+    gz = np.load(os.path.join(os.path.dirname(__file__), "golden", "vae_decoder_narrow.npz"))
+    vae, _, vsd = narrow_decoder_state_dict(gz["pq_bias"])
+    vae.load_state_dict(vsd)
+    seg, lat2 = segmentation_map_window(eng, vae, lat, c, uc, uniq, folder, t_start=22, feature_folder=base, exp_name=exp, noise=noise,
+                                        seed=17)
+    assert seg.shape == (Fn, 128, 128) and seg.dtype == torch.uint8 and all(torch.equal(lat2[k], res[k]) for k in res)
+    pos = np.stack([decode_first_stage(vae, res[(1, int(l))], 0.18215).cpu().numpy() for l in uniq])
+    neg = np.stack([decode_first_stage(vae, res[(-1, int(l))], 0.18215).cpu().numpy() for l in uniq])
+    ref_seg, _ = OPO.seg_maps(pos, neg, [int(l) for l in uniq])
+    assert np.array_equal(seg.cpu().numpy(), ref_seg)
+    seg_f, _ = segmentation_map_window(eng, vae, lat, c, uc, uniq, folder, t_start=22, feature_folder=base, exp_name=exp, noise=noise,
+                                       seed=17, filter_difference=True, label_maps=labels.reshape(Fn, 8, 8))
+    assert seg_f.shape == seg.shape and set(np.unique(seg_f.cpu().numpy())) <= set(int(l) for l in uniq)
 
 
 def test_c1_full_width_window_vs_oracle():

@@ -1,0 +1,113 @@
+// HIPCC_FLAGS: -ffp-contract=off
+// Step 5 of the reference driver (scripts/sampling/process_output.py): difference maps of the +lambda / -lambda modulated decodes
+// and the per-pixel arg-max over masks, on decoded frames that stay in HBM (no PNG/JPEG files).
+//   compute_difference        PO:8-29    uint8 frames, wrapped uint8 arithmetic, 5x5 Gaussian (sigma 3), "L" image
+//   filter_difference_map     PO:31-40   map * m + filter_s * map * (1 - m)
+//   get_seg_map_main          PO:75-167  map / (max + 1e-5), arg-max over the mask list, label lookup
+// HBM-bound byte work: one thread per output pixel, 25 neighbours x 6 loads served by L1/L2.  Built with -ffp-contract=off: the
+// blur is compared bit for bit with the oracle's separate multiplies and adds.
+#include "common.h"
+
+// frame pixel -> uint8 exactly like SDP:152-168: clamp((x + 1) / 2, 0, 1) * 255 in fp32, truncated
+__device__ __forceinline__ unsigned to_u8(float x) {
+    float t = (x + 1.0f) / 2.0f;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    return (unsigned)(t * 255.0f);
+}
+
+// PO:13: np.sqrt(np.sum((a - b) ** 2, axis=2)) on uint8 arrays: the subtraction and the square wrap modulo 256, the sum does not
+__device__ __forceinline__ double wrapped_distance(const float* __restrict__ a, const float* __restrict__ b, long long plane, long long pix) {
+    unsigned s = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned d = (to_u8(a[c * plane + pix]) - to_u8(b[c * plane + pix])) & 0xFFu;
+        s += (d * d) & 0xFFu;
+    }
+    return sqrt((double)s);
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}
+
+// pos/neg: fp32 NCHW [F][3][H][W] decoded frames; out: uint8 [F][H][W] = the "L" image of the blurred difference (PIL F -> L:
+// clip to [0, 255], truncate); fmax[f] = its maximum (uint atomics).  Gaussian taps g[0..2] = centre, +-1, +-2 (normalised).
+__global__ void __launch_bounds__(256) k_seg_difference(const float* __restrict__ pos, const float* __restrict__ neg, int F, int H, int W,
+                                                        double g0, double g1, double g2, unsigned char* __restrict__ out,
+                                                        unsigned* __restrict__ fmax) {
+    const long long plane = (long long)H * W;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)F * plane) return;
+    const int f = (int)(idx / plane);
+    const int y = (int)((idx % plane) / W), x = (int)(idx % W);
+    const float* a = pos + (long long)f * 3 * plane;
+    const float* b = neg + (long long)f * 3 * plane;
+    const double gk[3] = {g0, g1, g2};
+    double rows[5];
+#pragma unroll
+    for (int dy = -2; dy <= 2; ++dy) {
+        const long long r = (long long)reflect101(y + dy, H) * W;
+        double v[5];
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) v[dx + 2] = wrapped_distance(a, b, plane, r + reflect101(x + dx, W));
+        rows[dy + 2] = gk[0] * v[2] + gk[1] * (v[1] + v[3]) + gk[2] * (v[0] + v[4]);       // symmetric row filter
+    }
+    const double blur = gk[0] * rows[2] + gk[1] * (rows[1] + rows[3]) + gk[2] * (rows[0] + rows[4]);
+    const unsigned l = blur <= 0.0 ? 0u : (blur >= 255.0 ? 255u : (unsigned)blur);
+    out[idx] = (unsigned char)l;
+    atomicMax(&fmax[f], l);
+}
+
+// maps: uint8 [K][F][H][W]; mmax: [K][F]; weight: uint8 [K][F][H][W] (the label's mask resized to the frame, 0..255) or null;
+// labels: int [K]; seg: uint8 [F][H][W] = labels[argmax_k map_k / (max_k + 1e-5) (* filter)], first maximum wins (np.argmax)
+__global__ void __launch_bounds__(256) k_seg_argmax(const unsigned char* __restrict__ maps, const unsigned* __restrict__ mmax,
+                                                    const unsigned char* __restrict__ weight, double filter_s, const int* __restrict__ labels,
+                                                    int K, int F, long long plane, unsigned char* __restrict__ seg) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)F * plane) return;
+    const int f = (int)(idx / plane);
+    double best = -1.0;
+    int arg = 0;
+    for (int k = 0; k < K; ++k) {
+        const long long o = ((long long)k * F) * plane + idx;
+        double v = (double)maps[o] / ((double)mmax[k * F + f] + 1e-5);
+        if (weight) {
+            const double m = (double)weight[o] / 255.0;
+            v = v * m + filter_s * v * (1.0 - m);
+        }
+        if (v > best) {
+            best = v;
+            arg = k;
+        }
+    }
+    seg[idx] = (unsigned char)labels[arg];
+}
+
+extern "C" {
+
+int vidseg_seg_difference(const float* pos, const float* neg, int F, int H, int W, void* out_u8, void* fmax_u32, hipStream_t st) {
+    VS_REQUIRE(F > 0 && H >= 3 && W >= 3, "seg_difference: F=%d H=%d W=%d", F, H, W);
+    // cv2.getGaussianKernel(5, 3): exp(-(i-2)^2 / (2 sigma^2)) normalised; written out so host and oracle share the same doubles
+    const double g0 = 0.22254893673936782, g1 = 0.2105222740037377, g2 = 0.1782032576265784;
+    (void)hipMemsetAsync(fmax_u32, 0, sizeof(unsigned) * F, st);
+    const long long n = (long long)F * H * W;
+    k_seg_difference<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(pos, neg, F, H, W, g0, g1, g2, (unsigned char*)out_u8,
+                                                                          (unsigned*)fmax_u32);
+    VS_CHECK_LAUNCH("seg_difference");
+    return VS_OK;
+}
+
+int vidseg_seg_argmax(const void* maps_u8, const void* max_u32, const void* weight_u8, double filter_s, const int* labels, int K, int F, int H,
+                      int W, void* seg_u8, hipStream_t st) {
+    VS_REQUIRE(K > 0 && F > 0 && H > 0 && W > 0, "seg_argmax: K=%d F=%d H=%d W=%d", K, F, H, W);
+    const long long n = (long long)F * H * W;
+    k_seg_argmax<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>((const unsigned char*)maps_u8, (const unsigned*)max_u32,
+                                                                      (const unsigned char*)weight_u8, filter_s, labels, K, F, (long long)H * W,
+                                                                      (unsigned char*)seg_u8);
+    VS_CHECK_LAUNCH("seg_argmax");
+    return VS_OK;
+}
+
+}  // extern "C"

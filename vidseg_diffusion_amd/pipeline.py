@@ -342,6 +342,32 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
     return out
 
 
+def segmentation_map_window(engine: Engine, first_stage_model, latent, c, uc, unique_labels, masks_folder, *, label_maps=None,
+                            filter_difference=False, filter_s=0.7, scale_factor=0.18215, n_samples=None, **sweep_kw):
+    """Steps 4-5 for one window, HBM-resident: the 2*K modulated sampler passes (`modulation_sweep`, SDP:416-515), each final
+    latent through `decode_first_stage` (SDP:150-152), the +lambda / -lambda difference map per label and the arg-max over labels
+    (`process_output.get_seg_map_main`, SDP:517-523).  Returns (uint8 [F, H, W] raw segmentation map, the sweep's latents).
+    The reference writes PNG frames and JPEG difference maps in between; the JPEG round trip is the one step not reproduced."""
+    from . import process_output as PO
+    from .vae import decode_first_stage
+    labels = [int(v) for v in np.asarray(unique_labels).reshape(-1)]
+    lat = modulation_sweep(engine, latent, c, uc, labels, masks_folder, **sweep_kw)
+    maps, maxima = [], []
+    for lab in labels:                                                  # both signs of one label at a time: 2 decoded windows live
+        pos = decode_first_stage(first_stage_model, lat[(1, lab)], scale_factor, n_samples)
+        neg = decode_first_stage(first_stage_model, lat[(-1, lab)], scale_factor, n_samples)
+        m, mx = PO.difference_map(pos, neg)
+        maps.append(m)
+        maxima.append(mx)
+    maps, maxima = torch.stack(maps), torch.stack(maxima)
+    weights = None
+    if filter_difference:
+        if label_maps is None:
+            raise ValueError("filter_difference needs the Step 3 label maps [F, h, w]")
+        weights = PO.mask_weights(label_maps, labels, maps.shape[-2:])
+    return PO.seg_map(maps, maxima, labels, weights, filter_s), lat
+
+
 def segment_clip_from_frames(engine: Engine, first_stage_model, frames, c_fn, *, scale_factor=0.18215, batch_size=14, **kw):
     """Image-in variant of `segment_clip`: frames fp32 [T, 3, H, W] in [-1, 1] on the device are encoded window by window
     with `vae.encode_first_stage` (sgm/models/diffusion.py:138-151; sd_pipeline_vspw.py:294-307) before Steps 1-3b."""
