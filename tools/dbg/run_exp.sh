@@ -1,7 +1,13 @@
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/pmc
-VIDSEG_GEMM_SHAPES=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc/A -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap > /dev/null 2> gpurun_out/pmc/shapes.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc/B -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap > /dev/null 2>&1
-python tools/dbg/pmc_per_shape.py $(find gpurun_out/pmc/A -name "*.db" | head -1) $(find gpurun_out/pmc/B -name "*.db" | head -1) gpurun_out/pmc/shapes.log all > gpurun_out/pmc/per_shape_all.txt 2>&1
-rm -rf gpurun_out/pmc/A gpurun_out/pmc/B
+R=$GRAFT_REPO_ROOT
+cd $R
+mkdir -p gpurun_out/prof_i
+python bench.py > gpurun_out/prof_i/bench.json 2> gpurun_out/prof_i/bench.err
+python bench.py --no-overlap --no-cpu-baseline > gpurun_out/prof_i/bench_no_overlap.json 2>> gpurun_out/prof_i/bench.err
+python bench.py --vae --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_i/bench_vae.json 2>> gpurun_out/prof_i/bench.err
+python bench.py --config svd --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_i/bench_svd.json 2>> gpurun_out/prof_i/bench.err
+python bench.py --config svd --fp8-attn --masks 50 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_i/bench_svd_fp8_k50.json 2>> gpurun_out/prof_i/bench.err
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_i/kt -o i -- python bench.py --no-cpu-baseline > gpurun_out/prof_i/bench_under_rocprof.log 2>&1
+db=$(find gpurun_out/prof_i/kt -name "*.db" | head -1)
+python tools/prof_summary.py $db "r01_i: python bench.py --no-cpu-baseline under rocprofv3 --kernel-trace --stats (fp16 build, phased big tile, chunk-major K, window pipeline on)" > gpurun_out/prof_i/kernel_stats.md
+rm -rf gpurun_out/prof_i/kt
