@@ -161,6 +161,10 @@ int vidseg_attention_bf16(const void* q, int ldq, const void* k, int ldk, const 
 int vidseg_quant_fp8(const void* x, long long n, void* out_fp8, vidseg_stream_t stream);
 int vidseg_attention_fp8(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int H,
                          int Nq, int Nk, int head_dim, vidseg_stream_t stream);
+/* AE3DConv.time_mix_conv of the video first stage (sgm/modules/autoencoding/temporal_ae.py:84-107): Conv3d(C -> C, [3,1,1],
+ * padding [1,0,0]) over the T frames of each video; x fp32 [(b t)][xC][HW] (first C channels used), w fp32 [C][C][3]. */
+int vidseg_time_mix3_f32(const float* x, int BT, int xC, int C, long long HW, int T, const float* w, const float* bias, float* out,
+                         vidseg_stream_t stream);
 /* Step 5 (scripts/sampling/process_output.py) on decoded frames resident in HBM.
  * vidseg_seg_difference: compute_difference (PO:8-29) for one mask: pos/neg fp32 NCHW [F][3][H][W] decoded frames -> uint8 frames
  *   (SDP:152-168: clamp((x+1)/2,0,1)*255 truncated), wrapped-uint8 channel distance (PO:13), 5x5 Gaussian sigma 3 with reflect-101

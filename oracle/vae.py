@@ -8,9 +8,10 @@
     sgm/modules/diffusionmodules/model.py:604-748  Decoder.forward (Upsample :58-71)
     sgm/models/autoencoder.py:490-506              decode (post_quant_conv -> decoder)
     sgm/models/diffusion.py:117-136                decode_first_stage (z / scale_factor)
+    sgm/modules/autoencoding/temporal_ae.py:18-107, 293-349  VideoResBlock, AE3DConv, VideoDecoder (time_mode conv-only)
 
 Functional torch-CPU fp32, driven by the reference's state-dict keys.  Pinned by tests/golden/vae_encoder_narrow.npz and
-tests/golden/vae_decoder_narrow.npz (tools/gen_golden_vae.py runs the reference's own Encoder / Decoder /
+tests/golden/vae_{decoder,video_decoder}_narrow.npz (tools/gen_golden_vae.py runs the reference's own Encoder / Decoder /
 DiagonalGaussianDistribution).
 `round_bf16=True` rounds activations where the HIP path stores bf16 (format-error yardstick for the GPU tests).
 """
@@ -91,22 +92,52 @@ class VAEEncoderOracle:
 class VAEDecoderOracle(VAEEncoderOracle):
     """decoder.* / post_quant_conv.* keys; same block restatements as the encoder."""
 
-    def decode(self, z, scale_factor=1.0):
-        """z [B, embed, h, w] (already divided by nothing: scale_factor is applied here like decode_first_stage) -> [B, 3, 8h, 8w]."""
-        h = self.conv(z * (1.0 / scale_factor), "post_quant_conv", pad=0)
+    def gn5(self, x, p):
+        return F.group_norm(x, 32, self.sd[p + ".weight"], self.sd[p + ".bias"], 1e-5)      # GroupNorm32 of openaimodel.ResBlock
+
+    def vresnet(self, x, p, T):
+        """temporal_ae.py:18-81 VideoResBlock: ResnetBlock, then the dims=3 ResBlock time_stack and the learned alpha merge."""
+        x = self.resnet(x, p)
+        if T is None or not self.has(p + ".time_stack."):
+            return x
+        bt, c, hh, ww = x.shape
+        v = x.reshape(bt // T, T, c, hh, ww).permute(0, 2, 1, 3, 4)                          # (b t) c h w -> b c t h w
+        q = p + ".time_stack"
+        h = _bf(self.swish(self.gn5(v, q + ".in_layers.0")), self.rb)
+        h = _bf(F.conv3d(h, self.sd[q + ".in_layers.2.weight"], self.sd[q + ".in_layers.2.bias"], padding=(1, 0, 0)), self.rb)
+        h = _bf(self.swish(self.gn5(h, q + ".out_layers.0")), self.rb)
+        h = F.conv3d(h, self.sd[q + ".out_layers.3.weight"], self.sd[q + ".out_layers.3.bias"], padding=(1, 0, 0))
+        t = _bf(v + h, self.rb)
+        a = torch.sigmoid(self.sd[p + ".mix_factor"])
+        out = a * t + (1.0 - a) * v
+        return _bf(out.permute(0, 2, 1, 3, 4).reshape(bt, c, hh, ww), self.rb)
+
+    def decode(self, z, scale_factor=1.0, timesteps=None):
+        """z [B, embed, h, w] -> [B, 3, 8h, 8w] (decode_first_stage: z / scale_factor first).  `timesteps` = frames per video
+        for a VideoDecoder state dict (time_stack / time_mix_conv keys); post_quant_conv only if the state dict has one."""
+        T = timesteps
+        h = z * (1.0 / scale_factor)
+        if self.has("post_quant_conv."):
+            h = self.conv(h, "post_quant_conv", pad=0)
         h = _bf(self.conv(h, "decoder.conv_in"), self.rb)
-        h = self.resnet(h, "decoder.mid.block_1")
+        h = self.vresnet(h, "decoder.mid.block_1", T)
         h = self.attn(h, "decoder.mid.attn_1")
-        h = self.resnet(h, "decoder.mid.block_2")
+        h = self.vresnet(h, "decoder.mid.block_2", T)
         lvl = 0
         while self.has(f"decoder.up.{lvl + 1}."):
             lvl += 1
         for i in range(lvl, -1, -1):
             j = 0
             while self.has(f"decoder.up.{i}.block.{j}."):
-                h = self.resnet(h, f"decoder.up.{i}.block.{j}")
+                h = self.vresnet(h, f"decoder.up.{i}.block.{j}", T)
                 j += 1
             if self.has(f"decoder.up.{i}.upsample."):
                 h = _bf(self.conv(F.interpolate(h, scale_factor=2.0, mode="nearest"), f"decoder.up.{i}.upsample.conv"), self.rb)
         h = _bf(self.swish(self.gn(h, "decoder.norm_out")), self.rb)
-        return self.conv(h, "decoder.conv_out")
+        h = self.conv(h, "decoder.conv_out")
+        if T is not None and self.has("decoder.conv_out.time_mix_conv."):                    # AE3DConv, temporal_ae.py:84-107
+            bt, c, hh, ww = h.shape
+            v = h.reshape(bt // T, T, c, hh, ww).permute(0, 2, 1, 3, 4)
+            v = F.conv3d(v, self.sd["decoder.conv_out.time_mix_conv.weight"], self.sd["decoder.conv_out.time_mix_conv.bias"], padding=(1, 0, 0))
+            h = v.permute(0, 2, 1, 3, 4).reshape(bt, c, hh, ww)
+        return h

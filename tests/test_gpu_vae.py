@@ -61,6 +61,29 @@ def test_vae_decoder_vs_reference():
     assert np.array_equal(out1, out)
 
 
+def test_video_decoder_vs_reference():
+    """AutoencodingEngine + temporal_ae.VideoDecoder (svd.yaml first stage) vs the reference golden, T = 3 frames per video."""
+    from oracle.vae import VAEDecoderOracle
+    from tests.test_oracle_vae import narrow_video_decoder_state_dict
+    from vidseg_diffusion_amd._lib import VidsegError
+    from vidseg_diffusion_amd.vae import decode_first_stage
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vae_video_decoder_narrow.npz"))
+    net, shapes, sd = narrow_video_decoder_state_dict(g)
+    net.load_state_dict(sd)
+    T = int(g["T"])
+    z = torch.from_numpy(g["z"]).to(dev)
+    out = decode_first_stage(net, z, 0.18215, n_samples=T).cpu().numpy()           # one video per chunk, like en_and_decode_n_samples_a_time
+    fmt = nrms(VAEDecoderOracle(sd, round_bf16=act_mode()[0]).decode(torch.from_numpy(g["z"]), 0.18215, timesteps=T).numpy(), g["out"])
+    err = nrms(out, g["out"])
+    print("video decoder nrms", err, "16-bit format", fmt)
+    assert err < act_mode()[1] and err <= 1.5 * fmt + 5e-3, (err, fmt)
+    both = net.decode(z / 0.18215, timesteps=T).cpu().numpy()                        # both videos in one call (b = 2, t = 3)
+    assert nrms(both, g["out"]) < act_mode()[1]
+    with pytest.raises(VidsegError):
+        net.decode(z[:4])                                                           # no `timesteps`: refused, never a silent image decode
+
+
 def test_asymmetric_downsample_and_softmax_ops():
     from vidseg_diffusion_amd import ops
     dev = torch.device("cuda:0")

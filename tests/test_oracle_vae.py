@@ -48,6 +48,31 @@ def test_decoder_mirror_keys_and_oracle_match_reference():
     assert np.abs(out.numpy() - g["out"]).max() <= 2e-5 * np.abs(g["out"]).max()
 
 
+def narrow_video_decoder_state_dict(g):
+    """The mirror's AutoencodingEngine with a VideoDecoder, filled like tools/gen_golden_vae.py --video-decoder does."""
+    from vidseg_diffusion_amd.vae import AutoencodingEngine
+    dd = dict(VAE_NARROW, attn_type="vanilla")
+    net = AutoencodingEngine(encoder_config={"target": "sgm.modules.diffusionmodules.model.Encoder", "params": dd},
+                             decoder_config={"target": "sgm.modules.autoencoding.temporal_ae.VideoDecoder",
+                                             "params": dict(dd, video_kernel_size=[3, 1, 1])})
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items() if k.startswith("decoder.")}
+    sdn = synthetic.fill_state_dict(shapes, seed=9753, gain=1.0)
+    for i, k in enumerate(g["extra_keys"]):
+        sdn[str(k)] = g["extra_%d" % i]
+    return net, shapes, {k: torch.from_numpy(np.asarray(v)) for k, v in sdn.items()}
+
+
+def test_video_decoder_mirror_keys_and_oracle_match_reference():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vae_video_decoder_narrow.npz"))
+    net, shapes, sd = narrow_video_decoder_state_dict(g)
+    assert synthetic.state_dict_signature(shapes) == str(g["state_dict_signature"])     # temporal_ae.VideoDecoder keys and shapes
+    out = VAEDecoderOracle(sd).decode(torch.from_numpy(g["z"]), 0.18215, timesteps=int(g["T"]))
+    assert np.abs(out.numpy() - g["out"]).max() <= 2e-5 * np.abs(g["out"]).max()
+    # the time path matters: decoding the frames as independent images gives something else
+    img = VAEDecoderOracle(sd).decode(torch.from_numpy(g["z"]), 0.18215)
+    assert np.abs(img.numpy() - g["out"]).max() > 1e-2 * np.abs(g["out"]).max()
+
+
 def test_encoder_only_checkpoint_loads():
     net, shapes, sd = narrow_state_dict()
     sd["loss.logvar"] = torch.zeros(1)                                                  # training-only keys of a checkpoint are ignored

@@ -66,8 +66,37 @@ def main_decoder():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB; out absmax", float(np.abs(rec["out"]).max()), "rms", float(out.pow(2).mean().sqrt()))
 
 
+def main_video_decoder():
+    """tests/golden/vae_video_decoder_narrow.npz: the reference's temporal_ae.VideoDecoder (svd.yaml:119-133, narrow), T = 3."""
+    import_reference()
+    from sgm.modules.autoencoding.temporal_ae import VideoDecoder
+    torch.set_grad_enabled(False)
+    dec = VideoDecoder(**dict(VAE_NARROW, attn_type="vanilla", video_kernel_size=[3, 1, 1])).eval()
+    shapes = {"decoder." + k: tuple(v.shape) for k, v in dec.state_dict().items()}
+    sdn = synthetic.fill_state_dict(shapes, seed=9753, gain=1.0)
+    g = np.random.Generator(np.random.PCG64(79))
+    for k in sdn:                                        # the filler leaves 1-element and bias tensors trivial: make the time path count
+        if k.endswith("mix_factor"):
+            sdn[k] = g.uniform(-1.0, 1.0, sdn[k].shape).astype(np.float32)
+        if "time_mix_conv" in k or (k.endswith(".bias") and "time_stack" in k and "layers.0" not in k):
+            sdn[k] = (g.standard_normal(sdn[k].shape) * (0.3 if k.endswith("weight") else 0.05)).astype(np.float32)
+    sd = {k: torch.from_numpy(v) for k, v in sdn.items()}
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in sd.items()})
+    T = 3
+    z = (g.standard_normal((2 * T, 4, 8, 8)).astype(np.float32) * 0.18215 * 4)
+    out = dec(torch.from_numpy(z) / 0.18215, timesteps=T)
+    extra = {k: v for k, v in sdn.items() if k.endswith("mix_factor") or "time_mix_conv" in k or (k.endswith(".bias") and "time_stack" in k and "layers.0" not in k)}
+    rec = dict(z=z, out=out.numpy(), T=T, state_dict_signature=synthetic.state_dict_signature(shapes),
+               extra_keys=np.array(sorted(extra)), **{"extra_%d" % i: extra[k] for i, k in enumerate(sorted(extra))})
+    path = os.path.join(ROOT, "tests", "golden", "vae_video_decoder_narrow.npz")
+    np.savez_compressed(path, **rec)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; out absmax", float(np.abs(rec["out"]).max()), "rms", float(out.pow(2).mean().sqrt()))
+
+
 if __name__ == "__main__":
-    if "--decoder" in sys.argv:
+    if "--video-decoder" in sys.argv:
+        main_video_decoder()
+    elif "--decoder" in sys.argv:
         main_decoder()
     else:
         main()

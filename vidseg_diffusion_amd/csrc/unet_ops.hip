@@ -368,6 +368,27 @@ __global__ void __launch_bounds__(256, 3) k_attention(const bf16_t* __restrict__
     }
 }
 
+// AE3DConv.time_mix_conv of the video first stage (temporal_ae.py:84-107): Conv3d(C -> C, kernel [3,1,1], padding [1,0,0]) over the
+// frames of each video on the few output channels of conv_out.  x: fp32 [(b t)][xC][HW] (the first C of xC channels are used),
+// w: fp32 [C][C][3], out: fp32 [(b t)][C][HW].  HBM-bound elementwise work.
+__global__ void __launch_bounds__(256) k_time_mix3(const float* __restrict__ x, int BT, int xC, int C, long long HW, int T,
+                                                   const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)BT * HW) return;
+    const int bt = (int)(i / HW), t = bt % T;
+    const long long pix = i % HW;
+    for (int co = 0; co < C; ++co) {
+        float acc = bias[co];
+        for (int dt = 0; dt < 3; ++dt) {
+            const int tt = t + dt - 1;
+            if (tt < 0 || tt >= T) continue;
+            const float* xr = x + ((long long)(bt + dt - 1) * xC) * HW + pix;
+            for (int ci = 0; ci < C; ++ci) acc = fmaf(w[(co * C + ci) * 3 + dt], xr[(long long)ci * HW], acc);
+        }
+        out[((long long)bt * C + co) * HW + pix] = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // FP8 attention (BASELINE configs[4]): Q, K, V and the probabilities P in OCP e4m3, fp32 accumulation and softmax,
 // fp16/bf16 output.  Same schedule as k_attention (32 queries per wave, S^T = K Q^T so the softmax statistics are
@@ -1239,6 +1260,16 @@ int vidseg_attention_fp8(const void* q, int ldq, const void* k, int ldk, const v
         k_attention_fp8<true><<<dim3((Nq + 127) / 128, B * H), 256, 0, st>>>((const unsigned char*)q, ldq, (const unsigned char*)k, ldk,
                                                                               (const unsigned char*)v, ldv, (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
     VS_CHECK_LAUNCH("attention_fp8");
+    return VS_OK;
+}
+
+int vidseg_time_mix3_f32(const float* x, int BT, int xC, int C, long long HW, int T, const float* w, const float* bias, float* out,
+                         hipStream_t st) {
+    VS_REQUIRE(T >= 1 && BT % T == 0 && C >= 1 && C <= xC && C <= 8, "time_mix3: BT=%d T=%d C=%d xC=%d", BT, T, C, xC);
+    const long long n = (long long)BT * HW;
+    if (n == 0) return VS_OK;
+    k_time_mix3<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(x, BT, xC, C, HW, T, w, bias, out);
+    VS_CHECK_LAUNCH("time_mix3");
     return VS_OK;
 }
 

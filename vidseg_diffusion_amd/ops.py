@@ -28,6 +28,7 @@ _lib.register({
     "vidseg_attention_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "vidseg_attention_fp8": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "vidseg_quant_fp8": [_P, _L, _P, _P],
+    "vidseg_time_mix3_f32": [_P, _I, _I, _I, _L, _I, _P, _P, _P, _P],
     "vidseg_timestep_embedding": [_P, _I, _I, _F, _P, _P],
     "vidseg_silu_bf16": [_P, _L, _P, _P],
     "vidseg_f32_to_bf16": [_P, _L, _P, _P],
@@ -431,6 +432,14 @@ def alpha_blend(x_spatial, x_temporal, mix_factor):
     """sigmoid(mix) * spatial + (1 - sigmoid(mix)) * temporal (AlphaBlender, image_only_indicator == 0)."""
     out = torch.empty_like(x_spatial)
     call("vidseg_alpha_blend_bf16", ptr(x_spatial), ptr(x_temporal), ptr(mix_factor), x_spatial.numel(), ptr(out), stream())
+    return out
+
+
+def time_mix3(x_nchw_f32, w, bias, T, C):
+    """AE3DConv.time_mix_conv (temporal_ae.py:84-107) on fp32 NCHW [(b t), xC, H, W] -> [(b t), C, H, W]."""
+    BT, xC, H, W = x_nchw_f32.shape
+    out = torch.empty((BT, C, H, W), dtype=F32, device=x_nchw_f32.device)
+    call("vidseg_time_mix3_f32", ptr(x_nchw_f32), BT, xC, C, H * W, T, ptr(w), ptr(bias), ptr(out), stream())
     return out
 
 

@@ -16,7 +16,9 @@ into `conv_out`'s weights at pack time (exact algebra: W' = Wq Wc, b' = Wq bc + 
 Decode side (model.py:604-748 Decoder, :58-71 Upsample; autoencoder.py:490-506 decode; diffusion.py:117-136
 decode_first_stage): `post_quant_conv` (1x1, embed -> z) is folded into the decoder's `conv_in` (z = 4 input channels: the
 UNet's small-Cin kernel), the nearest-2x Upsample is folded into its conv's addressing (`up=2`), `conv_out` (128 -> 3) runs on
-the UNet's 4-output-channel kernel with a zero fourth filter.  The SVD `VideoDecoder` (temporal_ae.py) is not built.
+the UNet's 4-output-channel kernel with a zero fourth filter.  SVD's first stage (`AutoencodingEngine`, svd.yaml:98-133) uses
+`VideoDecoder` (temporal_ae.py:293-349, time_mode conv-only): every ResnetBlock gains a 3-D time stack (GroupNorm over
+(c/32, t, h, w), [3,1,1] convs: the video UNet's temporal-conv kernel) merged by a learned alpha, and conv_out a [3,1,1] frame mix.
 """
 from __future__ import annotations
 
@@ -25,7 +27,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import VidsegError
-from .unet import _meta
+from .unet import GroupNorm32, _meta
 
 
 def Normalize(in_channels, num_groups=32):
@@ -174,8 +176,68 @@ class Encoder(nn.Module):
         self.conv_out = _meta(nn.Conv2d, block_in, 2 * z_channels if double_z else z_channels, 3, padding=1)
 
 
+class _TimeStack3D(nn.Module):
+    """The dims=3 ResBlock of temporal_ae.VideoResBlock.time_stack (openaimodel.py ResBlock with emb_channels=0, skip_t_emb=True,
+    kernel [3,1,1]): GroupNorm32(eps 1e-5) over (c/32, t, h, w) -> SiLU -> Conv3d, twice, + identity skip."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.in_layers = nn.Sequential(_meta(GroupNorm32, 32, channels), nn.SiLU(),
+                                       _meta(nn.Conv3d, channels, channels, (3, 1, 1), padding=(1, 0, 0)))
+        self.out_layers = nn.Sequential(_meta(GroupNorm32, 32, channels), nn.SiLU(), nn.Dropout(p=0.0),
+                                        _meta(nn.Conv3d, channels, channels, (3, 1, 1), padding=(1, 0, 0)))
+
+    def pack(self, dev):
+        self.g1, self.b1 = ops.f32(self.in_layers[0].weight, dev), ops.f32(self.in_layers[0].bias, dev)
+        self.w1, self.cb1 = ops.pack_conv_temporal3(self.in_layers[2].weight, dev), ops.f32(self.in_layers[2].bias, dev)
+        self.g2, self.b2 = ops.f32(self.out_layers[0].weight, dev), ops.f32(self.out_layers[0].bias, dev)
+        self.w2, self.cb2 = ops.pack_conv_temporal3(self.out_layers[3].weight, dev), ops.f32(self.out_layers[3].bias, dev)
+
+    def run(self, x, T):
+        BT, H, W, C = x.shape
+        h = ops.groupnorm(x.view(BT // T, T * H, W, C), self.g1, self.b1, eps=1e-5, silu=True).view(BT, H, W, C)
+        h = ops.conv_temporal3(h, self.w1, self.cb1, T)
+        h = ops.groupnorm(h.view(BT // T, T * H, W, C), self.g2, self.b2, eps=1e-5, silu=True).view(BT, H, W, C)
+        return ops.conv_temporal3(h, self.w2, self.cb2, T, residual=x)
+
+
+class VideoResBlock(ResnetBlock):
+    """temporal_ae.py:18-81 (merge_strategy "learned"): spatial ResnetBlock, the 3-D time stack on top, and
+    sigmoid(mix_factor) * temporal + (1 - sigmoid(mix_factor)) * spatial."""
+
+    def __init__(self, *, in_channels, out_channels=None, dropout=0.0, **kw):
+        super().__init__(in_channels=in_channels, out_channels=out_channels, dropout=dropout)
+        self.time_stack = _TimeStack3D(self.out_channels)
+        self.mix_factor = nn.Parameter(torch.empty(1, device="meta"))
+
+    def pack(self, dev):
+        super().pack(dev)
+        self.time_stack.pack(dev)
+        self.mix = ops.f32(self.mix_factor, dev)
+
+    def run(self, x, T=None):
+        x = super().run(x)
+        return ops.alpha_blend(self.time_stack.run(x, T), x, self.mix)       # alpha weighs the TEMPORAL branch here (temporal_ae.py:77-78)
+
+
+class AE3DConv(nn.Conv2d):
+    """temporal_ae.py:84-107: the 2-D conv plus a Conv3d [3,1,1] over frames on its output channels."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, padding=1, device="meta"):
+        super().__init__(in_channels, out_channels, kernel_size, padding=padding, device=device)
+        self.time_mix_conv = nn.Conv3d(out_channels, out_channels, (3, 1, 1), padding=(1, 0, 0), device=device)
+
+
 class Decoder(nn.Module):
     """model.py:604-748 (attn_resolutions = [], attn_type "vanilla", no tanh_out / give_pre_end)."""
+
+    video = False
+
+    def _resblock(self, **kw):
+        return ResnetBlock(**kw)
+
+    def _conv_out(self, cin, cout):
+        return _meta(nn.Conv2d, cin, cout, 3, padding=1)
 
     def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions=(), dropout=0.0, resamp_with_conv=True,
                  in_channels, resolution, z_channels, give_pre_end=False, tanh_out=False, use_linear_attn=False,
@@ -189,9 +251,9 @@ class Decoder(nn.Module):
         block_in = ch * ch_mult[self.num_resolutions - 1]
         self.conv_in = _meta(nn.Conv2d, z_channels, block_in, 3, padding=1)
         self.mid = _Level()
-        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, dropout=dropout)
+        self.mid.block_1 = self._resblock(in_channels=block_in, out_channels=block_in, dropout=dropout)
         self.mid.attn_1 = AttnBlock(block_in)
-        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, dropout=dropout)
+        self.mid.block_2 = self._resblock(in_channels=block_in, out_channels=block_in, dropout=dropout)
         ups = []
         for i_level in reversed(range(self.num_resolutions)):
             block_out = ch * ch_mult[i_level]
@@ -199,14 +261,32 @@ class Decoder(nn.Module):
             level.block = nn.ModuleList()
             level.attn = nn.ModuleList()
             for _ in range(num_res_blocks + 1):
-                level.block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, dropout=dropout))
+                level.block.append(self._resblock(in_channels=block_in, out_channels=block_out, dropout=dropout))
                 block_in = block_out
             if i_level != 0:
                 level.upsample = Upsample(block_in, resamp_with_conv)
             ups.insert(0, level)                                     # `up.0` is the full-resolution level, like the reference
         self.up = nn.ModuleList(ups)
         self.norm_out = Normalize(block_in)
-        self.conv_out = _meta(nn.Conv2d, block_in, out_ch, 3, padding=1)
+        self.conv_out = self._conv_out(block_in, out_ch)
+
+
+class VideoDecoder(Decoder):
+    """temporal_ae.py:293-349 with time_mode "conv-only" (svd.yaml:119-133): every ResnetBlock is a VideoResBlock, conv_out an
+    AE3DConv; the mid attention stays the plain single-head AttnBlock."""
+    video = True
+
+    def __init__(self, *args, video_kernel_size=3, alpha=0.0, merge_strategy="learned", time_mode="conv-only", **kwargs):
+        ks = list(video_kernel_size) if isinstance(video_kernel_size, (list, tuple)) else [video_kernel_size] * 3
+        if time_mode != "conv-only" or merge_strategy != "learned" or ks != [3, 1, 1]:
+            raise NotImplementedError("VideoDecoder: only time_mode 'conv-only', merge_strategy 'learned', kernel [3,1,1] is on the path")
+        super().__init__(*args, **kwargs)
+
+    def _resblock(self, **kw):
+        return VideoResBlock(**kw)
+
+    def _conv_out(self, cin, cout):
+        return AE3DConv(cin, cout)
 
 
 class AutoencoderKL(nn.Module):
@@ -236,7 +316,7 @@ class AutoencoderKL(nn.Module):
         self._pack_decoder(dev)
         self._packed_on = dev
         e = self.encoder
-        self._enc_ready = not any(t.is_meta for t in list(e.parameters()) + list(self.quant_conv.parameters()))
+        self._enc_ready = not any(t.is_meta for t in list(e.parameters()) + (list(self.quant_conv.parameters()) if self.quant_conv is not None else []))
         if not self._enc_ready:                                       # decoder-only state dict
             return
         self.cin_w, self.cin_b = ops.pack_conv_in(e.conv_in.weight, dev), ops.f32(e.conv_in.bias, dev)
@@ -249,10 +329,13 @@ class AutoencoderKL(nn.Module):
             m.pack(dev)
         self.no_g, self.no_b = ops.f32(e.norm_out.weight, dev), ops.f32(e.norm_out.bias, dev)
         # conv_out (3x3, C -> 2z) followed by quant_conv (1x1, 2z -> 2*embed): one conv with W' = Wq Wc, b' = Wq bc + bq
-        wq = self.quant_conv.weight.detach().double().reshape(self.quant_conv.weight.shape[0], -1)
         wc = e.conv_out.weight.detach().double()
-        wf = torch.einsum("oz,zikl->oikl", wq, wc)
-        bf = wq @ e.conv_out.bias.detach().double() + self.quant_conv.bias.detach().double()
+        if self.quant_conv is not None:
+            wq = self.quant_conv.weight.detach().double().reshape(self.quant_conv.weight.shape[0], -1)
+            wf = torch.einsum("oz,zikl->oikl", wq, wc)
+            bf = wq @ e.conv_out.bias.detach().double() + self.quant_conv.bias.detach().double()
+        else:                                                          # AutoencodingEngine: the encoder's moments are used as they are
+            wf, bf = wc, e.conv_out.bias.detach().double()
         n_out = wf.shape[0]
         self.n_mom = n_out
         pad = (-n_out) % 8                                           # the GEMM epilogue writes 8 columns per lane
@@ -263,16 +346,20 @@ class AutoencoderKL(nn.Module):
 
     def _pack_decoder(self, dev):
         d = self.decoder
-        self._dec_ready = not any(t.is_meta for t in list(d.parameters()) + list(self.post_quant_conv.parameters()))
+        pq = self.post_quant_conv
+        self._dec_ready = not any(t.is_meta for t in list(d.parameters()) + (list(pq.parameters()) if pq is not None else []))
         if not self._dec_ready:                                       # encoder-only checkpoint
             return
         # post_quant_conv (1x1, embed -> z) then conv_in (3x3, z -> C): W'[o,e,kh,kw] = sum_z Wc[o,z,kh,kw] Wp[z,e]; the bias of
         # the 1x1 passes through the 3x3's zero padding only where the tap is inside the image, so it stays a separate input
         # channel: a constant-one plane appended to z carries it exactly (Cin = embed + 1 <= 8)
-        wp = self.post_quant_conv.weight.detach().double().reshape(self.post_quant_conv.weight.shape[0], -1)      # [z, e]
         wc = d.conv_in.weight.detach().double()                                                                     # [C, z, 3, 3]
-        w_e = torch.einsum("ozkl,ze->oekl", wc, wp)
-        w_one = torch.einsum("ozkl,z->okl", wc, self.post_quant_conv.bias.detach().double()).unsqueeze(1)
+        if pq is not None:
+            wp = pq.weight.detach().double().reshape(pq.weight.shape[0], -1)                                        # [z, e]
+            w_e = torch.einsum("ozkl,ze->oekl", wc, wp)
+            w_one = torch.einsum("ozkl,z->okl", wc, pq.bias.detach().double()).unsqueeze(1)
+        else:                                                          # AutoencodingEngine: z goes straight into conv_in
+            w_e, w_one = wc, wc.new_zeros((wc.shape[0], 1, 3, 3))
         wf = torch.cat([w_e, w_one], 1)                                                                             # [C, e+1, 3, 3]
         self.dec_cin = wf.shape[1]
         pad = (4 if self.dec_cin <= 4 else 8) - self.dec_cin
@@ -294,6 +381,10 @@ class AutoencoderKL(nn.Module):
             wo = torch.cat([wo, wo.new_zeros((4 - wo.shape[0],) + tuple(wo.shape[1:]))], 0)
             bo = torch.cat([bo, bo.new_zeros(4 - bo.shape[0])], 0)
         self.dout_w, self.dout_b = ops.pack_conv_out(wo, dev), ops.f32(bo, dev)
+        if d.video:
+            tm = d.conv_out.time_mix_conv
+            self.tmix_w = ops.f32(tm.weight.reshape(tm.weight.shape[0], tm.weight.shape[1], 3), dev)
+            self.tmix_b = ops.f32(tm.bias, dev)
 
     # ------------------------------------------------------------------ forward
     def moments(self, x):
@@ -331,24 +422,28 @@ class AutoencoderKL(nn.Module):
         z = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
         return (z, {}) if return_reg_log else z
 
-    def _decode_batch(self, z):
+    def _decode_batch(self, z, T=None):
         d = self.decoder
+        kw = {"T": T} if d.video else {}
         B, E, h, w = z.shape
         zin = torch.zeros((B, h, w, self.dec_cin_pad), dtype=torch.float32, device=z.device)
         zin[..., :E] = z.float().permute(0, 2, 3, 1)
         zin[..., E] = 1.0                                              # carries post_quant_conv's bias through the 3x3's padding
         x = ops.conv_in(zin, self.din_w, self.din_b)
-        x = d.mid.block_1.run(x)
+        x = d.mid.block_1.run(x, **kw)
         x = d.mid.attn_1.run(x)
-        x = d.mid.block_2.run(x)
+        x = d.mid.block_2.run(x, **kw)
         for i_level in reversed(range(d.num_resolutions)):
             level = d.up[i_level]
             for blk in level.block:
-                x = blk.run(x)
+                x = blk.run(x, **kw)
             if hasattr(level, "upsample"):
                 x = level.upsample.run(x)
         x = ops.groupnorm(x, self.dno_g, self.dno_b, eps=1e-6, silu=True)
-        return ops.conv_out4(x, self.dout_w, self.dout_b)[:, :d.out_ch]
+        y = ops.conv_out4(x, self.dout_w, self.dout_b)
+        if d.video:                                                    # AE3DConv.time_mix_conv over the frames of each video
+            return ops.time_mix3(y, self.tmix_w, self.tmix_b, T, d.out_ch)
+        return y[:, :d.out_ch]
 
     def decode(self, z, **decoder_kwargs):
         """autoencoder.py:490-506: post_quant_conv -> decoder, `max_batch_size` frames at a time.  z: fp32 NCHW [B, embed, h, w]
@@ -360,8 +455,32 @@ class AutoencoderKL(nn.Module):
         if not self._dec_ready:
             raise VidsegError("AutoencoderKL.decode: the loaded state dict has no decoder.* / post_quant_conv.* weights")
         bs = self.max_batch_size or z.shape[0]
-        outs = [self._decode_batch(z[i:i + bs]) for i in range(0, z.shape[0], bs)]
+        T = decoder_kwargs.get("timesteps")
+        if self.decoder.video:
+            if T is None or bs % T or z.shape[0] % T:
+                raise VidsegError("VideoDecoder.decode needs timesteps=T with whole videos per call (diffusion.py:126-129)")
+        outs = [self._decode_batch(z[i:i + bs], T) for i in range(0, z.shape[0], bs)]
         return torch.cat(outs, 0) if len(outs) > 1 else outs[0].contiguous()
+
+
+class AutoencodingEngine(AutoencoderKL):
+    """sgm/models/autoencoder.py:77-254 as svd.yaml:98-133 configures it: `encoder_config` (the plain Encoder), `decoder_config`
+    (temporal_ae.VideoDecoder or the image Decoder), DiagonalGaussianRegularizer -- no quant_conv / post_quant_conv."""
+
+    def __init__(self, *, encoder_config, decoder_config, loss_config=None, regularizer_config=None, ckpt_path=None, **ignored):
+        nn.Module.__init__(self)
+        self.encoder = Encoder(**encoder_config.get("params", {}))
+        video = str(decoder_config.get("target", "")).endswith("VideoDecoder")
+        self.decoder = (VideoDecoder if video else Decoder)(**decoder_config.get("params", {}))
+        self.quant_conv = self.post_quant_conv = None
+        self.embed_dim = decoder_config.get("params", {}).get("z_channels", 4)
+        self.max_batch_size = None
+        self._packed_on = None
+
+    def load_state_dict(self, state_dict, strict=False, assign=True):
+        own = {k: v for k, v in state_dict.items() if k.split(".")[0] in ("encoder", "decoder")}
+        self._packed_on = None
+        return nn.Module.load_state_dict(self, own, strict=strict, assign=True)
 
 
 def encode_first_stage(first_stage_model: AutoencoderKL, x, scale_factor=0.18215, n_samples=None, noise=None):
@@ -373,8 +492,10 @@ def encode_first_stage(first_stage_model: AutoencoderKL, x, scale_factor=0.18215
 
 
 def decode_first_stage(first_stage_model: AutoencoderKL, z, scale_factor=0.18215, n_samples=None):
-    """sgm/models/diffusion.py:117-136: z / scale_factor, decoded `n_samples` (en_and_decode_n_samples_a_time) at a time."""
+    """sgm/models/diffusion.py:117-136: z / scale_factor, decoded `n_samples` (en_and_decode_n_samples_a_time) at a time; a
+    VideoDecoder is told the number of frames of each chunk (`timesteps`)."""
     z = z.float() * (1.0 / scale_factor)
     n = n_samples or z.shape[0]
-    outs = [first_stage_model.decode(z[i:i + n]) for i in range(0, z.shape[0], n)]
+    video = first_stage_model.decoder.video
+    outs = [first_stage_model.decode(z[i:i + n], **({"timesteps": z[i:i + n].shape[0]} if video else {})) for i in range(0, z.shape[0], n)]
     return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
