@@ -136,6 +136,9 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("VIDSEG_DIST_BACKEND", "nccl")       # "gloo" + VIDSEG_ONE_GPU=1: dry-run of the N > 1 path on a 1-GPU box
+    if os.environ.get("VIDSEG_ONE_GPU") == "1":
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
@@ -143,7 +146,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     from vidseg_diffusion_amd import feature_extraction as FE
     from vidseg_diffusion_amd import ops, parallel, synthetic
