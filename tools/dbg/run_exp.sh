@@ -1,7 +1,3 @@
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/prof_svd
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_svd/kt -o s -- python bench.py --config svd --steps 2 --warmup 1 --no-cpu-baseline --no-overlap > gpurun_out/prof_svd/log.txt 2>&1
-db=$(find gpurun_out/prof_svd/kt -name "*.db" | head -1)
-python tools/prof_summary.py $db "r01_i: bench.py --config svd --steps 2 --warmup 1 --no-overlap under rocprofv3" > gpurun_out/prof_svd/kernel_stats.md
-rm -rf gpurun_out/prof_svd/kt
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_unet.py tests/test_gpu_vae.py -q -m gpu -x 2>&1 | tail -3
+VIDSEG_GEMM_BIG=2 timeout 120 python tools/dbg/ph_ksweep.py 2>&1 | grep "^M" | head -6
+for i in 1 2; do timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['family']['achieved'], {k: v['tflops'] for k, v in d['roofline']['family']['by_kernel'].items()})"; done

@@ -94,6 +94,9 @@ struct KCursor {
 };
 
 #define BK 64
+#ifndef PH_EXP
+#define PH_EXP 0                                               // kernel experiments (tools/dbg/build_exp.sh); 0 in the product build
+#endif
 
 __device__ __forceinline__ long long tap_row(const GemmParams& p, long long m) {
     if (p.tap_T <= 0) return m;
@@ -113,122 +116,158 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 // split-K partials) is 16 bytes per lane.  Only wave-level ordering is needed inside (LDS executes a wave's
 // instructions in order); the one block barrier separates the main loop's LDS reads from the staging writes.
 // ---------------------------------------------------------------------------------------------
+// phase 2 of the epilogue for one staged 32 x NCOLS tile: LPR = NCOLS / 8 lanes per row, 8 consecutive columns per lane.
+// `pre` = the staged values still need bias / per-sample vector / SiLU (everything but GEGLU, which is lane-local in phase 1).
+template <int LPR>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* stage, int mrow0, int ocol0, int nout, int lane, int split,
+                                              bool fin, bool pre) {
+    constexpr int EP_LD = 68, RPP = 64 / LPR;
+    const int lrow = lane / LPR, c8 = (lane % LPR) * 8;
+    const int n = ocol0 + c8;                                   // output column of element 0
+    if (n >= nout) return;
+    const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
+#pragma nounroll
+    for (int r0 = 0; r0 < 32; r0 += RPP) {
+        const int row = r0 + lrow;
+        const int m = mrow0 + row;                              // rows fit 31 bits (M * ldo may not: 64-bit only in the pointer math)
+        if (m >= (int)p.M) continue;
+        float v[8];
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + c8);
+        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + c8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = lo[e];
+            v[4 + e] = hi4[e];
+        }
+        if (!fin) {
+            float* wp = p.ws + ((long long)split * p.M + m) * p.N + n;
+            *reinterpret_cast<f32x4*>(wp) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(wp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            continue;
+        }
+        if (pre) {
+            if (p.bias) {                                       // 32 bytes per lane, L1-resident after the first pass
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] += b0[e];
+                    v[4 + e] += b1[e];
+                }
+            }
+            if (p.rowvec) {
+                const float* rvp = p.rowvec + (long long)(m / rps) * p.rv_stride + n;
+                const f32x4 r0v = *reinterpret_cast<const f32x4*>(rvp), r1v = *reinterpret_cast<const f32x4*>(rvp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] += r0v[e];
+                    v[4 + e] += r1v[e];
+                }
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+            }
+        }
+        if (p.rowadd) {
+            const float ra = p.rowadd[m];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += ra;
+        }
+        if (p.tap && n < 2 * p.tap_cols) {
+            f16x8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
+            const long long tr = tap_row(p, m) * p.tap_ld;
+            if (n < p.tap_cols)
+                *reinterpret_cast<f16x8*>(p.tap + tr + n) = t;
+            else if (p.tap2)
+                *reinterpret_cast<f16x8*>(p.tap2 + tr + (n - p.tap_cols)) = t;
+        }
+        if (p.residual) {
+            const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + (long long)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
+        }
+        const long long oo = (long long)m * p.ldo + n;
+        if (p.out) {
+            bf16x8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(v[e]);
+#if PH_EXP & 256                                               // experiment: no output stores (one conditional store keeps the values alive)
+            if (o[0] == 12345) *reinterpret_cast<bf16x8_t*>(p.out + oo) = o;
+#else
+            *reinterpret_cast<bf16x8_t*>(p.out + oo) = o;
+#endif
+        }
+        if (p.out_f32) {
+            *reinterpret_cast<f32x4*>(p.out_f32 + oo) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(p.out_f32 + oo + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+    }
+}
+
+// The loop over the MI x ceil(NJ/2) staged groups is ROLLED: phase 1 (accumulators -> LDS, a pure transposition except for GEGLU,
+// which needs value and gate of the same lane) is selected by a uniform switch, phase 2 exists once.  Unrolled, the epilogue was
+// ~40 k instructions per kernel and instruction-fetch bound (10 us per 256 x 320 tile); bias, per-sample vector and SiLU moved to
+// phase 2 (same order of fp32 operations as before: + bias, + vector, SiLU, + rowadd, + residual).
 template <int NJ, int MI = 2>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[MI][NJ], char* smem, long long mrow_base, int wcol_base,
                                               int lane, int wave, int split) {
     const int l31 = lane & 31, hi = lane >> 5;
     constexpr int EP_LD = 68;                                  // fp32 row stride of the staging tile (64 + 4 pad)
+    constexpr int NG = (NJ + 1) / 2;
     float* stage = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
     const bool geglu = p.act == 2;
     const int nout = geglu ? p.N / 2 : p.N;
     const bool fin = p.ksplit <= 1;                            // split-K partials carry no bias/emb/activation
     __syncthreads();                                           // main-loop LDS reads are done
+#pragma nounroll
+    for (int ig = 0; ig < MI * NG; ++ig) {
+        const int i = ig / NG, g = ig - i * NG;
+        const bool two = 2 * g + 1 < NJ;
+        const int wcol0 = wcol_base + g * 64;                  // first GEMM column of this 64-column group
+        const int mrow0 = (int)mrow_base + i * 32;
+        // ---- phase 1: accumulators -> LDS fp32 [32][ncols]
+        float bx = 0.f, bg = 0.f;
+        if (geglu && p.bias && (wcol0 + 32 + l31) < p.N) {
+            bx = p.bias[wcol0 + l31];
+            bg = p.bias[wcol0 + 32 + l31];
+        }
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int g = 0; g < (NJ + 1) / 2; ++g) {
+        for (int k = 0; k < MI * NG; ++k) {
+            if (ig != k) continue;                             // uniform
             constexpr int dummy = 0;
             (void)dummy;
-            const bool two = 2 * g + 1 < NJ;
-            const int wcol0 = wcol_base + g * 64;              // first GEMM column of this 64-column group
-            const int ncols = (geglu || !two) ? 32 : 64;       // staged columns per row
-            const int ocol0 = geglu ? wcol0 / 2 : wcol0;       // first OUTPUT column of the group
-            // ---- phase 1: accumulators (+bias, +emb vector, activation) -> LDS fp32 [32][ncols]
+            const int ki = k / NG, kg = k % NG;
             if (geglu) {
                 if constexpr (NJ % 2 == 0) {
-                    const bool cok = (wcol0 + 32 + l31) < p.N;
-                    const float bx = (p.bias && cok) ? p.bias[wcol0 + l31] : 0.f;
-                    const float bg = (p.bias && cok) ? p.bias[wcol0 + 32 + l31] : 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const float xv = acc[i][2 * g][r] + bx, gv = acc[i][2 * g + 1][r] + bg;
-                        stage[row * EP_LD + l31] = xv * gelu_erf(gv);
+                        stage[row * EP_LD + l31] = (acc[ki][2 * kg][r] + bx) * gelu_erf(acc[ki][2 * kg + 1][r] + bg);
                     }
                 }
             } else {
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
-                    if (2 * g + jj >= NJ) continue;
-                    const int n = wcol0 + jj * 32 + l31;
-                    const bool cok = n < p.N;
-                    const float bv = (p.bias && cok && fin) ? p.bias[n] : 0.f;
+                    if (2 * kg + jj >= NJ) continue;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        float v = acc[i][(2 * g + jj) < NJ ? (2 * g + jj) : 0][r] + bv;
-                        if (p.rowvec && cok && fin) {
-                            const long long m = mrow_base + i * 32 + row;
-                            if (m < p.M) v += p.rowvec[(m / p.rows_per_sample) * p.rv_stride + n];
-                        }
-                        if (p.act == 1 && fin) v = silu_f(v);
-                        stage[row * EP_LD + jj * 32 + l31] = v;
+                        stage[row * EP_LD + jj * 32 + l31] = acc[ki][(2 * kg + jj) < NJ ? (2 * kg + jj) : 0][r];
                     }
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            // ---- phase 2: 8 columns per lane, coalesced 16-byte global accesses
-            const int lpr = ncols / 8;                         // lanes per row: 8 or 4
-            const int rpp = 64 / lpr;                          // rows per pass
-            for (int r0 = 0; r0 < 32; r0 += rpp) {
-                const int row = r0 + lane / lpr, c8 = (lane % lpr) * 8;
-                const long long m = mrow_base + i * 32 + row;
-                const int n = ocol0 + c8;                      // output column of element 0
-                if (m < p.M && n < nout) {
-                    float v[8];
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + c8);
-                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + c8 + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = lo[e];
-                        v[4 + e] = hi4[e];
-                    }
-                    if (p.rowadd && fin) {
-                        const float ra = p.rowadd[m];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += ra;
-                    }
-                    if (!fin) {
-                        float* wp = p.ws + ((long long)split * p.M + m) * p.N + n;
-                        f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-                        *reinterpret_cast<f32x4*>(wp) = a;
-                        *reinterpret_cast<f32x4*>(wp + 4) = b;
-                        continue;
-                    }
-                    if (p.tap && n < p.tap_cols) {
-                        f16x8 t;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
-                        *reinterpret_cast<f16x8*>(p.tap + tap_row(p, m) * p.tap_ld + n) = t;
-                    }
-                    if (p.tap2 && n >= p.tap_cols && n < 2 * p.tap_cols) {
-                        f16x8 t;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
-                        *reinterpret_cast<f16x8*>(p.tap2 + tap_row(p, m) * p.tap_ld + (n - p.tap_cols)) = t;
-                    }
-                    if (p.residual) {
-                        const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + m * p.ldr + n);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
-                    }
-                    if (p.out) {
-                        bf16x8_t o;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(v[e]);
-                        *reinterpret_cast<bf16x8_t*>(p.out + m * p.ldo + n) = o;
-                    }
-                    if (p.out_f32) {
-                        f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-                        *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldo + n) = a;
-                        *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldo + n + 4) = b;
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase 2: 8 columns per lane, coalesced 16-byte global accesses
+        if (geglu || !two)
+            epilogue_rows<4>(p, stage, mrow0, geglu ? wcol0 / 2 : wcol0, nout, lane, split, fin, !geglu);
+        else
+            epilogue_rows<8>(p, stage, mrow0, wcol0, nout, lane, split, fin, true);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -827,9 +866,6 @@ __global__ void __launch_bounds__(WM * 128, MI == 1 ? 4 : (WM == 4 ? 1 : 2)) k_g
 // loads are outstanding, which covers everything phase q+1 reads; the barrier publishes it to the other waves.  Tiles beyond the
 // K range are staged with out-of-range buffer offsets (zeros, no memory traffic) so the counts stay uniform.
 // ---------------------------------------------------------------------------------------------
-#ifndef PH_EXP
-#define PH_EXP 0
-#endif
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -1046,14 +1082,20 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+#if !(PH_EXP & 128)                                            // experiment: no main loop
     for (int t = 0; t < nk; t += 2) {
         tile(t, 0);
         if (t + 1 < nk) tile(t + 1, 1);
     }
+#endif
     wait_vmcnt<0>();
     if (grp == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
+#if PH_EXP & 64                                                // experiment: no epilogue (one store keeps the accumulators alive)
+    if (acc[0][0][0] == 123.456f) p.out[0] = 1;
+#else
     gemm_epilogue<NJ, 2>(p, acc, smem, m0 + wm * 64, n0 + wn * (NJ * 32), lane, wave, split);
+#endif
 }
 
 // Split-K finish: sum the fp32 partials in split order (deterministic), then the same epilogue as above.
