@@ -1,3 +1,5 @@
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_unet.py tests/test_gpu_vae.py -q -m gpu -x 2>&1 | tail -3
-VIDSEG_GEMM_BIG=2 timeout 120 python tools/dbg/ph_ksweep.py 2>&1 | grep "^M" | head -6
-for i in 1 2; do timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['family']['achieved'], {k: v['tflops'] for k, v in d['roofline']['family']['by_kernel'].items()})"; done
+mkdir -p gpurun_out
+VIDSEG_GEMM_SHAPES=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap 2> gpurun_out/shapes_auto.log | tail -1 | cut -c1-120
+VIDSEG_GEMM_BIG=2 VIDSEG_GEMM_SHAPES=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap 2> gpurun_out/shapes_big2.log | tail -1 | cut -c1-120
+VIDSEG_GEMM_MID=2 VIDSEG_GEMM_SHAPES=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap 2> gpurun_out/shapes_mid2.log | tail -1 | cut -c1-120
+for t in auto big2 mid2; do python tools/dbg/shape_summary.py gpurun_out/shapes_$t.log > gpurun_out/shapes_$t.txt; done

@@ -1431,6 +1431,11 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             // measured per shape (tools/dbg/shape_summary.py): the big tile wins once the K loop is long enough to amortise its
             // unoverlapped prologue/epilogue (one block per CU) and the grid fills the chip
             big = big_mode == 2 || (fill >= 0.70 && p.K >= 960 && (S == 1 || p.K / S >= 1440));
+            // with the rolled epilogue (10 us fixed cost per tile instead of 27) the big tile also takes the short-K layers whose
+            // grid is at least a full round of 256 CUs: 114688x960x320 161 -> 151 us, 28672x1920x640 118 -> 109, 114688x320x640 96 -> 77;
+            // GEGLU and small-M shapes still lose (measured per shape, tools/dbg/shape_summary.py)
+            if (!big && big_mode == 1 && p.act != 2 && S == 1 && fill >= 0.85 && tiles_b >= 200 && p.K >= 320 && (p.N >= 640 || p.K >= 640))
+                big = true;
         }
         // panel width of the tile order: the `res` tiles resident on one XCD read (res/gn) A slabs and gn W slabs per pass
         static int panel_mode = -1;
