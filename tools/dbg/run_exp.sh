@@ -1,5 +1,17 @@
-mkdir -p gpurun_out
-VIDSEG_GEMM_SHAPES=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap 2> gpurun_out/shapes_auto.log | tail -1 | cut -c1-120
-VIDSEG_GEMM_BIG=2 VIDSEG_GEMM_SHAPES=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap 2> gpurun_out/shapes_big2.log | tail -1 | cut -c1-120
-VIDSEG_GEMM_MID=2 VIDSEG_GEMM_SHAPES=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap 2> gpurun_out/shapes_mid2.log | tail -1 | cut -c1-120
-for t in auto big2 mid2; do python tools/dbg/shape_summary.py gpurun_out/shapes_$t.log > gpurun_out/shapes_$t.txt; done
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+cd $R
+mkdir -p gpurun_out/prof_j
+python bench.py > gpurun_out/prof_j/bench.json 2> gpurun_out/prof_j/bench.err
+python bench.py --no-overlap --no-cpu-baseline > gpurun_out/prof_j/bench_no_overlap.json 2>> gpurun_out/prof_j/bench.err
+python bench.py --vae --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_j/bench_vae.json 2>> gpurun_out/prof_j/bench.err
+python bench.py --config svd --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_j/bench_svd.json 2>> gpurun_out/prof_j/bench.err
+python bench.py --config svd --fp8-attn --masks 50 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_j/bench_svd_fp8_k50.json 2>> gpurun_out/prof_j/bench.err
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_j/kt -o j -- python bench.py --no-cpu-baseline > gpurun_out/prof_j/bench_under_rocprof.log 2>&1
+db=$(find gpurun_out/prof_j/kt -name "*.db" | head -1)
+python tools/prof_summary.py $db "r01_j: python bench.py --no-cpu-baseline under rocprofv3 --kernel-trace --stats (fp16 build, phased big tile, chunk-major K, rolled epilogue, window pipeline on)" > gpurun_out/prof_j/kernel_stats.md
+rm -rf gpurun_out/prof_j/kt
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/prof_j/A -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/prof_j/B -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap > /dev/null 2>&1
+python tools/pmc_traffic.py $(find gpurun_out/prof_j/A -name "*.db" | head -1) $(find gpurun_out/prof_j/B -name "*.db" | head -1) gpurun_out/prof_j/traffic.json > /dev/null 2>&1
+rm -rf gpurun_out/prof_j/A gpurun_out/prof_j/B
