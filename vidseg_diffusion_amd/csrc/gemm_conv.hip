@@ -49,25 +49,38 @@ struct GemmParams {
     int tap_T, tap_S;        // >0: taps are written in the reference's temporal layout [(b s), t, c] (row permutation)
     const float* rowadd;     // per-row scalar added to every column before the residual (attention-output modulation
                              // lambda*mask[:,None], attention.py:646-663, 697-719) or nullptr
-    int gn;                  // tile columns per panel of the launch order (panel_tile)
+    int gn;                  // tile columns per panel of the launch order (map_tile)
     int taps, kchunk;        // K order of a conv weight row: k = (c / kchunk) * taps * kchunk + tap * kchunk + c % kchunk.
                              // kchunk = 64 (channel-chunk major: the taps of one 64-channel chunk are consecutive K-tiles, so the
                              // 9 shifted reads of an input pixel's 128-byte line are one K-tile apart and hit L1/L2 instead of
                              // going back to memory 9 times) when Cin and C0 are multiples of 64, else kchunk = Cin (tap major)
 };
 
-// Tile order inside an XCD's contiguous chunk of logical ids: panels of gn tile columns, row-major inside a panel, so the tiles
-// resident together on an XCD form a (resident/gn) x gn block and share A slabs along rows and W slabs along columns through
-// that XCD's L2 (gn = tiles_n is plain row-major; the host picks gn to minimise rows*A_slab + gn*W_slab, see launch_gemm).
-__device__ __forceinline__ void panel_tile(long long bid, long long tiles_m, int tiles_n, int gn, long long& tm, int& tn) {
-    const long long per = tiles_m * gn;
-    const int npan = (tiles_n + gn - 1) / gn;
-    const int panel = (int)min((long long)(npan - 1), bid / per);
-    const int pn0 = panel * gn;
-    const int w = min(gn, tiles_n - pn0);
-    const long long within = bid - panel * per;
-    tm = within / w;
-    tn = pn0 + (int)(within % w);
+// Tile order inside an XCD's contiguous chunk of logical ids (map_tile below): panels of gn tile columns, row-major inside a
+// panel, so the tiles resident together on an XCD form a (resident/gn) x gn block and share A slabs along rows and W slabs along
+// columns through that XCD's L2 (gn = tiles_n is plain row-major; the host picks gn to minimise rows*A_slab + gn*W_slab, see
+// launch_gemm).
+// blockIdx -> (K split, tile row, tile column) for the LDS-DMA kernels, all in unsigned 32-bit (a launch has < 2^31 blocks; the
+// 64-bit divisions this replaces were ~100 scalar instructions each, paid by every block).  Blocks go to XCDs round-robin by
+// blockIdx: each XCD gets one contiguous chunk of the (split, tile) space, so a K split's tiles (which share that split's slice of
+// W and of A's channels) meet in one L2; inside the chunk the tiles follow panel order.
+__device__ __forceinline__ void map_tile(const GemmParams& p, int BM, int BN, int& split, long long& tm, int& tn) {
+    const unsigned tiles_m = (unsigned)((p.M + BM - 1) / BM), tiles_n = (unsigned)((p.N + BN - 1) / BN);
+    const unsigned nwg = tiles_m * tiles_n;
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned tot = nwg * (unsigned)max(p.ksplit, 1);
+        const unsigned q = tot >> 3, r = tot & 7u, xcd = bid & 7u, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const unsigned sp = bid / nwg;
+    bid -= sp * nwg;
+    split = (int)sp;
+    const unsigned gn = (unsigned)p.gn, per = tiles_m * gn, npan = (tiles_n + gn - 1) / gn;
+    const unsigned panel = min(npan - 1, bid / per);
+    const unsigned pn0 = panel * gn, w = min(gn, tiles_n - pn0), within = bid - panel * per;
+    tm = (long long)(within / w);
+    tn = (int)(pn0 + within % w);
 }
 
 // position of the next K-tile in that order: chunk base channel cq, tap, offset inside the chunk
@@ -499,22 +512,9 @@ __global__ void __launch_bounds__(256, NST == 2 ? 4 : 3) k_gemm_dma(GemmParams p
     constexpr int BUF = 2 * TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const long long tiles_m = (p.M + 127) / 128;
-    const int tiles_n = (p.N + 127) / 128;
-    const long long nwg = tiles_m * tiles_n;
-    // blocks go to XCDs round-robin by blockIdx; give each XCD one contiguous chunk of the (split, tile) space, so a K split's
-    // tiles (which share that split's slice of W and of A's channels) meet in one L2
-    long long bid = blockIdx.x;
-    {
-        const long long tot = nwg * max(p.ksplit, 1);
-        const long long q = tot / 8, r = tot % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int split = (int)(bid / nwg);
-    bid -= split * nwg;
+    int split, tn;
     long long tm;
-    int tn;
-    panel_tile(bid, tiles_m, tiles_n, p.gn, tm, tn);
+    map_tile(p, 128, 128, split, tm, tn);
     const long long m0 = tm * 128;
     const int n0 = tn * 128;
 
@@ -697,22 +697,9 @@ __global__ void __launch_bounds__(WM * 128, MI == 1 ? 4 : (WM == 4 ? 1 : 2)) k_g
     constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, BUF = A_BYTES + B_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const long long tiles_m = (p.M + BM - 1) / BM;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const long long nwg = tiles_m * tiles_n;
-    // blocks go to XCDs round-robin by blockIdx; give each XCD one contiguous chunk of the (split, tile) space, so a K split's
-    // tiles (which share that split's slice of W and of A's channels) meet in one L2
-    long long bid = blockIdx.x;
-    {
-        const long long tot = nwg * max(p.ksplit, 1);
-        const long long q = tot / 8, r = tot % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int split = (int)(bid / nwg);
-    bid -= split * nwg;
+    int split, tn;
     long long tm;
-    int tn;
-    panel_tile(bid, tiles_m, tiles_n, p.gn, tm, tn);
+    map_tile(p, BM, BN, split, tm, tn);
     const long long m0 = tm * BM;
     const int n0 = tn * BN;
 
@@ -887,22 +874,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: DMA destinations and piece rows live in SGPRs
     const int wm = wave >> 1, wn = wave & 1, grp = wave >> 2;
-    const long long tiles_m = (p.M + BM - 1) / BM;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const long long nwg = tiles_m * tiles_n;
-    // blocks go to XCDs round-robin by blockIdx; give each XCD one contiguous chunk of the (split, tile) space, so a K split's
-    // tiles (which share that split's slice of W and of A's channels) meet in one L2
-    long long bid = blockIdx.x;
-    {
-        const long long tot = nwg * max(p.ksplit, 1);
-        const long long q = tot / 8, r = tot % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int split = (int)(bid / nwg);
-    bid -= split * nwg;
+    int split, tn;
     long long tm;
-    int tn;
-    panel_tile(bid, tiles_m, tiles_n, p.gn, tm, tn);
+    map_tile(p, BM, BN, split, tm, tn);
     const long long m0 = tm * BM;
     const int n0 = tn * BN;
 
