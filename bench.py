@@ -128,6 +128,9 @@ def main():
     ap.add_argument("--fp8-attn", action="store_true",
                     help="BASELINE configs[4]: e4m3 attention (q, k, v, P) on the long spatial self-attentions; reports the masks' agreement "
                          "with the 16-bit path of the same build")
+    ap.add_argument("--masks-only", action="store_true",
+                    help="opt-in pruning, NOT the reference's schedule and not the headline: the last step runs on the conditional half only and "
+                         "stops after decoder block 8 (pipeline.feature_pass(masks_only=True)); taps equal up to fp32 summation order")
     ap.add_argument("--masks", type=int, default=None, help="number of masks K (default 20; configs[4] uses 50)")
     args = ap.parse_args()
     global K_MASKS
@@ -182,7 +185,8 @@ def main():
         FE.FeatureStore.clear()
         FE.MaskStore.clear()
         return parallel.segment_windows_sharded(eng, lat, c, uc, noise=noise, num_masks=K_MASKS, num_steps=NUM_STEPS, t_start=T_START,
-                                                is_aggre_attn=True, is_refine_mask=args.refine, seed=17, rank=rank, world=world)
+                                                is_aggre_attn=True, is_refine_mask=args.refine, seed=17, rank=rank, world=world,
+                                                masks_only=args.masks_only)
 
     # N = 1: windows run through pipeline.WindowPipeline -- the analysis of step i (second HIP stream) overlaps the feature pass
     # of step i+1; every step is still a complete window (K-means included) and all of them finish inside the timed region.
@@ -198,6 +202,7 @@ def main():
                 step_no[0] += 1
                 FE.MaskStore.clear()
                 got = pipe.push(lat, c, uc, num_steps=NUM_STEPS, t_start=T_START, seed=17, noise=noise, keep_all_steps=False,
+                                masks_only=args.masks_only,
                                 exp_name=f"step{step_no[0] % 2}")
                 last = got if got is not None else last
             got = pipe.flush()
@@ -211,7 +216,8 @@ def main():
             for _ in range(n):
                 step_no[0] += 1
                 FE.MaskStore.clear()
-                got = spipe.push(lat, c, uc, noise=noise, num_steps=NUM_STEPS, t_start=T_START, seed=17, exp_name=f"r{rank}s{step_no[0] % 2}")
+                got = spipe.push(lat, c, uc, noise=noise, num_steps=NUM_STEPS, t_start=T_START, seed=17, exp_name=f"r{rank}s{step_no[0] % 2}",
+                                 masks_only=args.masks_only)
                 last = got if got is not None else last
             got = spipe.flush()
             return got if got is not None else last
@@ -292,6 +298,19 @@ def main():
                                          "window per GPU (latent 14x4x72x128), t_start=17 (8 CFG UNet evals, batch 28), spatial+temporal taps, "
                                          "is_aggre_attn, K-means K=20 + 4-NN, is_refine_mask (dense tracking + vote)")
             out["config"]["unet_evals_per_step"] = 8
+        if args.masks_only:                                              # never the headline: the reference's schedule runs every step in full
+            out["metric"] += " [masks-only pruning: NOT the reference schedule]"
+            out["config"]["workload"] += ("; OPT-IN PRUNING (--masks-only): the last UNet evaluation runs on the conditional half only and "
+                                          "stops after decoder block 8 (its other outputs are never read by Steps 3-3b)")
+            out["config"]["unet_evals_per_step"] = "2 full + 1 taps-only (cond half, blocks <= 8)"
+        if args.masks_only:                                              # outside the timed region: the same window on the full schedule
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from tools_metrics import matched_iou
+            args.masks_only = False
+            ref_labels = one_step()
+            args.masks_only = True
+            iou, exact = matched_iou(np.asarray(labels).reshape(-1), np.asarray(ref_labels).reshape(-1), K_MASKS)
+            out["masks_vs_full_schedule"] = {"iou": round(float(iou), 4), "identical_fraction": round(float(exact), 4)}
         if args.masks:
             out["metric"] = out["metric"].replace("20 masks", f"{K_MASKS} masks")
             out["config"]["workload"] = out["config"]["workload"].replace("K=20", f"K={K_MASKS}")

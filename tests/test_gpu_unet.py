@@ -505,3 +505,32 @@ def test_fp8_attention_path(env):
     assert nrms(out, base) < 5e-2, nrms(out, base)
     for b in taps:
         assert nrms(taps8[b], taps[b]) < 5e-2, (b, nrms(taps8[b], taps[b]))
+
+
+def test_masks_only_feature_pass(env):
+    """Opt-in pruning (pipeline.feature_pass(masks_only=True)): the last step on the conditional half only, stopped after output
+    block 8.  Every UNet operator is per sample, so the conditional-half taps equal the full pass's up to fp32 summation order
+    (the half batch changes split-K choices): another fp16 rounding of the same arithmetic, <= 2e-3 normalised rms here."""
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import build_sd_engine, segment_window
+    dev, g, net, sd = env
+    eng = build_sd_engine(net)
+    Fn, K = 4, 5
+    lat = torch.from_numpy(synthetic.latent_clip(Fn, 16, 16, seed=3)).to(dev)
+    cc = {"crossattn": torch.from_numpy(np.random.Generator(np.random.PCG64(4)).standard_normal((Fn, 7, 64)).astype(np.float32)).to(dev)}
+    uc = {"crossattn": torch.zeros_like(cc["crossattn"])}
+    noise = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).standard_normal(tuple(lat.shape)).astype(np.float32)).to(dev)
+    out = {}
+    for tag, kw in (("full", dict(keep_all_steps=False)), ("pruned", dict(masks_only=True))):
+        FE.FeatureStore.clear(); FE.MaskStore.clear()
+        labels, _ = segment_window(eng, lat, cc, uc, num_masks=K, is_refine_mask=True, seed=17, noise=noise, feature_folder="/nonexistent/mo",
+                                   exp_name=tag, **kw)
+        store = FE.FeatureStore.folder("/nonexistent/mo", tag)
+        out[tag] = (labels, {b: store[f"output_block_{b}_spatial_self_attn_q_time_24"][Fn:].float().cpu().numpy() for b in (6, 7, 8)})
+    from tools_metrics import matched_iou
+    for b in (6, 7, 8):
+        assert nrms(out["pruned"][1][b], out["full"][1][b]) < 2e-3, b
+    iou, exact = matched_iou(out["pruned"][0], out["full"][0], K)
+    assert iou >= 0.97 and exact >= 0.98, (iou, exact)
+    with pytest.raises(ValueError):
+        segment_window(eng, lat, cc, uc, num_masks=K, seed=17, noise=noise, feature_timestep="23", masks_only=True)

@@ -88,12 +88,17 @@ def resolve_windows(feat: torch.Tensor, tracks: Optional[torch.Tensor], ops: Cha
 
 
 def sharded_feature_pass(engine, latent, c, uc, *, noise=None, num_steps=25, t_start=22, seed=17, rank=0,
-                         feature_folder="features_outputs_VSPW", exp_name=None):
+                         feature_folder="features_outputs_VSPW", exp_name=None, masks_only=False):
     """This rank's UNet feature pass (Steps 1-2), enqueued on the current stream; only the taps the cross-window stage reads
     are kept (decoder blocks 6-8 at the last step).  Returns the handle for `sharded_resolve`."""
     from .pipeline import make_denoiser, save_feature_maps, seed_everything
     exp_name = exp_name or f"rank{rank}"
     F, _, lh, lw = latent.shape
+    if masks_only:                                      # opt-in pruning of the last step, see pipeline.feature_pass
+        from .pipeline import feature_pass
+        h = feature_pass(engine, latent, c, uc, num_steps=num_steps, t_start=t_start, seed=seed, feature_folder=feature_folder,
+                         exp_name=exp_name, noise=noise, keep_all_steps=False, masks_only=True)
+        return dict(F=F, fh=lh // 2, fw=lw // 2, seed=seed, feature_folder=feature_folder, exp_name=exp_name, done=h["done"])
     seed_everything(seed)
     sampler = engine.sampler
     denoiser = make_denoiser(engine, F)
@@ -165,7 +170,8 @@ class ShardedPipeline:
 
 
 def segment_windows_sharded(engine, latent, c, uc, *, noise=None, num_masks=20, num_steps=25, t_start=22, is_aggre_attn=True,
-                            is_refine_mask=False, seed=17, rank=0, world=1, feature_folder="features_outputs_VSPW", exp_name=None):
+                            is_refine_mask=False, seed=17, rank=0, world=1, feature_folder="features_outputs_VSPW", exp_name=None,
+                            masks_only=False):
     """Each rank segments its own window (`latent` is THIS rank's [F,4,h,w]); returns int64 labels:
     world == 1 -> [F, N] (exactly pipeline.segment_window); world > 1 -> [world, F, N], same on every rank."""
     from .pipeline import segment_window
@@ -173,9 +179,9 @@ def segment_windows_sharded(engine, latent, c, uc, *, noise=None, num_masks=20, 
     if world == 1:
         labels, _ = segment_window(engine, latent, c, uc, num_masks=num_masks, num_steps=num_steps, t_start=t_start,
                                    is_aggre_attn=is_aggre_attn, is_refine_mask=is_refine_mask, seed=seed, noise=noise,
-                                   feature_folder=feature_folder, exp_name=exp_name, keep_all_steps=False)
+                                   feature_folder=feature_folder, exp_name=exp_name, keep_all_steps=False, masks_only=masks_only)
         return labels
     h = sharded_feature_pass(engine, latent, c, uc, noise=noise, num_steps=num_steps, t_start=t_start, seed=seed, rank=rank,
-                             feature_folder=feature_folder, exp_name=exp_name)
+                             feature_folder=feature_folder, exp_name=exp_name, masks_only=masks_only)
     return sharded_resolve(engine, h, num_masks=num_masks, is_aggre_attn=is_aggre_attn, is_refine_mask=is_refine_mask, rank=rank,
                            world=world)

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import feature_extraction as FE
+from . import ops
 from .sampling import Denoiser, DiscreteDenoiser, EulerEDMSampler, OpenAIWrapper
 
 
@@ -83,8 +84,17 @@ class WindowState:
     ref_unique_labels: Optional[np.ndarray] = None
 
 
-def save_feature_maps(engine, store_folder, exp_name, i, xt=None, block_filter=None):
-    """ddim_sampler_callback -> save_feature_maps (sd_pipeline_vspw.py:103-139) into the FeatureStore."""
+def save_feature_maps(engine, store_folder, exp_name, i, xt=None, block_filter=None, pad_uncond=False):
+    """ddim_sampler_callback -> save_feature_maps (sd_pipeline_vspw.py:103-139) into the FeatureStore.
+    pad_uncond: the taps come from a conditional-half-only evaluation ([F, N, C]); they are stored as the second half of a
+    [2F, N, C] tensor whose first (unconditional) half is never read by Steps 3-3b (FE:550-551 keeps `feature_maps[num_frames:]`)."""
+    def put(name, t):
+        if pad_uncond:
+            full = torch.empty((2 * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            full[t.shape[0]:] = t
+            t = full
+        FE.FeatureStore.put(store_folder, exp_name, name, t)
+
     blocks = engine.model.diffusion_model.output_blocks
     for idx, block in enumerate(blocks):
         # SD driver tests "SpatialTransformer", SVD driver "SpatialVideoTransformer" (SDP:112, SVP:111)
@@ -93,13 +103,13 @@ def save_feature_maps(engine, store_folder, exp_name, i, xt=None, block_filter=N
                 continue
             tb = block[1].transformer_blocks[0]
             for an, a in (("self", tb.attn1), ("cross", tb.attn2)):
-                FE.FeatureStore.put(store_folder, exp_name, f"output_block_{idx}_spatial_{an}_attn_k_time_{i}", a.k)
-                FE.FeatureStore.put(store_folder, exp_name, f"output_block_{idx}_spatial_{an}_attn_q_time_{i}", a.q)
+                put(f"output_block_{idx}_spatial_{an}_attn_k_time_{i}", a.k)
+                put(f"output_block_{idx}_spatial_{an}_attn_q_time_{i}", a.q)
             if hasattr(block[1], "time_stack"):                                   # SVP:116-119
                 ts = block[1].time_stack[0]
                 for an, a in (("self", ts.attn1), ("cross", ts.attn2)):
-                    FE.FeatureStore.put(store_folder, exp_name, f"output_block_{idx}_temporal_{an}_attn_k_time_{i}", a.k)
-                    FE.FeatureStore.put(store_folder, exp_name, f"output_block_{idx}_temporal_{an}_attn_q_time_{i}", a.q)
+                    put(f"output_block_{idx}_temporal_{an}_attn_k_time_{i}", a.k)
+                    put(f"output_block_{idx}_temporal_{an}_attn_q_time_{i}", a.q)
     if xt is not None:
         FE.FeatureStore.put(store_folder, exp_name, f"xt_time_{i}", xt)
 
@@ -116,9 +126,17 @@ def make_denoiser(engine: Engine, num_frames: int):
 
 
 def feature_pass(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, num_steps=25, t_start=22, feature_timestep="24", seed=17,
-                 feature_folder="features_outputs_VSPW", exp_name="exp", noise=None, keep_all_steps=True):
+                 feature_folder="features_outputs_VSPW", exp_name="exp", noise=None, keep_all_steps=True, masks_only=False):
     """Steps 1-2 of one window (sd_pipeline_vspw.py:255, 336-357): reseed, add_noise, the Euler steps of the UNet with the dump
-    callback.  Everything is enqueued on the current HIP stream; returns the handle `analyse_window` needs."""
+    callback.  Everything is enqueued on the current HIP stream; returns the handle `analyse_window` needs.
+
+    masks_only=True (opt-in, not the reference's schedule): the evaluation at `feature_timestep` -- whose only consumers in
+    Steps 3-3b are the conditional half's Q taps of decoder blocks 6-8 -- runs on the conditional half alone and stops after
+    output block 8; the unconditional half, blocks 9-11, the output conv, the CFG combine and the Euler update of that step (all
+    dead for the masks) are skipped.  Needs keep_all_steps=False and feature_timestep = the last step; Step 4 (which reads every
+    step's dumps and x_t) needs the full pass.  The taps are the same arithmetic in another fp32 summation order (the half batch
+    changes split-K choices): 1.2e-3 normalised rms from the full pass at full size, i.e. the distance either has from an fp32
+    evaluation -- the masks are as close to the oracle's, not bit-identical to the full pass's."""
     F, _, lh, lw = latent.shape
     seed_everything(seed)                                                           # SDP:255
     sampler = engine.sampler
@@ -130,12 +148,35 @@ def feature_pass(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, num
         if i >= t_start and (keep_all_steps or i == want):
             save_feature_maps(engine, feature_folder, exp_name, i, xt=xt)
 
-    sampler(denoiser, x, cond=c, uc=uc, img_callback=callback, is_modulate=False, modulate_params=None, uc_list=None,
-            t_start=t_start, is_latent_blending=False)                              # Step 2, SDP:357
+    if masks_only:
+        if keep_all_steps or want != num_steps - 1 or want < t_start:
+            raise ValueError("masks_only needs keep_all_steps=False and feature_timestep = the last step")
+        if want > t_start:
+            x = sampler(denoiser, x, cond=c, uc=uc, img_callback=None, is_modulate=False, modulate_params=None, uc_list=None,
+                        t_start=t_start, t_end=want - 1, is_latent_blending=False)
+        else:                                                                       # one step only: the loop's entry scaling, SAM:45-59
+            x, _, _, _, _, _ = sampler.prepare_sampling_loop(x, c, uc, num_steps)
+        _taps_only_eval(engine, sampler, x, c, F, num_steps, want)
+        save_feature_maps(engine, feature_folder, exp_name, want, xt=None, block_filter=(6, 7, 8), pad_uncond=True)
+    else:
+        sampler(denoiser, x, cond=c, uc=uc, img_callback=callback, is_modulate=False, modulate_params=None, uc_list=None,
+                t_start=t_start, is_latent_blending=False)                          # Step 2, SDP:357
     done = torch.cuda.Event()
     done.record(torch.cuda.current_stream())
     return dict(F=F, fh=lh // 2, fw=lw // 2, t_start=t_start, feature_timestep=feature_timestep, seed=seed, feature_folder=feature_folder,
                 exp_name=exp_name, done=done)
+
+
+def _taps_only_eval(engine: Engine, sampler, x, c, F, num_steps, step):
+    """The network call of sampler step `step` (denoiser.py:23-46 scalings included) on the conditional half only, stopped after
+    output block 8: leaves the Q/K taps of blocks <= 8 on the attention modules as [F, N, C]."""
+    sigmas = sampler.discretization(sampler.num_steps if num_steps is None else num_steps, device="cpu")
+    den = engine.denoiser
+    sigma = den.possibly_quantize_sigma((torch.ones([F]) * sigmas[step]).float())
+    _, _, c_in, c_noise = den.scaling(sigma)
+    c_noise = den.possibly_quantize_c_noise(c_noise.reshape(sigma.shape))
+    extra = {"image_only_indicator": torch.zeros(1, F), "num_video_frames": F} if engine.video else {}
+    engine.model(ops.rows_axpby(x, c_in), c_noise.float().to(x.device), c, stop_after_block=8, **extra)
 
 
 def analyse_window(engine: Engine, h: dict, *, num_masks=20, is_aggre_attn=True, is_refine_mask=False, state: WindowState = None,
@@ -172,13 +213,15 @@ def analyse_window(engine: Engine, h: dict, *, num_masks=20, is_aggre_attn=True,
 def segment_window(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, num_masks=20, num_steps=25, t_start=22,
                    feature_timestep="24", is_aggre_attn=True, is_refine_mask=False, seed=17, state: WindowState = None,
                    frame_names=None, feature_folder="features_outputs_VSPW", exp_name="exp", gt_mask_path=None, noise=None,
-                   keep_all_steps=True):
+                   keep_all_steps=True, masks_only=False):
     """One 14-frame window: latent [F,4,h,w] fp32 (VAE output * 0.18215) -> cluster-id masks int64 [F, h/2 * w/2].
+    masks_only: see feature_pass (opt-in pruning of the work Steps 3-3b never read; implies keep_all_steps=False).
 
     Returns (labels [F, N] int64 numpy, state) -- `state` carries ref_mask/ref_feature_map/ref_unique_labels to the
     next window exactly like the driver's loop variables."""
     h = feature_pass(engine, latent, c, uc, num_steps=num_steps, t_start=t_start, feature_timestep=feature_timestep, seed=seed,
-                     feature_folder=feature_folder, exp_name=exp_name, noise=noise, keep_all_steps=keep_all_steps)
+                     feature_folder=feature_folder, exp_name=exp_name, noise=noise, keep_all_steps=keep_all_steps and not masks_only,
+                     masks_only=masks_only)
     return analyse_window(engine, h, num_masks=num_masks, is_aggre_attn=is_aggre_attn, is_refine_mask=is_refine_mask, state=state,
                           frame_names=frame_names, gt_mask_path=gt_mask_path)
 
@@ -222,7 +265,7 @@ class WindowPipeline:
         return out
 
 
-_FEATURE_KEYS = ("num_steps", "t_start", "feature_timestep", "seed", "feature_folder", "noise", "keep_all_steps")
+_FEATURE_KEYS = ("num_steps", "t_start", "feature_timestep", "seed", "feature_folder", "noise", "keep_all_steps", "masks_only")
 
 
 def segment_clip(engine, latents, c_fn, *, batch_size=14, overlap=True, exp_name="exp", **kw):

@@ -308,7 +308,7 @@ def get_modulate_lambda(modulate_lambda_start, modulate_lambda_end, modulate_sch
 class TimestepEmbedSequential(nn.Sequential):
     """openaimodel.py:67-114: children dispatched by type."""
 
-    def run(self, x, x_skip, emb_all, context, mod=None):
+    def run(self, x, x_skip, emb_all, context, mod=None, skip_resample=False):
         for layer in self:
             if isinstance(layer, ResBlock):
                 x = layer.run(x, x_skip, emb_all)
@@ -316,6 +316,8 @@ class TimestepEmbedSequential(nn.Sequential):
             elif isinstance(layer, SpatialTransformer):
                 x = layer.run(x, context, mod)
             elif isinstance(layer, (Upsample, Downsample)):
+                if skip_resample:                               # taps-only evaluation: nothing downstream reads this
+                    continue
                 x = layer.run(x)
             else:
                 raise VidsegError(f"unexpected layer {type(layer)}")
@@ -474,8 +476,10 @@ class UNetModel(nn.Module):
         return (is_mod, is_inj, mp) if (is_mod or is_inj) else None
 
     def forward_nhwc(self, x_nhwc_f32, timesteps, context_bf16, y=None, is_modulate_step=False, is_injected_step=False,
-                     modulate_params=None):
-        """x: fp32 NHWC [B, h, w, Cin]; context: bf16 [B, L, ctx]; returns fp32 NCHW [B, Cout, h, w]."""
+                     modulate_params=None, stop_after_block=None):
+        """x: fp32 NHWC [B, h, w, Cin]; context: bf16 [B, L, ctx]; returns fp32 NCHW [B, Cout, h, w].
+        stop_after_block=b: taps-only evaluation -- output blocks 0..b run (b without its Upsample), their Q/K taps are left on
+        the attention modules, and None is returned (pipeline.feature_pass(masks_only=True))."""
         if self._packed_on is None:
             self.pack(x_nhwc_f32.device)
         dev = x_nhwc_f32.device
@@ -489,12 +493,15 @@ class UNetModel(nn.Module):
         h = self.middle_block.run(h, None, emb_all, context_bf16)
         for i, blk in enumerate(self.output_blocks):
             mod = self._block_mod("output", i, blk, is_modulate_step, is_injected_step, modulate_params, dev)
+            if stop_after_block is not None and i == stop_after_block:
+                blk.run(h, hs.pop(), emb_all, context_bf16, mod, skip_resample=True)
+                return None
             h = blk.run(h, hs.pop(), emb_all, context_bf16, mod)                                         # OAI:911-948
         h = ops.groupnorm(h, self.out_g, self.out_beta, eps=1e-5, silu=True)
         return ops.conv_out4(h, self.out_w, self.out_b)
 
     def forward(self, x, timesteps=None, context=None, y=None, is_modulate_step=False, is_injected_step=False,
-                modulate_params=None, **kwargs):
+                modulate_params=None, stop_after_block=None, **kwargs):
         """Reference signature (openaimodel.py:831-841): x NCHW."""
         if (is_modulate_step or is_injected_step) and modulate_params is None:
             raise AssertionError("modulate_params is required for a modulated / injected step")
@@ -504,4 +511,4 @@ class UNetModel(nn.Module):
             raise VidsegError("UNetModel runs on a HIP device only (no CPU fallback)")
         xn = x.float().permute(0, 2, 3, 1).contiguous()
         ctx = context if context.dtype == ops.act_dtype() else ops.to_bf16(context.float().contiguous())
-        return self.forward_nhwc(xn, timesteps, ctx, y, is_modulate_step, is_injected_step, modulate_params)
+        return self.forward_nhwc(xn, timesteps, ctx, y, is_modulate_step, is_injected_step, modulate_params, stop_after_block)

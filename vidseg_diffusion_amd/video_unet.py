@@ -223,7 +223,7 @@ class SpatialVideoTransformer(SpatialTransformer):
 
 
 class VideoTimestepEmbedSequential(TimestepEmbedSequential):
-    def run(self, x, x_skip, emb_all, context, T=None, mod=None):
+    def run(self, x, x_skip, emb_all, context, T=None, mod=None, skip_resample=False):
         for layer in self:
             if isinstance(layer, VideoResBlock):
                 x = layer.run(x, x_skip, emb_all, T)
@@ -231,6 +231,8 @@ class VideoTimestepEmbedSequential(TimestepEmbedSequential):
             elif isinstance(layer, SpatialVideoTransformer):
                 x = layer.run(x, context, T, mod)
             elif isinstance(layer, (Upsample, Downsample)):
+                if skip_resample:
+                    continue
                 x = layer.run(x)
             else:
                 raise VidsegError(f"unexpected layer {type(layer)}")
@@ -336,7 +338,7 @@ class VideoUNet(UNetModel):
         return (is_mod, is_inj, mp) if (is_mod or is_inj) else None
 
     def forward_nhwc(self, x_nhwc_f32, timesteps, context_bf16, y=None, num_video_frames=None, is_modulate_step=False,
-                     is_injected_step=False, modulate_params=None):
+                     is_injected_step=False, modulate_params=None, stop_after_block=None):
         if num_video_frames is None:
             raise VidsegError("VideoUNet needs num_video_frames")
         T = int(num_video_frames)
@@ -354,12 +356,15 @@ class VideoUNet(UNetModel):
         h = self.middle_block.run(h, None, emb_all, context_bf16, T)
         for i, blk in enumerate(self.output_blocks):
             mod = self._block_mod("output", i, blk, is_modulate_step, is_injected_step, modulate_params, dev)
+            if stop_after_block is not None and i == stop_after_block:                                    # taps-only evaluation
+                blk.run(h, hs.pop(), emb_all, context_bf16, T, mod, skip_resample=True)
+                return None
             h = blk.run(h, hs.pop(), emb_all, context_bf16, T, mod)                                       # VM:521-562
         h = ops.groupnorm(h, self.out_g, self.out_beta, eps=1e-5, silu=True)
         return ops.conv_out4(h, self.out_w, self.out_b)
 
     def forward(self, x, timesteps=None, context=None, y=None, time_context=None, num_video_frames=None, image_only_indicator=None,
-                is_modulate_step=False, is_injected_step=False, modulate_params=None, **kwargs):
+                is_modulate_step=False, is_injected_step=False, modulate_params=None, stop_after_block=None, **kwargs):
         """Reference signature (video_model.py:451-463)."""
         if (is_modulate_step or is_injected_step) and modulate_params is None:
             raise AssertionError("modulate_params is required for a modulated / injected step")
@@ -371,4 +376,5 @@ class VideoUNet(UNetModel):
             raise VidsegError("VideoUNet runs on a HIP device only (no CPU fallback)")
         xn = x.float().permute(0, 2, 3, 1).contiguous()
         ctx = context if context.dtype == ops.act_dtype() else ops.to_bf16(context.float().contiguous())
-        return self.forward_nhwc(xn, timesteps, ctx, y, num_video_frames, is_modulate_step, is_injected_step, modulate_params)
+        return self.forward_nhwc(xn, timesteps, ctx, y, num_video_frames, is_modulate_step, is_injected_step, modulate_params,
+                                 stop_after_block)
