@@ -303,7 +303,7 @@ def main():
             out["config"]["workload"] += ("; OPT-IN PRUNING (--masks-only): the last UNet evaluation runs on the conditional half only and "
                                           "stops after decoder block 8 (its other outputs are never read by Steps 3-3b)")
             out["config"]["unet_evals_per_step"] = "2 full + 1 taps-only (cond half, blocks <= 8)"
-        if args.masks_only:                                              # outside the timed region: the same window on the full schedule
+        if args.masks_only and world == 1:                               # outside the timed region: the same window on the full schedule
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from tools_metrics import matched_iou
             args.masks_only = False
@@ -314,15 +314,16 @@ def main():
         if args.masks:
             out["metric"] = out["metric"].replace("20 masks", f"{K_MASKS} masks")
             out["config"]["workload"] = out["config"]["workload"].replace("K=20", f"K={K_MASKS}")
-        if args.fp8_attn:                                                # outside the timed region: the same window on the 16-bit kernels
+        if args.fp8_attn:
+            out["dtype"] += " + e4m3 attention (q, k, v, P; >= 1024 keys)"
+            out["config"]["workload"] += "; BASELINE configs[4] attention path: OCP e4m3 MFMA on the spatial self-attentions"
+        if args.fp8_attn and world == 1:                                 # outside the timed region: the same window on the 16-bit kernels
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from tools_metrics import matched_iou
             ops.set_attention_fp8(False)
             ref_labels = one_step()
             ops.set_attention_fp8(True)
             iou, exact = matched_iou(np.asarray(labels).reshape(-1), np.asarray(ref_labels).reshape(-1), K_MASKS)
-            out["dtype"] += " + e4m3 attention (q, k, v, P; >= 1024 keys)"
-            out["config"]["workload"] += "; BASELINE configs[4] attention path: OCP e4m3 MFMA on the spatial self-attentions"
             out["fp8_vs_16bit_masks"] = {"iou": round(float(iou), 4), "identical_fraction": round(float(exact), 4)}
         if args.vae:                                                     # outside the timed region, never part of `value`
             from vidseg_diffusion_amd.vae import AutoencoderKL, encode_first_stage
