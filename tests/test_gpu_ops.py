@@ -4,6 +4,8 @@ op evaluated on the CPU from the same bf16-rounded inputs.
 Tolerance (stated once): kernels accumulate in fp32 and round the result once to bf16, so
 |err| <= 2^-8 * |ref| (output rounding) + 1e-3 * max|ref| (accumulation-order slack).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -55,6 +57,99 @@ def test_linear_concat_rowvec_tap(dev):
     ref = torch.cat([a0, a1], -1) @ w.T + bias + rv[:, None, :]
     check(out, ref, "linear concat+rowvec")
     assert (tap.float().cpu() - ref[..., :64]).abs().max() <= 2.0 ** -10 * ref.abs().max() + 1e-3 * ref.abs().max()
+
+
+_EPI_CASES = [  # (M, K, N, rows_per_sample, env): every GEMM kernel of the family, ragged rows / columns, samples shorter than a 32-row block
+    (777, 320, 328, 37, {}),                                      # 128x128 LDS-DMA tile, ragged M and N, rows_per_sample > 32
+    (300, 128, 192, 5, {}),                                       # rows_per_sample < 32: per-row sample lookup
+    (1031, 1280, 320, 1031, {"VIDSEG_GEMM_BIG": "2"}),            # phased 256x320 tile forced (one ragged round)
+    (520, 2560, 512, 130, {"VIDSEG_GEMM_BIG": "2"}),              # phased 256x256 tile with split-K partials + finish kernel
+    (700, 640, 640, 100, {"VIDSEG_GEMM_MID": "2", "VIDSEG_GEMM_BIG": "0"}),   # 128x320 tile
+    (515, 192, 56, 103, {}),                                      # narrow-N register-staged kernel
+]
+
+
+@pytest.mark.parametrize("case", range(len(_EPI_CASES)))
+def test_gemm_epilogue_matrix(case):
+    """The shared (rolled) GEMM epilogue on every kernel of the family with everything switched on at once: bias, per-sample
+    vector, SiLU, per-row scalar, residual, fp16 taps (both), and the fp32 output form.  Runs in a subprocess because the tile
+    selection knobs are read once per process."""
+    import subprocess
+    import sys
+    M, K, N, rps, env = _EPI_CASES[case]
+    code = f"""
+import sys, torch
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+import torch.nn.functional as TF
+from vidseg_diffusion_amd import ops
+dev = torch.device("cuda:0")
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).bfloat16().float()
+M, K, N, rps = {M}, {K}, {N}, {rps}
+a, w, b = rnd((M, K), 1), rnd((N, K), 2, 0.05), rnd((N,), 3)
+ns = (M + rps - 1) // rps
+rv, ra, res = rnd((ns, N), 4), rnd((M,), 5, 0.5), rnd((M, N), 6)
+tc = 64 if N >= 128 else 8
+ad, wd = a.to(ops.act_dtype()).to(dev), ops.pack_linear(w, dev)
+for act in (ops.ACT_NONE, ops.ACT_SILU):
+    tap = torch.zeros((M, tc), dtype=torch.float16, device=dev)
+    tap2 = torch.zeros((M, tc), dtype=torch.float16, device=dev)
+    out = ops.linear(ad, wd, b.to(dev), rowvec=rv.to(dev), rows_per_sample=rps, residual=res.to(ops.act_dtype()).to(dev), act=act,
+                     tap=tap, tap2=tap2, tap_cols=tc, rowadd=ra.to(dev))
+    pre = a @ w.T + b + rv[torch.arange(M) // rps]
+    pre = TF.silu(pre) if act == ops.ACT_SILU else pre
+    pre = pre + ra[:, None]
+    ref = pre + res
+    err = (out.float().cpu() - ref).abs()
+    assert (err <= 2.0 ** -8 * ref.abs() + 1e-3 * ref.abs().max()).all(), ("out", act, float(err.max()))
+    for t, lo in ((tap, 0), (tap2, tc)):
+        e = (t.float().cpu() - pre[:, lo:lo + tc]).abs()
+        assert (e <= 2.0 ** -9 * pre.abs().max() + 1e-3 * pre.abs().max()).all(), ("tap", lo, float(e.max()))
+    o32 = ops.linear(ad, wd, b.to(dev), rowvec=rv.to(dev), rows_per_sample=rps, act=act, out_f32=True, rowadd=ra.to(dev))
+    assert ((o32.cpu() - pre).abs() <= 1e-3 * pre.abs().max() + 1e-5).all(), ("f32", act)
+print("ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("env", [{"VIDSEG_GEMM_BIG": "2"}, {"VIDSEG_GEMM_BIG": "2", "VIDSEG_GEMM_PH": "0"},
+                                 {"VIDSEG_GEMM_MID": "2", "VIDSEG_GEMM_BIG": "0"}, {"VIDSEG_GEMM_DMA": "3", "VIDSEG_GEMM_BIG": "0", "VIDSEG_GEMM_MID": "0"}])
+def test_conv3x3_on_every_tile(env):
+    """3x3 convolutions (concat input, stride 2, fused 2x upsample, ragged edges, chunk-major K order with a source switch inside the
+    K loop) forced onto each LDS-DMA kernel: phased big tile, unphased big tile, 128x320 tile, 3-stage 128x128 -- vs torch conv2d."""
+    import subprocess
+    import sys
+    code = f"""
+import sys, torch
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+import torch.nn.functional as TF
+from vidseg_diffusion_amd import ops
+dev = torch.device("cuda:0")
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).bfloat16().float()
+for (B, H, W, C0, C1, Co, st, up) in [(3, 37, 29, 192, 128, 256, 1, 1), (2, 24, 40, 128, 0, 320, 2, 1), (2, 9, 11, 64, 64, 640, 1, 2), (5, 16, 16, 320, 0, 64, 1, 1)]:
+    x0 = rnd((B, H, W, C0), 1)
+    x1 = rnd((B, H, W, C1), 2) if C1 else None
+    w, b = rnd((Co, C0 + C1, 3, 3), 3, 0.03), rnd((Co,), 4)
+    x = torch.cat([x0, x1], -1) if C1 else x0
+    xn = x.permute(0, 3, 1, 2)
+    if up == 2:
+        xn = TF.interpolate(xn, scale_factor=2, mode="nearest")
+    ref = TF.conv2d(xn, w, b, stride=st, padding=1)
+    rv = rnd((B, Co), 5)
+    res = rnd(tuple(ref.permute(0, 2, 3, 1).shape), 6)
+    ref = (ref + rv[:, :, None, None]).permute(0, 2, 3, 1) + res
+    out = ops.conv3x3(x0.to(ops.act_dtype()).to(dev), ops.pack_conv3x3(w, dev), b.to(dev), x1=x1.to(ops.act_dtype()).to(dev) if C1 else None,
+                      stride=st, up=up, rowvec=rv.to(dev), residual=res.to(ops.act_dtype()).to(dev)).float().cpu()
+    err = (out - ref).abs()
+    assert (err <= 2.0 ** -8 * ref.abs() + 1e-3 * ref.abs().max()).all(), ((B, H, W, C0, C1, Co, st, up), float(err.max()))
+print("ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.parametrize("M,K,inner", [(200, 64, 256), (130, 320, 1280)])
