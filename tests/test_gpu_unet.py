@@ -534,3 +534,37 @@ def test_masks_only_feature_pass(env):
     assert iou >= 0.97 and exact >= 0.98, (iou, exact)
     with pytest.raises(ValueError):
         segment_window(eng, lat, cc, uc, num_masks=K, seed=17, noise=noise, feature_timestep="23", masks_only=True)
+
+
+def test_masks_only_feature_pass_svd():
+    """The same opt-in pruning on the video UNet (cond-only batch = one video, image_only_indicator [1, F]): the spatial taps of
+    decoder blocks 6-8 and the temporal taps of block 8 at the last step vs the full schedule, and the same masks."""
+    from tools_metrics import matched_iou
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import build_svd_engine, segment_window
+    from vidseg_diffusion_amd.video_unet import VideoUNet
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "svd_sampler_narrow.npz"))
+    g = {k: z[k] for k in z.files}
+    net = VideoUNet(**synthetic.SVD_NARROW)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=4321).items()})
+    Fn = g["sm_latent"].shape[0]
+    eng = build_svd_engine(net, num_frames=Fn)
+    c = {k[2:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith("c_")}
+    uc = {k[3:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith("uc_")}
+    lat, noise = torch.from_numpy(g["sm_latent"]).to(dev), torch.from_numpy(g["sm_noise"]).to(dev)
+    out = {}
+    for tag, kw in (("full", dict(keep_all_steps=False)), ("pruned", dict(masks_only=True))):
+        FE.FeatureStore.clear(); FE.MaskStore.clear()
+        labels, _ = segment_window(eng, lat, c, uc, num_masks=4, t_start=17, is_refine_mask=True, seed=17, noise=noise,
+                                   feature_folder="/nonexistent/mosvd", exp_name=tag, **kw)
+        st = FE.FeatureStore.folder("/nonexistent/mosvd", tag)
+        taps = {b: st[f"output_block_{b}_spatial_self_attn_q_time_24"][Fn:].float().cpu().numpy() for b in (6, 7, 8)}
+        tq = st["output_block_8_temporal_self_attn_q_time_24"].float().cpu().numpy()
+        taps["t8"] = tq[tq.shape[0] // 2:]
+        out[tag] = (labels, taps)
+    for k in out["full"][1]:
+        assert nrms(out["pruned"][1][k], out["full"][1][k]) < 2e-3, k
+    iou, exact = matched_iou(out["pruned"][0], out["full"][0], 4)
+    assert iou >= 0.97 and exact >= 0.98, (iou, exact)
