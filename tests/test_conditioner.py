@@ -1,0 +1,68 @@
+"""The arithmetic part of the conditioner (vidseg_diffusion_amd/conditioner.py) vs the reference's own classes
+(tests/golden/conditioner.npz, tools/gen_golden_conditioner.py): ConcatTimestepEmbedderND bit for bit, GeneralConditioner's
+key routing / concatenation order / force-zero / (c, uc) pair on SVD's five-embedder layout (svd.yaml:38-96)."""
+import os
+
+import numpy as np
+import torch
+
+G = os.path.join(os.path.dirname(__file__), "golden", "conditioner.npz")
+
+
+def test_concat_timestep_embedder_matches_reference():
+    from vidseg_diffusion_amd.conditioner import ConcatTimestepEmbedderND
+    g = np.load(G)
+    e = ConcatTimestepEmbedderND(256)
+    assert np.array_equal(e(torch.from_numpy(g["fps_id"])).numpy(), g["emb_fps"])
+    assert np.array_equal(e(torch.from_numpy(g["cond_aug"])).numpy(), g["emb_aug"])
+    two = torch.stack([torch.from_numpy(g["fps_id"]), torch.from_numpy(g["motion"])], 1)
+    assert np.array_equal(e(two).numpy(), g["emb_two"])
+
+
+def test_general_conditioner_matches_reference():
+    from vidseg_diffusion_amd.conditioner import GeneralConditioner
+    g = np.load(G)
+    cfgs = [{"target": "sgm.modules.encoders.modules.FrozenOpenCLIPImagePredictionEmbedder", "input_key": "cond_frames_without_noise"},
+            {"target": "sgm.modules.encoders.modules.ConcatTimestepEmbedderND", "params": {"outdim": 256}, "input_key": "fps_id"},
+            {"target": "sgm.modules.encoders.modules.ConcatTimestepEmbedderND", "params": {"outdim": 256}, "input_key": "motion_bucket_id"},
+            {"target": "vidseg_diffusion_amd.conditioner.PrecomputedEmbedder", "input_key": "cond_frames"},
+            {"target": "sgm.modules.encoders.modules.ConcatTimestepEmbedderND", "params": {"outdim": 256}, "input_key": "cond_aug"}]
+    cond = GeneralConditioner(cfgs)
+    assert [e.input_key for e in cond.embedders] == ["cond_frames_without_noise", "fps_id", "motion_bucket_id", "cond_frames", "cond_aug"]
+    batch = {k[len("batch_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("batch_")}
+    c, uc = cond.get_unconditional_conditioning(batch, force_uc_zero_embeddings=["cond_frames", "cond_frames_without_noise"])
+    assert set(c) == {"crossattn", "vector", "concat"}
+    for k in c:
+        assert np.array_equal(c[k].numpy(), g["c_" + k]), k
+        assert np.array_equal(uc[k].numpy(), g["uc_" + k]), k
+    assert not uc["crossattn"].any() and not uc["concat"].any() and torch.equal(uc["vector"], c["vector"])
+
+
+def test_video_prediction_embedder_layout():
+    """(b t) c h w -> b () (t c) h w -> (b n_copies) (t c) h w with the posterior mode * scale_factor, on a stand-in encoder."""
+    from vidseg_diffusion_amd.conditioner import VideoPredictionEmbedderWithEncoder
+
+    class Enc:
+        def moments(self, x):                                    # [B, h, w, 2z] NHWC: mean = 2x of the first channel, logvar junk
+            b, _, hh, ww = x.shape
+            m = x[:, :1].permute(0, 2, 3, 1).repeat(1, 1, 1, 4) * 2.0
+            return torch.cat([m, torch.full_like(m, 7.0)], -1)
+    emb = VideoPredictionEmbedderWithEncoder(n_cond_frames=1, n_copies=3, is_ae=True, scale_factor=0.5, encoder=Enc(),
+                                             en_and_decode_n_samples_a_time=1)
+    vid = torch.arange(2 * 3 * 4 * 4, dtype=torch.float32).reshape(2, 3, 4, 4)
+    out = emb(vid)
+    assert out.shape == (6, 4, 4, 4)
+    for b in range(2):
+        for cpy in range(3):
+            assert torch.equal(out[b * 3 + cpy], vid[b, :1].repeat(4, 1, 1))     # 2.0 * 0.5 = 1
+
+
+def test_yaml_targets_resolve_to_the_mirror():
+    from vidseg_diffusion_amd import conditioner, util, vae
+    assert util.get_obj_from_str("sgm.modules.GeneralConditioner") is conditioner.GeneralConditioner
+    assert util.get_obj_from_str("sgm.modules.encoders.modules.ConcatTimestepEmbedderND") is conditioner.ConcatTimestepEmbedderND
+    assert util.get_obj_from_str("sgm.models.autoencoder.AutoencodingEngine") is vae.AutoencodingEngine
+    assert util.get_obj_from_str("sgm.modules.autoencoding.temporal_ae.VideoDecoder") is vae.VideoDecoder
+    cond = util.instantiate_from_config({"target": "sgm.modules.GeneralConditioner", "params": {"emb_models": [
+        {"target": "sgm.modules.encoders.modules.ConcatTimestepEmbedderND", "params": {"outdim": 8}, "input_key": "fps_id"}]}})
+    assert cond({"fps_id": torch.tensor([1.0, 2.0])})["vector"].shape == (2, 8)

@@ -84,6 +84,26 @@ def test_video_decoder_vs_reference():
         net.decode(z[:4])                                                           # no `timesteps`: refused, never a silent image decode
 
 
+def test_video_prediction_embedder_on_the_first_stage():
+    """SVD's `cond_frames` embedder (modules.py:951-1031, is_ae): posterior mode of the HIP encoder, repeated over the frames."""
+    from oracle.vae import VAEEncoderOracle
+    from tests.test_oracle_vae import VAE_NARROW, narrow_state_dict
+    from vidseg_diffusion_amd.conditioner import VideoPredictionEmbedderWithEncoder
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vae_encoder_narrow.npz"))
+    emb = VideoPredictionEmbedderWithEncoder(n_cond_frames=1, n_copies=3, is_ae=True, scale_factor=1.0, disable_encoder_autocast=True,
+                                             encoder_config={"target": "sgm.models.autoencoder.AutoencoderKLModeOnly",
+                                                             "params": {"embed_dim": 4, "ddconfig": VAE_NARROW}})
+    _, _, sd = narrow_state_dict()
+    emb.encoder.load_state_dict(sd)
+    out = emb(torch.from_numpy(g["x"]).to(dev)).cpu().numpy()
+    mean = g["moments"][:, :4]                                                   # reference moments: mean | logvar
+    assert out.shape == (6, 4, 8, 8)
+    for b in range(2):
+        for cpy in range(3):
+            assert nrms(out[b * 3 + cpy], mean[b]) < act_mode()[1]
+
+
 def test_asymmetric_downsample_and_softmax_ops():
     from vidseg_diffusion_amd import ops
     dev = torch.device("cuda:0")

@@ -45,12 +45,19 @@ _ALIASES = {
     "sgm.modules.diffusionmodules.wrappers": "vidseg_diffusion_amd.sampling",
     "sgm.util": "vidseg_diffusion_amd.util",
     "scripts.sampling.feature_extraction": "vidseg_diffusion_amd.feature_extraction",
+    "scripts.sampling.process_output": "vidseg_diffusion_amd.process_output",
+    "sgm.modules.encoders.modules": "vidseg_diffusion_amd.conditioner",
+    "sgm.models.autoencoder": "vidseg_diffusion_amd.vae",
+    "sgm.modules.autoencoding.temporal_ae": "vidseg_diffusion_amd.vae",
 }
+# YAML targets that name a class re-exported by a package __init__ (svd.yaml / sd_2_1.yaml: `sgm.modules.GeneralConditioner`):
+# resolved by get_obj_from_str only -- the package name itself is never replaced in sys.modules
+_TARGET_ONLY = {"sgm.modules": "vidseg_diffusion_amd.conditioner"}
 
 
 def get_obj_from_str(string, reload=False, invalidate_cache=True):
     module, cls = string.rsplit(".", 1)
-    module = _ALIASES.get(module, module)
+    module = _ALIASES.get(module, _TARGET_ONLY.get(module, module))
     if invalidate_cache:
         importlib.invalidate_caches()
     if reload:
@@ -71,7 +78,8 @@ def instantiate_from_config(config):
 def install_sgm_aliases():
     """Register `sgm.*` / `scripts.sampling.feature_extraction` module names that resolve to this package, so
     `from sgm.util import instantiate_from_config` etc. in the unmodified drivers import the MI355X path."""
-    for pkg in ("sgm", "sgm.modules", "sgm.modules.diffusionmodules", "scripts", "scripts.sampling"):
+    for pkg in ("sgm", "sgm.modules", "sgm.modules.diffusionmodules", "sgm.modules.encoders", "sgm.modules.autoencoding", "sgm.models",
+                "scripts", "scripts.sampling"):
         if pkg not in sys.modules:
             m = types.ModuleType(pkg)
             m.__path__ = []

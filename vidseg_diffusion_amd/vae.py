@@ -463,6 +463,19 @@ class AutoencoderKL(nn.Module):
         return torch.cat(outs, 0) if len(outs) > 1 else outs[0].contiguous()
 
 
+class AutoencoderKLModeOnly(AutoencoderKL):
+    """sgm/models/autoencoder.py:580-595: DiagonalGaussianRegularizer(sample=False) -- `encode` returns the posterior mode."""
+
+    def encode(self, x, return_reg_log=False, noise=None, scale=1.0):
+        bs = self.max_batch_size or x.shape[0]
+        outs = []
+        for i in range(0, x.shape[0], bs):
+            mom = self.moments(x[i:i + bs])
+            outs.append(mom[..., :mom.shape[-1] // 2].permute(0, 3, 1, 2) * scale)
+        z = (torch.cat(outs, 0) if len(outs) > 1 else outs[0]).contiguous()
+        return (z, {}) if return_reg_log else z
+
+
 class AutoencodingEngine(AutoencoderKL):
     """sgm/models/autoencoder.py:77-254 as svd.yaml:98-133 configures it: `encoder_config` (the plain Encoder), `decoder_config`
     (temporal_ae.VideoDecoder or the image Decoder), DiagonalGaussianRegularizer -- no quant_conv / post_quant_conv."""
