@@ -74,3 +74,13 @@ def get_seg_map(decoded, labels, *, label_maps=None, filter_difference=False, fi
             raise ValueError("filter_difference needs the Step 3 label maps")
         weights = mask_weights(label_maps, labels, maps.shape[-2:])
     return seg_map(maps, maxima, labels, weights, filter_s)
+
+
+def get_seg_map_main(exp_name, basecount, modulate_lambda, num_masks, num_frames, filter_difference, filter_s=0.7, resize_height=28,
+                     resize_width=52, unique_labels=None, base_folder=None, mask_folder=None, frame_name_list=None, feature_timestep="24",
+                     is_smooth=False, batch_id=None, color_map_path=None, color_map_mapping="order"):
+    """The reference's entry point (PO:75-167) works on the PNG / JPEG files its Step 4 wrote.  This package keeps the modulated
+    decodes in HBM, so the file-based form is not mirrored: call `pipeline.segmentation_map_window` (Steps 4-5 in one go) or
+    `get_seg_map(decoded, labels, ...)` on the decoded frames instead."""
+    raise VidsegError("get_seg_map_main(files on disk) is not mirrored: use pipeline.segmentation_map_window or "
+                      "process_output.get_seg_map on HBM-resident decoded frames")
