@@ -66,3 +66,47 @@ def test_yaml_targets_resolve_to_the_mirror():
     cond = util.instantiate_from_config({"target": "sgm.modules.GeneralConditioner", "params": {"emb_models": [
         {"target": "sgm.modules.encoders.modules.ConcatTimestepEmbedderND", "params": {"outdim": 8}, "input_key": "fps_id"}]}})
     assert cond({"fps_id": torch.tensor([1.0, 2.0])})["vector"].shape == (2, 8)
+
+
+def _narrow_model_config():
+    """The schema of configs/inference/sd_2_1.yaml (own text, narrow sizes): every `target:` is the reference's dotted path."""
+    dd = "sgm.modules.diffusionmodules."
+    vae = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2, 4, 4], num_res_blocks=2,
+               attn_resolutions=[], dropout=0.0)
+    return {"model": {"target": "sgm.models.diffusion.DiffusionEngine", "params": {
+        "scale_factor": 0.18215, "disable_first_stage_autocast": True,
+        "denoiser_config": {"target": dd + "denoiser.DiscreteDenoiser", "params": {
+            "num_idx": 1000, "scaling_config": {"target": dd + "denoiser_scaling.EpsScaling"},
+            "discretization_config": {"target": dd + "discretizer.LegacyDDPMDiscretization"}}},
+        "network_config": {"target": dd + "openaimodel.UNetModel", "params": dict(
+            use_checkpoint=True, in_channels=4, out_channels=4, model_channels=64, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+            channel_mult=[1, 2, 4, 4], num_head_channels=64, use_linear_in_transformer=True, transformer_depth=1, context_dim=64)},
+        "conditioner_config": {"target": "sgm.modules.GeneralConditioner", "params": {"emb_models": [
+            {"is_trainable": False, "input_key": "txt", "target": "sgm.modules.encoders.modules.FrozenOpenCLIPEmbedder",
+             "params": {"freeze": True, "layer": "penultimate"}}]}},
+        "first_stage_config": {"target": "sgm.models.autoencoder.AutoencoderKL", "params": {
+            "embed_dim": 4, "monitor": "val/rec_loss", "ddconfig": vae, "lossconfig": {"target": "torch.nn.Identity"}}},
+        "sampler_config": {"target": dd + "sampling.EulerEDMSampler", "params": {
+            "num_steps": 25, "discretization_config": {"target": dd + "discretizer.LegacyDDPMDiscretization"},
+            "guider_config": {"target": dd + "guiders.VanillaCFG", "params": {"scale": 5.0}}}}}}}
+
+
+def test_diffusion_engine_from_reference_style_config():
+    """The drivers' `instantiate_from_config(config.model)` on a config written in the reference's schema: every target resolves to
+    this package, and the attribute protocol the drivers poke is there."""
+    from vidseg_diffusion_amd import conditioner, engine, sampling, unet, util, vae
+    cfg = _narrow_model_config()
+    eng = util.instantiate_from_config(cfg["model"])
+    assert isinstance(eng, engine.DiffusionEngine) and isinstance(eng.model, sampling.OpenAIWrapper)
+    assert isinstance(eng.model.diffusion_model, unet.UNetModel) and isinstance(eng.denoiser, sampling.DiscreteDenoiser)
+    assert isinstance(eng.sampler, sampling.EulerEDMSampler) and isinstance(eng.first_stage_model, vae.AutoencoderKL)
+    assert isinstance(eng.conditioner, conditioner.GeneralConditioner) and eng.conditioner.embedders[0].input_key == "txt"
+    assert eng.scale_factor == 0.18215 and eng.en_and_decode_n_samples_a_time is None and eng.video is False
+    assert len(list(eng.model.diffusion_model.output_blocks)) == 12 and callable(eng.encode_first_stage) and callable(eng.decode_first_stage)
+    # checkpoint-style keys are routed by prefix; the OpenCLIP tower's keys are ignored, strangers reported
+    sd = {"model.diffusion_model." + k: torch.zeros(v.shape) for k, v in list(eng.model.diffusion_model.state_dict().items())[:3]}
+    sd["conditioner.embedders.0.model.ln_final.weight"] = torch.zeros(4)
+    sd["something.else"] = torch.zeros(1)
+    missing, unexpected = eng.load_state_dict(sd)
+    assert unexpected == ["something.else"] and len(missing) > 0 and all(k.startswith("model.diffusion_model.") for k in missing)
+    assert engine.engine_from_config(cfg).scale_factor == 0.18215

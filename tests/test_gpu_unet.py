@@ -568,3 +568,27 @@ def test_masks_only_feature_pass_svd():
         assert nrms(out["pruned"][1][k], out["full"][1][k]) < 2e-3, k
     iou, exact = matched_iou(out["pruned"][0], out["full"][0], 4)
     assert iou >= 0.97 and exact >= 0.98, (iou, exact)
+
+
+def test_engine_from_config_equals_hand_wired_engine(env):
+    """`engine.DiffusionEngine` instantiated from a reference-schema config (every target a reference dotted path), weights loaded
+    through checkpoint-style keys, drives Steps 1-3b exactly like the hand-wired `build_sd_engine`."""
+    from tests.test_conditioner import _narrow_model_config
+    from vidseg_diffusion_amd import feature_extraction as FE, util
+    from vidseg_diffusion_amd.pipeline import build_sd_engine, segment_window
+    dev, g, net, sd = env
+    eng2 = util.instantiate_from_config(_narrow_model_config()["model"])
+    missing, unexpected = eng2.load_state_dict({"model.diffusion_model." + k: v for k, v in sd.items()})
+    assert not unexpected and not missing
+    Fn, K = 4, 5
+    lat = torch.from_numpy(synthetic.latent_clip(Fn, 16, 16, seed=3)).to(dev)
+    cc = {"crossattn": torch.from_numpy(np.random.Generator(np.random.PCG64(4)).standard_normal((Fn, 7, 64)).astype(np.float32)).to(dev)}
+    uc = {"crossattn": torch.zeros_like(cc["crossattn"])}
+    noise = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).standard_normal(tuple(lat.shape)).astype(np.float32)).to(dev)
+    out = []
+    for tag, e in (("hand", build_sd_engine(net)), ("config", eng2)):
+        FE.FeatureStore.clear(); FE.MaskStore.clear()
+        labels, _ = segment_window(e, lat, cc, uc, num_masks=K, is_refine_mask=True, seed=17, noise=noise, feature_folder="/nonexistent/ec",
+                                   exp_name=tag, keep_all_steps=False)
+        out.append(labels)
+    assert np.array_equal(out[0], out[1])

@@ -1,0 +1,85 @@
+"""`DiffusionEngine` without Lightning (sgm/models/diffusion.py:19-151, inference subset): the object the reference's drivers
+build from `configs/inference/{sd_2_1,svd}.yaml` and then poke -- `.model` (`OpenAIWrapper(network)`), `.model.diffusion_model`,
+`.denoiser`, `.sampler`, `.conditioner`, `.first_stage_model`, `.scale_factor`, `.en_and_decode_n_samples_a_time`,
+`.encode_first_stage`, `.decode_first_stage`, `load_state_dict(sd, strict=False)` with the checkpoint's key prefixes
+(SURVEY.md §8(b)4).  Every `target:` string resolves through `util.instantiate_from_config`, i.e. to this package's mirrors.
+The pipeline functions take it wherever they take `pipeline.Engine` (they read `.model`, `.denoiser`, `.sampler`, `.video`).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch.nn as nn
+
+from .sampling import OpenAIWrapper
+from .util import default, instantiate_from_config
+
+UNCONDITIONAL_CONFIG = {"target": "sgm.modules.GeneralConditioner", "params": {"emb_models": []}}
+
+
+class DiffusionEngine(nn.Module):
+    def __init__(self, network_config, denoiser_config, first_stage_config, conditioner_config=None, sampler_config=None,
+                 optimizer_config=None, scheduler_config=None, loss_fn_config=None, network_wrapper=None, ckpt_path=None,
+                 use_ema=False, ema_decay_rate=0.9999, scale_factor: float = 1.0, disable_first_stage_autocast=False,
+                 input_key: str = "jpg", log_keys=None, no_cond_log=False, compile_model=False,
+                 en_and_decode_n_samples_a_time: Optional[int] = None):
+        super().__init__()
+        if use_ema or loss_fn_config is not None or compile_model:
+            raise NotImplementedError("DiffusionEngine: the training-side options (EMA, loss, torch.compile) are not on the path")
+        self.input_key, self.log_keys = input_key, log_keys
+        network = instantiate_from_config(network_config)
+        self.model = OpenAIWrapper(network)                                              # diffusion.py:49-51
+        self.denoiser = instantiate_from_config(denoiser_config)
+        self.sampler = instantiate_from_config(sampler_config) if sampler_config is not None else None
+        self.conditioner = instantiate_from_config(default(conditioner_config, UNCONDITIONAL_CONFIG))
+        self.first_stage_model = instantiate_from_config(first_stage_config)             # diffusion.py:103-108
+        self.scale_factor = scale_factor
+        self.disable_first_stage_autocast = disable_first_stage_autocast
+        self.en_and_decode_n_samples_a_time = en_and_decode_n_samples_a_time
+        self.video = hasattr(network, "forward_nhwc") and type(network).__name__ == "VideoUNet"
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path)
+
+    # ------------------------------------------------------------------ checkpoints (diffusion.py:85-101)
+    def init_from_ckpt(self, path: str):
+        from .util import load_checkpoint_state_dict
+        return self.load_state_dict(load_checkpoint_state_dict(path), strict=False)
+
+    def load_state_dict(self, state_dict, strict=False, assign=True):
+        """Keys as in the released checkpoints: `model.diffusion_model.*`, `first_stage_model.*`, `conditioner.*` (ignored: the
+        OpenCLIP towers are not part of this package), anything else reported as unexpected."""
+        parts = {"model.diffusion_model.": {}, "first_stage_model.": {}}
+        unexpected = []
+        for k, v in state_dict.items():
+            for pre, d in parts.items():
+                if k.startswith(pre):
+                    d[k[len(pre):]] = v
+                    break
+            else:
+                if not k.startswith("conditioner.") and not k.startswith("denoiser."):
+                    unexpected.append(k)
+        missing = []
+        if parts["model.diffusion_model."]:
+            r = self.model.diffusion_model.load_state_dict(parts["model.diffusion_model."], strict=False)
+            missing += ["model.diffusion_model." + k for k in getattr(r, "missing_keys", r[0] if isinstance(r, tuple) else [])]
+        if parts["first_stage_model."]:
+            r = self.first_stage_model.load_state_dict(parts["first_stage_model."], strict=False)
+            missing += ["first_stage_model." + k for k in getattr(r, "missing_keys", r[0] if isinstance(r, tuple) else [])]
+        return missing, unexpected
+
+    # ------------------------------------------------------------------ first stage (diffusion.py:117-151)
+    def encode_first_stage(self, x, noise=None):
+        from .vae import encode_first_stage
+        return encode_first_stage(self.first_stage_model, x, self.scale_factor, self.en_and_decode_n_samples_a_time, noise=noise)
+
+    def decode_first_stage(self, z):
+        from .vae import decode_first_stage
+        return decode_first_stage(self.first_stage_model, z, self.scale_factor, self.en_and_decode_n_samples_a_time)
+
+
+def engine_from_config(config: dict) -> DiffusionEngine:
+    """`instantiate_from_config(config.model)` of the drivers (sd_pipeline_vspw.py:553-580): `config` is the parsed YAML (a dict
+    with a `model:` entry, or that entry itself)."""
+    cfg = config.get("model", config)
+    params = dict(cfg.get("params", {}))
+    return DiffusionEngine(**params)

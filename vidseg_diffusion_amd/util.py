@@ -48,6 +48,7 @@ _ALIASES = {
     "scripts.sampling.process_output": "vidseg_diffusion_amd.process_output",
     "sgm.modules.encoders.modules": "vidseg_diffusion_amd.conditioner",
     "sgm.models.autoencoder": "vidseg_diffusion_amd.vae",
+    "sgm.models.diffusion": "vidseg_diffusion_amd.engine",
     "sgm.modules.autoencoding.temporal_ae": "vidseg_diffusion_amd.vae",
 }
 # YAML targets that name a class re-exported by a package __init__ (svd.yaml / sd_2_1.yaml: `sgm.modules.GeneralConditioner`):
