@@ -110,3 +110,51 @@ def test_diffusion_engine_from_reference_style_config():
     missing, unexpected = eng.load_state_dict(sd)
     assert unexpected == ["something.else"] and len(missing) > 0 and all(k.startswith("model.diffusion_model.") for k in missing)
     assert engine.engine_from_config(cfg).scale_factor == 0.18215
+
+
+def test_svd_style_config_builds_the_video_engine():
+    """The schema of configs/inference/svd.yaml (own text, narrow sizes): VideoUNet, v-prediction denoiser, the five-embedder
+    conditioner, AutoencodingEngine with the VideoDecoder, LinearPredictionGuider."""
+    from vidseg_diffusion_amd import conditioner, sampling, util, vae, video_unet
+    dd = "sgm.modules.diffusionmodules."
+    ae = dict(attn_type="vanilla", double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    emb = "sgm.modules.encoders.modules."
+    cfg = {"target": "sgm.models.diffusion.DiffusionEngine", "params": {
+        "scale_factor": 0.18215, "disable_first_stage_autocast": True,
+        "denoiser_config": {"target": dd + "denoiser.Denoiser", "params": {"scaling_config": {"target": dd + "denoiser_scaling.VScalingWithEDMcNoise"}}},
+        "network_config": {"target": dd + "video_model.VideoUNet", "params": dict(
+            adm_in_channels=96, num_classes="sequential", use_checkpoint=True, in_channels=8, out_channels=4, model_channels=64,
+            attention_resolutions=[4, 2, 1], num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_head_channels=64, use_linear_in_transformer=True,
+            transformer_depth=1, context_dim=64, spatial_transformer_attn_type="softmax-xformers", extra_ff_mix_layer=True,
+            use_spatial_context=True, merge_strategy="learned_with_images", video_kernel_size=[3, 1, 1])},
+        "conditioner_config": {"target": "sgm.modules.GeneralConditioner", "params": {"emb_models": [
+            {"is_trainable": False, "input_key": "cond_frames_without_noise", "target": emb + "FrozenOpenCLIPImagePredictionEmbedder",
+             "params": {"n_cond_frames": 1, "n_copies": 1, "open_clip_embedding_config": {"target": emb + "FrozenOpenCLIPImageEmbedder", "params": {"freeze": True}}}},
+            {"input_key": "fps_id", "is_trainable": False, "target": emb + "ConcatTimestepEmbedderND", "params": {"outdim": 32}},
+            {"input_key": "motion_bucket_id", "is_trainable": False, "target": emb + "ConcatTimestepEmbedderND", "params": {"outdim": 32}},
+            {"input_key": "cond_frames", "is_trainable": False, "target": emb + "VideoPredictionEmbedderWithEncoder", "params": {
+                "disable_encoder_autocast": True, "n_cond_frames": 1, "n_copies": 1, "is_ae": True,
+                "encoder_config": {"target": "sgm.models.autoencoder.AutoencoderKLModeOnly", "params": {
+                    "embed_dim": 4, "monitor": "val/rec_loss", "ddconfig": dict(ae, attn_type="vanilla-xformers"), "lossconfig": {"target": "torch.nn.Identity"}}}}},
+            {"input_key": "cond_aug", "is_trainable": False, "target": emb + "ConcatTimestepEmbedderND", "params": {"outdim": 32}}]}},
+        "first_stage_config": {"target": "sgm.models.autoencoder.AutoencodingEngine", "params": {
+            "loss_config": {"target": "torch.nn.Identity"},
+            "regularizer_config": {"target": "sgm.modules.autoencoding.regularizers.DiagonalGaussianRegularizer"},
+            "encoder_config": {"target": dd + "model.Encoder", "params": ae},
+            "decoder_config": {"target": "sgm.modules.autoencoding.temporal_ae.VideoDecoder", "params": dict(ae, video_kernel_size=[3, 1, 1])}}},
+        "sampler_config": {"target": dd + "sampling.EulerEDMSampler", "params": {
+            "num_steps": 25, "discretization_config": {"target": dd + "discretizer.EDMDiscretization", "params": {"sigma_max": 700.0}},
+            "guider_config": {"target": dd + "guiders.LinearPredictionGuider", "params": {"max_scale": 2.5, "min_scale": 1.0, "num_frames": 14}}}}}}
+    eng = util.instantiate_from_config(cfg)
+    assert eng.video and isinstance(eng.model.diffusion_model, video_unet.VideoUNet) and isinstance(eng.denoiser, sampling.Denoiser)
+    assert isinstance(eng.first_stage_model, vae.AutoencodingEngine) and eng.first_stage_model.decoder.video
+    assert isinstance(eng.sampler.guider, sampling.LinearPredictionGuider)
+    kinds = [type(e).__name__ for e in eng.conditioner.embedders]
+    assert kinds == ["PrecomputedEmbedder", "ConcatTimestepEmbedderND", "ConcatTimestepEmbedderND", "VideoPredictionEmbedderWithEncoder",
+                     "ConcatTimestepEmbedderND"]
+    assert isinstance(eng.conditioner.embedders[3].encoder, vae.AutoencoderKL)
+    # the vector conditioning the video UNet's label_emb takes: three 32-wide sinusoids = adm_in_channels 96
+    b = {"fps_id": torch.full((3,), 6.0), "motion_bucket_id": torch.full((3,), 127.0), "cond_aug": torch.full((3,), 0.02)}
+    vec = torch.cat([eng.conditioner.embedders[i](b[k]) for i, k in ((1, "fps_id"), (2, "motion_bucket_id"), (4, "cond_aug"))], 1)
+    assert vec.shape == (3, 96)
