@@ -592,3 +592,43 @@ def test_engine_from_config_equals_hand_wired_engine(env):
                                    exp_name=tag, keep_all_steps=False)
         out.append(labels)
     assert np.array_equal(out[0], out[1])
+
+
+def test_svd_steps_4_5_on_the_video_first_stage():
+    """Steps 1-5 on the video engine: masks, the temporal modulation sweep, decodes through AutoencodingEngine + VideoDecoder
+    (whole videos per call, `timesteps` = frames), difference maps and arg-max -- vs the oracle's Step 5 on the device's decodes."""
+    from oracle import process_output as OPO
+    from tests.test_oracle_vae import narrow_video_decoder_state_dict
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import build_svd_engine, segment_window, segmentation_map_window
+    from vidseg_diffusion_amd.vae import decode_first_stage
+    from vidseg_diffusion_amd.video_unet import VideoUNet
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "svd_sampler_narrow.npz"))
+    g = {k: z[k] for k in z.files}
+    net = VideoUNet(**synthetic.SVD_NARROW)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=4321).items()})
+    Fn = g["sm_latent"].shape[0]
+    eng = build_svd_engine(net, num_frames=Fn)
+    c = {k[2:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith("c_")}
+    uc = {k[3:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith("uc_")}
+    lat, noise = torch.from_numpy(g["sm_latent"]).to(dev), torch.from_numpy(g["sm_noise"]).to(dev)
+    gv = np.load(os.path.join(os.path.dirname(__file__), "golden", "vae_video_decoder_narrow.npz"))
+    vae, _, vsd = narrow_video_decoder_state_dict(gv)
+    vae.load_state_dict(vsd)
+    FE.FeatureStore.clear(); FE.MaskStore.clear()
+    base, exp, K = "/nonexistent/svd45", "w", 3
+    labels, _ = segment_window(eng, lat, c, uc, num_masks=K, t_start=22, seed=17, noise=noise, feature_folder=base, exp_name=exp,
+                               keep_all_steps=True)
+    uniq = np.unique(labels)
+    folder = os.path.join(base, exp, "match_gt_mask", f"output_block_8_output_block_7_output_block_6_spatial_self_attn_q_masks_{K}")
+    assert FE.MaskStore.get(folder) is not None
+    seg, lats = segmentation_map_window(eng, vae, lat, c, uc, uniq, folder, t_start=22, feature_folder=base, exp_name=exp, noise=noise,
+                                        seed=17, modulate_layer_type=("temporal",), modulate_attn_type=("self_attn",))
+    h, w = lat.shape[-2:]
+    assert seg.shape == (Fn, 8 * h, 8 * w) and set(np.unique(seg.cpu().numpy())) <= set(int(l) for l in uniq)
+    pos = np.stack([decode_first_stage(vae, lats[(1, int(l))], 0.18215).cpu().numpy() for l in uniq])
+    neg = np.stack([decode_first_stage(vae, lats[(-1, int(l))], 0.18215).cpu().numpy() for l in uniq])
+    ref_seg, _ = OPO.seg_maps(pos, neg, [int(l) for l in uniq])
+    assert np.array_equal(seg.cpu().numpy(), ref_seg)
