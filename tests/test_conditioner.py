@@ -4,6 +4,7 @@ key routing / concatenation order / force-zero / (c, uc) pair on SVD's five-embe
 import os
 
 import numpy as np
+import pytest
 import torch
 
 G = os.path.join(os.path.dirname(__file__), "golden", "conditioner.npz")
@@ -112,10 +113,8 @@ def test_diffusion_engine_from_reference_style_config():
     assert engine.engine_from_config(cfg).scale_factor == 0.18215
 
 
-def test_svd_style_config_builds_the_video_engine():
-    """The schema of configs/inference/svd.yaml (own text, narrow sizes): VideoUNet, v-prediction denoiser, the five-embedder
-    conditioner, AutoencodingEngine with the VideoDecoder, LinearPredictionGuider."""
-    from vidseg_diffusion_amd import conditioner, sampling, util, vae, video_unet
+def _narrow_svd_config():
+    """The schema of configs/inference/svd.yaml (own text, narrow sizes)."""
     dd = "sgm.modules.diffusionmodules."
     ae = dict(attn_type="vanilla", double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2, 4, 4],
               num_res_blocks=2, attn_resolutions=[], dropout=0.0)
@@ -146,6 +145,14 @@ def test_svd_style_config_builds_the_video_engine():
         "sampler_config": {"target": dd + "sampling.EulerEDMSampler", "params": {
             "num_steps": 25, "discretization_config": {"target": dd + "discretizer.EDMDiscretization", "params": {"sigma_max": 700.0}},
             "guider_config": {"target": dd + "guiders.LinearPredictionGuider", "params": {"max_scale": 2.5, "min_scale": 1.0, "num_frames": 14}}}}}}
+    return cfg
+
+
+def test_svd_style_config_builds_the_video_engine():
+    """The schema of configs/inference/svd.yaml (own text, narrow sizes): VideoUNet, v-prediction denoiser, the five-embedder
+    conditioner, AutoencodingEngine with the VideoDecoder, LinearPredictionGuider."""
+    from vidseg_diffusion_amd import conditioner, sampling, util, vae, video_unet
+    cfg = _narrow_svd_config()
     eng = util.instantiate_from_config(cfg)
     assert eng.video and isinstance(eng.model.diffusion_model, video_unet.VideoUNet) and isinstance(eng.denoiser, sampling.Denoiser)
     assert isinstance(eng.first_stage_model, vae.AutoencodingEngine) and eng.first_stage_model.decoder.video
@@ -158,3 +165,49 @@ def test_svd_style_config_builds_the_video_engine():
     b = {"fps_id": torch.full((3,), 6.0), "motion_bucket_id": torch.full((3,), 127.0), "cond_aug": torch.full((3,), 0.02)}
     vec = torch.cat([eng.conditioner.embedders[i](b[k]) for i, k in ((1, "fps_id"), (2, "motion_bucket_id"), (4, "cond_aug"))], 1)
     assert vec.shape == (3, 96)
+
+
+def _prefixed_checkpoint(eng, seed=3):
+    """A synthetic checkpoint with the released files' key layout for every parameter the engine owns."""
+    from vidseg_diffusion_amd import synthetic
+    sd = {}
+    for prefix, mod in (("model.diffusion_model.", eng.model.diffusion_model), ("first_stage_model.", eng.first_stage_model)):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        sd.update({prefix + k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=seed).items()})
+    for i, emb in enumerate(eng.conditioner.embedders):
+        if hasattr(emb, "encoder"):
+            shapes = {k: tuple(v.shape) for k, v in emb.encoder.state_dict().items()}
+            sd.update({f"conditioner.embedders.{i}.encoder.{k}": torch.from_numpy(v)
+                       for k, v in synthetic.fill_state_dict(shapes, seed=seed + 1).items()})
+    sd["conditioner.embedders.0.model.ln_final.weight"] = torch.zeros(4)          # an OpenCLIP tower key: ignored
+    return sd
+
+
+@pytest.mark.parametrize("kind", ["sd", "svd"])
+def test_ckpt_path_restores_every_parameter(tmp_path, kind):
+    """sgm/models/diffusion.py:85-101 -- `ckpt_path=` in the config (svd.yaml sets it): the raw checkpoint keys
+    (`model.diffusion_model.*`, `first_stage_model.*`, `conditioner.embedders.3.encoder.*`) reach their modules, nothing stays
+    on the meta device, nothing is reported missing or unexpected."""
+    from safetensors.torch import save_file
+    from vidseg_diffusion_amd import util
+    cfg = _narrow_model_config()["model"] if kind == "sd" else _narrow_svd_config()
+    eng0 = util.instantiate_from_config(cfg)
+    sd = _prefixed_checkpoint(eng0)
+    path = str(tmp_path / f"{kind}.safetensors")
+    save_file({k: v.contiguous() for k, v in sd.items()}, path)
+    cfg = dict(cfg, params=dict(cfg["params"], ckpt_path=path))
+    eng = util.instantiate_from_config(cfg)
+    assert not [n for n, p in eng.named_parameters() if p.is_meta]
+    missing, unexpected = eng.init_from_ckpt(path)
+    assert missing == [] and unexpected == []
+    k0 = next(iter(eng.model.diffusion_model.state_dict()))
+    assert torch.equal(eng.model.diffusion_model.state_dict()[k0], sd["model.diffusion_model." + k0])
+    if kind == "svd":
+        k3 = next(iter(eng.conditioner.embedders[3].encoder.state_dict()))
+        assert torch.equal(eng.conditioner.embedders[3].encoder.state_dict()[k3], sd["conditioner.embedders.3.encoder." + k3])
+    # the .ckpt route (torch.save({"state_dict": ...})) and an unknown suffix
+    p2 = str(tmp_path / f"{kind}.ckpt")
+    torch.save({"state_dict": sd}, p2)
+    assert util.instantiate_from_config(dict(cfg, params=dict(cfg["params"], ckpt_path=p2))).init_from_ckpt(p2) == ([], [])
+    with pytest.raises(NotImplementedError):
+        eng.init_from_ckpt(str(tmp_path / "weights.bin"))

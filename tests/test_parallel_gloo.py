@@ -71,16 +71,17 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("refine", [False, True])
-def test_two_rank_chain_matches_sequential_reference(refine):
-    world = 2
+@pytest.mark.parametrize("world,refine", [(2, False), (2, True), (8, True)])
+def test_chain_matches_sequential_reference(world, refine):
+    """world 2 and world 8 (BASELINE configs[3]: 8 windows, one per GPU): every rank ends with the labels of ALL windows, equal
+    to the reference's sequential window loop."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, refine, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(world))
+    res = dict(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

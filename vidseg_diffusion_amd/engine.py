@@ -42,13 +42,26 @@ class DiffusionEngine(nn.Module):
 
     # ------------------------------------------------------------------ checkpoints (diffusion.py:85-101)
     def init_from_ckpt(self, path: str):
-        from .util import load_checkpoint_state_dict
-        return self.load_state_dict(load_checkpoint_state_dict(path), strict=False)
+        """diffusion.py:85-101: the RAW checkpoint dict (Lightning prefixes kept: `model.diffusion_model.*`, `first_stage_model.*`,
+        `conditioner.embedders.N.*`) goes through `load_state_dict(strict=False)`; `.ckpt` -> torch.load(...)["state_dict"],
+        `.safetensors` -> safetensors; anything else is NotImplementedError like the reference."""
+        from .util import load_raw_checkpoint
+        missing, unexpected = self.load_state_dict(load_raw_checkpoint(path), strict=False)
+        print(f"Restored from {path} with {len(missing)} missing and {len(unexpected)} unexpected keys")
+        if missing:
+            print(f"Missing Keys: {missing}")
+        if unexpected:
+            print(f"Unexpected Keys: {unexpected}")
+        return missing, unexpected
 
     def load_state_dict(self, state_dict, strict=False, assign=True):
-        """Keys as in the released checkpoints: `model.diffusion_model.*`, `first_stage_model.*`, `conditioner.*` (ignored: the
-        OpenCLIP towers are not part of this package), anything else reported as unexpected."""
+        """Keys as in the released checkpoints, routed by prefix: `model.diffusion_model.*` -> the network,
+        `first_stage_model.*` -> the first stage, `conditioner.embedders.N.*` -> embedder N when it owns parameters (SVD's
+        `VideoPredictionEmbedderWithEncoder.encoder`, svd.yaml:66-91).  Keys of embedders that are stand-ins here (the OpenCLIP
+        towers, `PrecomputedEmbedder`) and `denoiser.*` buffers are ignored; anything else is reported as unexpected.
+        Returns (missing, unexpected) with the checkpoint's full key names."""
         parts = {"model.diffusion_model.": {}, "first_stage_model.": {}}
+        cond = {}
         unexpected = []
         for k, v in state_dict.items():
             for pre, d in parts.items():
@@ -56,15 +69,41 @@ class DiffusionEngine(nn.Module):
                     d[k[len(pre):]] = v
                     break
             else:
-                if not k.startswith("conditioner.") and not k.startswith("denoiser."):
+                if k.startswith("conditioner.embedders."):
+                    idx, _, rest = k[len("conditioner.embedders."):].partition(".")
+                    if idx.isdigit() and rest:
+                        cond.setdefault(int(idx), {})[rest] = v
+                    else:
+                        unexpected.append(k)
+                elif not k.startswith("conditioner.") and not k.startswith("denoiser."):
                     unexpected.append(k)
         missing = []
+
+        def _load(module, sub, prefix):
+            r = module.load_state_dict(sub, strict=False)
+            miss = getattr(r, "missing_keys", r[0] if isinstance(r, tuple) else [])
+            unex = getattr(r, "unexpected_keys", r[1] if isinstance(r, tuple) else [])
+            missing.extend(prefix + k for k in miss)
+            unexpected.extend(prefix + k for k in unex)
+
         if parts["model.diffusion_model."]:
-            r = self.model.diffusion_model.load_state_dict(parts["model.diffusion_model."], strict=False)
-            missing += ["model.diffusion_model." + k for k in getattr(r, "missing_keys", r[0] if isinstance(r, tuple) else [])]
+            _load(self.model.diffusion_model, parts["model.diffusion_model."], "model.diffusion_model.")
         if parts["first_stage_model."]:
-            r = self.first_stage_model.load_state_dict(parts["first_stage_model."], strict=False)
-            missing += ["first_stage_model." + k for k in getattr(r, "missing_keys", r[0] if isinstance(r, tuple) else [])]
+            _load(self.first_stage_model, parts["first_stage_model."], "first_stage_model.")
+        embedders = list(getattr(self.conditioner, "embedders", []))
+        for idx, sub in sorted(cond.items()):
+            if idx >= len(embedders):
+                unexpected.extend(f"conditioner.embedders.{idx}.{k}" for k in sub)
+                continue
+            emb = embedders[idx]
+            owner = getattr(emb, "encoder", None)                         # VideoPredictionEmbedderWithEncoder: `.encoder.*`
+            if owner is not None and any(True for _ in owner.parameters()):
+                enc = {k[len("encoder."):]: v for k, v in sub.items() if k.startswith("encoder.")}
+                unexpected.extend(f"conditioner.embedders.{idx}.{k}" for k in sub if not k.startswith("encoder."))
+                _load(owner, enc, f"conditioner.embedders.{idx}.encoder.")
+            elif any(True for _ in emb.parameters()):
+                _load(emb, sub, f"conditioner.embedders.{idx}.")
+            # else: a stand-in for a pretrained tower (PrecomputedEmbedder) -- its checkpoint keys have nowhere to go
         return missing, unexpected
 
     # ------------------------------------------------------------------ first stage (diffusion.py:117-151)

@@ -11,9 +11,11 @@ What shards and what is exchanged
   depends on features alone.  So every rank searches its window's top-4 neighbours in window r-1's features
   concurrently, and the label chain itself is a cheap gather resolved identically on every rank.
 * Exchange = ONE all-gather of the aggregated, normalised conditional-half features ([F*N, 640] fp16,
-  18.4 MB/rank at config 2) so each rank holds its predecessor's tokens, then one all-gather of the small
-  int32 results (neighbour indices [F*N,4], tracks [F,N]) and a broadcast of window 0's labels.  No other
-  data-path collective; no reduction.
+  18.4 MB/rank at config 2) so each rank holds its predecessor's tokens AND window 0's, then one all-gather of
+  the small int32 results (neighbour indices [F*N,4], tracks [F,N]).  Window 0's K-means runs redundantly on
+  every rank from the gathered copy (deterministic kernels: identical labels everywhere), concurrently with the
+  neighbour searches -- no rank waits at a broadcast for rank 0's clustering.  No other data-path collective;
+  no reduction.
 
 The orchestration below is backend-agnostic (tested under gloo, world_size 2, on CPU with oracle compute
 callbacks); `segment_windows_sharded` binds it to the HIP kernels.
@@ -51,16 +53,6 @@ def _all_gather(t: torch.Tensor, world: int):
     return out.view((world,) + tuple(t.shape))
 
 
-def _broadcast(t: torch.Tensor, src: int):
-    import torch.distributed as dist
-    if _host_staged(t):
-        h = t.cpu()
-        dist.broadcast(h, src=src)
-        t.copy_(h)
-    else:
-        dist.broadcast(t, src=src)
-
-
 def resolve_windows(feat: torch.Tensor, tracks: Optional[torch.Tensor], ops: ChainOps, rank: int, world: int, num_frames: int):
     """feat: this rank's normalised tokens fp16 [F*N, C]; tracks: this rank's dense tracks int32 [F, N] or None.
     Returns final labels of ALL windows, int32 [world, F*N], identical on every rank."""
@@ -68,13 +60,11 @@ def resolve_windows(feat: torch.Tensor, tracks: Optional[torch.Tensor], ops: Cha
     FN = feat.shape[0]
     all_feat = _all_gather(feat, world)                               # [W, F*N, C]   <- the RCCL all-gather over xGMI
     if rank == 0:
-        labels0 = ops.first_window_labels(all_feat[0]).to(torch.int32)
         nn_idx = torch.full((FN, 4), -1, dtype=torch.int32, device=feat.device)
     else:
-        labels0 = torch.empty(FN, dtype=torch.int32, device=feat.device)
         nn_idx = ops.knn_top4(all_feat[rank - 1], feat).to(torch.int32)
-    _broadcast(labels0, 0)
-    all_idx = _all_gather(nn_idx, world)                              # [W, F*N, 4]
+    all_idx = _all_gather(nn_idx, world)                              # [W, F*N, 4]   (issued before the K-means so it overlaps it)
+    labels0 = ops.first_window_labels(all_feat[0]).to(torch.int32)    # every rank, same bits (see module docstring)
     all_tracks = _all_gather(tracks, world) if tracks is not None else None
     out = []
     prev = labels0
@@ -88,26 +78,32 @@ def resolve_windows(feat: torch.Tensor, tracks: Optional[torch.Tensor], ops: Cha
 
 
 def sharded_feature_pass(engine, latent, c, uc, *, noise=None, num_steps=25, t_start=22, seed=17, rank=0,
-                         feature_folder="features_outputs_VSPW", exp_name=None, masks_only=False):
+                         feature_folder="features_outputs_VSPW", exp_name=None, masks_only=False, feature_timestep=None):
     """This rank's UNet feature pass (Steps 1-2), enqueued on the current stream; only the taps the cross-window stage reads
-    are kept (decoder blocks 6-8 at the last step).  Returns the handle for `sharded_resolve`."""
+    are kept (decoder blocks 6-8 at sampler step `feature_timestep`, default the last one, num_steps - 1 -- the drivers'
+    `feature_timestep="24"` for their 25 steps, sd_pipeline_vspw.py:633-645).  Returns the handle for `sharded_resolve`."""
     from .pipeline import make_denoiser, save_feature_maps, seed_everything
     exp_name = exp_name or f"rank{rank}"
     F, _, lh, lw = latent.shape
+    want = num_steps - 1 if feature_timestep is None else int(feature_timestep)
+    if not t_start <= want < num_steps:
+        raise ValueError(f"feature_timestep {want} is outside the sampled steps [{t_start}, {num_steps})")
     if masks_only:                                      # opt-in pruning of the last step, see pipeline.feature_pass
         from .pipeline import feature_pass
-        h = feature_pass(engine, latent, c, uc, num_steps=num_steps, t_start=t_start, seed=seed, feature_folder=feature_folder,
-                         exp_name=exp_name, noise=noise, keep_all_steps=False, masks_only=True)
-        return dict(F=F, fh=lh // 2, fw=lw // 2, seed=seed, feature_folder=feature_folder, exp_name=exp_name, done=h["done"])
+        h = feature_pass(engine, latent, c, uc, num_steps=num_steps, t_start=t_start, feature_timestep=str(want), seed=seed,
+                         feature_folder=feature_folder, exp_name=exp_name, noise=noise, keep_all_steps=False, masks_only=True)
+        return dict(F=F, fh=lh // 2, fw=lw // 2, seed=seed, feature_folder=feature_folder, exp_name=exp_name, done=h["done"],
+                    feature_timestep=want)
     seed_everything(seed)
     sampler = engine.sampler
     denoiser = make_denoiser(engine, F)
     x = sampler.add_noise(latent, cond=c, uc=uc, num_steps=num_steps, noise_level=t_start, noise=noise)
     sampler(denoiser, x, cond=c, uc=uc, t_start=t_start,
-            img_callback=lambda xt, i: save_feature_maps(engine, feature_folder, exp_name, i, xt=xt, block_filter=(6, 7, 8)) if i == 24 else None)
+            img_callback=lambda xt, i: save_feature_maps(engine, feature_folder, exp_name, i, xt=xt, block_filter=(6, 7, 8)) if i == want else None)
     done = torch.cuda.Event()
     done.record(torch.cuda.current_stream())
-    return dict(F=F, fh=lh // 2, fw=lw // 2, seed=seed, feature_folder=feature_folder, exp_name=exp_name, done=done)
+    return dict(F=F, fh=lh // 2, fw=lw // 2, seed=seed, feature_folder=feature_folder, exp_name=exp_name, done=done,
+                feature_timestep=want)
 
 
 def sharded_resolve(engine, h, *, num_masks=20, is_aggre_attn=True, is_refine_mask=False, rank=0, world=1):
@@ -121,11 +117,12 @@ def sharded_resolve(engine, h, *, num_masks=20, is_aggre_attn=True, is_refine_ma
     store = FE.FeatureStore.folder(h["feature_folder"], h["exp_name"])
     names = ["output_block_8", "output_block_7", "output_block_6"] if is_aggre_attn else \
         (["output_block_8"] if engine.video else ["output_block_7"])
-    blocks = [store[f"{n}_spatial_self_attn_q_time_24"] for n in names]
+    ts = h["feature_timestep"]
+    blocks = [store[f"{n}_spatial_self_attn_q_time_{ts}"] for n in names]
     _, feat = A.mean_normalize(blocks, F * N, F * N)
     tracks = None
     if is_refine_mask:
-        q7 = store["output_block_7_spatial_self_attn_q_time_24"]
+        q7 = store[f"output_block_7_spatial_self_attn_q_time_{ts}"]
         tracks, _ = A.dense_tracking(q7[F:2 * F].contiguous(), F, fh, fw)
 
     def first_window(feat0):
@@ -171,7 +168,7 @@ class ShardedPipeline:
 
 def segment_windows_sharded(engine, latent, c, uc, *, noise=None, num_masks=20, num_steps=25, t_start=22, is_aggre_attn=True,
                             is_refine_mask=False, seed=17, rank=0, world=1, feature_folder="features_outputs_VSPW", exp_name=None,
-                            masks_only=False):
+                            masks_only=False, feature_timestep=None):
     """Each rank segments its own window (`latent` is THIS rank's [F,4,h,w]); returns int64 labels:
     world == 1 -> [F, N] (exactly pipeline.segment_window); world > 1 -> [world, F, N], same on every rank."""
     from .pipeline import segment_window
@@ -179,9 +176,10 @@ def segment_windows_sharded(engine, latent, c, uc, *, noise=None, num_masks=20, 
     if world == 1:
         labels, _ = segment_window(engine, latent, c, uc, num_masks=num_masks, num_steps=num_steps, t_start=t_start,
                                    is_aggre_attn=is_aggre_attn, is_refine_mask=is_refine_mask, seed=seed, noise=noise,
-                                   feature_folder=feature_folder, exp_name=exp_name, keep_all_steps=False, masks_only=masks_only)
+                                   feature_folder=feature_folder, exp_name=exp_name, keep_all_steps=False, masks_only=masks_only,
+                                   feature_timestep=str(num_steps - 1 if feature_timestep is None else int(feature_timestep)))
         return labels
     h = sharded_feature_pass(engine, latent, c, uc, noise=noise, num_steps=num_steps, t_start=t_start, seed=seed, rank=rank,
-                             feature_folder=feature_folder, exp_name=exp_name, masks_only=masks_only)
+                             feature_folder=feature_folder, exp_name=exp_name, masks_only=masks_only, feature_timestep=feature_timestep)
     return sharded_resolve(engine, h, num_masks=num_masks, is_aggre_attn=is_aggre_attn, is_refine_mask=is_refine_mask, rank=rank,
                            world=world)

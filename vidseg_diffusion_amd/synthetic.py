@@ -101,6 +101,78 @@ def latent_clip(num_frames: int, h: int, w: int, seed: int = 1, channels: int = 
     return np.ascontiguousarray((lat * 0.18215 * 4.0).transpose(0, 3, 1, 2)).astype(np.float32)
 
 
+def region_labels(num_frames: int, h: int, w: int, num_regions: int, seed: int) -> np.ndarray:
+    """Ground-truth partition of every frame into `num_regions` drifting Voronoi cells, int64 [F, h, w].
+    Sites start on a jittered gy x gx grid (balanced cell areas) and drift by at most half a cell over the clip."""
+    g = _rng(seed)
+    gy = int(np.floor(np.sqrt(num_regions * h / w) + 0.5))
+    gy = max(1, min(gy, num_regions))
+    while num_regions % gy:
+        gy -= 1
+    gx = num_regions // gy
+    jy, jx = g.uniform(-0.2, 0.2, size=num_regions), g.uniform(-0.2, 0.2, size=num_regions)
+    vy, vx = g.uniform(-0.5, 0.5, size=num_regions), g.uniform(-0.5, 0.5, size=num_regions)
+    r = np.arange(num_regions)
+    cy = ((r // gx) + 0.5 + jy) * (h / gy)
+    cx = ((r % gx) + 0.5 + jx) * (w / gx)
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float64) + 0.5, np.arange(w, dtype=np.float64) + 0.5, indexing="ij")
+    out = np.empty((num_frames, h, w), dtype=np.int64)
+    for t in range(num_frames):
+        f = t / max(num_frames, 1)
+        d2 = (yy[..., None] - (cy + vy * f * (h / gy))) ** 2 + (xx[..., None] - (cx + vx * f * (w / gx))) ** 2
+        out[t] = np.argmin(d2, axis=-1)
+    return out
+
+
+def region_prototypes(num_regions: int, channels: int, seed: int, min_dist: float = 1.2) -> np.ndarray:
+    """`num_regions` unit-scale prototype vectors with pairwise Euclidean distance >= min_dist (rejection sampling on the
+    seeded stream), float64 [R, channels]."""
+    g = _rng(seed)
+    protos = []
+    while len(protos) < num_regions:
+        p = g.standard_normal(channels)
+        if all(np.sqrt(((p - q) ** 2).sum()) >= min_dist for q in protos):
+            protos.append(p)
+    return np.stack(protos)
+
+
+def region_clip(num_frames: int, h: int, w: int, num_regions: int = 20, seed: int = 1, channels: int = 4, amp: float = 1.5,
+                noise: float = 0.05) -> np.ndarray:
+    """Seeded piecewise-constant latent: `num_regions` drifting Voronoi cells, each with its own well-separated prototype
+    vector, + white noise; float32 [F, C, h, w] at the scale of an encode_first_stage output (std ~ 1).  The headline
+    workload (bench.py, tests at BASELINE configs[1]) uses it with num_regions = the number of masks, so that the K-means
+    problem Steps 3-3b solve has K natural clusters (a clip of K objects) instead of over-segmenting a 6-blob scene, whose
+    partition is decided by the last bits of the features."""
+    lab = region_labels(num_frames, h, w, num_regions, seed + 4000)
+    protos = region_prototypes(num_regions, channels, seed + 5000)
+    g = _rng(seed)
+    lat = protos[lab] * amp + noise * g.standard_normal((num_frames, h, w, channels))
+    return np.ascontiguousarray(lat.transpose(0, 3, 1, 2)).astype(np.float32)
+
+
+def scene_labels(num_frames: int, h: int, w: int, num_objects: int, cells: int, seed: int) -> np.ndarray:
+    """Object id of every latent pixel, int64 [F, h, w]: each frame is split into `cells` drifting Voronoi cells (see
+    `region_labels`); cell j shows object j * (num_objects // cells) + (f * (num_objects // cells)) // F, i.e. every cell cycles
+    through its own num_objects / cells objects over the clip, each staying a few consecutive frames."""
+    if num_objects % cells:
+        raise ValueError("num_objects must be a multiple of cells")
+    per = num_objects // cells
+    cell = region_labels(num_frames, h, w, cells, seed)
+    f = np.arange(num_frames)[:, None, None]
+    return cell * per + (f * per) // max(num_frames, 1)
+
+
+def scene_clip(num_frames: int, h: int, w: int, num_objects: int = 20, cells: int = 4, seed: int = 1, channels: int = 4,
+               amp: float = 1.5, noise: float = 0.05) -> np.ndarray:
+    """Piecewise-constant latent of a scene with `num_objects` objects of which `cells` are visible per frame as large regions
+    (`scene_labels`), each object with its own well-separated prototype vector, + white noise; float32 [F, C, h, w]."""
+    lab = scene_labels(num_frames, h, w, num_objects, cells, seed + 4000)
+    protos = region_prototypes(num_objects, channels, seed + 5000)
+    g = _rng(seed)
+    lat = protos[lab] * amp + noise * g.standard_normal((num_frames, h, w, channels))
+    return np.ascontiguousarray(lat.transpose(0, 3, 1, 2)).astype(np.float32)
+
+
 def sd_conditioning(num_frames: int, context_dim: int = 1024, seq: int = 77, seed: int = 1):
     """`c["crossattn"]` ~ N(0,1) [F, seq, ctx], `uc` zeros (force_uc_zero_embeddings,
     sd_pipeline_vspw.py:299-305); float32."""
@@ -110,14 +182,20 @@ def sd_conditioning(num_frames: int, context_dim: int = 1024, seq: int = 77, see
     return c, np.zeros_like(c)
 
 
-def fill_state_dict(shapes: dict, seed: int = 1234, gain: float = 1.0) -> dict:
+ZERO_INIT_MARKERS = (".out_layers.3.", ".proj_out.")      # openaimodel.py:306-314 (ResBlock out conv), :406 / attention.py:880-886
+
+
+def fill_state_dict(shapes: dict, seed: int = 1234, gain: float = 1.0, zero_gain: float = 1.0) -> dict:
     """Deterministic synthetic weights for a state dict given {name: shape}.
 
     Every tensor gets its own PCG64 stream keyed by (seed, sha256(name)), so the values do not depend
     on dict order or on which other tensors exist.  Matrices / conv kernels ~ N(0, gain/sqrt(fan_in))
     -- including the reference's zero-initialised modules (openaimodel.py:306-314, :828;
     attention.py:880-886), which would otherwise silence every residual branch -- 1-D ".weight"
-    (norm scales) ~ 1 + 0.1 N(0,1), biases ~ 0.05 N(0,1).  Returns float32 numpy arrays.
+    (norm scales) ~ 1 + 0.1 N(0,1), biases ~ 0.05 N(0,1).  `zero_gain` scales the weights AND biases of exactly those
+    zero-initialised modules (the output conv of every ResBlock and `proj_out` of every transformer): 1.0 is the generic
+    random network, a small value is a network near the reference's own initialisation, whose residual branches perturb
+    the skip path instead of replacing it.  Same random numbers for every zero_gain.  Returns float32 numpy arrays.
     """
     out = {}
     for name in sorted(shapes):
@@ -132,6 +210,8 @@ def fill_state_dict(shapes: dict, seed: int = 1234, gain: float = 1.0) -> dict:
             n = np.float32(1.0) + np.float32(0.1) * n
         else:
             n *= np.float32(0.05)
+        if zero_gain != 1.0 and any(m in "." + name for m in ZERO_INIT_MARKERS):
+            n *= np.float32(zero_gain)
         out[name] = n
     return out
 

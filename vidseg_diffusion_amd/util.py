@@ -137,6 +137,19 @@ def get_modulate_timestep_frames(start_timestep, end_timestep=None, num_frames=1
     raise ValueError(f"Unknown modulate timestep frames schedule: {schedule}")
 
 
+def load_raw_checkpoint(path):
+    """The checkpoint's full state dict with its Lightning key prefixes untouched (sgm/models/diffusion.py:85-95):
+    `.ckpt` -> torch.load(...)["state_dict"], `.safetensors` -> safetensors' load_file; other suffixes are not supported
+    (the reference raises NotImplementedError too).  Host-side file parsing only."""
+    if path.endswith("safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path, device="cpu")
+    if path.endswith("ckpt"):
+        sd = torch.load(path, map_location="cpu")
+        return sd["state_dict"] if "state_dict" in sd else sd
+    raise NotImplementedError(f"checkpoint format of {path!r} (expected .ckpt or .safetensors)")
+
+
 def load_checkpoint_state_dict(path, prefix="model.diffusion_model."):
     """The UNet part of an upstream checkpoint as a plain state dict for ``UNetModel/VideoUNet.load_state_dict`` --
     what ``load_model_from_config`` + ``DiffusionEngine.init_from_ckpt`` do for the network (sd_pipeline_vspw.py:553-580,
