@@ -12,6 +12,7 @@ import os
 import shutil
 import sys
 import tempfile
+import time
 
 import numpy as np
 import torch
@@ -31,6 +32,10 @@ CASES = [
     dict(name="c_5x24x24_c48_k6", F=5, h=24, w=24, C=48, K=6, seed=13, windows=1, gt=False),
     dict(name="d_3x20x25_c32_k4", F=3, h=20, w=25, C=32, K=4, seed=14, windows=1, gt=False),
     dict(name="e_14x16x16_c64_k10", F=14, h=16, w=16, C=64, K=10, seed=15, windows=1, gt=False),
+    # the benchmarked sizes (BASELINE configs[1] and configs[2]): 14 frames, 640 channels, K = 20; two chained windows, so the
+    # 14336 x 14336 (32256 x 32256) 4-NN label propagation of windows > 0 (feature_extraction.py:603-613) is in the fixture
+    dict(name="f_14x32x32_c640_k20", F=14, h=32, w=32, C=640, K=20, seed=1, windows=2, gt=False),
+    dict(name="g_14x36x64_c640_k20", F=14, h=36, w=64, C=640, K=20, seed=2, windows=2, gt=False, kmeans_masks=False),
 ]
 BLOCKS = ["output_block_8", "output_block_7", "output_block_6"]
 
@@ -89,7 +94,7 @@ def run_case(fe, case, out_dir):
             rec[f"w{win}_track_w"] = captured["w"].astype(np.int16)
             rec[f"w{win}_corrected_labels"] = np.asarray(ref_mask2).astype(np.int64)
             ref_mask = ref_mask2                                       # SDP:401 overwrites before next window
-            if win == 0:
+            if win == 0 and case.get("kmeans_masks", True):
                 np.random.seed(case["seed"])
                 fe.feature_extraction_main(
                     "kmeans_masks", K, 22, "output_block_8", exp, exp, "spatial_self_attn_q", h, w, "24",
@@ -111,8 +116,13 @@ def main():
     fe = import_reference()
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    only = set(sys.argv[1:])
     for case in CASES:
+        if only and case["name"] not in only and case["name"].split("_")[0] not in only:
+            continue
+        t0 = time.time()
         run_case(fe, case, out_dir)
+        print(f"  {case['name']}: {time.time() - t0:.1f} s")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,161 @@
+"""Generate tests/golden/c2_window.npz: ONE full-size window of BASELINE configs[1] through the REFERENCE.
+
+SD 2.1 topology at full width (model_channels 320, 865.9 M parameters), 14 frames at 512x512 (latent 14x4x64x64), CFG batch 28,
+25-step schedule with t_start = 22 (three Euler steps), Q taps of decoder blocks 6/7/8 at step 24, then the reference's own
+`feature_extraction_main("match_gt_mask")` with the 3-block aggregate and K = 20, and `correct_low_res_mask` on block 7 --
+i.e. sd_pipeline_vspw.py:336-405 on exactly the inputs bench.py uses for window 0:
+
+    latent  synthetic.region_clip(14, 64, 64, 20, seed=1)        weights  synthetic.fill_state_dict(seed=1234, zero_gain=ZERO_GAIN)
+    c / uc  synthetic.sd_conditioning(14, 1024, 77, seed=1)       noise    torch.randn(generator seed 100)
+
+Everything is imported read-only from /root/reference (fp32, CPU); build container only (~10 min on 8 cores, ~25 GB).
+The network is evaluated in batch chunks of 7 samples -- every operator of the UNet is per-sample (GroupNorm statistics and
+attention never cross the batch), so the values are those of the batch-28 call; the chunking only bounds memory.
+
+The fixture stores: the reference's labels (Step 3) and corrected labels (Step 3b), the final latent, and a subsample of the
+step-24 Q taps (every 16th token, every 2nd channel, conditional half of blocks 6/7/8 in fp16) with the full-tensor norms, plus
+sha256 of every input so the tests can detect drift of the generators.
+
+    python tools/gen_golden_c2_window.py
+"""
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from ref_import import REF, import_reference  # noqa: E402
+from vidseg_diffusion_amd import synthetic  # noqa: E402
+
+F, LAT, K, T_START, NUM_STEPS, CHUNK = 14, 64, 20, 22, 25, 7
+BLOCKS = ["output_block_8", "output_block_7", "output_block_6"]
+
+
+def main():
+    zero_gain = float(os.environ.get("C2_ZERO_GAIN", synthetic.HEADLINE["zero_gain"]))
+    out_path = os.environ.get("C2_OUT", os.path.join(ROOT, "tests", "golden", "c2_window.npz"))
+    fe = import_reference()
+    from sgm.modules.diffusionmodules.denoiser import DiscreteDenoiser
+    from sgm.modules.diffusionmodules.openaimodel import UNetModel
+    from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    from sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+    torch.set_grad_enabled(False)
+    t_all = time.time()
+    cfg = dict(synthetic.SD21_FULL)
+    net = UNetModel(use_checkpoint=False, **cfg).eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synthetic.fill_state_dict(shapes, seed=1234, zero_gain=zero_gain)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    del sd
+    rec = dict(state_dict_signature=synthetic.state_dict_signature(shapes), weight_seed=1234, zero_gain=zero_gain,
+               F=F, lat=LAT, K=K, t_start=T_START, num_steps=NUM_STEPS, seed=17)
+
+    lat = synthetic.headline_latent(F, LAT, LAT, window_id=0)
+    c, uc = synthetic.sd_conditioning(F, context_dim=cfg["context_dim"], seq=77, seed=1)
+    noise = torch.randn((F, 4, LAT, LAT), generator=torch.Generator().manual_seed(100))
+    rec.update(latent_sha256=synthetic.sha256_of(lat), c_sha256=synthetic.sha256_of(c), noise_sha256=synthetic.sha256_of(noise.numpy()))
+
+    # ---- batch-chunked network call (values identical to the batch-28 call, see module docstring) -------------------------
+    taps = {}
+    orig_forward = net.forward
+    attn = {b: net.output_blocks[b][1].transformer_blocks[0].attn1 for b in (6, 7, 8)}
+
+    def chunked_forward(x, timesteps=None, context=None, y=None, **kw):
+        outs, qs = [], {b: [] for b in attn}
+        for i in range(0, x.shape[0], CHUNK):
+            outs.append(orig_forward(x[i:i + CHUNK], timesteps=timesteps[i:i + CHUNK], context=context[i:i + CHUNK], y=y, **kw))
+            for b, a in attn.items():
+                qs[b].append(a.q)
+        for b, a in attn.items():
+            a.q = torch.cat(qs[b], 0)
+        return torch.cat(outs, 0)
+
+    net.forward = chunked_forward
+    dd = "sgm.modules.diffusionmodules."
+    denoiser_m = DiscreteDenoiser(scaling_config={"target": dd + "denoiser_scaling.EpsScaling"}, num_idx=1000,
+                                  discretization_config={"target": dd + "discretizer.LegacyDDPMDiscretization"})
+    sampler = EulerEDMSampler(discretization_config={"target": dd + "discretizer.LegacyDDPMDiscretization"},
+                              guider_config={"target": dd + "guiders.VanillaCFG", "params": {"scale": 5.0}}, num_steps=NUM_STEPS,
+                              s_churn=0, s_tmin=0, s_tmax=999, s_noise=1, device="cpu")
+    model = OpenAIWrapper(net)
+
+    def denoiser(inp, sigma, cc, is_modulate_step=False, is_injected_step=False, modulate_params=None):
+        return denoiser_m(model, inp, sigma, cc, is_modulate_step=is_modulate_step, is_injected_step=is_injected_step,
+                          modulate_params=modulate_params)
+
+    cond, ucond = {"crossattn": torch.from_numpy(c)}, {"crossattn": torch.from_numpy(uc)}
+    torch.manual_seed(100)                                   # add_noise draws torch.randn_like(x) (sampling.py:139): same stream
+    noised = sampler.add_noise(torch.from_numpy(lat).clone(), cond=cond, uc=ucond, num_steps=NUM_STEPS, noise_level=T_START)
+    sig = sampler.discretization(NUM_STEPS, device="cpu")
+    chk = (torch.from_numpy(lat) + noise * sig[T_START]) / torch.sqrt(1.0 + sig[0] ** 2.0)
+    assert torch.equal(noised, chk), "torch.randn_like under manual_seed(100) != Generator(100) draw"
+
+    xs = []
+
+    def cb(xt, i):
+        print(f"  step {i} done, {time.time() - t_all:.0f} s", flush=True)
+        xs.append(xt.clone().numpy())
+        if i == NUM_STEPS - 1:
+            for b, a in attn.items():
+                taps[b] = a.q.half()
+
+    final = sampler(denoiser, noised.clone(), cond=cond, uc=ucond, img_callback=cb, t_start=T_START)
+    rec.update(x_final=final.numpy().astype(np.float32), x_step_norms=np.array([np.linalg.norm(x.astype(np.float64)) for x in xs]),
+               x_step22_sub=xs[0][:, :, ::4, ::4].astype(np.float32))
+    for b in (6, 7, 8):
+        q = taps[b].numpy()                                   # fp16 [2F, 1024, 640], unconditional half first
+        rec[f"q{b}_sub"] = q[F:, ::16, ::2]                   # conditional half, every 16th token, every 2nd channel
+        rec[f"q{b}_norm"] = np.float64(np.linalg.norm(q[F:].astype(np.float64)))
+        rec[f"q{b}_sha256"] = synthetic.sha256_of(q)
+
+    # ---- Steps 3 / 3b through the reference's own analysis entry point ----------------------------------------------------
+    base = tempfile.mkdtemp(prefix="vidseg_c2_")
+    exp = "exp"
+    fm = os.path.join(base, exp, "feature_maps")
+    os.makedirs(fm)
+    for name, b in zip(BLOCKS, (8, 7, 6)):
+        torch.save(taps[b], os.path.join(fm, f"{name}_spatial_self_attn_q_time_24.pt"))
+    names = [f"{i:05d}" for i in range(F)]
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        np.random.seed(17)                                    # seed_everything(seed) of the window, SDP:255
+        ul, ref_mask, ref_fm = fe.feature_extraction_main(
+            "match_gt_mask", K, T_START, ",".join(BLOCKS), exp, exp, "spatial_self_attn_q", LAT // 2, LAT // 2, "24",
+            frame_name_list=names, base_folder=base, num_frames=F, ref_mask=None, ref_feature_map=None, ref_unique_labels=None,
+            gt_mask_path=None)
+        rec["unique_labels"] = np.asarray(ul)
+        rec["match_labels"] = np.asarray(ref_mask).astype(np.int16)
+        rec["ref_feature_sha256"] = synthetic.sha256_of(np.asarray(ref_fm))
+        folder = os.path.join(base, exp, "match_gt_mask", "_".join(BLOCKS) + f"_spatial_self_attn_q_masks_{K}")
+        _, ref_mask2, _ = fe.feature_extraction_main(
+            "correct_low_res_mask", K, T_START, "output_block_7", exp, exp, "spatial_self_attn_q", LAT // 2, LAT // 2, "24",
+            frame_name_list=names, base_folder=base, num_frames=F, ref_mask=ref_mask, ref_feature_map=ref_fm,
+            ref_unique_labels=ul, gt_mask_path=None, mask_folder=folder)
+        rec["corrected_labels"] = np.asarray(ref_mask2).astype(np.int16)
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(base, ignore_errors=True)
+    gt = synthetic.headline_partition(F, LAT, LAT, window_id=0)
+    rec["generating_partition_agreement"] = np.float64(_agreement(rec["match_labels"], gt, K))
+    import sklearn
+    rec["versions"] = np.array([f"torch {torch.__version__}", f"sklearn {sklearn.__version__}", f"numpy {np.__version__}"])
+    np.savez_compressed(out_path, **rec)
+    print("wrote", out_path, os.path.getsize(out_path) // 1024, "KiB in", f"{time.time() - t_all:.0f} s;",
+          "labels vs generating partition:", float(rec["generating_partition_agreement"]))
+
+
+def _agreement(labels, gt, K):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tools_metrics import matched_iou
+    return matched_iou(np.asarray(labels).reshape(-1), np.asarray(gt).reshape(-1), K)[1]
+
+
+if __name__ == "__main__":
+    main()
