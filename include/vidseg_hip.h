@@ -225,8 +225,12 @@ int vidseg_cfg_euler_step(float* x, const float* net_out, int F, int C, int HW, 
                           vidseg_stream_t stream);
 int vidseg_add_noise(float* x, const float* eps, long long n, float sigma, float inv_scale, vidseg_stream_t stream);
 
-/* registers a caller-owned fp32 device scratch for split-K partials (optional; without it split-K is off) */
+/* registers a caller-owned fp32 device scratch for split-K partials (optional; without it split-K is off):
+   set_workspace = default of the current device, bind_workspace = the scratch of launches on `stream` of the current device
+   (two streams must not share partials; the reference has no counterpart -- cuBLAS owns its workspaces, sgm/modules/attention.py
+   and openaimodel.py call F.linear / conv2d) */
 int vidseg_set_workspace(float* ws, long long floats);
+int vidseg_bind_workspace(vidseg_stream_t stream, float* ws, long long floats);
 
 /* opt-in HIP-event timing of the conv/linear MFMA kernel family (bench.py roofline); out = {ms, flops, launches} (host) */
 int vidseg_gemm_profile_begin(void);

@@ -1314,17 +1314,63 @@ int vidseg_gemm_profile_kinds(double* out) {
     return VS_OK;
 }
 
-static float* g_ws = nullptr;           // split-K workspace registered by the host (caller-owned device memory)
-static long long g_ws_floats = 0;
+// Split-K workspaces (caller-owned fp32 device memory).  One per (device, stream): two streams -- the two window lanes of
+// pipeline.WindowPipeline, or the two devices of one process -- must not share partials, and nothing orders their launches.
+// vidseg_bind_workspace registers the scratch the GEMMs launched on `stream` of the CURRENT device use; vidseg_set_workspace
+// registers the current device's default for streams without a binding.  The host keeps a scratch bound to a stream only while
+// every launch that uses it is ordered on that stream (ops.workspace does: one Workspace per (device, torch stream)).
+struct WsEntry {
+    int dev;
+    hipStream_t st;
+    bool any_stream;
+    float* ws;
+    long long floats;
+};
+static WsEntry g_ws_tab[64];
+static int g_ws_n = 0;
 
-int vidseg_set_workspace(float* ws, long long floats) {
-    g_ws = ws;
-    g_ws_floats = floats;
+static int ws_register(hipStream_t st, bool any_stream, float* ws, long long floats) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (int i = 0; i < g_ws_n; ++i)
+        if (g_ws_tab[i].dev == dev && g_ws_tab[i].any_stream == any_stream && (any_stream || g_ws_tab[i].st == st)) {
+            g_ws_tab[i].ws = ws;
+            g_ws_tab[i].floats = floats;
+            return VS_OK;
+        }
+    VS_REQUIRE(g_ws_n < 64, "workspace table full (%d bindings)", g_ws_n);
+    g_ws_tab[g_ws_n++] = WsEntry{dev, st, any_stream, ws, floats};
     return VS_OK;
+}
+
+int vidseg_set_workspace(float* ws, long long floats) { return ws_register(nullptr, true, ws, floats); }
+int vidseg_bind_workspace(hipStream_t stream, float* ws, long long floats) { return ws_register(stream, false, ws, floats); }
+
+static void ws_lookup(hipStream_t st, float*& ws, long long& floats) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    ws = nullptr;
+    floats = 0;
+    for (int i = 0; i < g_ws_n; ++i) {
+        const WsEntry& e = g_ws_tab[i];
+        if (e.dev != dev) continue;
+        if (!e.any_stream && e.st == st) {
+            ws = e.ws;
+            floats = e.floats;
+            return;
+        }
+        if (e.any_stream && !ws) {
+            ws = e.ws;
+            floats = e.floats;
+        }
+    }
 }
 
 static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     GemmParams p = p_in;
+    float* g_ws;
+    long long g_ws_floats;
+    ws_lookup(st, g_ws, g_ws_floats);
     VS_REQUIRE(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
     VS_REQUIRE(p.C0 % BK == 0 && p.C1 % BK == 0, "gemm: source channels (%d,%d) must be multiples of %d", p.C0, p.C1, BK);
     VS_REQUIRE(p.M > 0 && p.N > 0, "gemm: empty problem");

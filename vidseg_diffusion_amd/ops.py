@@ -44,6 +44,7 @@ _lib.register({
     "vidseg_axpy_f32": [_P, _P, _L, _F, _F, _P, _P],
     "vidseg_blend_f32": [_P, _P, _P, _L, _P, _P],
     "vidseg_set_workspace": [_P, _L],
+    "vidseg_bind_workspace": [_P, _P, _L],
     "vidseg_linear_bf16_ttap": [_P, _L, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "vidseg_conv_temporal3_bf16": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
     "vidseg_temporal_attention_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -183,23 +184,55 @@ def conv_out4(x, w, bias):
 
 
 class Workspace:
-    """Scratch for GroupNorm partials, sized once per device."""
+    """Scratch of ONE (device, stream): GroupNorm partial sums and per-(sample, channel) scale/shift, fp32 split-K partials.
+    Kernels that use it are ordered on that stream, so two streams (the window lanes of pipeline.WindowPipeline, the analysis
+    side stream) never share a buffer; the split-K scratch is bound to the stream inside the library (vidseg_bind_workspace)."""
 
-    def __init__(self, device, floats=1 << 24, splitk_floats=40 << 20):
+    def __init__(self, device, cuda_stream, floats=1 << 24, splitk_floats=40 << 20):
         self.part = torch.empty(floats, dtype=F32, device=device)
         self.stats = torch.empty(1 << 20, dtype=F32, device=device)          # GroupNorm per-(sample, channel) scale/shift
         self.splitk = torch.empty(splitk_floats, dtype=F32, device=device)   # fp32 split-K partials (160 MB)
-        call("vidseg_set_workspace", ptr(self.splitk), self.splitk.numel())
+        with torch.cuda.device(device):
+            call("vidseg_bind_workspace", cuda_stream, ptr(self.splitk), self.splitk.numel())
 
 
 _ws = {}
 
 
 def workspace(device) -> Workspace:
-    key = (device.type, device.index)
+    st = torch.cuda.current_stream(device).cuda_stream
+    key = (device.index if device.index is not None else torch.cuda.current_device(), st)
     if key not in _ws:
-        _ws[key] = Workspace(device)
+        _ws[key] = Workspace(device, st)
     return _ws[key]
+
+
+# ----------------------------------------------------------------------------- per-window caches
+# Values that are constant over the sampler steps of ONE window (the CFG-stacked conditioning, its 16-bit copy, the cross-attention
+# K/V projections of that context: attention.py:317-322 recomputes to_k(context) / to_v(context) in every block of every step) are
+# computed once per window.  `new_window()` (called by pipeline.feature_pass / parallel.sharded_feature_pass) starts a new epoch,
+# so nothing is ever carried from one window -- or one stream -- to the next; inside an epoch an entry is valid for exactly the
+# tensors it was made from (object identity + torch's in-place version counter; the entry keeps them alive).
+_EPOCH = 0
+_CACHE_ON = os.environ.get("VIDSEG_WINDOW_CACHE", "1") != "0"
+
+
+def new_window():
+    global _EPOCH
+    _EPOCH += 1
+
+
+def window_cached(owner, slot, deps, make):
+    """make() once per (epoch, deps) for `owner.<slot>`; deps: tuple of tensors the value is a pure function of."""
+    if not _CACHE_ON:
+        return make()
+    key = (_EPOCH,) + tuple((id(t), t._version) for t in deps)
+    ent = getattr(owner, slot, None)
+    if ent is not None and ent[0] == key:
+        return ent[2]
+    val = make()
+    setattr(owner, slot, (key, deps, val))
+    return val
 
 
 def groupnorm(x0, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True):

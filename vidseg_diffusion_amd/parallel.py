@@ -94,6 +94,8 @@ def sharded_feature_pass(engine, latent, c, uc, *, noise=None, num_steps=25, t_s
                          feature_folder=feature_folder, exp_name=exp_name, noise=noise, keep_all_steps=False, masks_only=True)
         return dict(F=F, fh=lh // 2, fw=lw // 2, seed=seed, feature_folder=feature_folder, exp_name=exp_name, done=h["done"],
                     feature_timestep=want)
+    from . import ops
+    ops.new_window()
     seed_everything(seed)
     sampler = engine.sampler
     denoiser = make_denoiser(engine, F)

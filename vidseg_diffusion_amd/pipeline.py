@@ -138,6 +138,7 @@ def feature_pass(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, num
     changes split-K choices): 1.2e-3 normalised rms from the full pass at full size, i.e. the distance either has from an fp32
     evaluation -- the masks are as close to the oracle's, not bit-identical to the full pass's."""
     F, _, lh, lw = latent.shape
+    ops.new_window()                                                                # per-window caches (ops.window_cached) start empty
     seed_everything(seed)                                                           # SDP:255
     sampler = engine.sampler
     denoiser = make_denoiser(engine, F)
@@ -227,22 +228,30 @@ def segment_window(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, n
 
 
 class WindowPipeline:
-    """Software pipeline over windows: the UNet feature pass of window w+1 is enqueued on the caller's stream BEFORE the analysis
-    of window w runs on a second HIP stream, so the latency-bound K-means / 4-NN / tracking kernels (and their host polls) of
-    one window hide behind the MFMA-bound feature pass of the next.  Results are identical to the sequential loop: the
-    feature passes are independent, the analysis chain keeps its order (sd_pipeline_vspw.py:228-409).
+    """Software pipeline over windows: the UNet feature pass of window w+1 is enqueued BEFORE the analysis of window w runs on
+    a second HIP stream, so the latency-bound K-means / 4-NN / tracking kernels (and their host polls) of one window hide
+    behind the MFMA-bound feature pass of the next.  Results are identical to the sequential loop: the feature passes are
+    independent, the analysis chain keeps its order (sd_pipeline_vspw.py:228-409).
+
+    lanes > 1: the feature passes of `lanes` consecutive windows are in flight at once, each on its own HIP stream (its own
+    split-K / GroupNorm scratch, ops.workspace).  The passes are the same launches on the same data -- only which kernels
+    share the chip at a given moment changes: the 28 = 4 * 7 samples of a CFG window leave every power-of-two tile grid at
+    7/8 of a round of 256 CUs (448 tiles of 256 rows at the 64x64 level, 224 at 32x32, ...), and the short launches of the
+    16x16 / 8x8 levels fill a fraction of the chip; a second window's kernels take the idle CUs.
 
         pipe = WindowPipeline(engine, **analysis_kwargs)
-        for ...: out = pipe.push(latent, c, uc, **feature_kwargs)   # -> labels of the PREVIOUS window (None the first time)
-        last = pipe.flush()
+        for ...: out = pipe.push(latent, c, uc, **feature_kwargs)   # -> labels of the window pushed `lanes` calls ago (None before)
+        rest = pipe.flush()                                         # -> labels of the last window (drain() returns all of them)
     """
 
-    def __init__(self, engine: Engine, chain=True, **analysis_kw):
+    def __init__(self, engine: Engine, chain=True, lanes=1, **analysis_kw):
         """chain=False treats every pushed window as the first window of its own clip (K-means every time)."""
         self.engine, self.analysis_kw, self.chain = engine, analysis_kw, chain
         self.side = torch.cuda.Stream()
+        self.lanes = [torch.cuda.Stream() for _ in range(lanes)] if lanes > 1 else [None]
         self.state = WindowState()
-        self.pending = None
+        self.pending = []
+        self.count = 0
 
     def _analyse(self, h):
         with torch.cuda.stream(self.side):
@@ -253,26 +262,38 @@ class WindowPipeline:
         return labels
 
     def push(self, latent, c, uc, **feature_kw):
-        h = feature_pass(self.engine, latent, c, uc, **feature_kw)                   # enqueue first: the GPU never waits for the host
-        out = self._analyse(self.pending) if self.pending is not None else None
-        self.pending = h
+        lane = self.lanes[self.count % len(self.lanes)]
+        self.count += 1
+        if lane is None:
+            h = feature_pass(self.engine, latent, c, uc, **feature_kw)               # enqueue first: the GPU never waits for the host
+        else:
+            lane.wait_stream(torch.cuda.current_stream())                            # the inputs were produced on the caller's stream
+            with torch.cuda.stream(lane):
+                h = feature_pass(self.engine, latent, c, uc, **feature_kw)
+        self.pending.append(h)
+        return self._analyse(self.pending.pop(0)) if len(self.pending) > len(self.lanes) else None
+
+    def drain(self):
+        """Analyse everything still in flight, in order; returns the list of label maps."""
+        out = [self._analyse(h) for h in self.pending]
+        self.pending = []
+        self.side.synchronize()
         return out
 
     def flush(self):
-        out = self._analyse(self.pending) if self.pending is not None else None
-        self.pending = None
-        self.side.synchronize()
-        return out
+        out = self.drain()
+        return out[-1] if out else None
 
 
 _FEATURE_KEYS = ("num_steps", "t_start", "feature_timestep", "seed", "feature_folder", "noise", "keep_all_steps", "masks_only")
 
 
-def segment_clip(engine, latents, c_fn, *, batch_size=14, overlap=True, exp_name="exp", **kw):
+def segment_clip(engine, latents, c_fn, *, batch_size=14, overlap=True, lanes=1, exp_name="exp", **kw):
     """Whole clip: windows processed in order with the state chained (sd_pipeline_vspw.py:228-409).
     `c_fn(start, end)` returns (c, uc) for a window.  Returns a list of (start, end, labels).
     overlap=True runs the windows through `WindowPipeline` (analysis of window w concurrent with the feature pass of window
-    w+1, identical results); the dumps of window b live under exp_name + f"_w{b}" while they are needed."""
+    w+1, `lanes` feature passes in flight; identical results); the dumps of window b live under exp_name + f"_w{b}" while
+    they are needed."""
     fkw = {k: v for k, v in kw.items() if k in _FEATURE_KEYS}
     akw = {k: v for k, v in kw.items() if k not in _FEATURE_KEYS}
     slices = window_slices(latents.shape[0], batch_size)
@@ -284,16 +305,15 @@ def segment_clip(engine, latents, c_fn, *, batch_size=14, overlap=True, exp_name
             labels, state = segment_window(engine, latents[s:e].contiguous(), c, uc, state=state, exp_name=f"{exp_name}_w{b}", **kw)
             out.append((s, e, labels))
         return out
-    pipe = WindowPipeline(engine, **akw)
+    pipe = WindowPipeline(engine, lanes=lanes, **akw)
+    done = []
     for b, (s, e) in enumerate(slices):
         c, uc = c_fn(s, e)
         prev = pipe.push(latents[s:e].contiguous(), c, uc, exp_name=f"{exp_name}_w{b}", **fkw)
         if prev is not None:
-            out.append((*slices[b - 1], prev))
-    last = pipe.flush()
-    if last is not None:
-        out.append((*slices[-1], last))
-    return out
+            done.append(prev)
+    done += pipe.drain()
+    return [(*slices[b], lab) for b, lab in enumerate(done)]
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -362,6 +382,7 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
     scale = _BLOCK_SCALE[blocks[0]]
     base_h, base_w = lh // 8, lw // 8                                   # H // (F*8) of the driver (latent = image / 8)
     sampler, denoiser = engine.sampler, make_denoiser(engine, F)
+    ops.new_window()
     seed_everything(seed)
     x0 = sampler.add_noise(latent, cond=c, uc=uc, num_steps=num_steps, noise_level=t_start, noise=noise)   # same start as Step 2
     out = {}

@@ -149,8 +149,8 @@ class Guider:
     def _cat_cond(self, c, uc, keys):
         c_out = dict()
         for k in c:
-            if k in keys:
-                c_out[k] = torch.cat((uc[k], c[k]), 0)                       # uc FIRST (feature_maps[num_frames:] relies on it)
+            if k in keys:                                                   # uc FIRST (feature_maps[num_frames:] relies on it)
+                c_out[k] = ops.window_cached(self, "_cat_" + k, (uc[k], c[k]), lambda k=k: torch.cat((uc[k], c[k]), 0))
             else:
                 assert c[k] == uc[k]
                 c_out[k] = c[k]

@@ -161,7 +161,15 @@ class CrossAttention(nn.Module):
             tq = torch.empty((B, N, C), dtype=F16, device=dev) if tap else None
             tk = torch.empty((B, L, C), dtype=F16, device=dev) if tap else None
             q = ops.linear(x, self.w_q, tap=tq, tap_cols=C)
-            kv = ops.linear(context, self.w_kv, tap=tk, tap_cols=C)
+            if tap:                                                              # the context is constant over a window's steps
+
+                def make_kv():
+                    t = torch.empty((B, L, C), dtype=F16, device=dev)
+                    return ops.linear(context, self.w_kv, tap=t, tap_cols=C), t
+
+                kv, tk = ops.window_cached(self, "_kv_tap", (context,), make_kv)
+            else:
+                kv = ops.window_cached(self, "_kv", (context,), lambda: ops.linear(context, self.w_kv))
             if inj_q is not None:
                 q = ops.f16_to_bf16(inj_q)
             k = ops.f16_to_bf16(inj_k) if inj_k is not None else kv[..., :C]
@@ -510,5 +518,6 @@ class UNetModel(nn.Module):
         if not x.is_cuda:
             raise VidsegError("UNetModel runs on a HIP device only (no CPU fallback)")
         xn = x.float().permute(0, 2, 3, 1).contiguous()
-        ctx = context if context.dtype == ops.act_dtype() else ops.to_bf16(context.float().contiguous())
+        ctx = context if context.dtype == ops.act_dtype() else \
+            ops.window_cached(self, "_ctx16", (context,), lambda: ops.to_bf16(context.float().contiguous()))
         return self.forward_nhwc(xn, timesteps, ctx, y, is_modulate_step, is_injected_step, modulate_params, stop_after_block)
