@@ -3,28 +3,36 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path over one 14-frame 512x512 clip window per GPU (BASELINE config 2:
-SD 2.1, 20 masks, is_aggre_attn on): add-noise -> 3 Euler steps (i = 22,23,24) of the full-size SD 2.1 UNet with
-classifier-free guidance (batch 2x14) and the reference's Q/K taps on every decoder transformer block -> 3-block
-aggregation -> K-means (n_init 10) -> 4-NN label propagation  => cluster-id masks [14, 32*32].
-Latents / conditioning / weights are synthetic, seeded and already resident in HBM when the timed region
-starts (VAE + conditioner excluded).  N > 1: one window per GPU (weak scaling), see
+A "step" = one pass of the hot path over one 14-frame 512x512 clip window per GPU (BASELINE configs[1]: SD 2.1, 20 masks,
+is_aggre_attn on): add-noise -> 3 Euler steps (i = 22,23,24) of the full-size SD 2.1 UNet with classifier-free guidance
+(batch 2x14) and the reference's Q/K taps on every decoder transformer block -> 3-block aggregation -> K-means (n_init 10)
+-> 4-NN label propagation  => cluster-id masks [14, 32*32].  Inputs are the synthetic headline workload of
+vidseg_diffusion_amd/synthetic.py (`HEADLINE`: a clip of 20 drifting regions, near-initialisation weights), seeded and
+already resident in HBM when the timed region starts (VAE + conditioner excluded); the same window was run
+through the REFERENCE in fp32 (tools/gen_golden_c2_window.py -> tests/golden/c2_window.npz), and `mask_iou_vs_reference`
+compares the masks of the timed run with the reference's.  N > 1: one window per GPU (weak scaling), see
 vidseg_diffusion_amd/parallel.py for the exchange.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      the single kernel with the most time in the timed region (normally k_gemm_ph<NJ>, the phased 256x320 /
                 256x256 LDS-DMA implicit-GEMM tile): achieved = algorithmic FLOPs (2*M*N*K per launch) / HIP-event time of its
-                launches, recorded on the launch stream inside the timed region; peak = 2500 TFLOP/s dense bf16
-                (MI355X_MICROARCH.md); traffic = PMC bytes per launch of that kernel (profiles/r01_traffic.json).
-                `family` = the same figures over ALL conv/linear launches (three kernels share the work).
-  cpu_baseline  the oracle ("port") timed on this box's host cores on a bounded sample (see `sample`).
-  mask_iou_vs_oracle  the metric's second half: HIP masks vs the all-fp32 oracle's on BASELINE configs[0] at full UNet width
-                (the case the CPU finishes in seconds), IoU up to a label permutation.
+                launches, recorded on the launch stream inside the timed region; peak = 2500 TFLOP/s dense 16-bit MFMA
+                (MI355X_MICROARCH.md); traffic = PMC bytes per launch of that kernel, measured IN THIS RUN by two rocprofv3
+                --pmc passes over one window of the same workload (FETCH_SIZE, WRITE_SIZE; gfx950 correction of the guide),
+                next to `algorithmic_bytes` per launch.  `family` = the same figures over ALL conv/linear launches.
+  cpu_baseline  the oracle ("port") timed on this box's host cores on a bounded sample (see `sample`), CPU model stated.
+  mask_iou_vs_reference  the metric's second half on THIS config: masks of the timed run vs the reference's fp32 masks.
+  chained_window  throughput when the windows are chained like one long clip (windows > 0: 14336^2 4-NN instead of K-means).
+  secondary     BASELINE configs[2] (SVD 14x576x1024, t_start 17, refinement) measured after the headline, fewer steps.
 """
 import argparse
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -33,17 +41,20 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-F_WIN, LAT, K_MASKS, T_START, NUM_STEPS = 14, 64, 20, 22, 25
+F_WIN, LAT, NUM_STEPS = 14, 64, 25
+GOLDEN_C2 = os.path.join(ROOT, "tests", "golden", "c2_window.npz")
 
 
 def make_inputs(dev, window_id, cfg, svd=False, lat_hw=(LAT, LAT)):
     from vidseg_diffusion_amd import synthetic
-    lat = torch.from_numpy(synthetic.latent_clip(F_WIN, lat_hw[0], lat_hw[1], seed=1 + window_id)).to(dev)
     g = torch.Generator().manual_seed(100 + window_id)
-    noise = torch.randn(lat.shape, generator=g).to(dev)
     if not svd:
+        lat = torch.from_numpy(synthetic.headline_latent(F_WIN, lat_hw[0], lat_hw[1], window_id=window_id)).to(dev)
+        noise = torch.randn(lat.shape, generator=g).to(dev)
         c, uc = synthetic.sd_conditioning(F_WIN, context_dim=cfg["context_dim"], seq=77, seed=1)
         return lat, {"crossattn": torch.from_numpy(c).to(dev)}, {"crossattn": torch.from_numpy(uc).to(dev)}, noise
+    lat = torch.from_numpy(synthetic.latent_clip(F_WIN, lat_hw[0], lat_hw[1], seed=1 + window_id)).to(dev)
+    noise = torch.randn(lat.shape, generator=g).to(dev)
     # SVD conditioning (svd_pipeline_vspw.py:300-311): CLIP-image token and frame-0 latent repeated over frames, fps/motion vector
     ctx = torch.randn((1, 1, cfg["context_dim"]), generator=g).repeat(F_WIN, 1, 1).to(dev)
     cat = lat[:1].repeat(F_WIN, 1, 1, 1) / 0.18215 * 0.2
@@ -53,60 +64,264 @@ def make_inputs(dev, window_id, cfg, svd=False, lat_hw=(LAT, LAT)):
     return lat, c, uc, noise
 
 
-def cpu_baseline(sd_cpu, cfg):
-    """Oracle on the host: one full-size UNet evaluation for ONE frame (CFG pair, batch 2) + the full-size analysis
-    stage on synthetic dumps; scaled to a 14-frame window: t = 3 steps * 14 frames * t_unet_frame + t_analysis."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd_cpu, cfg, k_masks):
+    """Oracle on the host (rank 0, N = 1): one full-size UNet evaluation of FOUR frames (CFG pairs, batch 8) in fp32 and once
+    more under bf16 autocast + the full-size analysis stage on synthetic dumps; scaled to a 14-frame window:
+    t = 3 steps * (14 / 4) * t_unet_4frames + t_analysis."""
     from oracle import analysis as OA
     from oracle.unet import UNetOracle
     from vidseg_diffusion_amd import synthetic
     torch.set_grad_enabled(False)
     cores = torch.get_num_threads()
     o = UNetOracle(sd_cpu)
-    x = torch.from_numpy(synthetic.latent_clip(1, LAT, LAT, seed=1)).repeat(2, 1, 1, 1)
-    c, uc = synthetic.sd_conditioning(1, context_dim=cfg["context_dim"])
+    nf = 4
+    x = torch.from_numpy(synthetic.headline_latent(nf, LAT, LAT)).repeat(2, 1, 1, 1)
+    c, uc = synthetic.sd_conditioning(nf, context_dim=cfg["context_dim"])
     ctx = torch.cat([torch.from_numpy(uc), torch.from_numpy(c)])
+    t = torch.full((2 * nf,), 958.0)
     t0 = time.time()
-    o.forward(x, torch.tensor([958.0, 958.0]), ctx)
+    o.forward(x, t, ctx)
     t_unet = time.time() - t0
+    t_bf16 = None
+    try:
+        t0 = time.time()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            o.forward(x, t, ctx)
+        t_bf16 = time.time() - t0
+    except Exception:                                                    # autocast coverage differs between torch builds
+        t_bf16 = None
     blocks, _ = synthetic.attention_q_dumps(F_WIN, LAT // 2, LAT // 2, 640, num_blocks=3, seed=1)
     t0 = time.time()
     np.random.seed(17)
-    OA.match_gt_mask(OA.aggregate_blocks(blocks), K_MASKS, np.random.mtrand._rand)
+    OA.match_gt_mask(OA.aggregate_blocks(blocks), k_masks, np.random.mtrand._rand)
     t_an = time.time() - t0
-    t_window = 3 * F_WIN * t_unet + t_an
-    return {"value": round(F_WIN / t_window, 5), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 on host: 1 full-size UNet eval of 1 frame (CFG batch 2, {t_unet:.1f}s) + full 14x32x32x640 K=20 "
-                      f"analysis ({t_an:.1f}s); window time = 3*14*t_unet + t_analysis = {t_window:.0f}s"}
+    per = 3 * (F_WIN / nf)
+    t_window = per * t_unet + t_an
+    out = {"value": round(F_WIN / t_window, 5), "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+           "sample": f"oracle fp32 on host: 1 full-size UNet eval of {nf} frames (CFG batch {2 * nf}, {t_unet:.1f}s) + full 14x32x32x640 "
+                     f"K={k_masks} analysis ({t_an:.1f}s); window time = 3*(14/{nf})*t_unet + t_analysis = {t_window:.0f}s"}
+    if t_bf16 is not None:
+        out["value_bf16_autocast"] = round(F_WIN / (per * t_bf16 + t_an), 5)
+        out["sample"] += f"; bf16 autocast: same UNet eval {t_bf16:.1f}s"
+    return out
 
 
-def mask_iou_check(eng, sd_cpu, cfg, dev):
-    """The metric's second half, on a case the CPU can finish in seconds: BASELINE configs[0] (4 frames at 256x256, K = 5, one
-    step) at FULL UNet width -- HIP pipeline vs the all-fp32 oracle, IoU up to a label permutation (tests/tools_metrics.py)."""
+def mask_iou_vs_reference(labels, refine, k_masks):
+    """Masks of the timed run (rank 0's window = window 0 of the headline clip) vs the labels the REFERENCE produced for the
+    same window in fp32 (tests/golden/c2_window.npz): matched IoU over clusters and the fraction of identical tokens."""
+    if not os.path.exists(GOLDEN_C2) or k_masks != 20:
+        return None
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle import pipeline as OP
-    from oracle.unet import UNetOracle
     from tools_metrics import matched_iou
-    from vidseg_diffusion_amd import feature_extraction as FE
-    from vidseg_diffusion_amd import synthetic
-    from vidseg_diffusion_amd.pipeline import segment_window
-    Fn, K, T0 = 4, 5, 24
-    lat = synthetic.latent_clip(Fn, 32, 32, seed=1)
-    c, ucn = synthetic.sd_conditioning(Fn, context_dim=cfg["context_dim"], seq=77, seed=1)
-    noise = torch.from_numpy(np.random.Generator(np.random.PCG64(9)).standard_normal(lat.shape).astype(np.float32))
-    t0 = time.time()
-    ref = OP.segment_window(UNetOracle(sd_cpu), torch.from_numpy(lat), torch.from_numpy(c), torch.from_numpy(ucn), noise, num_masks=K,
-                            t_start=T0, seed=17)
-    t_cpu = time.time() - t0
-    FE.FeatureStore.clear()
-    FE.MaskStore.clear()
-    labels, _ = segment_window(eng, torch.from_numpy(lat).to(dev), {"crossattn": torch.from_numpy(c).to(dev)},
-                               {"crossattn": torch.from_numpy(ucn).to(dev)}, num_masks=K, t_start=T0, seed=17, noise=noise.to(dev),
-                               feature_folder="/nonexistent/bench_iou", exp_name="c1")
-    FE.FeatureStore.clear()
-    FE.MaskStore.clear()
-    iou, exact = matched_iou(labels, ref["labels"], K)
+    g = np.load(GOLDEN_C2)
+    ref = g["corrected_labels" if refine else "match_labels"].astype(np.int64)
+    iou, exact = matched_iou(np.asarray(labels).reshape(-1), ref.reshape(-1), k_masks)
     return {"iou": round(float(iou), 4), "identical_fraction": round(float(exact), 4),
-            "case": f"BASELINE configs[0] at full width: 4x256x256, K=5, 1 step; fp32 oracle took {t_cpu:.1f}s on the host"}
+            "case": "BASELINE configs[1] at full size (this run's window 0: 14x512x512, K=20, 3 CFG steps, full-width UNet) vs the "
+                    "reference's fp32 masks for the same inputs (tests/golden/c2_window.npz, generated from /root/reference by "
+                    "tools/gen_golden_c2_window.py)" + ("; Step 3b (correct_low_res_mask) included" if refine else "")}
+
+
+def pmc_traffic(extra_args, timeout=240):
+    """HBM-side bytes per launch of every GEMM kernel, measured now: two separate rocprofv3 --kernel-trace --pmc passes
+    (FETCH_SIZE, then WRITE_SIZE) over one window of this workload in a child process.  rocprofv3 reports KB; on gfx950
+    FETCH_SIZE counts a wide (16 B/lane) coalesced read stream at exactly half its bytes (MI355X_MICROARCH.md, HBM) and every
+    operand load of these kernels is such a stream, so bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Memory-side L2 counters
+    (Infinity-Cache hits included): an upper bound on true HBM traffic.  Returns {kernel: (launches, bytes_per_launch)} or None."""
+    import sqlite3
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="vidseg_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    sums = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--steps", "1", "--warmup", "0"] + extra_args
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+            if not dbs:
+                return None
+            db = sqlite3.connect(dbs[0])
+            for name, val in db.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+                if "k_gemm" in name:
+                    a = sums.setdefault(name.split("(")[0].replace("void ", ""), {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
+                    a[counter][0] += 1
+                    a[counter][1] += float(val)
+        out = {}
+        for k, a in sums.items():
+            n = a["FETCH_SIZE"][0]
+            if n and n == a["WRITE_SIZE"][0]:
+                out[k] = (n, (2.0 * a["FETCH_SIZE"][1] + a["WRITE_SIZE"][1]) * 1024.0 / n)
+        return out or None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def build(svd, narrow, dev):
+    from vidseg_diffusion_amd import synthetic
+    from vidseg_diffusion_amd.pipeline import build_sd_engine, build_svd_engine
+    if svd:
+        from vidseg_diffusion_amd.video_unet import VideoUNet
+        cfg = dict(synthetic.SVD_NARROW if narrow else synthetic.SVD_FULL)
+        net = VideoUNet(**cfg)
+        zg = 1.0
+    else:
+        from vidseg_diffusion_amd.unet import UNetModel
+        cfg = dict(synthetic.SD21_NARROW if narrow else synthetic.SD21_FULL)
+        net = UNetModel(**cfg)
+        zg = synthetic.HEADLINE["zero_gain"]
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd_cpu = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=1234, zero_gain=zg).items()}
+    net.load_state_dict(sd_cpu)
+    net.pack(dev)
+    eng = build_svd_engine(net, num_frames=F_WIN, num_steps=NUM_STEPS) if svd else build_sd_engine(net, num_steps=NUM_STEPS, scale=5.0)
+    return eng, cfg, sd_cpu, sum(int(np.prod(s)) for s in shapes.values())
+
+
+def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False):
+    """Time `steps` steps of one config; returns (out dict for rank 0 | None, sd_cpu, cfg, eng, labels)."""
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd import ops, parallel
+    from vidseg_diffusion_amd.pipeline import WindowPipeline
+    k_masks = args.masks or 20
+    t_start = 17 if svd else 22
+    refine = True if svd else args.refine
+    eng, cfg, sd_cpu, n_params = build(svd, args.narrow, dev)
+    lat, c, uc, noise = make_inputs(dev, rank, cfg, svd=svd, lat_hw=(72, 128) if svd else (LAT, LAT))
+    torch.cuda.synchronize()
+    lanes = 1 if (args.no_overlap or args.pmc_child) else max(1, args.lanes)
+    overlap = not args.no_overlap and not args.pmc_child
+    fkw = dict(num_steps=NUM_STEPS, t_start=t_start, seed=17, noise=noise, masks_only=args.masks_only)
+    step_no = [0]
+
+    def name():
+        step_no[0] += 1
+        return f"r{rank}s{step_no[0] % (lanes + 3)}"
+
+    if world == 1 and overlap:
+        # windows run through pipeline.WindowPipeline: the analysis of step i (second HIP stream) overlaps the feature passes of the
+        # next `lanes` steps; every step is still a complete window (K-means included) and all of them finish inside the timed region
+        def run_steps(n, chain=False):
+            pipe = WindowPipeline(eng, chain=chain, lanes=lanes, num_masks=k_masks, is_aggre_attn=True, is_refine_mask=refine)
+            last = None
+            for _ in range(n):
+                FE.MaskStore.clear()
+                got = pipe.push(lat, c, uc, keep_all_steps=False, exp_name=name(), **fkw)
+                last = got if got is not None else last
+            rest = pipe.drain()
+            return rest[-1] if rest else last
+    elif world > 1 and overlap:
+        def run_steps(n, chain=False):
+            spipe = parallel.ShardedPipeline(eng, rank, world, lanes=lanes, num_masks=k_masks, is_aggre_attn=True, is_refine_mask=refine)
+            last = None
+            for _ in range(n):
+                FE.MaskStore.clear()
+                got = spipe.push(lat, c, uc, exp_name=name(), **fkw)
+                last = got if got is not None else last
+            rest = spipe.drain()
+            return rest[-1] if rest else last
+    else:
+        def run_steps(n, chain=False):
+            last = None
+            for _ in range(n):
+                FE.FeatureStore.clear()
+                FE.MaskStore.clear()
+                last = parallel.segment_windows_sharded(eng, lat, c, uc, noise=noise, num_masks=k_masks, num_steps=NUM_STEPS, t_start=t_start,
+                                                        is_aggre_attn=True, is_refine_mask=refine, seed=17, rank=rank, world=world,
+                                                        masks_only=args.masks_only)
+            return last
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if warmup:
+        run_steps(warmup)
+    barrier()
+    ops.gemm_profile_begin()
+    t0 = time.perf_counter()
+    labels = run_steps(steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_flops, k_launches = ops.gemm_profile_end()
+    kinds = ops.gemm_profile_kinds()
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0 or args.pmc_child:
+        return None, sd_cpu, cfg, eng, labels, run_steps
+
+    frames = F_WIN * world * steps
+    fam_tf = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
+    dom = max(kinds, key=lambda r: r[1])                                      # the single kernel with the most time in the region
+    achieved = (dom[2] / (dom[1] * 1e-3)) / 1e12 if dom[1] > 0 else 0.0
+    evals = 8 if svd else 3
+    if svd:
+        metric = f"segmented frames/sec (14-frame 576x1024 clip, {k_masks} masks, SVD)"
+        workload = (f"BASELINE configs[2]: SVD img2vid full-size VideoUNet ({n_params / 1e6:.1f}M params, random-init), 14-frame 576x1024 "
+                    f"window per GPU (latent 14x4x72x128), t_start=17 (8 CFG UNet evals, batch 28), spatial+temporal taps, "
+                    f"is_aggre_attn, K-means K={k_masks} + 4-NN, is_refine_mask (dense tracking + vote)")
+    else:
+        metric = f"segmented frames/sec (14-frame 512^2 clip, {k_masks} masks)"
+        workload = (f"BASELINE configs[1]: SD 2.1 full-size UNet ({n_params / 1e6:.1f}M params, synthetic near-init weights), 14-frame "
+                    f"512x512 window per GPU (latent 14x4x64x64, synthetic 20-region clip), 25-step schedule with t_start=22 (3 CFG UNet "
+                    f"evals, batch 28), Q/K taps on decoder blocks 3-11, is_aggre_attn (blocks 6,7,8), K-means K={k_masks} n_init=10 + 4-NN"
+                    + (", is_refine_mask" if refine else ""))
+    out = {
+        "metric": metric, "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16" if ops.act_dtype() == torch.float16 else "bf16", "data": "synthetic",
+        "config": {"workload": workload, "frames_per_gpu": F_WIN, "num_masks": k_masks, "unet_evals_per_step": evals,
+                   "parallelism": f"window-per-gpu x{world}",
+                   "overlap": (f"{lanes} feature pass(es) in flight on their own HIP streams; the analysis of a finished window runs on another "
+                               f"stream meanwhile; every step is a complete window and all finish inside the timed region") if overlap
+                   else "none (each window's analysis follows its own feature pass)"},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                     "frac": round(achieved / 2500.0, 4), "traffic": None, "kernel": dom[0],
+                     "launches_per_step": dom[3] // max(steps, 1),
+                     "avg_launch_us": round(1e3 * dom[1] / max(dom[3], 1), 2),
+                     "ms_per_step": round(dom[1] / steps, 3),
+                     "algorithmic_bytes": int(dom[4] / max(dom[3], 1)),
+                     # every conv / linear of the UNet runs on this kernel family; the family-wide figures:
+                     "family": {"achieved": round(fam_tf, 2), "frac": round(fam_tf / 2500.0, 4),
+                                "launches_per_step": k_launches // max(steps, 1), "gemm_ms_per_step": round(k_ms / steps, 3),
+                                "by_kernel": {n: {"ms_per_step": round(ms / steps, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 else 0.0,
+                                                  "launches_per_step": ln // max(steps, 1)} for (n, ms, fl, ln, _b) in kinds if ln}}},
+        "unique_labels": int(len(np.unique(labels))),
+    }
+    if lanes > 1:
+        out["roofline"]["note"] = (f"{lanes} windows share the chip: a launch's HIP-event time includes the moments its blocks wait for "
+                                   f"CUs held by the other lane's kernels, so per-kernel TFLOP/s read lower than with --lanes 1 while the "
+                                   f"whole-job rate is higher")
+    if args.masks_only:                                              # never the headline: the reference's schedule runs every step in full
+        out["metric"] += " [masks-only pruning: NOT the reference schedule]"
+        out["config"]["workload"] += ("; OPT-IN PRUNING (--masks-only): the last UNet evaluation runs on the conditional half only and "
+                                      "stops after decoder block 8 (its other outputs are never read by Steps 3-3b)")
+        out["config"]["unet_evals_per_step"] = f"{evals - 1} full + 1 taps-only (cond half, blocks <= 8)"
+    if args.fp8_attn:
+        out["dtype"] += " + e4m3 attention (q, k, v, P; >= 1024 keys)"
+        out["config"]["workload"] += "; BASELINE configs[4] attention path: OCP e4m3 MFMA on the spatial self-attentions"
+    return out, sd_cpu, cfg, eng, labels, run_steps
 
 
 def main():
@@ -118,10 +333,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--narrow", action="store_true", help="debug: narrow-width UNet (NOT the benchmark config)")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="run each window's analysis after its own feature pass instead of concurrently with the next one's")
-    ap.add_argument("--overlap-multi", action="store_true",
-                    help="N>1: also overlap (parallel.ShardedPipeline: collectives on a second stream). Verified with 2 gloo ranks on one "
-                         "GPU; off by default until it has run over RCCL on a multi-GPU node")
+                    help="run each window's analysis after its own feature pass instead of concurrently with the next ones'")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="feature passes in flight at once, each on its own HIP stream (pipeline.WindowPipeline / parallel.ShardedPipeline)")
     ap.add_argument("--vae", action="store_true", help="also time the first-stage encode of one window (reported beside the metric)")
     ap.add_argument("--config", default="sd", choices=["sd", "svd"],
                     help="sd = BASELINE configs[1] (headline); svd = configs[2]: SVD 14x576x1024, t_start 17, is_refine_mask")
@@ -132,10 +346,9 @@ def main():
                     help="opt-in pruning, NOT the reference's schedule and not the headline: the last step runs on the conditional half only and "
                          "stops after decoder block 8 (pipeline.feature_pass(masks_only=True)); taps equal up to fp32 summation order")
     ap.add_argument("--masks", type=int, default=None, help="number of masks K (default 20; configs[4] uses 50)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the chained-window figure, the in-run PMC passes and the SVD secondary")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # one window under rocprofv3 --pmc (see pmc_traffic)
     args = ap.parse_args()
-    global K_MASKS
-    if args.masks:
-        K_MASKS = args.masks
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -151,217 +364,116 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
-    from vidseg_diffusion_amd import feature_extraction as FE
-    from vidseg_diffusion_amd import ops, parallel, synthetic
-    from vidseg_diffusion_amd.pipeline import build_sd_engine
-    from vidseg_diffusion_amd.unet import UNetModel
-
+    from vidseg_diffusion_amd import ops
     svd = args.config == "svd"
+    k_masks = args.masks or 20
+    refine = True if svd else args.refine
     ops.set_attention_fp8(args.fp8_attn)
-    global T_START
-    if svd:
-        from vidseg_diffusion_amd.video_unet import VideoUNet
-        cfg = dict(synthetic.SVD_NARROW if args.narrow else synthetic.SVD_FULL)
-        net = VideoUNet(**cfg)
-        T_START = 17
-        args.refine = True
-    else:
-        cfg = dict(synthetic.SD21_NARROW if args.narrow else synthetic.SD21_FULL)
-        net = UNetModel(**cfg)
-    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
-    sd_cpu = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=1234).items()}
-    net.load_state_dict(sd_cpu)
-    net.pack(dev)
-    if svd:
-        from vidseg_diffusion_amd.pipeline import build_svd_engine
-        eng = build_svd_engine(net, num_frames=F_WIN, num_steps=NUM_STEPS)
-        lat, c, uc, noise = make_inputs(dev, rank, cfg, svd=True, lat_hw=(72, 128))
-    else:
-        eng = build_sd_engine(net, num_steps=NUM_STEPS, scale=5.0)
-        lat, c, uc, noise = make_inputs(dev, rank, cfg)
-    torch.cuda.synchronize()
+    out, sd_cpu, cfg, eng, labels, run_steps = run_config(args, svd, rank, world, dev, args.steps, args.warmup)
 
-    def one_step():
-        FE.FeatureStore.clear()
-        FE.MaskStore.clear()
-        return parallel.segment_windows_sharded(eng, lat, c, uc, noise=noise, num_masks=K_MASKS, num_steps=NUM_STEPS, t_start=T_START,
-                                                is_aggre_attn=True, is_refine_mask=args.refine, seed=17, rank=rank, world=world,
-                                                masks_only=args.masks_only)
-
-    # N = 1: windows run through pipeline.WindowPipeline -- the analysis of step i (second HIP stream) overlaps the feature pass
-    # of step i+1; every step is still a complete window (K-means included) and all of them finish inside the timed region.
-    overlap = world == 1 and not args.no_overlap
-    if overlap:
-        from vidseg_diffusion_amd.pipeline import WindowPipeline
-        pipe = WindowPipeline(eng, chain=False, num_masks=K_MASKS, is_aggre_attn=True, is_refine_mask=args.refine)
-        step_no = [0]
-
-        def run_steps(n):
-            last = None
-            for _ in range(n):
-                step_no[0] += 1
-                FE.MaskStore.clear()
-                got = pipe.push(lat, c, uc, num_steps=NUM_STEPS, t_start=T_START, seed=17, noise=noise, keep_all_steps=False,
-                                masks_only=args.masks_only,
-                                exp_name=f"step{step_no[0] % 2}")
-                last = got if got is not None else last
-            got = pipe.flush()
-            return got if got is not None else last
-    elif world > 1 and args.overlap_multi and not args.no_overlap:
-        spipe = parallel.ShardedPipeline(eng, rank, world, num_masks=K_MASKS, is_aggre_attn=True, is_refine_mask=args.refine)
-        step_no = [0]
-
-        def run_steps(n):
-            last = None
-            for _ in range(n):
-                step_no[0] += 1
-                FE.MaskStore.clear()
-                got = spipe.push(lat, c, uc, noise=noise, num_steps=NUM_STEPS, t_start=T_START, seed=17, exp_name=f"r{rank}s{step_no[0] % 2}",
-                                 masks_only=args.masks_only)
-                last = got if got is not None else last
-            got = spipe.flush()
-            return got if got is not None else last
-        overlap = True
-    else:
-        def run_steps(n):
-            last = None
-            for _ in range(n):
-                last = one_step()
-            return last
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    if args.warmup:
-        run_steps(args.warmup)
-    barrier()
-    ops.gemm_profile_begin()
-    t0 = time.perf_counter()
-    labels = run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    k_ms, k_flops, k_launches = ops.gemm_profile_end()
-    kinds = ops.gemm_profile_kinds()
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")           # PMC pass (separate rocprofv3 --pmc runs), see file
-    if os.path.exists(tpath) and not svd and not args.narrow:
-        with open(tpath) as fh:
-            tj = json.load(fh)
-            traffic = tj.get("traffic_bytes_per_launch")
-    if rank == 0:
-        frames = F_WIN * world * args.steps
-        fam_tf = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
-        dom = max(kinds, key=lambda r: r[1])                                  # the single kernel with the most time in the region
-        if traffic is not None:                                               # PMC pass: per-launch bytes of that kernel if recorded
-            for kname, rec in tj.get("per_kernel", {}).items():
-                if ("k_gemm_ph<5>" in kname and dom[0].startswith("k_gemm_ph")) or \
-                        ("k_gemm_dma<2>" in kname and dom[0].startswith("k_gemm_dma")):
-                    traffic = rec["traffic_bytes_per_launch"]
-                    break
-        achieved = (dom[2] / (dom[1] * 1e-3)) / 1e12 if dom[1] > 0 else 0.0
-        out = {
-            "metric": "segmented frames/sec (14-frame 512^2 clip, 20 masks)",
-            "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if ops.act_dtype() == torch.float16 else "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: SD 2.1 full-size UNet (865.9M params, random-init), 14-frame 512x512 window per GPU "
-                                   "(latent 14x4x64x64), 25-step schedule with t_start=22 (3 CFG UNet evals, batch 28), Q/K taps on decoder "
-                                   "blocks 3-11, is_aggre_attn (blocks 6,7,8), K-means K=20 n_init=10 + 4-NN"
-                                   + (", is_refine_mask" if args.refine else ""),
-                       "frames_per_gpu": F_WIN, "num_masks": K_MASKS, "unet_evals_per_step": 3, "parallelism": f"window-per-gpu x{world}",
-                       "overlap": "analysis of step i on a second HIP stream, concurrent with the feature pass of step i+1" if overlap
-                                  else "none (each window's analysis follows its own feature pass)"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": round(achieved / 2500.0, 4), "traffic": traffic, "kernel": dom[0],
-                         "launches_per_step": dom[3] // max(args.steps, 1),
-                         "avg_launch_us": round(1e3 * dom[1] / max(dom[3], 1), 2),
-                         "ms_per_step": round(dom[1] / args.steps, 3),
-                         # every conv / linear of the UNet runs on this kernel family; the family-wide figures:
-                         "family": {"achieved": round(fam_tf, 2), "frac": round(fam_tf / 2500.0, 4),
-                                    "launches_per_step": k_launches // max(args.steps, 1), "gemm_ms_per_step": round(k_ms / args.steps, 3),
-                                    "by_kernel": {n: {"ms_per_step": round(ms / args.steps, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 else 0.0,
-                                                      "launches_per_step": ln // max(args.steps, 1)} for (n, ms, fl, ln) in kinds if ln}}},
-            "unique_labels": int(len(np.unique(labels))),
-        }
-        if svd:
-            out["metric"] = "segmented frames/sec (14-frame 576x1024 clip, 20 masks, SVD)"
-            out["config"]["workload"] = ("BASELINE configs[2]: SVD img2vid full-size VideoUNet (1524.6M params, random-init), 14-frame 576x1024 "
-                                         "window per GPU (latent 14x4x72x128), t_start=17 (8 CFG UNet evals, batch 28), spatial+temporal taps, "
-                                         "is_aggre_attn, K-means K=20 + 4-NN, is_refine_mask (dense tracking + vote)")
-            out["config"]["unet_evals_per_step"] = 8
-        if args.masks_only:                                              # never the headline: the reference's schedule runs every step in full
-            out["metric"] += " [masks-only pruning: NOT the reference schedule]"
-            out["config"]["workload"] += ("; OPT-IN PRUNING (--masks-only): the last UNet evaluation runs on the conditional half only and "
-                                          "stops after decoder block 8 (its other outputs are never read by Steps 3-3b)")
-            out["config"]["unet_evals_per_step"] = "2 full + 1 taps-only (cond half, blocks <= 8)"
-        if args.masks_only and world == 1:                               # outside the timed region: the same window on the full schedule
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from tools_metrics import matched_iou
+    if out is not None:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from tools_metrics import matched_iou
+        if not svd and not args.narrow:
+            m = mask_iou_vs_reference(labels if world == 1 else np.asarray(labels)[0], refine, k_masks)
+            if m is not None:
+                out["mask_iou_vs_reference"] = m
+        if world == 1 and (args.masks_only or args.fp8_attn):        # outside the timed region: the same window on the plain path
+            saved = (args.masks_only, args.fp8_attn)
             args.masks_only = False
-            ref_labels = one_step()
-            args.masks_only = True
-            iou, exact = matched_iou(np.asarray(labels).reshape(-1), np.asarray(ref_labels).reshape(-1), K_MASKS)
-            out["masks_vs_full_schedule"] = {"iou": round(float(iou), 4), "identical_fraction": round(float(exact), 4)}
-        if args.masks:
-            out["metric"] = out["metric"].replace("20 masks", f"{K_MASKS} masks")
-            out["config"]["workload"] = out["config"]["workload"].replace("K=20", f"K={K_MASKS}")
-        if args.fp8_attn:
-            out["dtype"] += " + e4m3 attention (q, k, v, P; >= 1024 keys)"
-            out["config"]["workload"] += "; BASELINE configs[4] attention path: OCP e4m3 MFMA on the spatial self-attentions"
-        if args.fp8_attn and world == 1:                                 # outside the timed region: the same window on the 16-bit kernels
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from tools_metrics import matched_iou
             ops.set_attention_fp8(False)
-            ref_labels = one_step()
-            ops.set_attention_fp8(True)
-            iou, exact = matched_iou(np.asarray(labels).reshape(-1), np.asarray(ref_labels).reshape(-1), K_MASKS)
-            out["fp8_vs_16bit_masks"] = {"iou": round(float(iou), 4), "identical_fraction": round(float(exact), 4)}
-        if args.vae:                                                     # outside the timed region, never part of `value`
-            from vidseg_diffusion_amd.vae import AutoencoderKL, encode_first_stage
-            dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
-                      num_res_blocks=2, attn_resolutions=[], dropout=0.0)
-            vae = AutoencoderKL(embed_dim=4, ddconfig=dd)
-            vshapes = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
-            vae.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(vshapes, seed=99).items()})
-            ih, iw = (576, 1024) if svd else (512, 512)
-            frames = (torch.rand(F_WIN, 3, ih, iw) * 2 - 1).to(dev)
-            nz = torch.randn(F_WIN, 4, ih // 8, iw // 8)
-            for _ in range(2):
-                encode_first_stage(vae, frames, 0.18215, noise=nz)
+            from vidseg_diffusion_amd import feature_extraction as FE
+            from vidseg_diffusion_amd import parallel
+            FE.FeatureStore.clear()
+            lat, c, uc, noise = make_inputs(dev, rank, cfg, svd=svd, lat_hw=(72, 128) if svd else (LAT, LAT))
+            ref_labels = parallel.segment_windows_sharded(eng, lat, c, uc, noise=noise, num_masks=k_masks, num_steps=NUM_STEPS,
+                                                          t_start=17 if svd else 22, is_aggre_attn=True, is_refine_mask=refine, seed=17,
+                                                          rank=0, world=1)
+            args.masks_only = saved[0]
+            ops.set_attention_fp8(saved[1])
+            iou, exact = matched_iou(np.asarray(labels).reshape(-1), np.asarray(ref_labels).reshape(-1), k_masks)
+            key = "masks_vs_full_schedule" if saved[0] else "fp8_vs_16bit_masks"
+            out[key] = {"iou": round(float(iou), 4), "identical_fraction": round(float(exact), 4)}
+        plain = world == 1 and not args.no_secondary and not args.narrow and not args.masks_only and not args.fp8_attn
+        if plain and not args.no_overlap:                            # windows chained like one long clip (outside the headline timing)
+            n = max(3, min(args.steps, 8))
+            run_steps(2, chain=True)
             torch.cuda.synchronize()
-            tv = time.perf_counter()
-            for _ in range(3):
-                encode_first_stage(vae, frames, 0.18215, noise=nz)
+            t0 = time.perf_counter()
+            run_steps(n, chain=True)
             torch.cuda.synchronize()
-            enc_ms = 1e3 * (time.perf_counter() - tv) / 3
-            from vidseg_diffusion_amd.vae import decode_first_stage
-            zz = encode_first_stage(vae, frames, 0.18215, noise=nz)
-            for _ in range(2):
-                decode_first_stage(vae, zz, 0.18215)
-            torch.cuda.synchronize()
-            tv = time.perf_counter()
-            for _ in range(3):
-                decode_first_stage(vae, zz, 0.18215)
-            torch.cuda.synchronize()
-            out["first_stage"] = {"encode_ms_per_window": round(enc_ms, 2), "decode_ms_per_window": round(1e3 * (time.perf_counter() - tv) / 3, 2),
-                                  "frames": F_WIN, "image": [ih, iw],
-                                  "note": "AutoencoderKL.encode / .decode (SD image decoder), synthetic weights; excluded from `value`"}
-        if not args.no_cpu_baseline and not args.narrow and not svd and world == 1:     # host-side legs: rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg)
-            out["mask_iou_vs_oracle"] = mask_iou_check(eng, sd_cpu, cfg, dev)
+            dt = time.perf_counter() - t0
+            out["chained_window"] = {"value": round(F_WIN * n / dt, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n, 3), "steps": n,
+                                     "note": "the same windows chained as one clip (sd_pipeline_vspw.py:381-401): window 0 of the chain runs "
+                                             "K-means, every later one the 14336 x 14336 x 640 float64 4-NN against its predecessor "
+                                             "(feature_extraction.py:603-613)"}
+        if args.vae:                                                 # outside the timed region, never part of `value`
+            out["first_stage"] = first_stage_timing(dev, svd)
+        if plain and not svd:
+            tr = pmc_traffic(["--refine"] if args.refine else []) if os.environ.get("VIDSEG_BENCH_PMC", "1") != "0" else None
+            dom = out["roofline"]["kernel"]
+            key = "k_gemm_ph<5>" if dom.startswith("k_gemm_ph") else "k_gemm_dma<2>"
+            if tr and key in tr:
+                out["roofline"]["traffic"] = int(tr[key][1])
+                out["roofline"]["traffic_how"] = (f"this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over one window of "
+                                                  f"the same workload, {key}: {tr[key][0]} launches, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches")
+                out["roofline"]["traffic_by_kernel"] = {k: {"launches": n, "bytes_per_launch": int(b)} for k, (n, b) in sorted(tr.items())}
+            else:
+                static = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+                if static:
+                    with open(static[-1]) as fh:
+                        tj = json.load(fh)
+                    rec = tj.get("per_kernel", {}).get("void " + key) or tj.get("per_kernel", {}).get(key)
+                    if rec:
+                        out["roofline"]["traffic_static"] = {"bytes_per_launch": rec["traffic_bytes_per_launch"],
+                                                             "source": os.path.relpath(static[-1], ROOT) + " (an earlier PMC pass, not this run)"}
+        if not args.no_cpu_baseline and not args.narrow and not svd and world == 1:     # host-side leg: rank 0 at N = 1 only
+            out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, k_masks)
+        if plain and not svd:                                        # BASELINE configs[2] as a secondary record
+            del eng, sd_cpu, run_steps
+            torch.cuda.empty_cache()
+            try:
+                sec, *_ = run_config(args, True, rank, world, dev, steps=3, warmup=1, secondary=True)
+                out["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "unique_labels")}
+                out["secondary"]["roofline"] = {k: sec["roofline"][k] for k in ("achieved", "frac", "kernel", "family")}
+            except Exception as e:                                   # never lose the headline line to the secondary
+                out["secondary"] = {"error": repr(e)[:200]}
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def first_stage_timing(dev, svd):
+    from vidseg_diffusion_amd import synthetic
+    from vidseg_diffusion_amd.vae import AutoencoderKL, decode_first_stage, encode_first_stage
+    dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    vae = AutoencoderKL(embed_dim=4, ddconfig=dd)
+    vshapes = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+    vae.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(vshapes, seed=99).items()})
+    ih, iw = (576, 1024) if svd else (512, 512)
+    frames = (torch.rand(F_WIN, 3, ih, iw) * 2 - 1).to(dev)
+    nz = torch.randn(F_WIN, 4, ih // 8, iw // 8)
+    for _ in range(2):
+        encode_first_stage(vae, frames, 0.18215, noise=nz)
+    torch.cuda.synchronize()
+    tv = time.perf_counter()
+    for _ in range(3):
+        encode_first_stage(vae, frames, 0.18215, noise=nz)
+    torch.cuda.synchronize()
+    enc_ms = 1e3 * (time.perf_counter() - tv) / 3
+    zz = encode_first_stage(vae, frames, 0.18215, noise=nz)
+    for _ in range(2):
+        decode_first_stage(vae, zz, 0.18215)
+    torch.cuda.synchronize()
+    tv = time.perf_counter()
+    for _ in range(3):
+        decode_first_stage(vae, zz, 0.18215)
+    torch.cuda.synchronize()
+    return {"encode_ms_per_window": round(enc_ms, 2), "decode_ms_per_window": round(1e3 * (time.perf_counter() - tv) / 3, 2),
+            "frames": F_WIN, "image": [ih, iw],
+            "note": "AutoencoderKL.encode / .decode (SD image decoder), synthetic weights; excluded from `value`"}
 
 
 if __name__ == "__main__":

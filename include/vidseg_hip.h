@@ -33,8 +33,9 @@ typedef struct ihipStream_t* vidseg_stream_t; /* hipStream_t */
 
 int vidseg_version(void);
 const char* vidseg_last_error(void);
-/* 16-bit storage format of every `*_bf16` activation / weight argument below: 1 = IEEE fp16 (default build; the reference's
- * CUDA autocast dtype), 0 = bfloat16 (-DVIDSEG_ACT_BF16).  The entry-point names keep their historical `bf16` suffix. */
+/* 16-bit storage format of every `*_a16` entry point's activation / weight arguments ("a16" = the build's 16-bit activation
+ * type): 1 = IEEE fp16 (default build; the reference's CUDA autocast dtype), 0 = bfloat16 (-DVIDSEG_ACT_BF16).  Parameter names
+ * and comments that say "bf16" mean that 16-bit type. */
 int vidseg_act_dtype(void);
 
 /* ------------------------------------------------------------------------------------------------------
@@ -119,7 +120,7 @@ int vidseg_trajectory_vote(const int32_t* idx, const int32_t* labels, int F, int
  * bias + rowvec[sample]) + residual.  act: 0 none, 1 SiLU (OAI:605-609 time_embed), 2 GEGLU (ATT:89-96; w/bias
  * packed in 32-row value|gate groups).  tap/tap2: fp16 copies of output columns [0,tap_cols) / [tap_cols,2*tap_cols)
  * = the q / k dumps of ATT:330-331. */
-int vidseg_linear_bf16(const void* a0, const void* a1, int C0, int C1, long long M, const void* w, int N, const float* bias,
+int vidseg_linear_a16(const void* a0, const void* a1, int C0, int C1, long long M, const void* w, int N, const float* bias,
                        const float* rowvec, int rv_stride, int rows_per_sample, const void* residual, int ldr, void* out,
                        float* out_f32, int ldo, void* tap, void* tap2, int tap_cols, int tap_ld,
                        const float* rowadd /* per-row scalar: modulation lambda*mask[:,None], ATT:646-663, 697-719 */, int act,
@@ -130,13 +131,13 @@ int vidseg_linear_bf16(const void* a0, const void* a1, int C0, int C1, long long
  * (0,1,0,1)-padded stride-2 Downsample (sgm/modules/diffusionmodules/model.py:84-91); out_f32 (optional) receives an fp32
  * copy of the result (the VAE's conv_out moments).  Weight layout: [Cout][c/64][kh*3+kw][c%64] (channel-chunk-major K order:
  * the 9 taps of a 64-channel chunk are consecutive K-tiles; C0 and C1 are multiples of 64). */
-int vidseg_conv3x3_bf16(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up,
+int vidseg_conv3x3_a16(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up,
                         const void* w, int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual,
                         void* out, int pad, float* out_f32 /*opt*/, vidseg_stream_t stream);
 /* First stage (VAE encoder, model.py:487-600): row softmax of fp32 logits (the single-head dim-512 mid attention runs as
  * GEMM -> softmax -> GEMM, model.py:161-202) and DiagonalGaussianDistribution.sample * scale_factor
  * (distributions.py:24-41, sgm/models/diffusion.py:138-151); moments NHWC [B][HW][2Z] fp32, noise / out NCHW [B][Z][HW]. */
-int vidseg_softmax_rows_bf16(const float* x, long long rows, int cols, float scale, void* out_bf16, vidseg_stream_t stream);
+int vidseg_softmax_rows_a16(const float* x, long long rows, int cols, float scale, void* out_bf16, vidseg_stream_t stream);
 int vidseg_gaussian_sample(const float* moments_nhwc, const float* noise_nchw, int B, int HW, int Z, float scale, float* out_nchw,
                            vidseg_stream_t stream);
 /* OAI:638-644 input conv (Cin 4/8): x fp32 NHWC, w fp32 [3][3][Cin][Cout] -> bf16 NHWC. */
@@ -147,13 +148,13 @@ int vidseg_conv_out4(const void* x, const void* w, const float* bias, int B, int
                      vidseg_stream_t stream);
 /* GroupNorm32 (DU:276-278, fp32 statistics; eps 1e-5) / ATT:127 Normalize (eps 1e-6), optional SiLU.
    Scratch: part >= B*ceil(HW/64)*2*C floats (per-chunk partial sums), stats >= B*2*C floats (per-sample scale/shift). */
-int vidseg_groupnorm_nhwc_bf16(const void* x0, const void* x1, int C0, int C1, int B, int HW, int G, const float* gamma,
+int vidseg_groupnorm_nhwc_a16(const void* x0, const void* x1, int C0, int C1, int B, int HW, int G, const float* gamma,
                                const float* beta, float eps, int silu, float* part, int part_floats, float* stats, int stats_floats,
                                void* out, vidseg_stream_t stream);
-int vidseg_layernorm_bf16(const void* x, long long M, int C, const float* gamma, const float* beta, float eps, void* out,
+int vidseg_layernorm_a16(const void* x, long long M, int C, const float* gamma, const float* beta, float eps, void* out,
                           vidseg_stream_t stream);
 /* ATT:352-356 F.scaled_dot_product_attention per 64-wide head; q/k/v/o are column slices with leading dims. */
-int vidseg_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B,
+int vidseg_attention_a16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B,
                           int H, int Nq, int Nk, int head_dim, vidseg_stream_t stream);
 /* BASELINE configs[4] (fp8 attention path): the same operator (ATT:352-356) with q, k, v and the probabilities in OCP e4m3
  * (v_mfma_f32_32x32x16_fp8_fp8), fp32 softmax/accumulation, output in the activation dtype; strides in bytes = elements.
@@ -178,25 +179,25 @@ int vidseg_seg_argmax(const void* maps_u8, const void* max_u32, const void* weig
                       int H, int W, void* seg_u8, vidseg_stream_t stream);
 /* SVD (video) operators -- video_model.py:15-89 VideoResBlock, video_attention.py:18-489 */
 /* Conv3d kernel [3,1,1], padding [1,0,0] over frames; x NHWC [(b t)][HW][C], w [Cout][c/64][dt][c%64] (video_model.py:45-58) */
-int vidseg_conv_temporal3_bf16(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
+int vidseg_conv_temporal3_a16(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
                                const float* rowvec, int rv_stride, const void* residual, void* out, vidseg_stream_t stream);
 /* bias-free projection with fp16 taps in the reference's temporal layout [(b s), t, c] (video_attention.py:152, ATT:330) */
-int vidseg_linear_bf16_ttap(const void* a0, long long M, int C0, const void* w, int N, void* out, int ldo, void* tap, void* tap2,
+int vidseg_linear_a16_ttap(const void* a0, long long M, int C0, const void* w, int N, void* out, int ldo, void* tap, void* tap2,
                             int tap_cols, int tap_ld, int tap_T, int tap_S, vidseg_stream_t stream);
 /* attention across the T frames of each (sample, location), tokens kept in spatial order (video_attention.py:166-195) */
-int vidseg_temporal_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
+int vidseg_temporal_attention_a16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
                                    int Bv, int T, int S, int H, int head_dim, vidseg_stream_t stream);
 /* AlphaBlender 'learned_with_images', image_only_indicator == 0 (diffusionmodules/util.py:343-380) */
-int vidseg_alpha_blend_bf16(const void* x_spatial, const void* x_temporal, const float* mix_factor, long long n, void* out,
+int vidseg_alpha_blend_a16(const void* x_spatial, const void* x_temporal, const float* mix_factor, long long n, void* out,
                             vidseg_stream_t stream);
 /* tokens + frame-index embedding (video_attention.py:417-431) */
-int vidseg_add_rowvec_bf16(const void* x, const void* vec, long long rows, int C, int rows_per_sample, int nvec, void* out,
+int vidseg_add_rowvec_a16(const void* x, const void* vec, long long rows, int C, int rows_per_sample, int nvec, void* out,
                            vidseg_stream_t stream);
 /* DU:209-233 */
 int vidseg_timestep_embedding(const float* t, int B, int dim, float max_period, void* out, vidseg_stream_t stream);
-int vidseg_silu_bf16(const void* x, long long n, void* out, vidseg_stream_t stream);
-int vidseg_f32_to_bf16(const float* x, long long n, void* out, vidseg_stream_t stream);
-int vidseg_f16_to_bf16(const void* x, long long n, void* out, vidseg_stream_t stream); /* injected fp16 dumps -> bf16 operands */
+int vidseg_silu_a16(const void* x, long long n, void* out, vidseg_stream_t stream);
+int vidseg_f32_to_a16(const float* x, long long n, void* out, vidseg_stream_t stream);
+int vidseg_f16_to_a16(const void* x, long long n, void* out, vidseg_stream_t stream); /* injected fp16 dumps -> bf16 operands */
 
 /* ------------------------------------------------------------------------------------------------------
  * Sampler arithmetic on fp32 latents (SURVEY.md rows a2-a6, a17 latent blending)
@@ -237,6 +238,8 @@ int vidseg_gemm_profile_begin(void);
 int vidseg_gemm_profile_end(double* out);
 /* per-kernel split of the same region: out[12] = {ms, flops, launches} x {128x128 LDS-DMA, big tile, mid tile, 256x64} */
 int vidseg_gemm_profile_kinds(double* out);
+/* algorithmic HBM bytes of the same region per kernel, out[4] (every operand and result once; no split-K partials) */
+int vidseg_gemm_profile_bytes(double* out);
 
 #ifdef __cplusplus
 }

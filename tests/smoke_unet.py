@@ -1,13 +1,13 @@
-"""smoke(): one narrow-width SD UNet forward on cuda:0 checked against the oracle (test infrastructure import is
-confined to this smoke helper, which only __graft_entry__.smoke() calls)."""
+"""smoke(): one narrow-width SD UNet forward on cuda:0 checked against the oracle.  Test infrastructure (it imports `oracle`):
+lives under tests/ and is called by __graft_entry__.smoke() only."""
 import numpy as np
 import torch
 
 
 def run(dev):
     from oracle.unet import UNetOracle            # noqa: checker only
-    from . import synthetic
-    from .unet import UNetModel
+    from vidseg_diffusion_amd import synthetic
+    from vidseg_diffusion_amd.unet import UNetModel
     net = UNetModel(**synthetic.SD21_NARROW)
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     sd = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, 1234).items()}

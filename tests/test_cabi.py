@@ -50,8 +50,6 @@ def test_no_oracle_import_in_product():
     pkg = os.path.join(ROOT, "vidseg_diffusion_amd")
     for f in os.listdir(pkg):
         if f.endswith(".py"):
-            if f == "smoke_unet.py":
-                continue
             assert "oracle" not in re.sub(r'""".*?"""', "", open(os.path.join(pkg, f)).read(), flags=re.S).replace("oracle-backed", ""), f
 
 

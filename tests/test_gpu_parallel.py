@@ -47,6 +47,12 @@ def _worker(rank, world, port, q):
     first = pipe.push(lat, c, uc, noise=noise, seed=17, feature_folder="/nonexistent/par", exp_name=f"p{rank}b")
     second = pipe.flush()
     assert np.array_equal(first, labels) and np.array_equal(second, labels), "overlapped sharded steps differ from the plain one"
+    # two feature-pass lanes (two windows in flight on their own streams + scratch): same labels, delivered two pushes later
+    pipe = parallel.ShardedPipeline(eng, rank, world, lanes=2, num_masks=K, is_refine_mask=True)
+    got = [pipe.push(lat, c, uc, noise=noise, seed=17, feature_folder="/nonexistent/par", exp_name=f"l{rank}{i}") for i in range(3)]
+    assert got[0] is None and got[1] is None and np.array_equal(got[2], labels)
+    rest = pipe.drain()
+    assert len(rest) == 2 and all(np.array_equal(r, labels) for r in rest), "two-lane sharded steps differ from the plain one"
     q.put((rank, labels))
     dist.barrier()
     dist.destroy_process_group()

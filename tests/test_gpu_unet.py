@@ -460,13 +460,13 @@ def test_overlapped_clip_equals_sequential(env):
         from vidseg_diffusion_amd.pipeline import WindowPipeline, WindowState, segment_window, window_slices
         slices = window_slices(Ft, 4)
         if overlap:
-            pipe = WindowPipeline(eng, num_masks=4, is_refine_mask=True)
+            pipe = WindowPipeline(eng, lanes=overlap, num_masks=4, is_refine_mask=True)
             for b, (s, e) in enumerate(slices):
                 prev = pipe.push(lat[s:e].contiguous(), {"crossattn": cc[s:e]}, {"crossattn": ucc[s:e]}, t_start=22, seed=17,
                                  feature_folder="/nonexistent/ov" + tag, exp_name=f"w{b}", noise=noise_all[s:e].contiguous())
                 if prev is not None:
                     res.append(prev)
-            res.append(pipe.flush())
+            res += pipe.drain()
         else:
             st = WindowState()
             for b, (s, e) in enumerate(slices):
@@ -476,8 +476,10 @@ def test_overlapped_clip_equals_sequential(env):
                 res.append(lab)
         return res
 
-    a, b = run(False, "s"), run(True, "p")
-    assert len(a) == len(b) == 3
+    a, b, c2 = run(0, "s"), run(1, "p"), run(2, "q")              # sequential, one lane, two feature-pass lanes in flight
+    assert len(a) == len(b) == len(c2) == 3
+    for x, y in zip(a, c2):
+        assert np.array_equal(x, y), "two-lane pipeline differs from the sequential loop"
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     out = segment_clip(eng, lat, lambda s, e: ({"crossattn": cc[s:e]}, {"crossattn": ucc[s:e]}), batch_size=4, num_masks=4, t_start=22,

@@ -1,5 +1,5 @@
 """Join per-dispatch PMC values of the big GEMM tile with the shape log of the same run.
-usage: python tools/dbg/pmc_per_shape.py <FETCH.db> <WRITE.db> <shape log of the FETCH run>"""
+usage: python tools/pmc_per_shape.py <FETCH.db> <WRITE.db> <shape log of the FETCH run>"""
 import collections
 import re
 import sqlite3

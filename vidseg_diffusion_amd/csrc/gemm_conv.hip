@@ -1251,11 +1251,12 @@ struct GemmProf {
     size_t used = 0;
     double flops = 0.0;
     long long launches = 0;
-    struct Shape { long long M; int N, K, ksize, up, stride, act, ksplit, kind; };
+    struct Shape { long long M; int N, K, ksize, up, stride, act, ksplit, kind; double alg_bytes; };
     std::vector<Shape> shapes;      // one per event pair
 };
 static GemmProf g_prof;
 static double g_kind_stats[12];
+static double g_kind_bytes[4];
 
 static inline hipEvent_t prof_event() {
     if (g_prof.used == g_prof.ev.size()) {
@@ -1282,6 +1283,7 @@ int vidseg_gemm_profile_end(double* out) {
     g_prof.on = false;
     double ms = 0.0;
     for (int i = 0; i < 12; ++i) g_kind_stats[i] = 0.0;
+    for (int i = 0; i < 4; ++i) g_kind_bytes[i] = 0.0;
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
         float t = 0.f;
         hipError_t e = hipEventSynchronize(g_prof.ev[i + 1]);
@@ -1294,6 +1296,7 @@ int vidseg_gemm_profile_end(double* out) {
             g_kind_stats[kd * 3] += t;
             g_kind_stats[kd * 3 + 1] += 2.0 * (double)h.M * (double)h.N * (double)h.K;
             g_kind_stats[kd * 3 + 2] += 1.0;
+            g_kind_bytes[kd] += h.alg_bytes;
         }
         if (getenv("VIDSEG_GEMM_SHAPES") && i / 2 < g_prof.shapes.size()) {
             const GemmProf::Shape& h = g_prof.shapes[i / 2];
@@ -1311,6 +1314,14 @@ int vidseg_gemm_profile_end(double* out) {
 // k = 0: k_gemm_dma (128x128), 1: k_gemm_tile big (256x320 / 256x256), 2: k_gemm_tile mid (128x320), 3: k_gemm_conv<256,64>.
 int vidseg_gemm_profile_kinds(double* out) {
     for (int i = 0; i < 12; ++i) out[i] = g_kind_stats[i];
+    return VS_OK;
+}
+
+// Algorithmic HBM bytes of the same region per kernel (same order): every operand once -- the activation tensor(s) the launch
+// reads (the whole input image for a conv: the 9 taps re-read it through L1/L2, not through memory), the weight matrix, the
+// residual, and every output it writes (16-bit result, fp32 result, fp16 taps); split-K partials are NOT algorithmic.
+int vidseg_gemm_profile_bytes(double* out) {
+    for (int i = 0; i < 4; ++i) out[i] = g_kind_bytes[i];
     return VS_OK;
 }
 
@@ -1527,14 +1538,20 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     }
     if (g_prof.on) {
         (void)hipEventRecord(prof_event(), st);
-        g_prof.shapes.push_back({p.M, p.N, p.K, p.ksize, p.up, p.stride, p.act, p.ksplit, kind});
+        const double n_out = p.act == 2 ? p.N / 2 : p.N;
+        double ab = (double)p.x0_bytes + (double)p.x1_bytes + 2.0 * (double)p.N * (double)p.K;
+        if (p.residual) ab += 2.0 * (double)p.M * n_out;
+        if (p.out) ab += 2.0 * (double)p.M * n_out;
+        if (p.out_f32) ab += 4.0 * (double)p.M * n_out;
+        if (p.tap) ab += 2.0 * (double)p.M * (double)p.tap_cols * (p.tap2 ? 2.0 : 1.0);
+        g_prof.shapes.push_back({p.M, p.N, p.K, p.ksize, p.up, p.stride, p.act, p.ksplit, kind, ab});
     }
     VS_CHECK_LAUNCH("gemm_conv");
     return VS_OK;
 }
 
 // out[M][N] = A[M][K] @ W[N][K]^T (+bias)(+rowvec)(act)(+residual); A may be the channel concat of two [M][C] tensors.
-int vidseg_linear_bf16(const void* a0, const void* a1, int C0, int C1, long long M, const void* w, int N, const float* bias,
+int vidseg_linear_a16(const void* a0, const void* a1, int C0, int C1, long long M, const void* w, int N, const float* bias,
                        const float* rowvec, int rv_stride, int rows_per_sample, const void* residual, int ldr, void* out,
                        float* out_f32, int ldo, void* tap, void* tap2, int tap_cols, int tap_ld, const float* rowadd, int act,
                        hipStream_t st) {
@@ -1572,8 +1589,8 @@ int vidseg_linear_bf16(const void* a0, const void* a1, int C0, int C1, long long
     return launch_gemm(p, st);
 }
 
-// Same as vidseg_linear_bf16 with the fp16 taps written in the temporal layout [(b s), t, c] (video_attention.py:152).
-int vidseg_linear_bf16_ttap(const void* a0, long long M, int C0, const void* w, int N, void* out, int ldo, void* tap, void* tap2,
+// Same as vidseg_linear_a16 with the fp16 taps written in the temporal layout [(b s), t, c] (video_attention.py:152).
+int vidseg_linear_a16_ttap(const void* a0, long long M, int C0, const void* w, int N, void* out, int ldo, void* tap, void* tap2,
                             int tap_cols, int tap_ld, int tap_T, int tap_S, hipStream_t st) {
     GemmParams p{};
     p.x0 = (const bf16_t*)a0;
@@ -1601,7 +1618,7 @@ int vidseg_linear_bf16_ttap(const void* a0, long long M, int C0, const void* w, 
 
 // Conv3d with kernel [3,1,1], padding [1,0,0] over frames (video_model.py:45-58): x NHWC bf16 [(b t)][HW][C],
 // w packed [Cout][c/64][dt][c%64] (chunk-major K order, see GemmParams), + bias + per-sample emb vector + residual.
-int vidseg_conv_temporal3_bf16(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
+int vidseg_conv_temporal3_a16(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
                                const float* rowvec, int rv_stride, const void* residual, void* out, hipStream_t st) {
     VS_REQUIRE(T >= 1 && BT % T == 0, "conv_temporal3: BT=%d T=%d", BT, T);
     GemmParams p{};
@@ -1631,7 +1648,7 @@ int vidseg_conv_temporal3_bf16(const void* x, int C, int BT, int HW, int T, cons
 }
 
 // 3x3 convolution, padding 1, NHWC bf16 activations, weight packed [Cout][c/64][kh*3+kw][c%64] (chunk-major K order).
-int vidseg_conv3x3_bf16(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up, const void* w,
+int vidseg_conv3x3_a16(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up, const void* w,
                         int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual, void* out,
                         int pad, float* out_f32, hipStream_t st) {
     VS_REQUIRE((stride == 1 || stride == 2) && (up == 1 || up == 2) && (pad == 0 || pad == 1), "conv3x3: stride=%d up=%d pad=%d", stride,

@@ -1180,7 +1180,7 @@ __global__ void k_gaussian_sample(const float* __restrict__ moments, const float
 
 extern "C" {
 
-int vidseg_groupnorm_nhwc_bf16(const void* x0, const void* x1, int C0, int C1, int B, int HW, int G, const float* gamma,
+int vidseg_groupnorm_nhwc_a16(const void* x0, const void* x1, int C0, int C1, int B, int HW, int G, const float* gamma,
                                const float* beta, float eps, int silu, float* part, int part_floats, float* stats, int stats_floats,
                                void* out, hipStream_t st) {
     const int C = C0 + (x1 ? C1 : 0);
@@ -1202,7 +1202,7 @@ int vidseg_groupnorm_nhwc_bf16(const void* x0, const void* x1, int C0, int C1, i
     return VS_OK;
 }
 
-int vidseg_layernorm_bf16(const void* x, long long M, int C, const float* gamma, const float* beta, float eps, void* out,
+int vidseg_layernorm_a16(const void* x, long long M, int C, const float* gamma, const float* beta, float eps, void* out,
                           hipStream_t st) {
     VS_REQUIRE(C % 8 == 0 && C <= 2048, "layernorm: C=%d", C);
     if (M == 0) return VS_OK;
@@ -1211,7 +1211,7 @@ int vidseg_layernorm_bf16(const void* x, long long M, int C, const float* gamma,
     return VS_OK;
 }
 
-int vidseg_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int H,
+int vidseg_attention_a16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int H,
                           int Nq, int Nk, int head_dim, hipStream_t st) {
     VS_REQUIRE(head_dim == 64, "attention: head_dim=%d (only 64 is on the path)", head_dim);
     VS_REQUIRE(Nq > 0 && Nk > 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attention: bad sizes/strides");
@@ -1273,7 +1273,7 @@ int vidseg_time_mix3_f32(const float* x, int BT, int xC, int C, long long HW, in
     return VS_OK;
 }
 
-int vidseg_softmax_rows_bf16(const float* x, long long rows, int cols, float scale, void* out_bf16, hipStream_t st) {
+int vidseg_softmax_rows_a16(const float* x, long long rows, int cols, float scale, void* out_bf16, hipStream_t st) {
     VS_REQUIRE(cols % 4 == 0 && cols > 0, "softmax_rows: cols=%d must be a positive multiple of 4", cols);
     if (rows == 0) return VS_OK;
     k_softmax_rows<<<dim3((unsigned)((rows + 3) / 4)), 256, 0, st>>>(x, rows, cols, scale * 1.44269504088896340736f, (bf16_t*)out_bf16);
@@ -1297,20 +1297,20 @@ int vidseg_timestep_embedding(const float* t, int B, int dim, float max_period, 
     return VS_OK;
 }
 
-int vidseg_silu_bf16(const void* x, long long n, void* out, hipStream_t st) {
+int vidseg_silu_a16(const void* x, long long n, void* out, hipStream_t st) {
     k_silu_bf16<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>((const bf16_t*)x, n, (bf16_t*)out);
     VS_CHECK_LAUNCH("silu");
     return VS_OK;
 }
 
-int vidseg_f16_to_bf16(const void* x, long long n, void* out, hipStream_t st) {
+int vidseg_f16_to_a16(const void* x, long long n, void* out, hipStream_t st) {
     if (n == 0) return VS_OK;
     k_f16_to_bf16<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>((const f16*)x, n, (bf16_t*)out);
     VS_CHECK_LAUNCH("f16_to_bf16");
     return VS_OK;
 }
 
-int vidseg_f32_to_bf16(const float* x, long long n, void* out, hipStream_t st) {
+int vidseg_f32_to_a16(const float* x, long long n, void* out, hipStream_t st) {
     k_f32_to_bf16<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(x, n, (bf16_t*)out);
     VS_CHECK_LAUNCH("f32_to_bf16");
     return VS_OK;
@@ -1391,7 +1391,7 @@ int vidseg_blend_f32(const float* x, const float* y, const float* m, long long n
     return VS_OK;
 }
 
-int vidseg_temporal_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int Bv,
+int vidseg_temporal_attention_a16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int Bv,
                                    int T, int S, int H, int head_dim, hipStream_t st) {
     VS_REQUIRE(head_dim == 64 && T >= 1 && T <= 32, "temporal_attention: head_dim=%d T=%d (64, <=32)", head_dim, T);
     VS_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "temporal_attention: strides must be multiples of 8");
@@ -1409,7 +1409,7 @@ int vidseg_temporal_attention_bf16(const void* q, int ldq, const void* k, int ld
     return VS_OK;
 }
 
-int vidseg_alpha_blend_bf16(const void* x_spatial, const void* x_temporal, const float* mix_factor, long long n, void* out,
+int vidseg_alpha_blend_a16(const void* x_spatial, const void* x_temporal, const float* mix_factor, long long n, void* out,
                             hipStream_t st) {
     VS_REQUIRE(n % 8 == 0, "alpha_blend: n must be a multiple of 8");
     if (n == 0) return VS_OK;
@@ -1419,7 +1419,7 @@ int vidseg_alpha_blend_bf16(const void* x_spatial, const void* x_temporal, const
     return VS_OK;
 }
 
-int vidseg_add_rowvec_bf16(const void* x, const void* vec, long long rows, int C, int rows_per_sample, int nvec, void* out,
+int vidseg_add_rowvec_a16(const void* x, const void* vec, long long rows, int C, int rows_per_sample, int nvec, void* out,
                            hipStream_t st) {
     VS_REQUIRE(C % 8 == 0 && rows_per_sample > 0 && nvec > 0, "add_rowvec: C=%d", C);
     const long long n = rows * (C / 8);

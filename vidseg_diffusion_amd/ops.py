@@ -17,22 +17,22 @@ from ._lib import call, ptr, stream
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
 _lib.register({
-    "vidseg_linear_bf16": [_P, _P, _I, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P],
-    "vidseg_conv3x3_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P],
-    "vidseg_softmax_rows_bf16": [_P, _L, _I, _F, _P, _P],
+    "vidseg_linear_a16": [_P, _P, _I, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P],
+    "vidseg_conv3x3_a16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P],
+    "vidseg_softmax_rows_a16": [_P, _L, _I, _F, _P, _P],
     "vidseg_gaussian_sample": [_P, _P, _I, _I, _I, _F, _P, _P],
     "vidseg_conv_in": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "vidseg_conv_out4": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
-    "vidseg_groupnorm_nhwc_bf16": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _I, _P, _P],
-    "vidseg_layernorm_bf16": [_P, _L, _I, _P, _P, _F, _P, _P],
-    "vidseg_attention_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vidseg_groupnorm_nhwc_a16": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _I, _P, _P],
+    "vidseg_layernorm_a16": [_P, _L, _I, _P, _P, _F, _P, _P],
+    "vidseg_attention_a16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "vidseg_attention_fp8": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "vidseg_quant_fp8": [_P, _L, _P, _P],
     "vidseg_time_mix3_f32": [_P, _I, _I, _I, _L, _I, _P, _P, _P, _P],
     "vidseg_timestep_embedding": [_P, _I, _I, _F, _P, _P],
-    "vidseg_silu_bf16": [_P, _L, _P, _P],
-    "vidseg_f32_to_bf16": [_P, _L, _P, _P],
-    "vidseg_f16_to_bf16": [_P, _L, _P, _P],
+    "vidseg_silu_a16": [_P, _L, _P, _P],
+    "vidseg_f32_to_a16": [_P, _L, _P, _P],
+    "vidseg_f16_to_a16": [_P, _L, _P, _P],
     "vidseg_prepare_net_input": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P],
     "vidseg_cfg_euler_step": [_P, _P, _I, _I, _I, _F, _F, _P, _F, _F, _F, _P, _P],
     "vidseg_add_noise": [_P, _P, _L, _F, _F, _P],
@@ -45,14 +45,15 @@ _lib.register({
     "vidseg_blend_f32": [_P, _P, _P, _L, _P, _P],
     "vidseg_set_workspace": [_P, _L],
     "vidseg_bind_workspace": [_P, _P, _L],
-    "vidseg_linear_bf16_ttap": [_P, _L, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P],
-    "vidseg_conv_temporal3_bf16": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
-    "vidseg_temporal_attention_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
-    "vidseg_alpha_blend_bf16": [_P, _P, _P, _L, _P, _P],
-    "vidseg_add_rowvec_bf16": [_P, _P, _L, _I, _I, _I, _P, _P],
+    "vidseg_linear_a16_ttap": [_P, _L, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "vidseg_conv_temporal3_a16": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
+    "vidseg_temporal_attention_a16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vidseg_alpha_blend_a16": [_P, _P, _P, _L, _P, _P],
+    "vidseg_add_rowvec_a16": [_P, _P, _L, _I, _I, _I, _P, _P],
     "vidseg_gemm_profile_begin": [],
     "vidseg_gemm_profile_end": [_P],
     "vidseg_gemm_profile_kinds": [_P],
+    "vidseg_gemm_profile_bytes": [_P],
 })
 
 
@@ -124,7 +125,7 @@ def linear(a, w, bias=None, *, a1=None, rowvec=None, rows_per_sample=0, residual
     N = w.shape[0]
     n_out = N // 2 if act == ACT_GEGLU else N
     out = torch.empty(a.shape[:-1] + (n_out,), dtype=F32 if out_f32 else act_dtype(), device=a.device)
-    call("vidseg_linear_bf16", ptr(a), ptr(a1), C0, C1, M, ptr(w), N, ptr(bias), ptr(rowvec),
+    call("vidseg_linear_a16", ptr(a), ptr(a1), C0, C1, M, ptr(w), N, ptr(bias), ptr(rowvec),
          rowvec.stride(0) if rowvec is not None else 0, rows_per_sample, ptr(residual),
          residual.shape[-1] if residual is not None else 0,
          None if out_f32 else ptr(out), ptr(out) if out_f32 else None, n_out,
@@ -144,7 +145,7 @@ def conv3x3(x0, w, bias, *, x1=None, stride=1, up=1, rowvec=None, residual=None,
     Wo = (W * up + 2 - 3) // stride + 1
     out = torch.empty((B, Ho, Wo, Cout), dtype=act_dtype(), device=x0.device)
     out32 = torch.empty((B, Ho, Wo, Cout), dtype=F32, device=x0.device) if want_f32 else None
-    call("vidseg_conv3x3_bf16", ptr(x0), ptr(x1), C0, C1, B, H, W, stride, up, ptr(w), Cout, ptr(bias), ptr(rowvec),
+    call("vidseg_conv3x3_a16", ptr(x0), ptr(x1), C0, C1, B, H, W, stride, up, ptr(w), Cout, ptr(bias), ptr(rowvec),
          rowvec.stride(0) if rowvec is not None else 0, ptr(residual), ptr(out), pad, ptr(out32), stream())
     return (out, out32) if want_f32 else out
 
@@ -153,7 +154,7 @@ def softmax_rows(x_f32, scale):
     """softmax(scale * x) over the last dim of an fp32 matrix -> bf16 (first-stage mid attention)."""
     cols = x_f32.shape[-1]
     out = torch.empty(x_f32.shape, dtype=act_dtype(), device=x_f32.device)
-    call("vidseg_softmax_rows_bf16", ptr(x_f32), x_f32.numel() // cols, cols, float(scale), ptr(out), stream())
+    call("vidseg_softmax_rows_a16", ptr(x_f32), x_f32.numel() // cols, cols, float(scale), ptr(out), stream())
     return out
 
 
@@ -248,7 +249,7 @@ def groupnorm(x0, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True):
     if B * 2 * (C0 + C1) > ws.stats.numel():
         ws.stats = torch.empty(B * 2 * (C0 + C1), dtype=F32, device=x0.device)
     out = torch.empty(x0.shape[:-1] + (C0 + C1,), dtype=act_dtype(), device=x0.device)
-    call("vidseg_groupnorm_nhwc_bf16", ptr(x0), ptr(x1), C0, C1, B, HW, groups, ptr(gamma), ptr(beta), eps, int(silu),
+    call("vidseg_groupnorm_nhwc_a16", ptr(x0), ptr(x1), C0, C1, B, HW, groups, ptr(gamma), ptr(beta), eps, int(silu),
          ptr(ws.part), ws.part.numel(), ptr(ws.stats), ws.stats.numel(), ptr(out), stream())
     return out
 
@@ -256,7 +257,7 @@ def groupnorm(x0, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True):
 def layernorm(x, gamma, beta, eps=1e-5):
     C = x.shape[-1]
     out = torch.empty_like(x)
-    call("vidseg_layernorm_bf16", ptr(x), x.numel() // C, C, ptr(gamma), ptr(beta), eps, ptr(out), stream())
+    call("vidseg_layernorm_a16", ptr(x), x.numel() // C, C, ptr(gamma), ptr(beta), eps, ptr(out), stream())
     return out
 
 
@@ -301,7 +302,7 @@ def attention(q, k, v, heads, *, q_ld=None, k_ld=None, v_ld=None, Nq=None, Nk=No
         call("vidseg_attention_fp8", pq, q_ld or q.stride(1), pk, k_ld or k.stride(1), pv, v_ld or v.stride(1), ptr(out), heads * 64,
              B, heads, Nq, Nk, 64, stream())
         return out
-    call("vidseg_attention_bf16", q.data_ptr(), q_ld or q.stride(1), k.data_ptr(), k_ld or k.stride(1), v.data_ptr(),
+    call("vidseg_attention_a16", q.data_ptr(), q_ld or q.stride(1), k.data_ptr(), k_ld or k.stride(1), v.data_ptr(),
          v_ld or v.stride(1), ptr(out), heads * 64, B, heads, Nq, Nk, 64, stream())
     return out
 
@@ -314,20 +315,20 @@ def timestep_embedding(t, dim, max_period=10000.0):
 
 def silu(x):
     out = torch.empty_like(x)
-    call("vidseg_silu_bf16", ptr(x), x.numel(), ptr(out), stream())
+    call("vidseg_silu_a16", ptr(x), x.numel(), ptr(out), stream())
     return out
 
 
 def f16_to_bf16(x):
     out = torch.empty(x.shape, dtype=act_dtype(), device=x.device)
     xc = x.contiguous()
-    call("vidseg_f16_to_bf16", ptr(xc), xc.numel(), ptr(out), stream())
+    call("vidseg_f16_to_a16", ptr(xc), xc.numel(), ptr(out), stream())
     return out
 
 
 def to_bf16(x):
     out = torch.empty(x.shape, dtype=act_dtype(), device=x.device)
-    call("vidseg_f32_to_bf16", ptr(x), x.numel(), ptr(out), stream())
+    call("vidseg_f32_to_a16", ptr(x), x.numel(), ptr(out), stream())
     return out
 
 
@@ -415,10 +416,12 @@ GEMM_KIND_NAMES = ("k_gemm_dma (128x128, LDS-DMA)", "k_gemm_ph<NJ> (256x320 / 25
 
 
 def gemm_profile_kinds():
-    """Per-kernel split of the region closed by gemm_profile_end: list of (name, ms, flops, launches)."""
+    """Per-kernel split of the region closed by gemm_profile_end: list of (name, ms, flops, launches, algorithmic_bytes)."""
     out = (ctypes.c_double * 12)()
     call("vidseg_gemm_profile_kinds", out)
-    return [(GEMM_KIND_NAMES[k], float(out[3 * k]), float(out[3 * k + 1]), int(out[3 * k + 2])) for k in range(4)]
+    ab = (ctypes.c_double * 4)()
+    call("vidseg_gemm_profile_bytes", ab)
+    return [(GEMM_KIND_NAMES[k], float(out[3 * k]), float(out[3 * k + 1]), int(out[3 * k + 2]), float(ab[k])) for k in range(4)]
 
 
 # ----------------------------------------------------------------------------- video (SVD) operators
@@ -436,7 +439,7 @@ def conv_temporal3(x, w, bias, T, *, rowvec=None, residual=None):
     BT, H, W, C = x.shape
     Cout = w.shape[0]
     out = torch.empty((BT, H, W, Cout), dtype=act_dtype(), device=x.device)
-    call("vidseg_conv_temporal3_bf16", ptr(x), C, BT, H * W, T, ptr(w), Cout, ptr(bias), ptr(rowvec),
+    call("vidseg_conv_temporal3_a16", ptr(x), C, BT, H * W, T, ptr(w), Cout, ptr(bias), ptr(rowvec),
          rowvec.stride(0) if rowvec is not None else 0, ptr(residual), ptr(out), stream())
     return out
 
@@ -448,7 +451,7 @@ def linear_temporal_tap(a, w, T, S, tap, tap2, tap_cols):
     M = a.numel() // C0
     N = w.shape[0]
     out = torch.empty(a.shape[:-1] + (N,), dtype=act_dtype(), device=a.device)
-    call("vidseg_linear_bf16_ttap", ptr(a), M, C0, ptr(w), N, ptr(out), N, ptr(tap), ptr(tap2), tap_cols,
+    call("vidseg_linear_a16_ttap", ptr(a), M, C0, ptr(w), N, ptr(out), N, ptr(tap), ptr(tap2), tap_cols,
          tap.shape[-1] if tap is not None else 0, T if tap is not None else 0, S, stream())
     return out
 
@@ -456,7 +459,7 @@ def linear_temporal_tap(a, w, T, S, tap, tap2, tap_cols):
 def temporal_attention(q, k, v, heads, Bv, T, S):
     """Attention across the T frames of every (sample, location); q/k/v rows in spatial order (b t) s."""
     out = torch.empty((Bv * T, S, heads * 64), dtype=act_dtype(), device=q.device)
-    call("vidseg_temporal_attention_bf16", q.data_ptr(), q.stride(-2), k.data_ptr(), k.stride(-2), v.data_ptr(), v.stride(-2),
+    call("vidseg_temporal_attention_a16", q.data_ptr(), q.stride(-2), k.data_ptr(), k.stride(-2), v.data_ptr(), v.stride(-2),
          ptr(out), heads * 64, Bv, T, S, heads, 64, stream())
     return out
 
@@ -464,7 +467,7 @@ def temporal_attention(q, k, v, heads, Bv, T, S):
 def alpha_blend(x_spatial, x_temporal, mix_factor):
     """sigmoid(mix) * spatial + (1 - sigmoid(mix)) * temporal (AlphaBlender, image_only_indicator == 0)."""
     out = torch.empty_like(x_spatial)
-    call("vidseg_alpha_blend_bf16", ptr(x_spatial), ptr(x_temporal), ptr(mix_factor), x_spatial.numel(), ptr(out), stream())
+    call("vidseg_alpha_blend_a16", ptr(x_spatial), ptr(x_temporal), ptr(mix_factor), x_spatial.numel(), ptr(out), stream())
     return out
 
 
@@ -480,5 +483,5 @@ def add_rowvec(x, vec, rows_per_sample):
     """x[(sample, row), :] + vec[sample % len(vec), :]  (bf16)."""
     C = x.shape[-1]
     out = torch.empty_like(x)
-    call("vidseg_add_rowvec_bf16", ptr(x), ptr(vec), x.numel() // C, C, rows_per_sample, vec.shape[0], ptr(out), stream())
+    call("vidseg_add_rowvec_a16", ptr(x), ptr(vec), x.numel() // C, C, rows_per_sample, vec.shape[0], ptr(out), stream())
     return out

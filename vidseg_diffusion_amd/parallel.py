@@ -143,29 +143,41 @@ def sharded_resolve(engine, h, *, num_masks=20, is_aggre_attn=True, is_refine_ma
 
 class ShardedPipeline:
     """The multi-rank counterpart of pipeline.WindowPipeline: step i's cross-window stage (collectives included) runs on a second
-    HIP stream while step i+1's feature pass is already queued on the caller's stream.  Every rank pushes/flushes in the same
-    order, so the collectives of all ranks stay matched."""
+    HIP stream while the feature passes of the next `lanes` steps are already queued (each lane on its own stream).  Every rank
+    pushes/flushes in the same order, so the collectives of all ranks stay matched."""
 
-    def __init__(self, engine, rank, world, **resolve_kw):
+    def __init__(self, engine, rank, world, lanes=1, **resolve_kw):
         self.engine, self.rank, self.world, self.resolve_kw = engine, rank, world, resolve_kw
         self.side = torch.cuda.Stream()
-        self.pending = None
+        self.lanes = [torch.cuda.Stream() for _ in range(lanes)] if lanes > 1 else [None]
+        self.pending = []
+        self.count = 0
 
     def _resolve(self, h):
         with torch.cuda.stream(self.side):
             return sharded_resolve(self.engine, h, rank=self.rank, world=self.world, **self.resolve_kw)
 
     def push(self, latent, c, uc, **feature_kw):
-        h = sharded_feature_pass(self.engine, latent, c, uc, rank=self.rank, **feature_kw)
-        out = self._resolve(self.pending) if self.pending is not None else None
-        self.pending = h
+        lane = self.lanes[self.count % len(self.lanes)]
+        self.count += 1
+        if lane is None:
+            h = sharded_feature_pass(self.engine, latent, c, uc, rank=self.rank, **feature_kw)
+        else:
+            lane.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(lane):
+                h = sharded_feature_pass(self.engine, latent, c, uc, rank=self.rank, **feature_kw)
+        self.pending.append(h)
+        return self._resolve(self.pending.pop(0)) if len(self.pending) > len(self.lanes) else None
+
+    def drain(self):
+        out = [self._resolve(h) for h in self.pending]
+        self.pending = []
+        self.side.synchronize()
         return out
 
     def flush(self):
-        out = self._resolve(self.pending) if self.pending is not None else None
-        self.pending = None
-        self.side.synchronize()
-        return out
+        out = self.drain()
+        return out[-1] if out else None
 
 
 def segment_windows_sharded(engine, latent, c, uc, *, noise=None, num_masks=20, num_steps=25, t_start=22, is_aggre_attn=True,
