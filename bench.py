@@ -23,6 +23,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
   cpu_baseline  the oracle ("port") timed on this box's host cores on a bounded sample (see `sample`), CPU model stated.
   mask_iou_vs_reference  the metric's second half on THIS config: masks of the timed run vs the reference's fp32 masks.
   chained_window  throughput when the windows are chained like one long clip (windows > 0: 14336^2 4-NN instead of K-means).
+  two_lanes     throughput with two feature passes in flight (--lanes 2); the headline keeps one so that per-launch times are clean.
   secondary     BASELINE configs[2] (SVD 14x576x1024, t_start 17, refinement) measured after the headline, fewer steps.
 """
 import argparse
@@ -212,13 +213,13 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False):
 
     def name():
         step_no[0] += 1
-        return f"r{rank}s{step_no[0] % (lanes + 3)}"
+        return f"r{rank}s{step_no[0] % 6}"
 
     if world == 1 and overlap:
         # windows run through pipeline.WindowPipeline: the analysis of step i (second HIP stream) overlaps the feature passes of the
         # next `lanes` steps; every step is still a complete window (K-means included) and all of them finish inside the timed region
-        def run_steps(n, chain=False):
-            pipe = WindowPipeline(eng, chain=chain, lanes=lanes, num_masks=k_masks, is_aggre_attn=True, is_refine_mask=refine)
+        def run_steps(n, chain=False, nl=None):
+            pipe = WindowPipeline(eng, chain=chain, lanes=nl or lanes, num_masks=k_masks, is_aggre_attn=True, is_refine_mask=refine)
             last = None
             for _ in range(n):
                 FE.MaskStore.clear()
@@ -227,8 +228,8 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False):
             rest = pipe.drain()
             return rest[-1] if rest else last
     elif world > 1 and overlap:
-        def run_steps(n, chain=False):
-            spipe = parallel.ShardedPipeline(eng, rank, world, lanes=lanes, num_masks=k_masks, is_aggre_attn=True, is_refine_mask=refine)
+        def run_steps(n, chain=False, nl=None):
+            spipe = parallel.ShardedPipeline(eng, rank, world, lanes=nl or lanes, num_masks=k_masks, is_aggre_attn=True, is_refine_mask=refine)
             last = None
             for _ in range(n):
                 FE.MaskStore.clear()
@@ -237,7 +238,7 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False):
             rest = spipe.drain()
             return rest[-1] if rest else last
     else:
-        def run_steps(n, chain=False):
+        def run_steps(n, chain=False, nl=None):
             last = None
             for _ in range(n):
                 FE.FeatureStore.clear()
@@ -334,8 +335,10 @@ def main():
     ap.add_argument("--narrow", action="store_true", help="debug: narrow-width UNet (NOT the benchmark config)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run each window's analysis after its own feature pass instead of concurrently with the next ones'")
-    ap.add_argument("--lanes", type=int, default=2,
-                    help="feature passes in flight at once, each on its own HIP stream (pipeline.WindowPipeline / parallel.ShardedPipeline)")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="feature passes in flight at once, each on its own HIP stream (pipeline.WindowPipeline / parallel.ShardedPipeline). "
+                         "Default 1: every launch then has the chip to itself and its HIP-event time is its own (the roofline object); 2 is "
+                         "~4 %% faster end to end and is reported as `two_lanes`")
     ap.add_argument("--vae", action="store_true", help="also time the first-stage encode of one window (reported beside the metric)")
     ap.add_argument("--config", default="sd", choices=["sd", "svd"],
                     help="sd = BASELINE configs[1] (headline); svd = configs[2]: SVD 14x576x1024, t_start 17, is_refine_mask")
@@ -407,6 +410,19 @@ def main():
                                      "note": "the same windows chained as one clip (sd_pipeline_vspw.py:381-401): window 0 of the chain runs "
                                              "K-means, every later one the 14336 x 14336 x 640 float64 4-NN against its predecessor "
                                              "(feature_extraction.py:603-613)"}
+        if plain and not args.no_overlap and args.lanes == 1:        # two feature passes in flight (outside the headline timing)
+            n = max(4, min(args.steps, 10))
+            run_steps(3, nl=2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(n, nl=2)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out["two_lanes"] = {"value": round(F_WIN * n / dt, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n, 3), "steps": n,
+                                "note": "pipeline.WindowPipeline(lanes=2): the feature passes of two consecutive windows in flight on their own "
+                                        "HIP streams (same launches, same masks: tests/test_gpu_unet.py::test_overlapped_clip_equals_sequential); "
+                                        "a second window's kernels take the CUs a launch leaves idle (28 = 4*7 samples fill 7/8 of a round of "
+                                        "256 CUs with power-of-two tiles)"}
         if args.vae:                                                 # outside the timed region, never part of `value`
             out["first_stage"] = first_stage_timing(dev, svd)
         if plain and not svd:
