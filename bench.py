@@ -257,7 +257,8 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False):
     if warmup:
         run_steps(warmup)
     barrier()
-    ops.gemm_profile_begin()
+    if os.environ.get("VIDSEG_BENCH_NOPROF") != "1":                      # A/B knob: what the per-launch HIP events cost the timed region
+        ops.gemm_profile_begin()
     t0 = time.perf_counter()
     labels = run_steps(steps)
     barrier()
@@ -428,7 +429,7 @@ def main():
         if plain and not svd:
             tr = pmc_traffic(["--refine"] if args.refine else []) if os.environ.get("VIDSEG_BENCH_PMC", "1") != "0" else None
             dom = out["roofline"]["kernel"]
-            key = "k_gemm_ph<5>" if dom.startswith("k_gemm_ph") else "k_gemm_dma<2>"
+            key = "k_gemm_p7" if dom.startswith("k_gemm_p7") else ("k_gemm_ph<5>" if dom.startswith("k_gemm_ph") else "k_gemm_dma<2>")
             if tr and key in tr:
                 out["roofline"]["traffic"] = int(tr[key][1])
                 out["roofline"]["traffic_how"] = (f"this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over one window of "

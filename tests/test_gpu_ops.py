@@ -65,6 +65,9 @@ _EPI_CASES = [  # (M, K, N, rows_per_sample, env): every GEMM kernel of the fami
     (1031, 1280, 320, 1031, {"VIDSEG_GEMM_BIG": "2"}),            # phased 256x320 tile forced (one ragged round)
     (520, 2560, 512, 130, {"VIDSEG_GEMM_BIG": "2"}),              # phased 256x256 tile with split-K partials + finish kernel
     (700, 640, 640, 100, {"VIDSEG_GEMM_MID": "2", "VIDSEG_GEMM_BIG": "0"}),   # 128x320 tile
+    (1031, 1280, 320, 1031, {"VIDSEG_GEMM_BIG": "2", "VIDSEG_GEMM_P7": "2"}),  # 224x320 tile (16x16x32 fragments), ragged last tile row
+    (1500, 2560, 640, 130, {"VIDSEG_GEMM_BIG": "2", "VIDSEG_GEMM_P7": "2"}),   # 224x320 tile with split-K partials + finish kernel
+    (224 * 9, 320, 960, 224, {"VIDSEG_GEMM_BIG": "2", "VIDSEG_GEMM_P7": "2"}),  # 224x320 tile, short K (5 K-tiles), three tile columns
     (515, 192, 56, 103, {}),                                      # narrow-N register-staged kernel
 ]
 
@@ -115,10 +118,12 @@ print("ok")
 
 
 @pytest.mark.parametrize("env", [{"VIDSEG_GEMM_BIG": "2"}, {"VIDSEG_GEMM_BIG": "2", "VIDSEG_GEMM_PH": "0"},
+                                 {"VIDSEG_GEMM_BIG": "2", "VIDSEG_GEMM_P7": "2"},
                                  {"VIDSEG_GEMM_MID": "2", "VIDSEG_GEMM_BIG": "0"}, {"VIDSEG_GEMM_DMA": "3", "VIDSEG_GEMM_BIG": "0", "VIDSEG_GEMM_MID": "0"}])
 def test_conv3x3_on_every_tile(env):
     """3x3 convolutions (concat input, stride 2, fused 2x upsample, ragged edges, chunk-major K order with a source switch inside the
-    K loop) forced onto each LDS-DMA kernel: phased big tile, unphased big tile, 128x320 tile, 3-stage 128x128 -- vs torch conv2d."""
+    K loop) forced onto each LDS-DMA kernel: phased big tile, unphased big tile, 224x320 tile (k_gemm_p7, for Cout = 320 / 640),
+    128x320 tile, 3-stage 128x128 -- vs torch conv2d."""
     import subprocess
     import sys
     code = f"""

@@ -59,6 +59,9 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {   // one v_
 __device__ __forceinline__ f32x16 mfma_32x32x16(vs_s16x8 a, vs_s16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mfma_16x16x32(vs_s16x8 a, vs_s16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 #else
 #define VIDSEG_ACT_IS_F16 1
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
@@ -71,6 +74,9 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {   // RNE pa
 }
 __device__ __forceinline__ f32x16 mfma_32x32x16(vs_s16x8 a, vs_s16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_16x16x32(vs_s16x8 a, vs_s16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 #endif
 

@@ -137,19 +137,20 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 // split-K partials) is 16 bytes per lane.  Only wave-level ordering is needed inside (LDS executes a wave's
 // instructions in order); the one block barrier separates the main loop's LDS reads from the staging writes.
 // ---------------------------------------------------------------------------------------------
-// phase 2 of the epilogue for one staged 32 x NCOLS tile: LPR = NCOLS / 8 lanes per row, 8 consecutive columns per lane.
+// phase 2 of the epilogue for one staged [nrows <= 32][NC8 * 8] fp32 tile (row stride EP_LD floats): every lane takes 8
+// consecutive columns of one row per pass, 64 cells per pass in row-major cell order (NC8 = 4 / 8: 16 / 8 rows per pass, the
+// original layout; NC8 = 10: the 80-column wave tile of k_gemm_p7).
 // `pre` = the staged values still need bias / per-sample vector / SiLU (everything but GEGLU, which is lane-local in phase 1).
-template <int LPR>
-__device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* stage, int mrow0, int ocol0, int nout, int lane, int split,
-                                              bool fin, bool pre) {
-    constexpr int EP_LD = 68, RPP = 64 / LPR;
-    const int lrow = lane / LPR, c8 = (lane % LPR) * 8;
-    const int n = ocol0 + c8;                                   // output column of element 0
-    if (n >= nout) return;
+template <int NC8, int EP_LD>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* stage, int mrow0, int nrows, int ocol0, int nout, int lane,
+                                              int split, bool fin, bool pre) {
     const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
+    const int ncell = nrows * NC8;
 #pragma nounroll
-    for (int r0 = 0; r0 < 32; r0 += RPP) {
-        const int row = r0 + lrow;
+    for (int cell = lane; cell < ncell; cell += 64) {
+        const int row = cell / NC8, c8 = (cell - row * NC8) * 8;
+        const int n = ocol0 + c8;                               // output column of element 0
+        if (n >= nout) continue;
         const int m = mrow0 + row;                              // rows fit 31 bits (M * ldo may not: 64-bit only in the pointer math)
         if (m >= (int)p.M) continue;
         float v[8];
@@ -284,9 +285,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         __builtin_amdgcn_wave_barrier();
         // ---- phase 2: 8 columns per lane, coalesced 16-byte global accesses
         if (geglu || !two)
-            epilogue_rows<4>(p, stage, mrow0, geglu ? wcol0 / 2 : wcol0, nout, lane, split, fin, !geglu);
+            epilogue_rows<4, EP_LD>(p, stage, mrow0, 32, geglu ? wcol0 / 2 : wcol0, nout, lane, split, fin, !geglu);
         else
-            epilogue_rows<8>(p, stage, mrow0, wcol0, nout, lane, split, fin, true);
+            epilogue_rows<8, EP_LD>(p, stage, mrow0, 32, wcol0, nout, lane, split, fin, true);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
@@ -1080,6 +1081,223 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_gemm_p7: the phased big tile for M = 7 * 2^k * 32.  A CFG window has 2 * 14 = 28 = 4 * 7 samples, so every GEMM of the
+// UNet has M = 7 * 2^k rows and any power-of-two tile height leaves the grid at 7/8 of a round of 256 CUs (448 tiles of
+// 256 rows at the 64x64 level, 224 at 32x32, 112 / 28 before split-K below).  This tile is 224 x 320: 512 / 256 / 128 / 32
+// tiles on the same layers -- whole rounds.  224 = 7 * 32 cannot be split over 8 waves in 32-row fragments, so the
+// fragments are v_mfma_f32_16x16x32: wave grid 2 (M) x 4 (N), wave tile 112 x 80 = 7 x 5 fragments (35 accumulators of 4
+// registers; 7 A + 5 B fragment reads per 35 MFMAs of 16 cycles -- the same LDS bytes per flop as the 64 x 160 wave tile).
+// Staging, LDS image, swizzle, group schedule and the counted waits are those of k_gemm_ph<5>, bit for bit: the A region
+// keeps 256 rows and the rows 224..255 of a tile are staged with out-of-range offsets (zeros, no memory traffic), so every
+// wave still issues 9 DMA instructions per K-tile.  A B block g is now the four 16-row strips {wn * 80 + g * 16 ..} that
+// phase g reads.  Phase j = B fragment column j over the whole BK = 64: 14 MFMAs (7 A fragments x 2 k-steps, 224 cycles).
+// ---------------------------------------------------------------------------------------------
+template <int MI, int NJ>
+__device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc)[MI][NJ], char* smem, int mrow_base, int wcol_base, int lane,
+                                                int wave, int split) {
+    constexpr int EP_LD = NJ * 16 + 4;                         // fp32 row stride of the staging tile
+    constexpr int NG = (MI + 1) / 2;                           // 32-row groups (two 16-row fragments each)
+    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
+    const int l15 = lane & 15, q = lane >> 4;
+    const bool fin = p.ksplit <= 1;                            // split-K partials carry no bias/emb/activation
+    __syncthreads();                                           // main-loop LDS reads are done
+#pragma nounroll
+    for (int ig = 0; ig < NG; ++ig) {
+        const int nrows = (2 * ig + 1 < MI) ? 32 : 16;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            if (ig != k) continue;                             // uniform: accumulator indices stay compile-time
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                if (2 * k + ii >= MI) continue;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        stage[(ii * 16 + q * 4 + r) * EP_LD + j * 16 + l15] = acc[(2 * k + ii) < MI ? (2 * k + ii) : 0][j][r];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        epilogue_rows<NJ * 2, EP_LD>(p, stage, mrow_base + ig * 32, nrows, wcol_base, p.N, lane, split, fin, true);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void __launch_bounds__(512, 2) k_gemm_p7(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NJ = 5, MI = 7;
+    constexpr int BM = 224, BN = 320, RB = 128;
+    constexpr int A_BYTES = 256 * RB, B_BYTES = BN * RB;                 // LDS map: A[0] A[1] B[0] B[1]; A keeps 256 rows (see above)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
+    int split, tn;
+    long long tm;
+    map_tile(p, BM, BN, split, tm, tn);
+    const long long m0 = tm * BM;
+    const int n0 = tn * BN;
+
+    constexpr unsigned OOB = 0xF0000000u;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w), 0, (int)((long long)p.N * p.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x0), 0, (int)p.x0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x1 ? p.x1 : p.x0), 0, (int)p.x1_bytes, 0x00020000);
+
+    const int HWo = p.Hout * p.Wout;
+    const int upsh = p.up - 1;
+    const int Hup = p.Hin << upsh, Wup = p.Win << upsh;
+    const int lrow = lane >> 3, lch = lane & 7;
+    const unsigned swz16 = (unsigned)((lch ^ (((wave & 1) << 2) | (lrow >> 1))) << 4);
+    const int hb = p.ksize == 1 ? 1 : (p.tmode ? p.T : Hup), wb = (p.ksize == 1 || p.tmode) ? 1 : Wup;
+    const int wmul = p.tmode ? HWo : p.Win;
+    int a_base[4], a_hw[4];                                            // a_hw = (ih0 + 0x4000) << 16 | (iw0 + 0x4000)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int r = (s4 >> 1) * 128 + (wave + 8 * (s4 & 1)) * 8 + lrow;
+        const long long m = m0 + r;
+        const bool ok = r < BM && m < p.M;                             // rows 224..255 of the LDS image belong to no tile
+        const int mm = ok ? (int)m : 0;
+        int ih0 = 0, iw0 = 0;
+        if (p.ksize == 1) {
+            a_base[s4] = mm;
+        } else if (p.tmode) {
+            const int t = (mm / HWo) % p.T;
+            a_base[s4] = mm - t * HWo;
+            ih0 = t - 1;
+        } else {
+            const int b = mm / HWo, rem = mm - b * HWo;
+            const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
+            a_base[s4] = b * p.Hin * p.Win;
+            ih0 = oh * p.stride - p.pad;
+            iw0 = ow * p.stride - p.pad;
+        }
+        if (!ok) ih0 = -0x4000;
+        a_hw[s4] = ((ih0 + 0x4000) << 16) | (iw0 + 0x4000);
+    }
+    // B block g = the 16-row strips wn * 80 + g * 16 .. of the four wave columns; piece `wave` = strip wave >> 1, rows (wave & 1) * 8 ..
+    const int b_r0 = (wave >> 1) * 80 + (wave & 1) * 8;
+    const int b_n = n0 + b_r0 + lrow;                                        // + g*16: the weight row this lane stages for block g
+    const unsigned b_off0 = (unsigned)((long long)b_n * p.K * 2) + swz16;
+    const unsigned b_gstep = (unsigned)p.K * 32u;                            // 16 weight rows
+    const int nk_all = p.K / 64;
+    const int ks_begin = p.ksplit > 1 ? (int)((long long)nk_all * split / p.ksplit) : 0;
+    const int ks_end = p.ksplit > 1 ? (int)((long long)nk_all * (split + 1) / p.ksplit) : nk_all;
+    const int nk = ks_end - ks_begin;
+    KCursor cur;
+    cur.init(ks_begin * 64, p.taps, p.kchunk);
+    int t_kh = 0, t_kw = 0, t_Cs = 0, t_cc = 0;
+    bool a_second = false;
+    auto stage = [&](int g, int u, int buf) {
+        const bool live = u < nk;
+        if (g == 0) {
+            const int c0 = cur.c0();
+            a_second = c0 >= p.C0;
+            t_Cs = a_second ? p.C1 : p.C0;
+            t_cc = a_second ? c0 - p.C0 : c0;
+            const int t3 = cur.tap / 3;
+            t_kh = p.tmode ? cur.tap : t3;
+            t_kw = p.tmode ? 0 : cur.tap - t3 * 3;
+            cur.advance(64, p.taps, p.kchunk);
+        }
+        if (g < 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int s4 = g * 2 + i;
+                char* dst = smem + buf * A_BYTES + (g * 128 + (wave + 8 * i) * 8) * RB;
+                const int ih = (a_hw[s4] >> 16) - 0x4000 + t_kh, iw = (a_hw[s4] & 0xFFFF) - 0x4000 + t_kw;
+                const bool ok = live && (unsigned)ih < (unsigned)hb && (unsigned)iw < (unsigned)wb;
+                const int pix = a_base[s4] + (ih >> upsh) * wmul + (iw >> upsh);
+                const unsigned off = ok ? (unsigned)(pix * t_Cs + t_cc) * 2u + swz16 : OOB;
+                if (a_second)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+            }
+        }
+        char* dst = smem + 2 * A_BYTES + buf * B_BYTES + (b_r0 + g * 16) * RB;
+        const unsigned off = (live && b_n + g * 16 < p.N) ? b_off0 + (unsigned)g * b_gstep + (unsigned)(ks_begin + u) * 128u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+    };
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int sw = (l15 >> 1) & 7;                                    // every fragment row is l15 + a multiple of 16
+    const int arow = (wm * 112 + l15) * RB, brow = 2 * A_BYTES + (wn * 80 + l15) * RB;
+
+    // prologue: everything the steady state would have issued before phase (0, 0)
+#pragma unroll
+    for (int g = 0; g < NJ; ++g) stage(g, 0, 0);
+#pragma unroll
+    for (int g = 0; g + 2 < NJ; ++g) stage(g, 1, 1);
+    constexpr int CNT_ALL = 2 * (NJ + 4);
+    constexpr auto cnt = [](int pos) { return (pos == 2 || pos == 3) ? 3 : 1; };
+    wait_vmcnt<CNT_ALL - 8>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+
+    bf16x8_t fa[MI][2];
+    auto tile = [&](int t, int buf) {
+        const char* A = smem + buf * A_BYTES + arow;
+        const char* B = smem + buf * B_BYTES + brow;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            // ---- read section
+            bf16x8_t fb[2];
+            if (j == 0) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) fa[i][kk] = *reinterpret_cast<const bf16x8_t*>(A + i * 16 * RB + (((kk * 4 + l4) ^ sw) << 4));
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fb[kk] = *reinterpret_cast<const bf16x8_t*>(B + j * 16 * RB + (((kk * 4 + l4) ^ sw) << 4));
+            if (j >= 2)
+                stage(j - 2, t + 2, buf);
+            else
+                stage(j - 2 + NJ, t + 1, buf ^ 1);
+            // counted wait for what phase j+1 reads
+            const int jn = (j + 1) % NJ;
+            if (jn == 0)
+                wait_vmcnt<CNT_ALL - 8>();
+            else if (cnt(jn) + cnt((jn + 1) % NJ) + cnt((jn + 2) % NJ) == 7)
+                wait_vmcnt<CNT_ALL - 7>();
+            else if (cnt(jn) + cnt((jn + 1) % NJ) + cnt((jn + 2) % NJ) == 5)
+                wait_vmcnt<CNT_ALL - 5>();
+            else
+                wait_vmcnt<CNT_ALL - 3>();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- matrix section
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = mfma_16x16x32(fa[i][kk], fb[kk], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int t = 0; t < nk; t += 2) {
+        tile(t, 0);
+        if (t + 1 < nk) tile(t + 1, 1);
+    }
+    wait_vmcnt<0>();
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    gemm_epilogue16<MI, NJ>(p, acc, smem, (int)m0 + wm * 112, n0 + wn * 80, lane, wave, split);
+}
+
 // Split-K finish: sum the fp32 partials in split order (deterministic), then the same epilogue as above.
 __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
     const long long i8 = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1255,13 +1473,16 @@ struct GemmProf {
     std::vector<Shape> shapes;      // one per event pair
 };
 static GemmProf g_prof;
-static double g_kind_stats[12];
-static double g_kind_bytes[4];
+static double g_kind_stats[15];
+static double g_kind_bytes[5];
 
 static inline hipEvent_t prof_event() {
     if (g_prof.used == g_prof.ev.size()) {
         hipEvent_t e;
-        (void)hipEventCreate(&e);
+        // no system-scope release at the record: the default flag flushes the L2 to make the kernels' results host-visible at
+        // every event (measured: the 1200 records of a window cost 4-5 % of the step); timing needs no such fence
+        static const unsigned flags = getenv("VIDSEG_PROF_SYSFENCE") ? hipEventDefault : hipEventDisableSystemFence;
+        (void)hipEventCreateWithFlags(&e, flags);
         g_prof.ev.push_back(e);
     }
     return g_prof.ev[g_prof.used++];
@@ -1282,8 +1503,8 @@ int vidseg_gemm_profile_begin(void) {
 int vidseg_gemm_profile_end(double* out) {
     g_prof.on = false;
     double ms = 0.0;
-    for (int i = 0; i < 12; ++i) g_kind_stats[i] = 0.0;
-    for (int i = 0; i < 4; ++i) g_kind_bytes[i] = 0.0;
+    for (int i = 0; i < 15; ++i) g_kind_stats[i] = 0.0;
+    for (int i = 0; i < 5; ++i) g_kind_bytes[i] = 0.0;
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
         float t = 0.f;
         hipError_t e = hipEventSynchronize(g_prof.ev[i + 1]);
@@ -1292,7 +1513,7 @@ int vidseg_gemm_profile_end(double* out) {
         ms += t;
         if (i / 2 < g_prof.shapes.size()) {
             const GemmProf::Shape& h = g_prof.shapes[i / 2];
-            const int kd = h.kind >= 0 && h.kind < 4 ? h.kind : 0;
+            const int kd = h.kind >= 0 && h.kind < 5 ? h.kind : 0;
             g_kind_stats[kd * 3] += t;
             g_kind_stats[kd * 3 + 1] += 2.0 * (double)h.M * (double)h.N * (double)h.K;
             g_kind_stats[kd * 3 + 2] += 1.0;
@@ -1311,9 +1532,10 @@ int vidseg_gemm_profile_end(double* out) {
 }
 
 // Per-kernel split of the last profiled region: out[k*3 + {0,1,2}] = {milliseconds, algorithmic FLOPs, launches} for
-// k = 0: k_gemm_dma (128x128), 1: k_gemm_tile big (256x320 / 256x256), 2: k_gemm_tile mid (128x320), 3: k_gemm_conv<256,64>.
+// k = 0: k_gemm_dma (128x128), 1: k_gemm_ph big (256x320 / 256x256), 2: k_gemm_tile mid (128x320), 3: k_gemm_conv<256,64>,
+// 4: k_gemm_p7 (224x320).
 int vidseg_gemm_profile_kinds(double* out) {
-    for (int i = 0; i < 12; ++i) out[i] = g_kind_stats[i];
+    for (int i = 0; i < 15; ++i) out[i] = g_kind_stats[i];
     return VS_OK;
 }
 
@@ -1321,7 +1543,7 @@ int vidseg_gemm_profile_kinds(double* out) {
 // reads (the whole input image for a conv: the 9 taps re-read it through L1/L2, not through memory), the weight matrix, the
 // residual, and every output it writes (16-bit result, fp32 result, fp16 taps); split-K partials are NOT algorithmic.
 int vidseg_gemm_profile_bytes(double* out) {
-    for (int i = 0; i < 4; ++i) out[i] = g_kind_bytes[i];
+    for (int i = 0; i < 5; ++i) out[i] = g_kind_bytes[i];
     return VS_OK;
 }
 
@@ -1413,7 +1635,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         k_gemm_conv<256, 64><<<dim3((unsigned)tiles), 256, 2 * (256 + 64) * BK * 2, st>>>(p);
     } else {
         const int nk = p.K / BK;
-        static int nosplit = -1, use_dma = -1, big_mode = -1, mid_mode = -1, ph_mode = 0;
+        static int nosplit = -1, use_dma = -1, big_mode = -1, mid_mode = -1, ph_mode = 0, p7_mode = 1;
         constexpr int MID_LDS = 8 * 32 * 68 * 4;               // epilogue staging of 8 waves (69.6 KiB) > 2 x (128+320) x 64 B
         if (nosplit < 0) {
             const char* e = getenv("VIDSEG_NO_SPLITK");
@@ -1434,6 +1656,9 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             ph_mode = e ? atoi(e) : 1;
             (void)hipFuncSetAttribute((const void*)k_gemm_ph<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
             (void)hipFuncSetAttribute((const void*)k_gemm_ph<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
+            e = getenv("VIDSEG_GEMM_P7");                        // 224 x 320 tile (k_gemm_p7): 0 never, 1 where it fills the chip better, 2 whenever legal
+            p7_mode = e ? atoi(e) : 1;
+            (void)hipFuncSetAttribute((const void*)k_gemm_p7, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
         }
         // Blocks run in rounds over the resident slots, so the last round's fill decides the efficiency.  Pick the K
         // split that maximises fill / (1 + cost of writing+reading the fp32 partials); deterministic finish kernel.
@@ -1461,19 +1686,36 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         // measured (tools/dbg/shape_summary.py): the 128 x 320 8-wave tile only beats 128 x 128 on the 32x32-level projections
         // (28672 x 640 x 640: 61 -> 50 us); K = 320 layers and under-filled grids lose
         const bool mid_ok = tiles_mid >= 448 && p.K >= 640 && p.N <= 640 && p.act == 0;
-        bool big = false;
+        bool big = false, p7 = false;
         int S = 1;
         if (big_mode && p.M >= 256) {
             S = pick_split(tiles_b, 256);
-            const long long items = tiles_b * S;
-            const double fill = (double)items / (double)(((items + 255) / 256) * 256);
+            long long items = tiles_b * S;
+            double fill = (double)items / (double)(((items + 255) / 256) * 256);
+            // the 224-row tile: useful work per occupied CU-round = grid fill x the rows of the last tile row that exist.  A window's
+            // M = 28 * H * W makes it 1.0 where the 256-row tile gives 0.875 (see k_gemm_p7)
+            if (p7_mode && ph_mode && NJ == 5 && p.act != 2) {
+                const long long tm7 = (p.M + 223) / 224, tiles_7 = tm7 * ((p.N + 319) / 320);
+                const int S7 = pick_split(tiles_7, 256);
+                const long long items7 = tiles_7 * S7;
+                const double fill7 = (double)items7 / (double)(((items7 + 255) / 256) * 256);
+                const double eff7 = fill7 * (double)p.M / (double)(tm7 * 224);
+                const double eff8 = fill * (double)p.M / (double)(((p.M + 255) / 256) * 256);
+                if (eff7 > eff8 * 1.04 || p7_mode == 2) {
+                    p7 = true;
+                    S = S7;
+                    items = items7;
+                    fill = fill7;
+                }
+            }
+            const long long tiles_sel = items / S;               // tile count of the chosen height
             // measured per shape (tools/dbg/shape_summary.py): the big tile wins once the K loop is long enough to amortise its
             // unoverlapped prologue/epilogue (one block per CU) and the grid fills the chip
             big = big_mode == 2 || (fill >= 0.70 && p.K >= 960 && (S == 1 || p.K / S >= 1440));
             // with the rolled epilogue (10 us fixed cost per tile instead of 27) the big tile also takes the short-K layers whose
             // grid is at least a full round of 256 CUs: 114688x960x320 161 -> 151 us, 28672x1920x640 118 -> 109, 114688x320x640 96 -> 77;
             // GEGLU and small-M shapes still lose (measured per shape, tools/dbg/shape_summary.py)
-            if (!big && big_mode == 1 && p.act != 2 && S == 1 && fill >= 0.85 && tiles_b >= 200 && p.K >= 320 && (p.N >= 640 || p.K >= 640))
+            if (!big && big_mode == 1 && p.act != 2 && S == 1 && fill >= 0.85 && tiles_sel >= 200 && p.K >= 320 && (p.N >= 640 || p.K >= 640))
                 big = true;
         }
         // panel width of the tile order: the `res` tiles resident on one XCD read (res/gn) A slabs and gn W slabs per pass
@@ -1495,7 +1737,14 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             }
             return best;
         };
-        if (big) {
+        if (big && p7) {
+            p.ksplit = S;
+            p.ws = S > 1 ? g_ws : nullptr;
+            p.gn = pick_gn(224, 320, 32, S);
+            const long long tiles_7 = ((p.M + 223) / 224) * ((p.N + 319) / 320);
+            k_gemm_p7<<<dim3((unsigned)(tiles_7 * S)), 512, 2 * (256 + 320) * 128, st>>>(p);
+            kind = 4;
+        } else if (big) {
             p.ksplit = S;
             p.ws = S > 1 ? g_ws : nullptr;
             p.gn = pick_gn(256, NJ * 64, 32, S);

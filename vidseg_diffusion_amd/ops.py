@@ -412,16 +412,17 @@ def gemm_profile_end():
 
 
 GEMM_KIND_NAMES = ("k_gemm_dma (128x128, LDS-DMA)", "k_gemm_ph<NJ> (256x320 / 256x256, LDS-DMA, phased)",
-                   "k_gemm_tile<NJ,4,32,1> (128x320, LDS-DMA)", "k_gemm_conv<256,64>")
+                   "k_gemm_tile<NJ,4,32,1> (128x320, LDS-DMA)", "k_gemm_conv<256,64>", "k_gemm_p7 (224x320, LDS-DMA, phased, 16x16x32 MFMA)")
 
 
 def gemm_profile_kinds():
     """Per-kernel split of the region closed by gemm_profile_end: list of (name, ms, flops, launches, algorithmic_bytes)."""
-    out = (ctypes.c_double * 12)()
+    nk = len(GEMM_KIND_NAMES)
+    out = (ctypes.c_double * (3 * nk))()
     call("vidseg_gemm_profile_kinds", out)
-    ab = (ctypes.c_double * 4)()
+    ab = (ctypes.c_double * nk)()
     call("vidseg_gemm_profile_bytes", ab)
-    return [(GEMM_KIND_NAMES[k], float(out[3 * k]), float(out[3 * k + 1]), int(out[3 * k + 2]), float(ab[k])) for k in range(4)]
+    return [(GEMM_KIND_NAMES[k], float(out[3 * k]), float(out[3 * k + 1]), int(out[3 * k + 2]), float(ab[k])) for k in range(nk)]
 
 
 # ----------------------------------------------------------------------------- video (SVD) operators
