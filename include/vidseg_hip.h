@@ -175,6 +175,8 @@ int vidseg_time_mix3_f32(const float* x, int BT, int xC, int C, long long HW, in
  *   filter_difference_map (PO:31-40) with weight_u8 [K][F][H][W] (the label's mask image resized to the frame, 0..255) and
  *   filter_s, arg-max over the K masks (first maximum), seg_u8 [F][H][W] = labels[arg]. */
 int vidseg_seg_difference(const float* pos, const float* neg, int F, int H, int W, void* out_u8, void* fmax_u32, vidseg_stream_t stream);
+/* the same on the uint8 HWC [F][H][W][3] images process_output.py:9-10 reads back from the PNG files of Step 4 */
+int vidseg_seg_difference_u8(const void* pos, const void* neg, int F, int H, int W, void* out_u8, void* fmax_u32, vidseg_stream_t stream);
 int vidseg_seg_argmax(const void* maps_u8, const void* max_u32, const void* weight_u8, double filter_s, const int* labels, int K, int F,
                       int H, int W, void* seg_u8, vidseg_stream_t stream);
 /* SVD (video) operators -- video_model.py:15-89 VideoResBlock, video_attention.py:18-489 */

@@ -8,9 +8,11 @@
 
 PARITY UNPINNED for the blur: OpenCV is not installed in the build container, so cv2.GaussianBlur is restated
 from its documentation (getGaussianKernel(5, 3) = normalised exp(-(i-2)^2 / 18), separable, BORDER_REFLECT_101, float64) and
-checked only against a direct 2-D numpy evaluation; the wrapping uint8 arithmetic IS pinned (it is numpy's own, evaluated
-literally below).  The reference's JPEG save / re-load of every difference map (PO:19, 119) is a lossy codec round trip and
-is not reproduced here or on the device: the "L" image is used as is.
+checked against a direct 2-D numpy evaluation and against scipy.ndimage's independent separable correlation with mirror
+borders (tests/test_oracle_process_output.py); the result is truncated to uint8, so only a float64 value within ~1e-13 of an
+integer could depend on the summation order.  The wrapping uint8 arithmetic IS pinned (it is numpy's own, evaluated literally
+below).  The reference's JPEG save / re-load of every difference map (PO:19, 119) is reproduced with `jpeg=True` through PIL,
+the codec the reference itself calls (the HBM-resident default skips it).
 """
 from __future__ import annotations
 
@@ -45,11 +47,31 @@ def compute_difference(img1_u8, img2_u8):
     return np.clip(difference, 0.0, 255.0).astype(np.uint8)                  # PIL "F" -> "L": clip, truncate
 
 
-def seg_maps(pos, neg, labels, weights=None, filter_s=0.7):
+def jpeg_roundtrip(img_u8):
+    """PO:18-19, 119: Image.fromarray(.).convert("L").save(x.jpg) with PIL's defaults, then np.array(Image.open(x.jpg))."""
+    import io
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(img_u8).convert("L").save(buf, format="JPEG")
+    buf.seek(0)
+    return np.array(Image.open(buf))
+
+
+def seg_maps(pos, neg, labels, weights=None, filter_s=0.7, jpeg=False):
     """pos/neg: float32 [K, F, 3, H, W] decoded +lambda / -lambda frames per mask (in `labels` order); weights: uint8
     [K, F, H, W] resized mask images or None.  Returns uint8 [F, H, W] (PO:119-161)."""
-    K, F = pos.shape[:2]
-    maps = np.stack([np.stack([compute_difference(a, b) for a, b in zip(frames_to_uint8(pos[k]), frames_to_uint8(neg[k]))]) for k in range(K)])
+    K = pos.shape[0]
+    return seg_maps_u8(np.stack([frames_to_uint8(pos[k]) for k in range(K)]), np.stack([frames_to_uint8(neg[k]) for k in range(K)]),
+                       labels, weights, filter_s, jpeg)
+
+
+def seg_maps_u8(pos_u8, neg_u8, labels, weights=None, filter_s=0.7, jpeg=False):
+    """The same from the uint8 HWC images [K, F, H, W, 3] the reference reads back from its PNGs; jpeg: the difference maps go
+    through the JPEG save / re-load before they are normalised (the reference's file-based behaviour)."""
+    K, F = pos_u8.shape[:2]
+    maps = np.stack([np.stack([compute_difference(a, b) for a, b in zip(pos_u8[k], neg_u8[k])]) for k in range(K)])
+    if jpeg:
+        maps = np.stack([np.stack([jpeg_roundtrip(maps[k, f]) for f in range(F)]) for k in range(K)])
     all_maps = []
     for k in range(K):
         per_frame = []

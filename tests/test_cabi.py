@@ -79,3 +79,39 @@ def test_checkpoint_and_dump_file_formats(tmp_path):
     assert files == [str(tmp_path / "exp" / "feature_maps" / "output_block_7_spatial_self_attn_q_time_24.pt")]
     assert torch.equal(torch.load(files[0]), q)
     FE.FeatureStore.clear()
+
+
+def test_png_mask_folder_round_trip(tmp_path):
+    """The Step 3 -> Step 4 hand-off on disk (feature_extraction.py:618-636 writes `kmeans_time_{t}_frame_{name}/mask_{l}.png`,
+    sd_pipeline_vspw.py:64-101 reads them back): the PNG folder written with VIDSEG_WRITE_PNG gives `load_feature_masks` exactly
+    what the in-HBM MaskStore entry gives it -- same resolution and resized to another decoder block's resolution."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import load_feature_masks
+    F, h, w, labels = 3, 8, 8, np.array([2, 5, 7])
+    g = np.random.Generator(np.random.PCG64(11))
+    lab = labels[g.integers(0, 3, (F, h, w))].astype(np.int32)
+    names = ["00007", "00008", "00010"]
+    folder = str(tmp_path / "exp" / "match_gt_mask" / "output_block_7_spatial_self_attn_q_masks_3")
+    FE._write_png_masks(folder, torch.from_numpy(lab), names, 24, labels, True)
+    for i, n in enumerate(names):                                        # the reference's layout and pixel values
+        for l in labels:
+            m = np.array(Image.open(os.path.join(folder, f"kmeans_time_24_frame_{n}", f"mask_{l}.png")))
+            assert m.shape == (h, w) and m.dtype == np.uint8 and np.array_equal(m, np.where(lab[i] == l, 255, 0))
+    cpu = torch.device("cpu")
+    FE.MaskStore.clear()
+    for block, base in ((7, 2), (10, 2)):                                # block 7: 8x8 = the stored resolution; block 10: PIL-resized to 16x16
+        from_png = load_feature_masks(folder, 5, num_frames=F, feature_timestep="24", modulate_block_idx=block, base_height=base,
+                                      base_width=base, frame_name_list=names, device=cpu)
+        FE.MaskStore.put(folder, torch.from_numpy(lab.reshape(F, -1)), names, labels)
+        from_store = load_feature_masks(folder, 5, num_frames=F, feature_timestep="24", modulate_block_idx=block, base_height=base,
+                                        base_width=base, frame_name_list=names, device=cpu)
+        FE.MaskStore.clear()
+        assert len(from_png) == len(from_store) == F
+        for a, b in zip(from_png, from_store):
+            assert a.dtype == torch.float64 and torch.equal(a, b)
+            assert a.numel() == (base * (4 if block == 7 else 8)) ** 2
+    same_res = load_feature_masks(folder, 5, num_frames=F, modulate_block_idx=7, base_height=2, base_width=2, frame_name_list=names, device=cpu)
+    assert torch.equal(same_res[0], torch.from_numpy((lab[0] == 5).astype(np.float64).reshape(-1)))

@@ -67,3 +67,68 @@ def test_decode_to_seg_map_end_to_end():
     ref, _ = OPO.seg_maps(pos, neg, labels)
     assert seg.shape == (2, 64, 64) and np.array_equal(seg, ref)
     assert len(np.unique(seg)) > 1
+
+
+def test_jpeg_compat_mode_vs_oracle():
+    """process_output.py:18-19, 119: with jpeg_compat the difference maps take the reference's JPEG save / re-load (PIL's codec on
+    both sides) before they are normalised: device == oracle bit for bit, and the maxima are those of the re-loaded images."""
+    from oracle import process_output as OPO
+    from vidseg_diffusion_amd import process_output as PO
+    dev = torch.device("cuda:0")
+    K, F, H, W = 4, 2, 48, 40
+    pos, neg = _case(77, K, F, H, W)
+    labels = [1, 4, 6, 9]
+    decoded = {}
+    for k, lab in enumerate(labels):
+        decoded[(1.0, lab)] = torch.from_numpy(pos[k]).to(dev)
+        decoded[(-1.0, lab)] = torch.from_numpy(neg[k]).to(dev)
+    ref_j, _ = OPO.seg_maps(pos, neg, labels, jpeg=True)
+    seg_j = PO.get_seg_map(decoded, labels, jpeg_compat=True).cpu().numpy()
+    assert np.array_equal(seg_j, ref_j)
+    m, _ = PO.difference_map(decoded[(1.0, 4)], decoded[(-1.0, 4)])
+    mj, mxj = PO.jpeg_roundtrip(m)
+    assert np.array_equal(mj.cpu().numpy()[0], OPO.jpeg_roundtrip(m.cpu().numpy()[0]))
+    assert np.array_equal(mxj.cpu().numpy(), mj.cpu().numpy().reshape(F, -1).max(axis=1))
+
+
+@pytest.mark.parametrize("filt", [False, True])
+def test_file_based_get_seg_map_main(tmp_path, filt):
+    """The reference's entry point and folder layout (process_output.py:42-167): PNG frames of the +lambda / -lambda decodes in,
+    JPEG difference maps and raw PNG / colour JPEG segmentation maps out -- equal to the oracle evaluating the reference's
+    expressions on the same files' pixels (uint8 images, JPEG round trip, LANCZOS-resized Step 3 mask PNGs)."""
+    import os
+    from PIL import Image
+    from oracle import process_output as OPO
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd import process_output as PO
+    K, F, H, W, lam, base_count = 3, 2, 40, 56, 50.0, 3
+    labels = np.array([2, 5, 7])
+    names = ["00012", "00013"]
+    g = np.random.Generator(np.random.PCG64(31))
+    base, exp = str(tmp_path), "clip"
+    pos = g.integers(0, 256, (K, F, H, W, 3), dtype=np.uint8)
+    neg = pos.copy()
+    for k in range(K):
+        neg[k, :, 5 + 9 * k:15 + 9 * k, 4 + 12 * k:24 + 12 * k] = g.integers(0, 256, (F, 10, 20, 3), dtype=np.uint8)
+    for k, lab in enumerate(labels):
+        for sign, arr in ((lam, pos), (-lam, neg)):
+            d = os.path.join(base, exp, "modulated_output", f"{base_count:06d}_l_{sign}_mask_{lab}")
+            os.makedirs(d)
+            for f, n in enumerate(names):
+                Image.fromarray(arr[k, f]).save(os.path.join(d, f"{n}.png"))
+    lm = labels[g.integers(0, K, (F, 10, 14))].astype(np.int32)
+    mask_folder = os.path.join(base, exp, "match_gt_mask", "masks_3")
+    FE._write_png_masks(mask_folder, torch.from_numpy(lm), names, 24, labels, True)
+    seg = PO.get_seg_map_main(exp, base_count, lam, K, F, filt, filter_s=0.7, unique_labels=labels, base_folder=base,
+                              mask_folder=mask_folder, frame_name_list=names, feature_timestep="24")
+    weights = PO.mask_weights(lm, labels, (H, W)) if filt else None
+    ref, _ = OPO.seg_maps_u8(pos, neg, labels, weights=weights, filter_s=0.7, jpeg=True)
+    assert seg.shape == (F, H, W) and np.array_equal(seg, ref)
+    suffix = "_f_0.7" if filt else ""
+    for f, n in enumerate(names):
+        raw = np.array(Image.open(os.path.join(base, exp, f"segmentation_map_raw{suffix}", f"{base_count:06d}_l_{lam}", f"{n}.png")))
+        assert np.array_equal(raw, ref[f])
+        assert os.path.exists(os.path.join(base, exp, f"segmentation_map{suffix}", f"{base_count:06d}_l_{lam}", f"{n}.jpg"))
+        jm = np.array(Image.open(os.path.join(base, exp, "difference_map", "original_map", f"{base_count:06d}_l_{lam}_mask_5", f"{n}.jpg")))
+        assert jm.shape == (H, W)
+    assert len(np.unique(seg)) > 1

@@ -43,3 +43,37 @@ def test_seg_maps_argmax_and_filter():
     w[2] = 255
     seg_f, _ = PO.seg_maps(pos, neg, [4, 7, 9], weights=w, filter_s=0.0)
     assert seg_f[0, 8, 12] == 9 and seg_f[0, 4, 5] != 7
+
+
+def test_gaussian_blur_vs_scipy_separable():
+    """An independent implementation of the documented definition: scipy.ndimage.correlate1d along both axes with 'mirror'
+    borders (= BORDER_REFLECT_101) and cv2.getGaussianKernel(5, 3)'s formula."""
+    from scipy import ndimage
+    g = np.random.Generator(np.random.PCG64(6))
+    d = np.sqrt(g.integers(0, 3 * 255, (37, 29)).astype(np.float64))
+    f = np.exp(-((np.arange(5) - 2.0) ** 2) / (2 * 3.0 ** 2))
+    k = f / f.sum()
+    ref = ndimage.correlate1d(ndimage.correlate1d(d, k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+    got = PO.gaussian_blur_5_3(d)
+    assert np.abs(got - ref).max() < 1e-12
+    assert np.array_equal(np.clip(got, 0, 255).astype(np.uint8), np.clip(ref, 0, 255).astype(np.uint8))
+
+
+def test_jpeg_roundtrip_is_pils_codec_and_changes_the_maps():
+    """PO:18-19 / 119: the difference maps pass through a JPEG file.  The oracle calls the same PIL codec the reference does."""
+    import io
+    from PIL import Image
+    g = np.random.Generator(np.random.PCG64(7))
+    img = (g.random((40, 56)) * 200).astype(np.uint8)
+    img[10:20, 10:30] = 250
+    back = PO.jpeg_roundtrip(img)
+    buf = io.BytesIO()
+    Image.fromarray(img).convert("L").save(buf, format="JPEG")
+    assert np.array_equal(back, np.array(Image.open(io.BytesIO(buf.getvalue()))))
+    assert back.shape == img.shape and back.dtype == np.uint8 and not np.array_equal(back, img)
+    K, F, H, W = 2, 1, 24, 32
+    pos = g.standard_normal((K, F, 3, H, W)).astype(np.float32)
+    neg = pos + g.standard_normal((K, F, 3, H, W)).astype(np.float32) * 0.4
+    a, _ = PO.seg_maps(pos, neg, [1, 2])
+    b, _ = PO.seg_maps(pos, neg, [1, 2], jpeg=True)
+    assert a.shape == b.shape == (F, H, W)

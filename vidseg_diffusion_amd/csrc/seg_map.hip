@@ -15,12 +15,23 @@ __device__ __forceinline__ unsigned to_u8(float x) {
     return (unsigned)(t * 255.0f);
 }
 
-// PO:13: np.sqrt(np.sum((a - b) ** 2, axis=2)) on uint8 arrays: the subtraction and the square wrap modulo 256, the sum does not
+// PO:13: np.sqrt(np.sum((a - b) ** 2, axis=2)) on uint8 arrays: the subtraction and the square wrap modulo 256, the sum does not.
+// Two input forms: decoded frames fp32 NCHW (converted like the driver does before it writes the PNG) or the PNG's own uint8 HWC.
 __device__ __forceinline__ double wrapped_distance(const float* __restrict__ a, const float* __restrict__ b, long long plane, long long pix) {
     unsigned s = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const unsigned d = (to_u8(a[c * plane + pix]) - to_u8(b[c * plane + pix])) & 0xFFu;
+        s += (d * d) & 0xFFu;
+    }
+    return sqrt((double)s);
+}
+__device__ __forceinline__ double wrapped_distance(const unsigned char* __restrict__ a, const unsigned char* __restrict__ b, long long plane,
+                                                   long long pix) {
+    unsigned s = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned d = ((unsigned)a[pix * 3 + c] - (unsigned)b[pix * 3 + c]) & 0xFFu;
         s += (d * d) & 0xFFu;
     }
     return sqrt((double)s);
@@ -34,7 +45,8 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 
 // pos/neg: fp32 NCHW [F][3][H][W] decoded frames; out: uint8 [F][H][W] = the "L" image of the blurred difference (PIL F -> L:
 // clip to [0, 255], truncate); fmax[f] = its maximum (uint atomics).  Gaussian taps g[0..2] = centre, +-1, +-2 (normalised).
-__global__ void __launch_bounds__(256) k_seg_difference(const float* __restrict__ pos, const float* __restrict__ neg, int F, int H, int W,
+template <typename T>
+__global__ void __launch_bounds__(256) k_seg_difference(const T* __restrict__ pos, const T* __restrict__ neg, int F, int H, int W,
                                                         double g0, double g1, double g2, unsigned char* __restrict__ out,
                                                         unsigned* __restrict__ fmax) {
     const long long plane = (long long)H * W;
@@ -42,8 +54,8 @@ __global__ void __launch_bounds__(256) k_seg_difference(const float* __restrict_
     if (idx >= (long long)F * plane) return;
     const int f = (int)(idx / plane);
     const int y = (int)((idx % plane) / W), x = (int)(idx % W);
-    const float* a = pos + (long long)f * 3 * plane;
-    const float* b = neg + (long long)f * 3 * plane;
+    const T* a = pos + (long long)f * 3 * plane;
+    const T* b = neg + (long long)f * 3 * plane;
     const double gk[3] = {g0, g1, g2};
     double rows[5];
 #pragma unroll
@@ -93,9 +105,21 @@ int vidseg_seg_difference(const float* pos, const float* neg, int F, int H, int 
     const double g0 = 0.22254893673936782, g1 = 0.2105222740037377, g2 = 0.1782032576265784;
     (void)hipMemsetAsync(fmax_u32, 0, sizeof(unsigned) * F, st);
     const long long n = (long long)F * H * W;
-    k_seg_difference<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(pos, neg, F, H, W, g0, g1, g2, (unsigned char*)out_u8,
-                                                                          (unsigned*)fmax_u32);
+    k_seg_difference<float><<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(pos, neg, F, H, W, g0, g1, g2, (unsigned char*)out_u8,
+                                                                                 (unsigned*)fmax_u32);
     VS_CHECK_LAUNCH("seg_difference");
+    return VS_OK;
+}
+
+// the same on the uint8 HWC images the reference reads back from its PNG files (PO:9-10): pos/neg [F][H][W][3]
+int vidseg_seg_difference_u8(const void* pos, const void* neg, int F, int H, int W, void* out_u8, void* fmax_u32, hipStream_t st) {
+    VS_REQUIRE(F > 0 && H >= 3 && W >= 3, "seg_difference_u8: F=%d H=%d W=%d", F, H, W);
+    const double g0 = 0.22254893673936782, g1 = 0.2105222740037377, g2 = 0.1782032576265784;
+    (void)hipMemsetAsync(fmax_u32, 0, sizeof(unsigned) * F, st);
+    const long long n = (long long)F * H * W;
+    k_seg_difference<unsigned char><<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(
+        (const unsigned char*)pos, (const unsigned char*)neg, F, H, W, g0, g1, g2, (unsigned char*)out_u8, (unsigned*)fmax_u32);
+    VS_CHECK_LAUNCH("seg_difference_u8");
     return VS_OK;
 }
 
