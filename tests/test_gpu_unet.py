@@ -247,7 +247,8 @@ def test_modulated_injected_pass_vs_reference(env):
         # the modulation must actually have moved the sample the way the reference's did
         d_ref = g[f"mod_{tag}_final"] - g["feat_final"]
         d_got = final.cpu().numpy() - feat.cpu().numpy()
-        assert nrms(d_got, d_ref) < 0.35, nrms(d_got, d_ref)
+        print("modulated", tag, "delta nrms", round(nrms(d_got, d_ref), 4), "delta/ref", round(float(np.abs(d_ref).mean() / np.abs(g["feat_final"]).mean()), 4))
+        assert nrms(d_got, d_ref) < (5e-2 if act_mode()[0] == "f16" else 0.35), nrms(d_got, d_ref)
 
 
 def test_inversion_vs_reference(env):
@@ -260,6 +261,7 @@ def test_inversion_vs_reference(env):
     x, lats = eng.sampler.inversion(lambda inp, s, cc, **k: eng.denoiser(eng.model, inp, s, cc), torch.from_numpy(g["sm_latent"]).to(dev),
                                     cond=c, uc=uc, num_steps=25)
     assert len(lats) == 26
+    assert lats[-1] is x                                             # SAM:294 rescales in place: the list's last entry IS the result
     assert nrms(lats[5].cpu().numpy(), g["inv_step5"]) < act_mode()[1]
     # 24 network steps up to sigma = 14.6 with random weights amplify rounding chaotically: the bf16 FORMAT alone (oracle
     # in bf16-rounding mode) ends 14 % away from the fp32 reference; the HIP path must not be worse than that.
@@ -270,6 +272,54 @@ def test_inversion_vs_reference(env):
     err = nrms(x.cpu().numpy(), g["inv_final"])
     print("inversion nrms", err, "16-bit format", fmt)
     assert err <= 1.5 * fmt + 1e-2
+
+
+def test_smooth_latent_schedule(env):
+    """is_smooth_latent (sampling.py:117-125, 199-212): at steps 23 / 24 the denoised latent is decoded, frames with
+    (frame_id - {1, 2}) % 3 == 0 are replaced by the mean of their neighbours, and the result is encoded again.  Checked with a
+    transparent first stage (decode = encode = identity on the latent) against a replay of the reference's loop on the
+    unsmoothed run's denoised latents -- the schedule and the arithmetic, independent of any VAE."""
+    from vidseg_diffusion_amd.pipeline import build_sd_engine
+    dev, g, net, sd = env
+    eng = build_sd_engine(net)
+    Fn = 7
+    lat = torch.from_numpy(synthetic.latent_clip(Fn, 16, 16, seed=4)).to(dev)
+    cc, ucc = synthetic.sd_conditioning(Fn, context_dim=64, seq=7, seed=5)
+    c, uc = {"crossattn": torch.from_numpy(cc).to(dev)}, {"crossattn": torch.from_numpy(ucc).to(dev)}
+    noise = torch.randn(lat.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+    x0 = eng.sampler.add_noise(lat, cond=c, uc=uc, num_steps=25, noise_level=22, noise=noise)
+    seen = []
+
+    class Transparent:
+        def decode_first_stage(self, z):
+            seen.append(z.clone())
+            return z.clone()
+
+        def encode_first_stage(self, x):
+            return x
+
+    def denoiser(inp, sigma, cc_, **k):
+        return eng.denoiser(eng.model, inp, sigma, cc_)
+
+    with pytest.raises(AssertionError):
+        eng.sampler(denoiser, x0.clone(), cond=c, uc=uc, t_start=22, is_smooth_latent=True, model=None)
+    xs = []
+    out = eng.sampler(denoiser, x0.clone(), cond=c, uc=uc, t_start=22, is_smooth_latent=True, model=Transparent(),
+                      img_callback=lambda xt, i: xs.append(xt.clone()))
+    assert len(seen) == 2 and len(xs) == 3                           # steps 23 and 24 only
+    sig = eng.sampler.discretization(25)
+    x = xs[0]                                                        # state after step 22 (no smoothing there)
+    for k, (i, off) in enumerate(((23, 1), (24, 2))):
+        den = seen[k].cpu().numpy().copy()
+        for f in range(1, Fn - 1):
+            if (f - off) % 3 == 0:
+                den[f] = 0.5 * (den[f - 1] + den[f + 1])
+        s0, s1 = float(sig[i]), float(sig[i + 1])
+        xn = x.cpu().numpy()
+        x = torch.from_numpy(xn + (xn - den) / s0 * (s1 - s0)).to(dev)   # to_d + euler_step (SAM:125-131)
+        assert np.abs(x.cpu().numpy() - xs[k + 1].cpu().numpy()).max() <= 1e-5 * np.abs(xn).max() + 1e-6
+    plain = eng.sampler(denoiser, x0.clone(), cond=c, uc=uc, t_start=22)
+    assert not torch.equal(plain, out)
 
 
 def test_svd_modulated_injected_pass_vs_reference():
@@ -325,9 +375,9 @@ def test_svd_modulated_injected_pass_vs_reference():
         print("svd modulated", tag, "lambda", lam, "step nrms", [round(e, 4) for e in errs], "delta nrms", round(nrms(d_got, d_ref), 4),
               "delta/ref", round(float(np.abs(d_ref).mean() / np.abs(g["feat_final"]).mean()), 4))
         assert max(errs) < act_mode()[1]
-        # the modulation must actually have moved the sample the way the reference's did (large-lambda cases dominate rounding)
-        if abs(lam) >= 1000:
-            assert nrms(d_got, d_ref) < 0.35, nrms(d_got, d_ref)
+        # the modulation must actually have moved the sample the way the reference's did: the DIFFERENCE between the modulated
+        # and the unmodulated final latent within 2 % of the reference's difference (measured 3.5e-3), for lambda = 50 and 2000 alike
+        assert nrms(d_got, d_ref) < (2e-2 if act_mode()[0] == "f16" else 0.35), nrms(d_got, d_ref)
 
 
 def test_modulation_sweep_step4(env):

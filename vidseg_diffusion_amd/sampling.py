@@ -260,7 +260,7 @@ class SingleStepDiffusionSampler(BaseDiffusionSampler):
 
 
 class EDMSampler(SingleStepDiffusionSampler):
-    """sampling.py:92-296 (Euler path; s_churn noise injection supported; is_smooth_latent needs the VAE -> not built)."""
+    """sampling.py:92-296 (Euler path; s_churn noise injection; is_smooth_latent through the engine's first stage)."""
 
     def __init__(self, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -268,8 +268,6 @@ class EDMSampler(SingleStepDiffusionSampler):
 
     def sampler_step(self, sigma, next_sigma, denoiser, x, cond, uc=None, gamma=0.0, is_modulate_step=False,
                      is_injected_step=False, modulate_params=None, is_smooth_latent=False, model=None, smooth_step_size=None):
-        if is_smooth_latent:
-            raise NotImplementedError("is_smooth_latent decodes through the VAE, which is outside the built path")
         sigma_hat = sigma * (gamma + 1.0)
         if gamma > 0:
             eps = torch.randn_like(x) * self.s_noise
@@ -279,6 +277,14 @@ class EDMSampler(SingleStepDiffusionSampler):
         else:
             denoised = self.denoise(x, denoiser, sigma_hat, cond, uc, is_modulate_step=is_modulate_step,
                                     is_injected_step=is_injected_step, modulate_params=modulate_params)
+        if is_smooth_latent:                                                   # SAM:117-125: smooth in pixel space through the first stage
+            if model is None:
+                raise AssertionError("is_smooth_latent needs model= (the engine with decode_first_stage / encode_first_stage)")
+            frames = model.decode_first_stage(denoised).contiguous()
+            for frame_id in range(1, frames.shape[0] - 1):
+                if (frame_id - smooth_step_size) % 3 == 0:
+                    frames[frame_id] = ops.axpy(frames[frame_id - 1].contiguous(), frames[frame_id + 1].contiguous(), 1.0, 0.5)
+            denoised = model.encode_first_stage(frames)
         x = ops.euler_update(x, denoised, sigma_hat, next_sigma)               # to_d + euler_step (SAM:125-131)
         return self.possible_correction_step(x, None, None, None, next_sigma, denoiser, cond, uc)
 
@@ -317,9 +323,11 @@ class EDMSampler(SingleStepDiffusionSampler):
                     modulate_params["modulate_timestep_frames_group"] = list(range(modulate_params["num_frames"]))
             if uc_list is not None:
                 uc = uc_list[i]
+            smooth_step = is_smooth_latent and i in (23, 24)                   # SAM:199-212: steps 23 / 24 with offsets 1 / 2
             x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc, gamma,
                                   is_modulate_step=is_modulate_step, is_injected_step=is_injected_step,
-                                  modulate_params=modulate_params, is_smooth_latent=False, model=model)
+                                  modulate_params=modulate_params, is_smooth_latent=smooth_step, model=model,
+                                  smooth_step_size=(i - 22) if smooth_step else None)
             if is_latent_blending:                                             # sampling.py:229-250
                 if modulate_params["latent_mask_start"] <= i <= modulate_params["latent_mask_end"]:
                     xh, xw = x.shape[-2], x.shape[-1]
@@ -348,6 +356,7 @@ class EDMSampler(SingleStepDiffusionSampler):
             x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc, gamma)
             latents_list.append(x)
         x = ops.scale(x, 1.0 / float(torch.sqrt(1.0 + sigmas[-1] ** 2.0)))
+        latents_list[-1] = x                           # SAM:294 divides in place: the list's last entry is the rescaled tensor too
         return x, latents_list
 
 
