@@ -559,6 +559,63 @@ def test_fp8_attention_path(env):
         assert nrms(taps8[b], taps[b]) < 5e-2, (b, nrms(taps8[b], taps[b]))
 
 
+def test_fp8_attention_path_video_unet_and_k50():
+    """BASELINE configs[4] on the VideoUNet (SVD): the spatial self / cross attentions of every SpatialVideoTransformer on the
+    e4m3 kernel (temporal attention over T frames stays 16-bit: its sequences are 14 keys long).  No reference exists for an
+    fp8 path; bars: UNet output and the spatial / temporal Q taps of block 8 within 5e-2 normalised rms of the 16-bit path,
+    and one window at K = 50 masks runs end to end with the refinement (the configs[4] mask count)."""
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd import ops
+    from vidseg_diffusion_amd.pipeline import build_svd_engine, segment_window
+    from vidseg_diffusion_amd.video_unet import VideoUNet
+    from tools_metrics import matched_iou
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_svd_narrow.npz"))
+    g = {k: z[k] for k in z.files}
+    net = VideoUNet(**synthetic.SVD_NARROW)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=4321).items()})
+    T = int(g["T"])
+    x, t, ctx, y = (torch.from_numpy(g[k]).to(dev) for k in ("fw_x", "fw_t", "fw_ctx", "fw_y"))
+
+    def fwd():
+        out = net(x, timesteps=t, context=ctx, y=y, num_video_frames=T, image_only_indicator=torch.zeros(2, T)).cpu().numpy()
+        b8 = net.output_blocks[8][1]
+        return out, b8.transformer_blocks[0].attn1.q.float().cpu().numpy(), b8.time_stack[0].attn1.q.float().cpu().numpy()
+
+    base = fwd()
+    prev = ops.set_attention_fp8(True, min_keys=0)
+    try:
+        got = fwd()
+        # one window of the SVD engine at K = 50 on the fp8 path vs the 16-bit path (narrow width, 5 frames of 16x16 latents)
+        Fn, K = 5, 50
+        eng = build_svd_engine(net, num_frames=Fn)
+        gen = torch.Generator().manual_seed(3)
+        lat = torch.from_numpy(synthetic.latent_clip(Fn, 16, 16, seed=11)).to(dev)
+        c = {"crossattn": torch.randn((1, 1, 64), generator=gen).repeat(Fn, 1, 1).to(dev), "concat": (lat[:1].repeat(Fn, 1, 1, 1) * 0.5),
+             "vector": torch.randn((1, 64), generator=gen).repeat(Fn, 1).to(dev)}
+        uc = {"crossattn": torch.zeros_like(c["crossattn"]), "concat": torch.zeros_like(c["concat"]), "vector": c["vector"].clone()}
+        noise = torch.randn(lat.shape, generator=gen).to(dev)
+        res = {}
+        for tag, on in (("fp8", True), ("a16", False)):
+            ops.set_attention_fp8(on, min_keys=0)
+            FE.FeatureStore.clear(); FE.MaskStore.clear()
+            res[tag], _ = segment_window(eng, lat, c, uc, num_masks=K, t_start=22, is_refine_mask=True, seed=17, noise=noise,
+                                         feature_folder="/nonexistent/fp8k50", exp_name=tag, keep_all_steps=False)
+    finally:
+        ops.set_attention_fp8(prev)
+        FE.FeatureStore.clear(); FE.MaskStore.clear()
+    assert not np.array_equal(got[0], base[0]), "the fp8 switch did not change the attention kernel"
+    for name, a, b in zip(("output", "spatial q8", "temporal q8"), got, base):
+        e = nrms(a, b)
+        print(f"video unet fp8 vs 16-bit {name}: nrms {e:.3e}")
+        assert e < 5e-2, (name, e)
+    for tag in res:
+        assert res[tag].shape == (Fn, 64) and len(np.unique(res[tag])) <= K
+    iou, same = matched_iou(res["fp8"], res["a16"], K)
+    print(f"K=50 narrow SVD window, fp8 vs 16-bit masks: IoU {iou:.3f}, identical {same:.3f}")
+
+
 def test_masks_only_feature_pass(env):
     """Opt-in pruning (pipeline.feature_pass(masks_only=True)): the last step on the conditional half only, stopped after output
     block 8.  Every UNet operator is per sample, so the conditional-half taps equal the full pass's up to fp32 summation order
