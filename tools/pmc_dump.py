@@ -1,0 +1,9 @@
+"""Average per-dispatch PMC values of the kernels whose name contains argv[2] from a rocprofv3 results db: python tools/pmc_dump.py <db> <substr>"""
+import collections, sqlite3, sys
+db = sqlite3.connect(sys.argv[1])
+acc = collections.defaultdict(lambda: [0, 0.0])
+for name, cn, val in db.execute("select kernel_name, counter_name, value from counters_collection"):
+    if sys.argv[2] in name:
+        a = acc[cn]; a[0] += 1; a[1] += float(val)
+for cn, (n, v) in sorted(acc.items()):
+    print(f"{cn:40s} {v / n:16.1f}  (n={n})")

@@ -1088,7 +1088,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
 // tiles on the same layers -- whole rounds.  224 = 7 * 32 cannot be split over 8 waves in 32-row fragments, so the
 // fragments are v_mfma_f32_16x16x32: wave grid 2 (M) x 4 (N), wave tile 112 x 80 = 7 x 5 fragments (35 accumulators of 4
 // registers; 7 A + 5 B fragment reads per 35 MFMAs of 16 cycles -- the same LDS bytes per flop as the 64 x 160 wave tile).
-// Staging, LDS image, swizzle, group schedule and the counted waits are those of k_gemm_ph<5>, bit for bit: the A region
+// Staging pieces, LDS image and swizzle are those of k_gemm_ph<5> (the staging SCHEDULE is its own, see the kernel): the A region
 // keeps 256 rows and the rows 224..255 of a tile are staged with out-of-range offsets (zeros, no memory traffic), so every
 // wave still issues 9 DMA instructions per K-tile.  A B block g is now the four 16-row strips {wn * 80 + g * 16 ..} that
 // phase g reads.  Phase j = B fragment column j over the whole BK = 64: 14 MFMAs (7 A fragments x 2 k-steps, 224 cycles).
@@ -1189,9 +1189,11 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7(GemmParams p) {
     cur.init(ks_begin * 64, p.taps, p.kchunk);
     int t_kh = 0, t_kw = 0, t_Cs = 0, t_cc = 0;
     bool a_second = false;
-    auto stage = [&](int g, int u, int buf) {
+    // One A set (s4: rows (s4 >> 1) * 128 + (wave + 8 * (s4 & 1)) * 8 .., one DMA instruction per wave) / one B block of tile u into
+    // buffer buf.  The K cursor moves when set 0 of a tile is staged; the sets of one tile are staged in order 0, 1, 2, 3.
+    auto stage_a = [&](int s4, int u, int buf) {
         const bool live = u < nk;
-        if (g == 0) {
+        if (s4 == 0) {
             const int c0 = cur.c0();
             a_second = c0 >= p.C0;
             t_Cs = a_second ? p.C1 : p.C0;
@@ -1201,21 +1203,18 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7(GemmParams p) {
             t_kw = p.tmode ? 0 : cur.tap - t3 * 3;
             cur.advance(64, p.taps, p.kchunk);
         }
-        if (g < 2) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int s4 = g * 2 + i;
-                char* dst = smem + buf * A_BYTES + (g * 128 + (wave + 8 * i) * 8) * RB;
-                const int ih = (a_hw[s4] >> 16) - 0x4000 + t_kh, iw = (a_hw[s4] & 0xFFFF) - 0x4000 + t_kw;
-                const bool ok = live && (unsigned)ih < (unsigned)hb && (unsigned)iw < (unsigned)wb;
-                const int pix = a_base[s4] + (ih >> upsh) * wmul + (iw >> upsh);
-                const unsigned off = ok ? (unsigned)(pix * t_Cs + t_cc) * 2u + swz16 : OOB;
-                if (a_second)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
-                else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
-            }
-        }
+        char* dst = smem + buf * A_BYTES + ((s4 >> 1) * 128 + (wave + 8 * (s4 & 1)) * 8) * RB;
+        const int ih = (a_hw[s4] >> 16) - 0x4000 + t_kh, iw = (a_hw[s4] & 0xFFFF) - 0x4000 + t_kw;
+        const bool ok = live && (unsigned)ih < (unsigned)hb && (unsigned)iw < (unsigned)wb;
+        const int pix = a_base[s4] + (ih >> upsh) * wmul + (iw >> upsh);
+        const unsigned off = ok ? (unsigned)(pix * t_Cs + t_cc) * 2u + swz16 : OOB;
+        if (a_second)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+    };
+    auto stage_b = [&](int g, int u, int buf) {
+        const bool live = u < nk;
         char* dst = smem + 2 * A_BYTES + buf * B_BYTES + (b_r0 + g * 16) * RB;
         const unsigned off = (live && b_n + g * 16 < p.N) ? b_off0 + (unsigned)g * b_gstep + (unsigned)(ks_begin + u) * 128u : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
@@ -1232,14 +1231,25 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7(GemmParams p) {
     const int sw = (l15 >> 1) & 7;                                    // every fragment row is l15 + a multiple of 16
     const int arow = (wm * 112 + l15) * RB, brow = 2 * A_BYTES + (wn * 80 + l15) * RB;
 
-    // prologue: everything the steady state would have issued before phase (0, 0)
+    // Staging schedule: one A set + one B block per phase -- phases 2, 3, 4 of tile t stage (A set j-2, B block j-2) of tile t+2 into
+    // tile t's buffer (its A rows were last read in phase 0, its B block j-2 in phase j-2: two phases earlier), phase 0 stages
+    // (A set 3, B block 3) and phase 1 B block 4 of tile t+1: 2,2,2,2,1 DMA instructions per wave and phase (k_gemm_ph's groups are
+    // 3,3,1,1,1; an LDS-DMA instruction costs its wave 100-185 cycles inside a read section, MI355X_MICROARCH.md; measured -1 %).
+    // Per-wave issue order of a tile: A0 B0 A1 B1 A2 B2 A3 B3 B4.
+    // prologue: everything the steady state would have issued before phase (0, 0); that phase needs A0..A3 and B0 of tile 0, so B3,
+    // B4 and tile 1's six loads may still fly
 #pragma unroll
-    for (int g = 0; g < NJ; ++g) stage(g, 0, 0);
+    for (int g = 0; g < 4; ++g) {
+        stage_a(g, 0, 0);
+        stage_b(g, 0, 0);
+    }
+    stage_b(4, 0, 0);
 #pragma unroll
-    for (int g = 0; g + 2 < NJ; ++g) stage(g, 1, 1);
-    constexpr int CNT_ALL = 2 * (NJ + 4);
-    constexpr auto cnt = [](int pos) { return (pos == 2 || pos == 3) ? 3 : 1; };
-    wait_vmcnt<CNT_ALL - 8>();
+    for (int g = 0; g < 3; ++g) {
+        stage_a(g, 1, 1);
+        stage_b(g, 1, 1);
+    }
+    wait_vmcnt<8>();
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();
 
@@ -1252,31 +1262,38 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7(GemmParams p) {
             // ---- read section
             bf16x8_t fb[2];
             if (j == 0) {
+                // only the first k-step's A fragments ahead of the barrier; the second k-step's are read inside the matrix section,
+                // under this wave's own first seven MFMAs (the A rows of tile t are not restaged before phase (t, 2)): -0.7 %
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) fa[i][kk] = *reinterpret_cast<const bf16x8_t*>(A + i * 16 * RB + (((kk * 4 + l4) ^ sw) << 4));
+                for (int i = 0; i < MI; ++i) fa[i][0] = *reinterpret_cast<const bf16x8_t*>(A + i * 16 * RB + ((l4 ^ sw) << 4));
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) fb[kk] = *reinterpret_cast<const bf16x8_t*>(B + j * 16 * RB + (((kk * 4 + l4) ^ sw) << 4));
-            if (j >= 2)
-                stage(j - 2, t + 2, buf);
-            else
-                stage(j - 2 + NJ, t + 1, buf ^ 1);
-            // counted wait for what phase j+1 reads
+            if (j >= 2) {
+                stage_a(j - 2, t + 2, buf);
+                stage_b(j - 2, t + 2, buf);
+            } else {
+                if (j == 0) stage_a(3, t + 1, buf ^ 1);
+                stage_b(j + 3, t + 1, buf ^ 1);
+            }
+            // counted wait for what phase j+1 reads = the loads this wave issued after the last one that phase needs: phase (t+1, 0)
+            // needs A3(t+1), issued first in phase (t, 0) -> B3 + 1 + 2 + 2 + 2 = 8 younger loads; B block g was issued seven phases
+            // before the phase that reads it -> 12 or 13 younger loads
             const int jn = (j + 1) % NJ;
             if (jn == 0)
-                wait_vmcnt<CNT_ALL - 8>();
-            else if (cnt(jn) + cnt((jn + 1) % NJ) + cnt((jn + 2) % NJ) == 7)
-                wait_vmcnt<CNT_ALL - 7>();
-            else if (cnt(jn) + cnt((jn + 1) % NJ) + cnt((jn + 2) % NJ) == 5)
-                wait_vmcnt<CNT_ALL - 5>();
+                wait_vmcnt<8>();
+            else if (jn == 1 || jn == 4)
+                wait_vmcnt<13>();
             else
-                wait_vmcnt<CNT_ALL - 3>();
+                wait_vmcnt<12>();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             // ---- matrix section
+            if (j == 0) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i][1] = *reinterpret_cast<const bf16x8_t*>(A + i * 16 * RB + (((4 + l4) ^ sw) << 4));
+            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
