@@ -147,10 +147,11 @@ int vidseg_conv_in(const float* x, const float* w, const float* bias, int B, int
 int vidseg_conv_out4(const void* x, const void* w, const float* bias, int B, int H, int W, int Cin, float* out_f32_nchw,
                      vidseg_stream_t stream);
 /* GroupNorm32 (DU:276-278, fp32 statistics; eps 1e-5) / ATT:127 Normalize (eps 1e-6), optional SiLU.
-   Scratch: part >= B*ceil(HW/64)*2*C floats (per-chunk partial sums), stats >= B*2*C floats (per-sample scale/shift). */
+   rows_per_chunk = rows of one sample a block reduces / normalises (the host picks it so that B*ceil(HW/rows_per_chunk) fills the
+   chip).  Scratch: part >= B*ceil(HW/rows_per_chunk)*2*C floats (per-chunk partial sums), stats >= B*2*C floats (scale/shift). */
 int vidseg_groupnorm_nhwc_a16(const void* x0, const void* x1, int C0, int C1, int B, int HW, int G, const float* gamma,
-                               const float* beta, float eps, int silu, float* part, int part_floats, float* stats, int stats_floats,
-                               void* out, vidseg_stream_t stream);
+                               const float* beta, float eps, int silu, int rows_per_chunk, float* part, int part_floats, float* stats,
+                               int stats_floats, void* out, vidseg_stream_t stream);
 int vidseg_layernorm_a16(const void* x, long long M, int C, const float* gamma, const float* beta, float eps, void* out,
                           vidseg_stream_t stream);
 /* ATT:352-356 F.scaled_dot_product_attention per 64-wide head; q/k/v/o are column slices with leading dims. */

@@ -23,13 +23,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from tools_metrics import matched_iou  # noqa: E402
 
 DESIGNS = [
-    ("blobs6", dict(kind="blob")),
     ("reg20", dict(kind="region", R=20, amp=1.5, noise=0.05)),
-    ("scene20x4", dict(kind="scene", R=20, cells=4, amp=1.5, noise=0.05)),
-    ("scene20x2", dict(kind="scene", R=20, cells=2, amp=1.5, noise=0.05)),
-    ("scene20x5", dict(kind="scene", R=20, cells=5, amp=1.5, noise=0.05)),
+    ("lat20_a1.0", dict(kind="region", R=20, amp=1.0, noise=0.05, protos="lattice")),
+    ("lat20_a1.5", dict(kind="region", R=20, amp=1.5, noise=0.05, protos="lattice")),
+    ("lat20_a2.0", dict(kind="region", R=20, amp=2.0, noise=0.05, protos="lattice")),
 ]
-ZERO_GAINS = [float(v) for v in os.environ.get("PROBE_ZERO_GAINS", "1.0,0.3,0.1").split(",")]
+ZERO_GAINS = [float(v) for v in os.environ.get("PROBE_ZERO_GAINS", "0.3,0.1").split(",")]
 
 
 def make_latent(d, F, lat):
@@ -40,7 +39,7 @@ def make_latent(d, F, lat):
         x = synthetic.scene_clip(F, lat, lat, num_objects=d["R"], cells=d["cells"], seed=1, amp=d["amp"], noise=d["noise"])
         gt = synthetic.scene_labels(F, lat, lat, d["R"], d["cells"], 1 + 4000)
     else:
-        x = synthetic.region_clip(F, lat, lat, num_regions=d["R"], seed=1, amp=d["amp"], noise=d["noise"])
+        x = synthetic.region_clip(F, lat, lat, num_regions=d["R"], seed=1, amp=d["amp"], noise=d["noise"], protos=d.get("protos", "random"))
         gt = synthetic.region_labels(F, lat, lat, d["R"], 1 + 4000)
     return x, gt[:, ::2, ::2].reshape(F, -1)                       # token grid = latent / 2 (top-left latent pixel of each token)
 
@@ -82,16 +81,19 @@ def main():
             lat, gt = make_latent(d, F, LAT)
             lat = torch.from_numpy(lat).to(dev)
             res = {}
-            for variant, mo in (("full", False), ("half", True)):
+            for variant, mo in (("full", False), ("half", True), ("gn64", False)):
                 FE.FeatureStore.clear()
                 FE.MaskStore.clear()
+                ops._GN_RPC_FORCE = 64 if variant == "gn64" else 0     # another summation order of the GroupNorm statistics
                 labels, _ = segment_window(eng, lat, c, uc, num_masks=K, num_steps=25, t_start=22, seed=17, noise=noise,
                                            keep_all_steps=False, masks_only=mo, feature_folder="/nonexistent/probe", exp_name="p")
                 res[variant] = np.asarray(labels).reshape(F, -1)
                 rec[f"zg{zg}_{name}_{variant}"] = res[variant].astype(np.int16)
+            ops._GN_RPC_FORCE = 0
+            iou3, ex3 = matched_iou(res["full"], res["gn64"], K)
             iou, ex = matched_iou(res["full"], res["half"], K)
             sizes = np.sort(np.bincount(res["full"].reshape(-1), minlength=K))[::-1]
-            line = f"zg={zg:<4} {name:12s} [{act}] full vs half: IoU {iou:.4f} identical {ex:.4f}; sizes {sizes[:3]}..{sizes[-3:]}"
+            line = f"zg={zg:<4} {name:12s} [{act}] full vs half: IoU {iou:.4f} identical {ex:.4f}; vs gn64: IoU {iou3:.4f} identical {ex3:.4f}; sizes {sizes[:3]}..{sizes[-3:]}"
             if gt is not None:
                 giou, gex = matched_iou(res["full"], gt, max(K, d["R"]))
                 line += f"; vs generating partition IoU {giou:.3f} identical {gex:.3f}"

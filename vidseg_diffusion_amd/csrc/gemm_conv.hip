@@ -1320,26 +1320,47 @@ __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
     const long long i8 = (long long)blockIdx.x * 256 + threadIdx.x;
     const int n8 = p.N / 8;
     if (i8 >= p.M * n8) return;
-    const long long m = i8 / n8;
-    const int n = (int)(i8 % n8) * 8;
+    const int m = (int)(i8 / n8);                                 // rows fit 31 bits
+    const int n = (int)(i8 - (long long)m * n8) * 8;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    for (int s = 0; s < p.ksplit; ++s) {
-        const float* wp = p.ws + ((long long)s * p.M + m) * p.N + n;
+    const float* wp = p.ws + (long long)m * p.N + n;
+    const long long sstride = p.M * p.N;
+    for (int s = 0; s < p.ksplit; ++s) {                           // ascending split order: deterministic
         const f32x4 a = *reinterpret_cast<const f32x4*>(wp), b = *reinterpret_cast<const f32x4*>(wp + 4);
+        wp += sstride;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             v[e] += a[e];
             v[4 + e] += b[e];
         }
     }
+    if (p.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        if (p.bias) v[e] += p.bias[n + e];
-        if (p.rowvec) v[e] += p.rowvec[(m / p.rows_per_sample) * p.rv_stride + n + e];
-        if (p.act == 1) v[e] = silu_f(v[e]);
-        if (p.rowadd) v[e] += p.rowadd[m];
+        for (int e = 0; e < 4; ++e) {
+            v[e] += b0[e];
+            v[4 + e] += b1[e];
+        }
+    }
+    if (p.rowvec) {
+        const float* rvp = p.rowvec + (long long)(m / p.rows_per_sample) * p.rv_stride + n;
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rvp), r1 = *reinterpret_cast<const f32x4*>(rvp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] += r0[e];
+            v[4 + e] += r1[e];
+        }
+    }
+    if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+    }
+    if (p.rowadd) {
+        const float ra = p.rowadd[m];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += ra;
     }
     if (p.tap && n < p.tap_cols) {
         f16x8 t;
@@ -1354,7 +1375,7 @@ __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
         *reinterpret_cast<f16x8*>(p.tap2 + tap_row(p, m) * p.tap_ld + (n - p.tap_cols)) = t;
     }
     if (p.residual) {
-        const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + m * p.ldr + n);
+        const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + (long long)m * p.ldr + n);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
     }
@@ -1362,12 +1383,12 @@ __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
         bf16x8_t o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(v[e]);
-        *reinterpret_cast<bf16x8_t*>(p.out + m * p.ldo + n) = o;
+        *reinterpret_cast<bf16x8_t*>(p.out + (long long)m * p.ldo + n) = o;
     }
     if (p.out_f32) {
         f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-        *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldo + n) = a;
-        *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldo + n + 4) = b;
+        *reinterpret_cast<f32x4*>(p.out_f32 + (long long)m * p.ldo + n) = a;
+        *reinterpret_cast<f32x4*>(p.out_f32 + (long long)m * p.ldo + n + 4) = b;
     }
 }
 

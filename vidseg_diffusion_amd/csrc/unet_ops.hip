@@ -24,17 +24,18 @@ __device__ __forceinline__ const bf16_t* src_ptr(const bf16_t* x0, const bf16_t*
 // Thread layout shared by pass 1 and pass 3: a block covers `rpb` consecutive rows at a time, thread t owns channels
 // 8*(t % (C/8)).. of row (t / (C/8)); the channel octet (and with it gamma/beta/scale/shift and the concat source) is
 // fixed for the thread's lifetime, rows advance by rpb.  A block touches rpb*C*2 contiguous bytes per iteration.
-#define GN_ROWS_PER_CHUNK 64
+// Rows per chunk (= per block) are chosen by the host (ops.gn_rows_per_chunk): 64 where that already gives >= 1024 blocks, fewer at
+// the low-resolution levels -- a 28 x 8 x 8 x 2560 tensor as 28 blocks of 64 sequential row iterations took 30 us for 3.7 MB.
 
 __global__ void __launch_bounds__(1024) k_gn_partial(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, int C0, int C1, int HW,
-                                                     int rpb, int nchunk, float* __restrict__ part) {
+                                                     int rpb, int nchunk, int rpc, float* __restrict__ part) {
     extern __shared__ float gn_red[];                      // [rpb][2][C]
     const int C = C0 + C1, c8n = C / 8;
     const int tid = threadIdx.x;
     const int lrow = tid / c8n, c = (tid - lrow * c8n) * 8;
     const int b = blockIdx.y, ch = blockIdx.x;
     const bool active = lrow < rpb;
-    const int r0 = ch * GN_ROWS_PER_CHUNK, r1 = min(HW, r0 + GN_ROWS_PER_CHUNK);
+    const int r0 = ch * rpc, r1 = min(HW, r0 + rpc);
     float s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
@@ -109,13 +110,13 @@ __global__ void __launch_bounds__(256) k_gn_stats(const float* __restrict__ part
 }
 
 __global__ void __launch_bounds__(1024) k_gn_apply(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, int C0, int C1, int HW,
-                                                   int rpb, const float* __restrict__ stats, int silu, bf16_t* __restrict__ out) {
+                                                   int rpb, int rpc, const float* __restrict__ stats, int silu, bf16_t* __restrict__ out) {
     const int C = C0 + C1, c8n = C / 8;
     const int tid = threadIdx.x;
     const int lrow = tid / c8n, c = (tid - lrow * c8n) * 8;
     if (lrow >= rpb) return;
     const int b = blockIdx.y;
-    const int r0 = blockIdx.x * GN_ROWS_PER_CHUNK, r1 = min(HW, r0 + GN_ROWS_PER_CHUNK);
+    const int r0 = blockIdx.x * rpc, r1 = min(HW, r0 + rpc);
     const float* st = stats + (long long)b * 2 * C;
     const f32x4 sc0 = *reinterpret_cast<const f32x4*>(st + c), sc1 = *reinterpret_cast<const f32x4*>(st + c + 4);
     const f32x4 sh0 = *reinterpret_cast<const f32x4*>(st + C + c), sh1 = *reinterpret_cast<const f32x4*>(st + C + c + 4);
@@ -1181,11 +1182,12 @@ __global__ void k_gaussian_sample(const float* __restrict__ moments, const float
 extern "C" {
 
 int vidseg_groupnorm_nhwc_a16(const void* x0, const void* x1, int C0, int C1, int B, int HW, int G, const float* gamma,
-                               const float* beta, float eps, int silu, float* part, int part_floats, float* stats, int stats_floats,
-                               void* out, hipStream_t st) {
+                               const float* beta, float eps, int silu, int rows_per_chunk, float* part, int part_floats, float* stats,
+                               int stats_floats, void* out, hipStream_t st) {
     const int C = C0 + (x1 ? C1 : 0);
     VS_REQUIRE(C % G == 0 && C0 % 8 == 0 && (!x1 || C1 % 8 == 0) && C <= 8192, "groupnorm: C0=%d C1=%d G=%d", C0, C1, G);
-    const int nchunk = (HW + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK;
+    VS_REQUIRE(rows_per_chunk >= 1, "groupnorm: rows_per_chunk=%d", rows_per_chunk);
+    const int nchunk = (HW + rows_per_chunk - 1) / rows_per_chunk;
     VS_REQUIRE((long long)B * nchunk * 2 * C <= part_floats, "groupnorm: partial buffer too small (%lld > %d)",
                (long long)B * nchunk * 2 * C, part_floats);
     VS_REQUIRE((long long)B * 2 * C <= stats_floats, "groupnorm: scale/shift buffer too small (%lld > %d)", (long long)B * 2 * C,
@@ -1194,9 +1196,9 @@ int vidseg_groupnorm_nhwc_a16(const void* x0, const void* x1, int C0, int C1, in
     const int rpb = c8n >= 256 ? 1 : 256 / c8n;               // rows a block covers per iteration
     const int nthr = ((c8n * rpb + 63) / 64) * 64;
     k_gn_partial<<<dim3(nchunk, B), nthr, (size_t)rpb * 2 * C * sizeof(float), st>>>((const bf16_t*)x0, (const bf16_t*)x1, C0,
-                                                                                      x1 ? C1 : 0, HW, rpb, nchunk, part);
+                                                                                      x1 ? C1 : 0, HW, rpb, nchunk, rows_per_chunk, part);
     k_gn_stats<<<dim3(G, B), 256, 0, st>>>(part, C, G, HW, nchunk, eps, gamma, beta, stats);
-    k_gn_apply<<<dim3(nchunk, B), nthr, 0, st>>>((const bf16_t*)x0, (const bf16_t*)x1, C0, x1 ? C1 : 0, HW, rpb, stats, silu,
+    k_gn_apply<<<dim3(nchunk, B), nthr, 0, st>>>((const bf16_t*)x0, (const bf16_t*)x1, C0, x1 ? C1 : 0, HW, rpb, rows_per_chunk, stats, silu,
                                                  (bf16_t*)out);
     VS_CHECK_LAUNCH("groupnorm");
     return VS_OK;

@@ -23,7 +23,7 @@ _lib.register({
     "vidseg_gaussian_sample": [_P, _P, _I, _I, _I, _F, _P, _P],
     "vidseg_conv_in": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "vidseg_conv_out4": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
-    "vidseg_groupnorm_nhwc_a16": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _I, _P, _P],
+    "vidseg_groupnorm_nhwc_a16": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _I, _P, _I, _P, _I, _P, _P],
     "vidseg_layernorm_a16": [_P, _L, _I, _P, _P, _F, _P, _P],
     "vidseg_attention_a16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "vidseg_attention_fp8": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -236,6 +236,19 @@ def window_cached(owner, slot, deps, make):
     return val
 
 
+_GN_RPC_FORCE = int(os.environ.get("VIDSEG_GN_RPC", "0"))       # experiments: a fixed chunk (another fp32 summation order of the statistics)
+
+
+def gn_rows_per_chunk(B, HW):
+    """Rows of one sample per GroupNorm block: 64 where that already gives >= 1024 blocks, halved (down to 4) until it does."""
+    if _GN_RPC_FORCE:
+        return _GN_RPC_FORCE
+    rpc = 64
+    while rpc > 4 and B * ((HW + rpc - 1) // rpc) < 1024:
+        rpc //= 2
+    return rpc
+
+
 def groupnorm(x0, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True):
     """GroupNorm32 (+SiLU) over NHWC bf16 [B, H, W, C0] (+concat x1) -> bf16 [B, H, W, C0+C1]."""
     B = x0.shape[0]
@@ -243,13 +256,14 @@ def groupnorm(x0, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True):
     C1 = x1.shape[-1] if x1 is not None else 0
     HW = x0.numel() // (B * C0)
     ws = workspace(x0.device)
-    need = B * ((HW + 63) // 64) * 2 * (C0 + C1)                     # per-chunk partial sums (GN_ROWS_PER_CHUNK = 64)
+    rpc = gn_rows_per_chunk(B, HW)
+    need = B * ((HW + rpc - 1) // rpc) * 2 * (C0 + C1)                # per-chunk partial sums
     if need > ws.part.numel():                                        # first-stage activations at 576x1024 need 33 M floats
         ws.part = torch.empty(need, dtype=F32, device=x0.device)
     if B * 2 * (C0 + C1) > ws.stats.numel():
         ws.stats = torch.empty(B * 2 * (C0 + C1), dtype=F32, device=x0.device)
     out = torch.empty(x0.shape[:-1] + (C0 + C1,), dtype=act_dtype(), device=x0.device)
-    call("vidseg_groupnorm_nhwc_a16", ptr(x0), ptr(x1), C0, C1, B, HW, groups, ptr(gamma), ptr(beta), eps, int(silu),
+    call("vidseg_groupnorm_nhwc_a16", ptr(x0), ptr(x1), C0, C1, B, HW, groups, ptr(gamma), ptr(beta), eps, int(silu), rpc,
          ptr(ws.part), ws.part.numel(), ptr(ws.stats), ws.stats.numel(), ptr(out), stream())
     return out
 

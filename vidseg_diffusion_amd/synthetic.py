@@ -124,10 +124,18 @@ def region_labels(num_frames: int, h: int, w: int, num_regions: int, seed: int) 
     return out
 
 
-def region_prototypes(num_regions: int, channels: int, seed: int, min_dist: float = 1.2) -> np.ndarray:
-    """`num_regions` unit-scale prototype vectors with pairwise Euclidean distance >= min_dist (rejection sampling on the
-    seeded stream), float64 [R, channels]."""
+def region_prototypes(num_regions: int, channels: int, seed: int, min_dist: float = 1.2, kind: str = "random") -> np.ndarray:
+    """`num_regions` prototype vectors, float64 [R, channels].  kind="random": unit-scale normal draws with pairwise Euclidean
+    distance >= min_dist (rejection sampling on the seeded stream).  kind="lattice" (channels = 4, R <= 24): a seeded choice
+    among the 16 vertices (+-1, +-1, +-1, +-1) and the 8 axis points +-2 e_i -- every point has norm 2 (rms 1 per channel) and
+    every pair is at least 2 apart, the densest such set in four dimensions (the 24-cell)."""
     g = _rng(seed)
+    if kind == "lattice":
+        if channels != 4 or num_regions > 24:
+            raise ValueError("lattice prototypes: 4 channels, at most 24 regions")
+        pts = [[a, b, c, d] for a in (-1, 1) for b in (-1, 1) for c in (-1, 1) for d in (-1, 1)]
+        pts += [[2 * sgn if i == ax else 0 for i in range(4)] for ax in range(4) for sgn in (-1, 1)]
+        return np.asarray(pts, dtype=np.float64)[g.permutation(24)[:num_regions]]
     protos = []
     while len(protos) < num_regions:
         p = g.standard_normal(channels)
@@ -137,16 +145,16 @@ def region_prototypes(num_regions: int, channels: int, seed: int, min_dist: floa
 
 
 def region_clip(num_frames: int, h: int, w: int, num_regions: int = 20, seed: int = 1, channels: int = 4, amp: float = 1.5,
-                noise: float = 0.05) -> np.ndarray:
+                noise: float = 0.05, protos: str = "random") -> np.ndarray:
     """Seeded piecewise-constant latent: `num_regions` drifting Voronoi cells, each with its own well-separated prototype
     vector, + white noise; float32 [F, C, h, w] at the scale of an encode_first_stage output (std ~ 1).  The headline
     workload (bench.py, tests at BASELINE configs[1]) uses it with num_regions = the number of masks, so that the K-means
     problem Steps 3-3b solve has K natural clusters (a clip of K objects) instead of over-segmenting a 6-blob scene, whose
     partition is decided by the last bits of the features."""
     lab = region_labels(num_frames, h, w, num_regions, seed + 4000)
-    protos = region_prototypes(num_regions, channels, seed + 5000)
+    pv = region_prototypes(num_regions, channels, seed + 5000, kind=protos)
     g = _rng(seed)
-    lat = protos[lab] * amp + noise * g.standard_normal((num_frames, h, w, channels))
+    lat = pv[lab] * amp + noise * g.standard_normal((num_frames, h, w, channels))
     return np.ascontiguousarray(lat.transpose(0, 3, 1, 2)).astype(np.float32)
 
 
@@ -155,12 +163,12 @@ def region_clip(num_frames: int, h: int, w: int, num_regions: int = 20, seed: in
 # propagated from frame 0, feature_extraction.py:546-643) has K natural clusters -- through a network near the reference's own
 # initialisation (zero_gain): with the generic random network the K = 20 partition of the 6-blob clip was decided by the last
 # bits of the taps (16 % of the tokens moved under an fp16-rounding-level perturbation; tools/cond_probe.py measures this).
-HEADLINE = dict(num_regions=20, amp=1.5, noise=0.05, zero_gain=0.3)
+HEADLINE = dict(num_regions=20, amp=2.0, noise=0.05, zero_gain=0.3, protos="lattice")
 
 
 def headline_latent(num_frames: int, h: int, w: int, window_id: int = 0) -> np.ndarray:
     return region_clip(num_frames, h, w, num_regions=HEADLINE["num_regions"], seed=1 + window_id, amp=HEADLINE["amp"],
-                       noise=HEADLINE["noise"])
+                       noise=HEADLINE["noise"], protos=HEADLINE["protos"])
 
 
 def headline_partition(num_frames: int, h: int, w: int, window_id: int = 0) -> np.ndarray:
