@@ -240,12 +240,15 @@ _GN_RPC_FORCE = int(os.environ.get("VIDSEG_GN_RPC", "0"))       # experiments: a
 
 
 def gn_rows_per_chunk(B, HW):
-    """Rows of one sample per GroupNorm block: 64 where that already gives >= 1024 blocks, halved (down to 4) until it does."""
+    """Rows of one sample per GroupNorm block: HW / 64 clamped to [4, 64] and rounded down to a power of two -- at least 64 (16 for an
+    8 x 8 map) blocks per sample.  A function of HW alone: the chunking fixes the fp32 summation order of the statistics, and a
+    sample's result must not depend on how many other samples share the launch (chunked first-stage decodes, the batch-chunked
+    reference runs)."""
     if _GN_RPC_FORCE:
         return _GN_RPC_FORCE
-    rpc = 64
-    while rpc > 4 and B * ((HW + rpc - 1) // rpc) < 1024:
-        rpc //= 2
+    rpc = 4
+    while rpc < 64 and rpc * 2 * 64 <= HW:
+        rpc *= 2
     return rpc
 
 
