@@ -7,8 +7,8 @@ import sys
 
 
 ALL = len(sys.argv) > 4 and sys.argv[4] == "all"      # every kernel of the family instead of the big tile only
-FAM = ("k_gemm_ph", "k_gemm_dma", "k_gemm_tile", "k_gemm_conv") if ALL else ("k_gemm_ph",)
-KINDS = (0, 1, 2, 3) if ALL else (1,)
+FAM = ("k_gemm_ph", "k_gemm_p7", "k_gemm_dma", "k_gemm_tile", "k_gemm_conv") if ALL else ("k_gemm_ph", "k_gemm_p7")
+KINDS = (0, 1, 2, 3, 4) if ALL else (1, 4)
 
 
 def vals(db_path, counter):
