@@ -160,8 +160,26 @@ def feature_pass(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, num
         _taps_only_eval(engine, sampler, x, c, F, num_steps, want)
         save_feature_maps(engine, feature_folder, exp_name, want, xt=None, block_filter=(6, 7, 8), pad_uncond=True)
     else:
-        sampler(denoiser, x, cond=c, uc=uc, img_callback=callback, is_modulate=False, modulate_params=None, uc_list=None,
-                t_start=t_start, is_latent_blending=False)                          # Step 2, SDP:357
+        net = engine.model.diffusion_model
+        if keep_all_steps or not hasattr(net, "tap_mode"):
+            den = denoiser
+        else:
+            # only step `want` is dumped: the fp16 Q/K tap copies of the other steps (1.5 GB per evaluation at config 2) would be
+            # written and never read.  The network's outputs do not depend on the taps.
+            calls, mode0 = [0], net.tap_mode
+
+            def den(inp, sigma, cc, **kw):
+                net.tap_mode = mode0 if t_start + calls[0] == want else "none"
+                net._set_taps()
+                calls[0] += 1
+                return denoiser(inp, sigma, cc, **kw)
+        try:
+            sampler(den, x, cond=c, uc=uc, img_callback=callback, is_modulate=False, modulate_params=None, uc_list=None,
+                    t_start=t_start, is_latent_blending=False)                      # Step 2, SDP:357
+        finally:
+            if den is not denoiser:
+                net.tap_mode = mode0
+                net._set_taps()
     done = torch.cuda.Event()
     done.record(torch.cuda.current_stream())
     return dict(F=F, fh=lh // 2, fw=lw // 2, t_start=t_start, feature_timestep=feature_timestep, seed=seed, feature_folder=feature_folder,
