@@ -714,12 +714,19 @@ __global__ void __launch_bounds__(256, 3) k_attention_mx8(const unsigned char* _
 
 // Two query blocks per wave (64 queries): every K / V fragment read from LDS feeds two MFMAs -- half the LDS traffic per
 // flop of k_attention, at twice the accumulator registers (occupancy 2).
-template <bool RAGGED>
+// TRV: the V tile stays row-major in LDS ([key][d], 192-B rows: two ds_write_b128 per thread instead of sixteen ds_write_b16) and
+// the V^T fragment of the PV MFMA comes from the gfx950 transpose read ds_read_b64_tr_b16: inside a 16-lane group, lane i passes
+// the address of row i >> 2, columns 4 (i & 3) .. +3 of a [4 keys][16 d] block and receives column i, keys 0..3
+// (tools/ubench/tr_layout.hip checks this on the device).  Row stride 48 dwords puts the 4 rows x 2 d-groups of a 32-lane half
+// on all 64 banks once.
+#define VR_LD 96
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+template <bool RAGGED, bool TRV>
 __global__ void __launch_bounds__(256, 2) k_attention2(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                    const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo, int Nq,
                                                    int Nk, int H, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) char sK2[2][64 * 128];          // K tile [key][d], 16-B slot XOR swizzle, double buffered
-    __shared__ __attribute__((aligned(16))) bf16_t sVt2[2][64 * VT_LD];     // V tile transposed [d][key]
+    __shared__ __attribute__((aligned(16))) bf16_t sVt2[2][64 * (TRV ? VR_LD : VT_LD)];     // V tile: transposed [d][key], or [key][d] (TRV)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     int bh, qb;
@@ -766,10 +773,16 @@ __global__ void __launch_bounds__(256, 2) k_attention2(const bf16_t* __restrict_
         for (int i = 0; i < 2; ++i) {
             const int r = (tid >> 3) + 32 * i;
             *reinterpret_cast<u32x4*>(sK2[buf] + r * 128 + ((st_ch ^ (r & 7)) << 4)) = rk[i];
+            if (TRV) {
+                *reinterpret_cast<bf16x8_t*>(sVt2[buf] + r * VR_LD + st_ch * 8) = rv[i];
+            } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sVt2[buf][(st_ch * 8 + e) * VT_LD + r] = (bf16_t)rv[i][e];
+                for (int e = 0; e < 8; ++e) sVt2[buf][(st_ch * 8 + e) * VT_LD + r] = (bf16_t)rv[i][e];
+            }
         }
     };
+    // TRV: this lane's address inside the [4 keys][16 d] block of its 16-lane group (keys 4 hi + .., d-group (lane >> 4) & 1)
+    const int vtr_base = (4 * hi + ((lane & 15) >> 2)) * VR_LD + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
     stage_load(0);
     stage_store(0);
     __syncthreads();
@@ -852,11 +865,21 @@ __global__ void __launch_bounds__(256, 2) k_attention2(const bf16_t* __restrict_
                 const int kb = j * 32 + s * 16 + 4 * hi;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const bf16_t* vr = sVt + (i * 32 + l31) * VT_LD + kb;
-                    const u32x2 lo = *reinterpret_cast<const u32x2*>(vr);
-                    const u32x2 hi2 = *reinterpret_cast<const u32x2*>(vr + 8);
-                    u32x4 pv = {lo[0], lo[1], hi2[0], hi2[1]};
-                    const bf16x8_t fv = *reinterpret_cast<bf16x8_t*>(&pv);
+                    bf16x8_t fv;
+                    if (TRV) {
+                        typedef __attribute__((address_space(3))) s16x4_t* lds4_t;
+                        const bf16_t* vr = sVt + vtr_base + (j * 32 + s * 16) * VR_LD + i * 32;
+                        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)vr);
+                        const s16x4_t hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vr + 8 * VR_LD));
+                        struct { s16x4_t a, b; } pv = {lo, hi2};
+                        fv = *reinterpret_cast<bf16x8_t*>(&pv);
+                    } else {
+                        const bf16_t* vr = sVt + (i * 32 + l31) * VT_LD + kb;
+                        const u32x2 lo = *reinterpret_cast<const u32x2*>(vr);
+                        const u32x2 hi2 = *reinterpret_cast<const u32x2*>(vr + 8);
+                        u32x4 pv = {lo[0], lo[1], hi2[0], hi2[1]};
+                        fv = *reinterpret_cast<bf16x8_t*>(&pv);
+                    }
 #pragma unroll
                     for (int qb = 0; qb < 2; ++qb) {
                         u32x4 pw = {pk[qb][j][s * 4 + 0], pk[qb][j][s * 4 + 1], pk[qb][j][s * 4 + 2], pk[qb][j][s * 4 + 3]};
@@ -1221,9 +1244,14 @@ int vidseg_attention_a16(const void* q, int ldq, const void* k, int ldk, const v
     // 64 queries per wave for long sequences (measured: 4096 tokens 1034 -> 947 us, 1024 tokens unchanged); VIDSEG_ATTN2=0 disables
     static int attn2 = -1;
     if (attn2 < 0) { const char* e = getenv("VIDSEG_ATTN2"); attn2 = e ? atoi(e) : 1; }
-    if (attn2 && Nk % 64 == 0 && Nq >= 2048)
-        k_attention2<false><<<dim3((Nq + 255) / 256, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
-                                                                            (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
+    static int attn_tr = -1;                                               // VIDSEG_ATTN_TR=0: V transposed by the LDS store instead
+    if (attn_tr < 0) { const char* e = getenv("VIDSEG_ATTN_TR"); attn_tr = e ? atoi(e) : 1; }
+    if (attn2 && Nk % 64 == 0 && Nq >= 2048 && attn_tr)
+        k_attention2<false, true><<<dim3((Nq + 255) / 256, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v,
+                                                                                  ldv, (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
+    else if (attn2 && Nk % 64 == 0 && Nq >= 2048)
+        k_attention2<false, false><<<dim3((Nq + 255) / 256, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v,
+                                                                                   ldv, (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
     else if (Nk % 64 == 0)
         k_attention<false><<<dim3((Nq + 127) / 128, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
                                                                            (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
