@@ -1,0 +1,12 @@
+"""Experiment builds of the same C ABI with extra -D flags: python tools/build_exp.py NAME -DFOO=1 ...  writes
+vidseg_diffusion_amd/libvidseg_exp_NAME.so; load it with VIDSEG_LIB=libvidseg_exp_NAME.so (see _lib.py)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as G  # noqa: E402
+
+name, defines = sys.argv[1], sys.argv[2:]
+G._build_variant(os.path.join(ROOT, "vidseg_diffusion_amd", f"libvidseg_exp_{name}.so"), f".exp_{name}", defines, True)
+print("built", name, defines)

@@ -240,6 +240,8 @@ __global__ void __launch_bounds__(256, 3) k_attention(const bf16_t* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(fq[s]));        // Q has landed before the loop (see k_attention2)
 
     const int ntiles = (Nk + 63) / 64;
     // K/V staging: global -> registers one tile ahead (issued before the MFMAs of the current tile), registers -> LDS
@@ -271,7 +273,7 @@ __global__ void __launch_bounds__(256, 3) k_attention(const bf16_t* __restrict__
         const int k0 = t * 64;
         const char* sK = sK2[t & 1];
         const bf16_t* sVt = sVt2[t & 1];
-        if (t + 1 < ntiles) stage_load(t + 1);
+        stage_load(t + 1);                                  // unconditional (keys clamp to Nk - 1), see k_attention2
         // S^T[j] : rows = keys j*32 + .., cols = queries
         f32x16 sacc[2];
 #pragma unroll
@@ -349,7 +351,7 @@ __global__ void __launch_bounds__(256, 3) k_attention(const bf16_t* __restrict__
                     oacc[i] = mfma_32x32x16(fv, fp, oacc[i]);
                 }
             }
-        if (t + 1 < ntiles) stage_store((t + 1) & 1);
+        stage_store((t + 1) & 1);
         __syncthreads();
     }
     // write O: lane owns query q0 + l31; oacc[i][r] is d = i*32 + (r&3) + 8*(r>>2) + 4*hi
@@ -441,6 +443,8 @@ __global__ void __launch_bounds__(256, 3) k_attention_fp8(const unsigned char* _
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(fq[s]));        // Q has landed before the loop (see k_attention2)
 
     const int ntiles = (Nk + 63) / 64;
     // staging: thread -> (key = tid>>2, 16-byte chunk tid&3) of the 64 x 64-byte K and V tiles, one tile ahead in registers
@@ -465,7 +469,7 @@ __global__ void __launch_bounds__(256, 3) k_attention_fp8(const unsigned char* _
         const int k0 = t * 64;
         const unsigned char* sK = sK2[t & 1];
         const unsigned char* sVt = sVt2[t & 1];
-        if (t + 1 < ntiles) stage_load(t + 1);
+        stage_load(t + 1);                                  // unconditional (keys clamp to Nk - 1), see k_attention2
         f32x16 sacc[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -543,7 +547,7 @@ __global__ void __launch_bounds__(256, 3) k_attention_fp8(const unsigned char* _
                     oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(*reinterpret_cast<const long*>(&pv), fp, oacc[i], 0, 0, 0);
                 }
             }
-        if (t + 1 < ntiles) stage_store((t + 1) & 1);
+        stage_store((t + 1) & 1);
         __syncthreads();
     }
     const int qi = q0 + l31;
@@ -599,6 +603,7 @@ __global__ void __launch_bounds__(256, 3) k_attention_mx8(const unsigned char* _
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    asm volatile("" ::"v"(fq));                             // Q has landed before the loop (see k_attention2)
 
     const int ntiles = (Nk + 63) / 64;
     u32x4 rk, rv;
@@ -621,7 +626,7 @@ __global__ void __launch_bounds__(256, 3) k_attention_mx8(const unsigned char* _
         const int k0 = t * 64;
         const unsigned char* sK = sK2[t & 1];
         const unsigned char* sVt = sVt2[t & 1];
-        if (t + 1 < ntiles) stage_load(t + 1);
+        stage_load(t + 1);                                  // unconditional (keys clamp to Nk - 1), see k_attention2
         f32x16 sacc[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -694,7 +699,7 @@ __global__ void __launch_bounds__(256, 3) k_attention_mx8(const unsigned char* _
             const v8i_t fv = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
             oacc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fv, fp, oacc[i], 0, 0, 0, ONE, 0, ONE);
         }
-        if (t + 1 < ntiles) stage_store((t + 1) & 1);
+        stage_store((t + 1) & 1);
         __syncthreads();
     }
     const int qi = q0 + l31;
@@ -753,6 +758,10 @@ __global__ void __launch_bounds__(256, 2) k_attention2(const bf16_t* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[qb][i][r] = 0.f;
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)                          // Q has landed before the loop: no vmcnt bookkeeping for it inside
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(fq[qb][s]));
 
     const int ntiles = (Nk + 63) / 64;
     // K/V staging: global -> registers one tile ahead (issued before the MFMAs of the current tile), registers -> LDS
@@ -790,7 +799,7 @@ __global__ void __launch_bounds__(256, 2) k_attention2(const bf16_t* __restrict_
         const int k0 = t * 64;
         const char* sK = sK2[t & 1];
         const bf16_t* sVt = sVt2[t & 1];
-        if (t + 1 < ntiles) stage_load(t + 1);
+        stage_load(t + 1);        // unconditional (keys clamp to Nk - 1): a skipped load would make the compiler drain vmcnt inside the S MFMAs
         // S^T[j] : rows = keys j*32 + .., cols = queries
         f32x16 sacc[2][2];                                             // [query block][key block j]
 #pragma unroll
@@ -813,6 +822,14 @@ __global__ void __launch_bounds__(256, 2) k_attention2(const bf16_t* __restrict_
         unsigned pk[2][2][8];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
+#if VS_ATTN_ABLATE & 2                                                         /* no softmax at all: P = S */
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) pk[qb][j][r >> 1] = pack2_bf16(sacc[qb][j][r], sacc[qb][j][r + 1]);
+            l_run[qb] = 1.f;
+            continue;
+#endif
         // online softmax for this lane's query; key index of sacc[qb][j][r] = k0 + j*32 + (r&3) + 8*(r>>2) + 4*hi.
             // VALU budget matters as much as MFMA here: max on raw scores, scale folded into one fma per element,
             // masking only on the ragged last tile, O rescale skipped when no lane's running max moved.
@@ -839,7 +856,11 @@ __global__ void __launch_bounds__(256, 2) k_attention2(const bf16_t* __restrict_
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const vs_f32x2 a = vs_f32x2{sacc[qb][j][r], sacc[qb][j][r + 1]} * sc2 + mn2;        // v_pk_fma_f32
+#if VS_ATTN_ABLATE & 1                                                         /* experiment builds only (tools/build_exp.py) */
+                    const vs_f32x2 p = a;
+#else
                     const vs_f32x2 p = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+#endif
                     psum2 += p;                                                               // v_pk_add_f32
                     pk[qb][j][r >> 1] = pack2_bf16(p[0], p[1]);
                 }
@@ -888,7 +909,7 @@ __global__ void __launch_bounds__(256, 2) k_attention2(const bf16_t* __restrict_
                     }
                 }
             }
-        if (t + 1 < ntiles) stage_store((t + 1) & 1);
+        stage_store((t + 1) & 1);
         __syncthreads();
     }
     // write O: lane owns query q0 + l31; oacc[i][r] is d = i*32 + (r&3) + 8*(r>>2) + 4*hi
