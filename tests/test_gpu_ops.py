@@ -248,6 +248,32 @@ def test_attention(dev, B, H, Nq, Nk):
     assert ((out - ref).abs() <= tol).all(), f"attention max err {(out - ref).abs().max():.4g}"
 
 
+def test_attention_reference_moves(dev):
+    """k_attention3 keeps a lazily updated softmax reference instead of the running maximum: scores that keep growing along the
+    key axis (each 64-key tile ~6 above the one before in log2 units, and one late outlier key) force the re-referencing path
+    on every few tiles; scores that collapse after the first tile leave the reference far above the rest of the row."""
+    from vidseg_diffusion_amd import ops
+    B, H, N = 1, 2, 2304
+    C = H * 64
+    g = torch.Generator().manual_seed(5)
+    u = torch.randn((64,), generator=g)
+    u = u / u.norm()
+    for kind in ("grow", "collapse"):
+        q = 0.3 * torch.randn((B, N, H, 64), generator=g) + 8.0 * u
+        ramp = torch.linspace(0.0, 1.0, N) if kind == "grow" else (torch.arange(N) < 64).float()
+        k = 0.3 * torch.randn((B, N, H, 64), generator=g) + (38.0 * ramp)[None, :, None, None] * u
+        if kind == "grow":
+            k[:, 2000] += 20.0 * u
+        v = torch.randn((B, N, H, 64), generator=g)
+        q, k, v = (t.reshape(B, N, C).to(ops.act_dtype()) for t in (q, k, v))
+        qh, kh, vh = (t.float().view(B, N, H, 64).transpose(1, 2) for t in (q, k, v))
+        ref = TF.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, N, C)
+        out = ops.attention(q.to(dev), k.to(dev), v.to(dev), H).float().cpu()
+        assert torch.isfinite(out).all()
+        tol = (2.0 ** -7) * ref.abs() + 2e-3 * ref.abs().max()
+        assert ((out - ref).abs() <= tol).all(), f"{kind}: attention max err {(out - ref).abs().max():.4g}"
+
+
 def test_attention_fused_qkv_strides(dev):
     from vidseg_diffusion_amd import ops
     B, H, N = 2, 2, 128

@@ -1,3 +1,5 @@
+// HIPCC_FLAGS: -fno-slp-vectorize
+// (packed fp32 VALU beside MFMAs costs ~10 cycles an instruction and does not overlap them: tools/ubench/mfma_valu.hip)
 // Non-GEMM UNet operators for gfx950 on NHWC bf16 activations: GroupNorm(+SiLU) over an optional
 // two-source channel concat, LayerNorm, flash-style attention (head dim 64, MFMA), timestep embedding,
 // and the sampler's small elementwise steps.
@@ -932,6 +934,426 @@ __global__ void __launch_bounds__(256, 2) k_attention2(const bf16_t* __restrict_
     }
 }
 
+// k_attention2's tile schedule with a softmax whose common path is 32 exp2 + 16 packed adds + 16 conversions per 32 queries and
+// nothing else.  PMC on k_attention2 (tools/pmc_attn.sh): 279 VALU instructions per wave and K/V tile against 32 MFMAs -- the
+// kernel is bound by VALU issue slots (MFMA pipe 40 % busy), so the instructions that are not exp / row sum / conversion go:
+//   * Q is pre-multiplied by dim_head^-0.5 log2(e) once, in the prologue (one extra 16-bit rounding of Q);
+//   * the running reference m of a query is SUBTRACTED BY THE MATRIX PIPE: a fifth K-step per S block multiplies a constant
+//     [1 0 0 ...] K-side fragment with a Q-side fragment holding -m (m is kept 16-bit-representable, so the product is exact
+//     and every use of m sees the same value) -- the accumulator comes out as the exp2 argument;
+//   * m is not the running maximum but any reference that keeps p in range: it is set from the true row maximum on the first
+//     tile and again only when a tile's row sum exceeds 2^12 (p is carried in 16 bits, accumulators in fp32), so the per-tile
+//     max / compare / rescale chain is off the common path.  softmax is invariant to m; only rounding-level differences.
+template <bool RAGGED>
+__global__ void __launch_bounds__(256, 2) k_attention3(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                                                   const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo, int Nq,
+                                                   int Nk, int H, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) char sK2[2][64 * 128];          // K tile [key][d], 16-B slot XOR swizzle, double buffered
+    __shared__ __attribute__((aligned(16))) bf16_t sV2[2][64 * VR_LD];      // V tile [key][d], read with ds_read_b64_tr_b16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int bh, qb0;
+    attn_block(bh, qb0);
+    const int b = bh / H, h = bh % H;
+    const int q0 = qb0 * 256 + wave * 64;
+    const bf16_t* qp = q + (long long)b * Nq * ldq + h * 64;
+    const bf16_t* kp = k + (long long)b * Nk * ldk + h * 64;
+    const bf16_t* vp = v + (long long)b * Nk * ldv + h * 64;
+
+    bf16x8_t fq[2][4];                                      // Q^T scaled, as the MFMA B operand: query q0 + l31, d = s*16 + hi*8 .. +8
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = min(q0 + qb * 32 + l31, Nq - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8_t raw = *reinterpret_cast<const bf16x8_t*>(qp + (long long)qi * ldq + s * 16 + hi * 8);
+            u32x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                w[e] = pack2_bf16(bf16_to_f32((bf16_t)raw[2 * e]) * scale_log2e, bf16_to_f32((bf16_t)raw[2 * e + 1]) * scale_log2e);
+            fq[qb][s] = *reinterpret_cast<bf16x8_t*>(&w);
+        }
+    }
+    // the fifth K-step: K side = e_0 (k-slot 0 lives in the hi == 0 lanes), Q side = -m of this lane's query in slot 0
+    u32x4 one_w = {hi == 0 ? (unsigned)f32_to_bf16(1.0f) : 0u, 0u, 0u, 0u};
+    const bf16x8_t fone = *reinterpret_cast<bf16x8_t*>(&one_w);
+    u32x4 fm_w[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    f32x16 oacc[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qb][i][r] = 0.f;
+    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(fq[qb][s]));
+
+    const int ntiles = (Nk + 63) / 64;
+    u32x4 rk[2];
+    bf16x8_t rv[2];
+    const int st_ch = tid & 7;
+    auto stage_load = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = min(t * 64 + (tid >> 3) + 32 * i, Nk - 1);
+            rk[i] = *reinterpret_cast<const u32x4*>(kp + (long long)key * ldk + st_ch * 8);
+            rv[i] = *reinterpret_cast<const bf16x8_t*>(vp + (long long)key * ldv + st_ch * 8);
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (tid >> 3) + 32 * i;
+            *reinterpret_cast<u32x4*>(sK2[buf] + r * 128 + ((st_ch ^ (r & 7)) << 4)) = rk[i];
+            *reinterpret_cast<bf16x8_t*>(sV2[buf] + r * VR_LD + st_ch * 8) = rv[i];
+        }
+    };
+    const int vtr_base = (4 * hi + ((lane & 15) >> 2)) * VR_LD + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * 64;
+        const char* sK = sK2[t & 1];
+        const bf16_t* sV = sV2[t & 1];
+        stage_load(t + 1);
+        f32x16 sacc[2][2];                                             // [query block][key block j]: S^T scale log2e - m
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                sacc[qb][j] = mfma_32x32x16(fone, *reinterpret_cast<bf16x8_t*>(&fm_w[qb]),
+                                            f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = j * 32 + l31;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int ch = s * 2 + hi;
+                const bf16x8_t fk = *reinterpret_cast<const bf16x8_t*>(sK + r * 128 + ((ch ^ (r & 7)) << 4));
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) sacc[qb][j] = mfma_32x32x16(fk, fq[qb][s], sacc[qb][j]);
+            }
+        }
+        unsigned pk[2][2][8];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            if (RAGGED && k0 + 64 > Nk) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = k0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (key >= Nk) sacc[qb][j][r] = -INFINITY;
+                    }
+            }
+            float ps4[4] = {0.f, 0.f, 0.f, 0.f};                      // plain v_add_f32: packed fp32 does not overlap MFMAs
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(sacc[qb][j][r]), p1 = __builtin_amdgcn_exp2f(sacc[qb][j][r + 1]);
+                    ps4[(r >> 1) & 1] += p0;
+                    ps4[2 + ((r >> 1) & 1)] += p1;
+                    pk[qb][j][r >> 1] = pack2_bf16(p0, p1);
+                }
+            float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+            psum += __shfl_xor(psum, 32, 64);
+            if (t == 0 || __any(!(psum <= 4096.f))) {
+                // re-reference: m <- the 16-bit rounding of (m + row maximum of this tile), never lowered after the first tile
+                float mx = sacc[qb][0][0];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qb][j][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = bf16_to_f32(f32_to_bf16(m_run[qb] + mx));
+                float d = m_new - m_run[qb];
+                if (t > 0) d = fmaxf(d, 0.f);
+                const vs_f32x2 d2 = {d, d};
+                vs_f32x2 psum2 = {0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const vs_f32x2 a = vs_f32x2{sacc[qb][j][r], sacc[qb][j][r + 1]} - d2;
+                        const vs_f32x2 p = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                        psum2 += p;
+                        pk[qb][j][r >> 1] = pack2_bf16(p[0], p[1]);
+                    }
+                psum = psum2[0] + psum2[1];
+                psum += __shfl_xor(psum, 32, 64);
+                if (t > 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(-d);
+                    l_run[qb] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[qb][i][r] *= alpha;
+                }
+                m_run[qb] += d;
+                fm_w[qb][0] = hi == 0 ? (unsigned)f32_to_bf16(-m_run[qb]) : 0u;
+            }
+            l_run[qb] += psum;
+        }
+        // O^T[qb][i] += V^T[d-block i] P^T[qb] : each V fragment is read once and used for both query blocks
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    typedef __attribute__((address_space(3))) s16x4_t* lds4_t;
+                    const bf16_t* vr = sV + vtr_base + (j * 32 + s * 16) * VR_LD + i * 32;
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)vr);
+                    const s16x4_t hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vr + 8 * VR_LD));
+                    struct { s16x4_t a, b; } pv = {lo, hi2};
+                    const bf16x8_t fv = *reinterpret_cast<bf16x8_t*>(&pv);
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) {
+                        u32x4 pw = {pk[qb][j][s * 4 + 0], pk[qb][j][s * 4 + 1], pk[qb][j][s * 4 + 2], pk[qb][j][s * 4 + 3]};
+                        const bf16x8_t fp = *reinterpret_cast<bf16x8_t*>(&pw);
+                        oacc[qb][i] = mfma_32x32x16(fv, fp, oacc[qb][i]);
+                    }
+                }
+            }
+        stage_store((t + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = q0 + qb * 32 + l31;
+        if (qi < Nq) {
+            const float inv = 1.0f / l_run[qb];
+            bf16_t* op = o + ((long long)b * Nq + qi) * ldo + h * 64;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    unsigned w0 = (unsigned)f32_to_bf16(oacc[qb][i][g * 4 + 0] * inv) | ((unsigned)f32_to_bf16(oacc[qb][i][g * 4 + 1] * inv) << 16);
+                    unsigned w1 = (unsigned)f32_to_bf16(oacc[qb][i][g * 4 + 2] * inv) | ((unsigned)f32_to_bf16(oacc[qb][i][g * 4 + 3] * inv) << 16);
+                    *reinterpret_cast<u32x2*>(op + i * 32 + 8 * g + 4 * hi) = u32x2{w0, w1};
+                }
+        }
+    }
+}
+
+// k_attention3 software-pipelined inside the wave.  The two waves a SIMD holds run the same phases and fall into step (the one
+// that lags gets the matrix pipe to itself and catches up), so MFMA and softmax VALU never overlapped across waves: MFMA-busy +
+// VALU-active was 93 % of the cycles.  Here the unit of work is a 32-key half tile u: while the matrix pipe computes S(u+1), the
+// VALU turns S(u) into P(u) in the same basic block (straight-line since k_attention3: exp2, row sum, conversion), then P(u) V(u).
+// K is staged two tiles ahead (ring of 3) because S(t+1, first half) runs before the end-of-tile barrier of tile t; V one (ring of 2).
+template <int OCC>
+__global__ void __launch_bounds__(256, OCC) k_attention4(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                                                   const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo, int Nq,
+                                                   int Nk, int H, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) char sK3[3][64 * 128];          // K tile [key][d], 16-B slot XOR swizzle
+    __shared__ __attribute__((aligned(16))) bf16_t sV2[2][64 * VR_LD];      // V tile [key][d], read with ds_read_b64_tr_b16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int bh, qb0;
+    attn_block(bh, qb0);
+    const int b = bh / H, h = bh % H;
+    const int q0 = qb0 * 256 + wave * 64;
+    const bf16_t* qp = q + (long long)b * Nq * ldq + h * 64;
+    const bf16_t* kp = k + (long long)b * Nk * ldk + h * 64;
+    const bf16_t* vp = v + (long long)b * Nk * ldv + h * 64;
+
+    bf16x8_t fq[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = min(q0 + qb * 32 + l31, Nq - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8_t raw = *reinterpret_cast<const bf16x8_t*>(qp + (long long)qi * ldq + s * 16 + hi * 8);
+            u32x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                w[e] = pack2_bf16(bf16_to_f32((bf16_t)raw[2 * e]) * scale_log2e, bf16_to_f32((bf16_t)raw[2 * e + 1]) * scale_log2e);
+            fq[qb][s] = *reinterpret_cast<bf16x8_t*>(&w);
+        }
+    }
+    u32x4 one_w = {hi == 0 ? (unsigned)f32_to_bf16(1.0f) : 0u, 0u, 0u, 0u};
+    const bf16x8_t fone = *reinterpret_cast<bf16x8_t*>(&one_w);
+    u32x4 fm_w[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    f32x16 oacc[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qb][i][r] = 0.f;
+    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+
+    const int ntiles = Nk / 64;
+    u32x4 rk[2];
+    bf16x8_t rv[2];
+    const int st_ch = tid & 7;
+    auto load_k = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rk[i] = *reinterpret_cast<const u32x4*>(kp + (long long)min(t * 64 + (tid >> 3) + 32 * i, Nk - 1) * ldk + st_ch * 8);
+    };
+    auto load_v = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rv[i] = *reinterpret_cast<const bf16x8_t*>(vp + (long long)min(t * 64 + (tid >> 3) + 32 * i, Nk - 1) * ldv + st_ch * 8);
+    };
+    auto store_k = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (tid >> 3) + 32 * i;
+            *reinterpret_cast<u32x4*>(sK3[slot] + r * 128 + ((st_ch ^ (r & 7)) << 4)) = rk[i];
+        }
+    };
+    auto store_v = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<bf16x8_t*>(sV2[slot] + ((tid >> 3) + 32 * i) * VR_LD + st_ch * 8) = rv[i];
+    };
+    const int vtr_base = (4 * hi + ((lane & 15) >> 2)) * VR_LD + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // S^T of the 32 keys j*32.. of a K tile, both query blocks, already minus m (the e_0 x (-m) K-step)
+    auto s_unit = [&](const char* sK, int j, f32x16 (&sa)[2]) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) sa[qb] = mfma_32x32x16(fone, *reinterpret_cast<bf16x8_t*>(&fm_w[qb]), zero16);
+        const int r = j * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ch = s * 2 + hi;
+            const bf16x8_t fk = *reinterpret_cast<const bf16x8_t*>(sK + r * 128 + ((ch ^ (r & 7)) << 4));
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) sa[qb] = mfma_32x32x16(fk, fq[qb][s], sa[qb]);
+        }
+    };
+    // common path of the softmax of one unit: p = exp2(S - m), row sums, 16-bit P; returns the row sum of each query block
+    auto p_unit = [&](const f32x16 (&sa)[2], unsigned (&pk)[2][8], float (&psum)[2]) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(sa[qb][r]), p1 = __builtin_amdgcn_exp2f(sa[qb][r + 1]);
+                ps4[(r >> 1) & 1] += p0;
+                ps4[2 + ((r >> 1) & 1)] += p1;
+                pk[qb][r >> 1] = pack2_bf16(p0, p1);
+            }
+            const float ps = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+            psum[qb] = ps + __shfl_xor(ps, 32, 64);
+        }
+    };
+    // re-reference (first unit, or a row sum left the 16-bit range): m <- 16-bit rounding of m + row max, P and the row sum redone,
+    // O and l rescaled, and the S block already computed against the old m (`other`) shifted too
+    auto fix_unit = [&](f32x16 (&sa)[2], f32x16 (&other)[2], unsigned (&pk)[2][8], float (&psum)[2], bool first) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float mx = sa[qb][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sa[qb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = bf16_to_f32(f32_to_bf16(m_run[qb] + mx));
+            float d = m_new - m_run[qb];
+            if (!first) d = fmaxf(d, 0.f);
+            const vs_f32x2 d2 = {d, d};
+            vs_f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const vs_f32x2 a = vs_f32x2{sa[qb][r], sa[qb][r + 1]} - d2;
+                const vs_f32x2 p = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                ps2 += p;
+                pk[qb][r >> 1] = pack2_bf16(p[0], p[1]);
+                other[qb][r] -= d;
+                other[qb][r + 1] -= d;
+            }
+            const float ps = ps2[0] + ps2[1];
+            psum[qb] = ps + __shfl_xor(ps, 32, 64);
+            if (!first) {
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[qb][i][r] *= alpha;
+            }
+            m_run[qb] += d;
+            fm_w[qb][0] = hi == 0 ? (unsigned)f32_to_bf16(-m_run[qb]) : 0u;
+        }
+    };
+    // O^T[qb][i] += V^T[d-block i](keys j*32..) P^T[qb]
+    auto pv_unit = [&](const bf16_t* sV, int j, const unsigned (&pk)[2][8]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                typedef __attribute__((address_space(3))) s16x4_t* lds4_t;
+                const bf16_t* vr = sV + vtr_base + (j * 32 + s * 16) * VR_LD + i * 32;
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)vr);
+                const s16x4_t hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vr + 8 * VR_LD));
+                struct { s16x4_t a, b; } pv = {lo, hi2};
+                const bf16x8_t fv = *reinterpret_cast<bf16x8_t*>(&pv);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    u32x4 pw = {pk[qb][s * 4 + 0], pk[qb][s * 4 + 1], pk[qb][s * 4 + 2], pk[qb][s * 4 + 3]};
+                    oacc[qb][i] = mfma_32x32x16(fv, *reinterpret_cast<bf16x8_t*>(&pw), oacc[qb][i]);
+                }
+            }
+    };
+
+    load_k(0);
+    load_v(0);
+    store_k(0);
+    store_v(0);
+    load_k(1);
+    store_k(1);
+    __syncthreads();
+    f32x16 sA[2], sB[2];
+    s_unit(sK3[0], 0, sA);
+    int kslot = 0;                                                      // ring slot of K(t)
+    for (int t = 0; t < ntiles; ++t) {
+        const int kslot1 = kslot == 2 ? 0 : kslot + 1, kslot2 = kslot1 == 2 ? 0 : kslot1 + 1;
+        const bf16_t* sV = sV2[t & 1];
+        load_k(t + 2);
+        load_v(t + 1);
+        unsigned pk[2][8];
+        float psum[2];
+        // X0: S(t, second half) on the matrix pipe beside P(t, first half) on the VALU
+        s_unit(sK3[kslot], 1, sB);
+        p_unit(sA, pk, psum);
+        if (t == 0 || __any(!(psum[0] <= 4096.f) || !(psum[1] <= 4096.f))) fix_unit(sA, sB, pk, psum, t == 0);
+        l_run[0] += psum[0];
+        l_run[1] += psum[1];
+        // Y0 + X1: P V of the first half, then S(t+1, first half) beside P(t, second half)
+        pv_unit(sV, 0, pk);
+        s_unit(sK3[kslot1], 0, sA);
+        p_unit(sB, pk, psum);
+        if (__any(!(psum[0] <= 4096.f) || !(psum[1] <= 4096.f))) fix_unit(sB, sA, pk, psum, false);
+        l_run[0] += psum[0];
+        l_run[1] += psum[1];
+        pv_unit(sV, 1, pk);
+        store_k(kslot2);
+        store_v((t + 1) & 1);
+        __syncthreads();
+        kslot = kslot1;
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = q0 + qb * 32 + l31;
+        if (qi < Nq) {
+            const float inv = 1.0f / l_run[qb];
+            bf16_t* op = o + ((long long)b * Nq + qi) * ldo + h * 64;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    unsigned w0 = (unsigned)f32_to_bf16(oacc[qb][i][g * 4 + 0] * inv) | ((unsigned)f32_to_bf16(oacc[qb][i][g * 4 + 1] * inv) << 16);
+                    unsigned w1 = (unsigned)f32_to_bf16(oacc[qb][i][g * 4 + 2] * inv) | ((unsigned)f32_to_bf16(oacc[qb][i][g * 4 + 3] * inv) << 16);
+                    *reinterpret_cast<u32x2*>(op + i * 32 + 8 * g + 4 * hi) = u32x2{w0, w1};
+                }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // timestep_embedding (sgm/modules/diffusionmodules/util.py:209-233): [cos(t f_i) | sin(t f_i)], bf16 out
 // ---------------------------------------------------------------------------------------------
@@ -1267,7 +1689,17 @@ int vidseg_attention_a16(const void* q, int ldq, const void* k, int ldk, const v
     if (attn2 < 0) { const char* e = getenv("VIDSEG_ATTN2"); attn2 = e ? atoi(e) : 1; }
     static int attn_tr = -1;                                               // VIDSEG_ATTN_TR=0: V transposed by the LDS store instead
     if (attn_tr < 0) { const char* e = getenv("VIDSEG_ATTN_TR"); attn_tr = e ? atoi(e) : 1; }
-    if (attn2 && Nk % 64 == 0 && Nq >= 2048 && attn_tr)
+    static int attn3 = -1;                                                 // VIDSEG_ATTN3=0: k_attention2's per-tile running maximum
+    if (attn3 < 0) { const char* e = getenv("VIDSEG_ATTN3"); attn3 = e ? atoi(e) : 1; }
+    static int attn4 = -1;                                                 // VIDSEG_ATTN4=0: k_attention3 (same softmax, not pipelined)
+    if (attn4 < 0) { const char* e = getenv("VIDSEG_ATTN4"); attn4 = e ? atoi(e) : 1; }
+    if (attn2 && attn3 && attn4 && Nk % 64 == 0 && Nq >= 2048)
+        (attn4 == 2 ? k_attention4<1> : k_attention4<2>)<<<dim3((Nq + 255) / 256, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
+                                                                     (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
+    else if (attn2 && attn3 && Nk % 64 == 0 && Nq >= 2048)
+        k_attention3<false><<<dim3((Nq + 255) / 256, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
+                                                                            (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
+    else if (attn2 && Nk % 64 == 0 && Nq >= 2048 && attn_tr)
         k_attention2<false, true><<<dim3((Nq + 255) / 256, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v,
                                                                                   ldv, (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
     else if (attn2 && Nk % 64 == 0 && Nq >= 2048)
