@@ -1146,6 +1146,12 @@ __global__ void __launch_bounds__(256, 2) k_attention3(const bf16_t* __restrict_
 // VALU-active was 93 % of the cycles.  Here the unit of work is a 32-key half tile u: while the matrix pipe computes S(u+1), the
 // VALU turns S(u) into P(u) in the same basic block (straight-line since k_attention3: exp2, row sum, conversion), then P(u) V(u).
 // K is staged two tiles ahead (ring of 3) because S(t+1, first half) runs before the end-of-tile barrier of tile t; V one (ring of 2).
+#ifdef VS_ATTN_STAMPS                                      /* experiment builds only: s_memtime at the phase boundaries of tiles 8..11 */
+__device__ unsigned long long vs_attn_stamps[4 * 8 * 8];
+#define VS_STAMP(i) do { if (blockIdx.x == 3 && blockIdx.y == 7 && lane == 0 && t >= 8 && t < 12) vs_attn_stamps[(wave * 4 + (t - 8)) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define VS_STAMP(i)
+#endif
 template <int OCC>
 __global__ void __launch_bounds__(256, OCC) k_attention4(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                    const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo, int Nq,
@@ -1313,6 +1319,7 @@ __global__ void __launch_bounds__(256, OCC) k_attention4(const bf16_t* __restric
     for (int t = 0; t < ntiles; ++t) {
         const int kslot1 = kslot == 2 ? 0 : kslot + 1, kslot2 = kslot1 == 2 ? 0 : kslot1 + 1;
         const bf16_t* sV = sV2[t & 1];
+        VS_STAMP(0);
         load_k(t + 2);
         load_v(t + 1);
         unsigned pk[2][8];
@@ -1320,20 +1327,26 @@ __global__ void __launch_bounds__(256, OCC) k_attention4(const bf16_t* __restric
         // X0: S(t, second half) on the matrix pipe beside P(t, first half) on the VALU
         s_unit(sK3[kslot], 1, sB);
         p_unit(sA, pk, psum);
+        VS_STAMP(1);
         if (t == 0 || __any(!(psum[0] <= 4096.f) || !(psum[1] <= 4096.f))) fix_unit(sA, sB, pk, psum, t == 0);
         l_run[0] += psum[0];
         l_run[1] += psum[1];
         // Y0 + X1: P V of the first half, then S(t+1, first half) beside P(t, second half)
         pv_unit(sV, 0, pk);
+        VS_STAMP(2);
         s_unit(sK3[kslot1], 0, sA);
         p_unit(sB, pk, psum);
+        VS_STAMP(3);
         if (__any(!(psum[0] <= 4096.f) || !(psum[1] <= 4096.f))) fix_unit(sB, sA, pk, psum, false);
         l_run[0] += psum[0];
         l_run[1] += psum[1];
         pv_unit(sV, 1, pk);
+        VS_STAMP(4);
         store_k(kslot2);
         store_v((t + 1) & 1);
+        VS_STAMP(5);
         __syncthreads();
+        VS_STAMP(6);
         kslot = kslot1;
     }
 #pragma unroll
@@ -1679,30 +1692,39 @@ int vidseg_layernorm_a16(const void* x, long long M, int C, const float* gamma, 
     return VS_OK;
 }
 
+#ifdef VS_ATTN_STAMPS
+extern "C" int vidseg_debug_attn_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vs_attn_stamps), sizeof(unsigned long long) * 4 * 8 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int vidseg_attention_a16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int H,
                           int Nq, int Nk, int head_dim, hipStream_t st) {
     VS_REQUIRE(head_dim == 64, "attention: head_dim=%d (only 64 is on the path)", head_dim);
     VS_REQUIRE(Nq > 0 && Nk > 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attention: bad sizes/strides");
     const float scale_log2e = 0.125f * 1.44269504088896340736f;           // dim_head ** -0.5 * log2(e)
-    // 64 queries per wave for long sequences (measured: 4096 tokens 1034 -> 947 us, 1024 tokens unchanged); VIDSEG_ATTN2=0 disables
+    // 64 queries per wave for sequences >= 1024 (k_attention3 vs k_attention: 4096 tokens 1034 -> 720 us, 1024 tokens 132 -> 110 us, 256
+    // tokens 27.7 -> 29.7 us so those stay on k_attention); VIDSEG_ATTN2=0 disables
     static int attn2 = -1;
     if (attn2 < 0) { const char* e = getenv("VIDSEG_ATTN2"); attn2 = e ? atoi(e) : 1; }
     static int attn_tr = -1;                                               // VIDSEG_ATTN_TR=0: V transposed by the LDS store instead
     if (attn_tr < 0) { const char* e = getenv("VIDSEG_ATTN_TR"); attn_tr = e ? atoi(e) : 1; }
     static int attn3 = -1;                                                 // VIDSEG_ATTN3=0: k_attention2's per-tile running maximum
     if (attn3 < 0) { const char* e = getenv("VIDSEG_ATTN3"); attn3 = e ? atoi(e) : 1; }
+    static int minq = -1;                                                  // VIDSEG_ATTN2_MINQ: shortest sequence the 64-queries-per-wave kernels take
+    if (minq < 0) { const char* e = getenv("VIDSEG_ATTN2_MINQ"); minq = e ? atoi(e) : 1024; }
     static int attn4 = -1;                                                 // VIDSEG_ATTN4=0: k_attention3 (same softmax, not pipelined)
     if (attn4 < 0) { const char* e = getenv("VIDSEG_ATTN4"); attn4 = e ? atoi(e) : 1; }
-    if (attn2 && attn3 && attn4 && Nk % 64 == 0 && Nq >= 2048)
+    if (attn2 && attn3 && attn4 && Nk % 64 == 0 && Nq >= minq)
         (attn4 == 2 ? k_attention4<1> : k_attention4<2>)<<<dim3((Nq + 255) / 256, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
                                                                      (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
-    else if (attn2 && attn3 && Nk % 64 == 0 && Nq >= 2048)
+    else if (attn2 && attn3 && Nk % 64 == 0 && Nq >= minq)
         k_attention3<false><<<dim3((Nq + 255) / 256, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
                                                                             (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
-    else if (attn2 && Nk % 64 == 0 && Nq >= 2048 && attn_tr)
+    else if (attn2 && Nk % 64 == 0 && Nq >= minq && attn_tr)
         k_attention2<false, true><<<dim3((Nq + 255) / 256, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v,
                                                                                   ldv, (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
-    else if (attn2 && Nk % 64 == 0 && Nq >= 2048)
+    else if (attn2 && Nk % 64 == 0 && Nq >= minq)
         k_attention2<false, false><<<dim3((Nq + 255) / 256, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v,
                                                                                    ldv, (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
     else if (Nk % 64 == 0)
