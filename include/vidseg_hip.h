@@ -239,10 +239,10 @@ int vidseg_bind_workspace(vidseg_stream_t stream, float* ws, long long floats);
 /* opt-in HIP-event timing of the conv/linear MFMA kernel family (bench.py roofline); out = {ms, flops, launches} (host) */
 int vidseg_gemm_profile_begin(void);
 int vidseg_gemm_profile_end(double* out);
-/* per-kernel split of the same region: out[15] = {ms, flops, launches} x {128x128 LDS-DMA, 256-row big tile, mid tile, 256x64,
-   224-row big tile} */
+/* per-kernel split of the same region: out[18] = {ms, flops, launches} x {128x128 LDS-DMA, 256-row big tile, mid tile, 256x64,
+   224-row big tile, weight-stationary streaming} */
 int vidseg_gemm_profile_kinds(double* out);
-/* algorithmic HBM bytes of the same region per kernel, out[5] (every operand and result once; no split-K partials) */
+/* algorithmic HBM bytes of the same region per kernel, out[6] (every operand and result once; no split-K partials) */
 int vidseg_gemm_profile_bytes(double* out);
 
 #ifdef __cplusplus

@@ -69,6 +69,10 @@ _EPI_CASES = [  # (M, K, N, rows_per_sample, env): every GEMM kernel of the fami
     (1500, 2560, 640, 130, {"VIDSEG_GEMM_BIG": "2", "VIDSEG_GEMM_P7": "2"}),   # 224x320 tile with split-K partials + finish kernel
     (224 * 9, 320, 960, 224, {"VIDSEG_GEMM_BIG": "2", "VIDSEG_GEMM_P7": "2"}),  # 224x320 tile, short K (5 K-tiles), three tile columns
     (515, 192, 56, 103, {}),                                      # narrow-N register-staged kernel
+    (1000, 320, 320, 37, {"VIDSEG_GEMM_WS": "2"}),                # weight-stationary streaming kernel, K = 320: two 160-column panels, ragged M
+    (4099, 320, 960, 224, {"VIDSEG_GEMM_WS": "2"}),               # ... six panels (two of an XCD's 32 blocks idle), ragged M
+    (2100, 640, 640, 130, {"VIDSEG_GEMM_WS": "2"}),               # ... K = 640: eight 80-column panels, ring refilled inside the tile
+    (40000, 320, 320, 5000, {}),                                  # ... as selected by default (M >= 16384), several tiles per wave
 ]
 
 
@@ -337,3 +341,14 @@ def test_timestep_embedding(dev):
     ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
     out = ops.timestep_embedding(t.to(dev), 320).float().cpu()
     assert (out - ref).abs().max() <= 2.0 ** -8 + 2e-3          # bf16 output; fp32 sin/cos argument error at t~1000
+
+
+@pytest.mark.parametrize("M,K,N", [(20000, 320, 320), (16390, 320, 960), (17000, 640, 640)])
+def test_linear_weight_stationary_fast_epilogues(dev, M, K, N):
+    """k_gemm_ws with its straight-line epilogues (bias only / bias + residual, 16-bit result), ragged last tile."""
+    from vidseg_diffusion_amd import ops
+    a, w, b, res = rnd((M, K), 1), rnd((N, K), 2, 0.05), rnd((N,), 3), rnd((M, N), 4)
+    ad, wd = a.to(ops.act_dtype()).to(dev), ops.pack_linear(w, dev)
+    check(ops.linear(ad, wd, b.to(dev)), a @ w.T + b, "ws linear+bias")
+    check(ops.linear(ad, wd, None), a @ w.T, "ws linear")
+    check(ops.linear(ad, wd, b.to(dev), residual=res.to(ops.act_dtype()).to(dev)), a @ w.T + b + res, "ws linear+bias+residual")

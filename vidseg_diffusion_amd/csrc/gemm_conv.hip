@@ -1587,8 +1587,8 @@ struct GemmProf {
     std::vector<Shape> shapes;      // one per event pair
 };
 static GemmProf g_prof;
-static double g_kind_stats[15];
-static double g_kind_bytes[5];
+static double g_kind_stats[18];
+static double g_kind_bytes[6];
 
 static inline hipEvent_t prof_event() {
     if (g_prof.used == g_prof.ev.size()) {
@@ -1600,6 +1600,167 @@ static inline hipEvent_t prof_event() {
         g_prof.ev.push_back(e);
     }
     return g_prof.ev[g_prof.used++];
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gemm_ws: weight-stationary streaming GEMM for the short-K linears (K = 320 at the 64x64 level, K = 640 at 32x32), the
+// shapes where every tiled kernel above spends more time in its per-tile prologue / epilogue than in its K loop (114688 x 320 x
+// 320: 54 us against an 18 us HBM floor).  One persistent 8-wave block per CU keeps a W panel of BN = 16 NJ columns x all of K
+// in LDS (100 KB) for its whole life; every wave then streams its own 32-row tiles of A straight from global memory into MFMA
+// operand registers (a lane's 16 bytes = 8 consecutive k of one row; a ring of ten k-steps, refilled as it is consumed, runs
+// across tile boundaries) -- no A staging, no barrier after the panel load, waves never wait for each other.  The product is
+// formed transposed (W fragment as the MFMA A operand), so a lane holds four consecutive output columns of one row and the
+// epilogue stages 16-byte pieces through a per-wave fp32 buffer into the same epilogue_rows as every other kernel.
+// Blocks on one XCD (blockIdx & 7) take the same row ranges for the different panels, so A is re-read from that XCD's L2.
+// ---------------------------------------------------------------------------------------------
+// EPI 0: the shared epilogue_rows (every option); 1 / 2: bias (+ residual) and a 16-bit result only, straight-line: a lane's
+// three 8-column cells of an 8-row pass sit at fixed columns, so their bias lives in registers, the residual of the NEXT pass is
+// requested before the stores of this one (vmcnt retires in order: a load queued behind stores waits for them), and the
+// compiler's counted waits do the rest.
+template <int NJ, int KT, int EPI>
+__global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cpx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BN = NJ * 16, K = KT * 32, EP_LD = BN + 4, RING = 10;
+    constexpr int W_BYTES = KT * NJ * 1024;                    // [k-step][fragment][lane] x 16 B: a fragment read is lane-linear
+    static_assert(KT % RING == 0, "the A ring is indexed by k-step mod 10");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, qx = blockIdx.x >> 3;
+    if (qx >= cpx * np) return;
+    const int panel = qx % np, chunk = xcd * cpx + qx / np;
+    const int pbase = panel * BN;
+    // W panel -> LDS: slot (kk, j, g, n16) holds W[pbase + 16 j + n16][32 kk + 8 g .. +8]
+    {
+        constexpr int NSLOT = KT * NJ * 64, PER = (NSLOT + 511) / 512;      // 13 pieces per thread, all in flight before the first store
+        bf16x8_t wv[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int sidx = min(tid + 512 * u, NSLOT - 1);
+            const int l = sidx & 63, f = sidx >> 6, j = f % NJ, kk = f / NJ;
+            wv[u] = *reinterpret_cast<const bf16x8_t*>(p.w + (long long)(pbase + 16 * j + (l & 15)) * K + 32 * kk + 8 * (l >> 4));
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if (tid + 512 * u < NSLOT) *reinterpret_cast<bf16x8_t*>(smem + (tid + 512 * u) * 16) = wv[u];
+    }
+    __syncthreads();
+    float* stage = reinterpret_cast<float*>(smem + W_BYTES) + wave * (8 * EP_LD);
+    const int ttot = (int)((p.M + 31) / 32), nchunk = 8 * cpx, tpc = (ttot + nchunk - 1) / nchunk;
+    const int t_begin = chunk * tpc, t_end = min(t_begin + tpc, ttot);
+    const int l15 = lane & 15, q = lane >> 4;
+    const int mlast = (int)p.M - 1;
+    const bf16_t* abase = p.x0 + 8 * q;
+    bf16x8_t areg[RING][2];
+    auto load_a = [&](int slot, int tile, int kk) {            // rows past M clamp to the last one (their results are never stored)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = min(tile * 32 + 16 * i + l15, mlast);
+            areg[slot][i] = *reinterpret_cast<const bf16x8_t*>(abase + (long long)m * K + 32 * kk);
+        }
+    };
+    // fast epilogue: this lane's cells of an 8-row pass (cell = lane + 64 c over 8 rows x BN / 8 columns-of-eight)
+    constexpr int NC8 = BN / 8, NCELL = (8 * NC8 + 63) / 64;
+    int crow[NCELL], ccol[NCELL];
+    bool cval[NCELL];
+    float cbias[NCELL][8];
+#pragma unroll
+    for (int c = 0; c < NCELL; ++c) {
+        const int cell = lane + 64 * c;
+        cval[c] = cell < 8 * NC8;
+        crow[c] = cval[c] ? cell / NC8 : 0;
+        ccol[c] = cval[c] ? (cell % NC8) * 8 : 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cbias[c][e] = (EPI && p.bias) ? p.bias[pbase + ccol[c] + e] : 0.f;
+    }
+    int t = t_begin + wave;
+    if (t >= t_end) return;
+#pragma unroll
+    for (int s = 0; s < RING; ++s) load_a(s, t, s);
+    for (; t < t_end; t += 8) {
+        const int tn = t + 8 < t_end ? t + 8 : t;              // the tile whose first k-steps refill the ring at the end of this one
+        f32x4 acc[2][NJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            const int slot = kk % RING;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(smem + ((kk * NJ + j) * 64 + lane) * 16);
+                acc[0][j] = mfma_16x16x32(wf, areg[slot][0], acc[0][j]);
+                acc[1][j] = mfma_16x16x32(wf, areg[slot][1], acc[1][j]);
+            }
+            if (kk + RING < KT)
+                load_a(slot, t, kk + RING);
+            else
+                load_a(slot, tn, kk + RING - KT);
+            __builtin_amdgcn_sched_barrier(0);                 // keep each refill where its slot frees up (the scheduler sinks them all
+        }                                                      // below the last MFMA otherwise)
+        // epilogue: four passes of 8 rows; lanes whose row lies in the pass write their 16 columns-of-four, then every lane
+        // takes 8-column cells of the staged rows (bias, residual, taps ... exactly as the tiled kernels)
+        if (EPI) {
+            bf16x8_t rr[2][NCELL];
+            auto load_res = [&](int pass, int buf) {
+#pragma unroll
+                for (int c = 0; c < NCELL; ++c) {
+                    const int m = min(t * 32 + 8 * pass + crow[c], mlast);
+                    rr[buf][c] = *reinterpret_cast<const bf16x8_t*>(p.residual + (long long)m * p.ldr + pbase + ccol[c]);
+                }
+            };
+            if (EPI == 2) load_res(0, 0);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int i = pass >> 1, h = pass & 1;
+                if ((l15 >> 3) == h) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(stage + (l15 & 7) * EP_LD + 16 * j + 4 * q) = acc[i][j];
+                }
+                if (EPI == 2 && pass < 3) load_res(pass + 1, (pass + 1) & 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int c = 0; c < NCELL; ++c) {
+                    if (!cval[c]) continue;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + crow[c] * EP_LD + ccol[c]);
+                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(stage + crow[c] * EP_LD + ccol[c] + 4);
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = lo[e] + cbias[c][e];
+                        v[4 + e] = hi4[e] + cbias[c][4 + e];
+                    }
+                    if (EPI == 2) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[pass & 1][c][e]);
+                    }
+                    bf16x8_t o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(v[e]);
+                    const int m = t * 32 + 8 * pass + crow[c];
+                    if (m <= mlast) *reinterpret_cast<bf16x8_t*>(p.out + (long long)m * p.ldo + pbase + ccol[c]) = o;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if ((l15 >> 3) == h) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(stage + (l15 & 7) * EP_LD + 16 * j + 4 * q) = acc[i][j];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                epilogue_rows<NJ * 2, EP_LD>(p, stage, t * 32 + 16 * i + 8 * h, 8, pbase, p.N, lane, 0, true, true);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+    }
 }
 
 extern "C" {
@@ -1617,8 +1778,8 @@ int vidseg_gemm_profile_begin(void) {
 int vidseg_gemm_profile_end(double* out) {
     g_prof.on = false;
     double ms = 0.0;
-    for (int i = 0; i < 15; ++i) g_kind_stats[i] = 0.0;
-    for (int i = 0; i < 5; ++i) g_kind_bytes[i] = 0.0;
+    for (int i = 0; i < 18; ++i) g_kind_stats[i] = 0.0;
+    for (int i = 0; i < 6; ++i) g_kind_bytes[i] = 0.0;
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
         float t = 0.f;
         hipError_t e = hipEventSynchronize(g_prof.ev[i + 1]);
@@ -1627,7 +1788,7 @@ int vidseg_gemm_profile_end(double* out) {
         ms += t;
         if (i / 2 < g_prof.shapes.size()) {
             const GemmProf::Shape& h = g_prof.shapes[i / 2];
-            const int kd = h.kind >= 0 && h.kind < 5 ? h.kind : 0;
+            const int kd = h.kind >= 0 && h.kind < 6 ? h.kind : 0;
             g_kind_stats[kd * 3] += t;
             g_kind_stats[kd * 3 + 1] += 2.0 * (double)h.M * (double)h.N * (double)h.K;
             g_kind_stats[kd * 3 + 2] += 1.0;
@@ -1647,9 +1808,9 @@ int vidseg_gemm_profile_end(double* out) {
 
 // Per-kernel split of the last profiled region: out[k*3 + {0,1,2}] = {milliseconds, algorithmic FLOPs, launches} for
 // k = 0: k_gemm_dma (128x128), 1: k_gemm_ph big (256x320 / 256x256), 2: k_gemm_tile mid (128x320), 3: k_gemm_conv<256,64>,
-// 4: k_gemm_p7 (224x320).
+// 4: k_gemm_p7 (224x320), 5: k_gemm_ws (weight-stationary streaming, short K).
 int vidseg_gemm_profile_kinds(double* out) {
-    for (int i = 0; i < 15; ++i) out[i] = g_kind_stats[i];
+    for (int i = 0; i < 18; ++i) out[i] = g_kind_stats[i];
     return VS_OK;
 }
 
@@ -1657,7 +1818,7 @@ int vidseg_gemm_profile_kinds(double* out) {
 // reads (the whole input image for a conv: the 9 taps re-read it through L1/L2, not through memory), the weight matrix, the
 // residual, and every output it writes (16-bit result, fp32 result, fp16 taps); split-K partials are NOT algorithmic.
 int vidseg_gemm_profile_bytes(double* out) {
-    for (int i = 0; i < 5; ++i) out[i] = g_kind_bytes[i];
+    for (int i = 0; i < 6; ++i) out[i] = g_kind_bytes[i];
     return VS_OK;
 }
 
@@ -1743,7 +1904,41 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     p.ksplit = 1;
     p.ws = nullptr;
     int kind = 0;                                              // 0: 128x128, 1: big, 2: mid, 3: narrow (profile log only)
-    if (narrow) {
+    // weight-stationary streaming kernel: plain linears with K = 320 (160-column panels) or K = 640 (80-column panels) and enough
+    // rows to give every wave of the 256 persistent blocks a few 32-row tiles; the 32 blocks of an XCD split into np panels x
+    // cpx row chunks, and the launch is taken only when at most 2 of them stay idle.  VIDSEG_GEMM_WS=0 disables.
+    static int ws_mode = -1;
+    if (ws_mode < 0) {
+        const char* e = getenv("VIDSEG_GEMM_WS");
+        ws_mode = e ? atoi(e) : 1;
+        (void)hipFuncSetAttribute((const void*)k_gemm_ws<10, 10, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 1024 + 8 * 8 * 164 * 4);
+        (void)hipFuncSetAttribute((const void*)k_gemm_ws<10, 10, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 1024 + 8 * 8 * 164 * 4);
+        (void)hipFuncSetAttribute((const void*)k_gemm_ws<10, 10, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 1024 + 8 * 8 * 164 * 4);
+        (void)hipFuncSetAttribute((const void*)k_gemm_ws<5, 20, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 20 * 1024 + 8 * 8 * 84 * 4);
+        (void)hipFuncSetAttribute((const void*)k_gemm_ws<5, 20, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 20 * 1024 + 8 * 8 * 84 * 4);
+        (void)hipFuncSetAttribute((const void*)k_gemm_ws<5, 20, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 20 * 1024 + 8 * 8 * 84 * 4);
+    }
+    const int ws_bn = p.K == 320 ? 160 : 80;
+    const int ws_np = p.N / ws_bn;
+    const bool ws_ok = ws_mode && p.ksize == 1 && !p.x1 && p.C1 == 0 && p.C0 == p.K && (p.K == 320 || p.K == 640) && p.act != 2 &&
+                       p.tmode == 0 && p.N % ws_bn == 0 && ws_np >= 1 && ws_np <= 32 && (32 % ws_np) <= 2 &&
+                       (ws_mode == 2 || p.M >= 16384);     // VIDSEG_GEMM_WS=2: whenever legal (tests)
+    if (ws_ok) {
+        kind = 5;
+        const int cpx = 32 / ws_np;
+        const bool plain = p.out && !p.out_f32 && !p.rowvec && !p.rowadd && !p.tap && p.act == 0;
+        const int epi = !plain ? 0 : (p.residual ? 2 : 1);
+        const size_t l320 = 10 * 10 * 1024 + 8 * 8 * 164 * 4, l640 = 5 * 20 * 1024 + 8 * 8 * 84 * 4;
+        if (p.K == 320) {
+            if (epi == 0) k_gemm_ws<10, 10, 0><<<dim3(256), 512, l320, st>>>(p, ws_np, cpx);
+            else if (epi == 1) k_gemm_ws<10, 10, 1><<<dim3(256), 512, l320, st>>>(p, ws_np, cpx);
+            else k_gemm_ws<10, 10, 2><<<dim3(256), 512, l320, st>>>(p, ws_np, cpx);
+        } else {
+            if (epi == 0) k_gemm_ws<5, 20, 0><<<dim3(256), 512, l640, st>>>(p, ws_np, cpx);
+            else if (epi == 1) k_gemm_ws<5, 20, 1><<<dim3(256), 512, l640, st>>>(p, ws_np, cpx);
+            else k_gemm_ws<5, 20, 2><<<dim3(256), 512, l640, st>>>(p, ws_np, cpx);
+        }
+    } else if (narrow) {
         kind = 3;
         const long long tiles = ((p.M + 255) / 256) * ((p.N + 63) / 64);
         k_gemm_conv<256, 64><<<dim3((unsigned)tiles), 256, 2 * (256 + 64) * BK * 2, st>>>(p);
