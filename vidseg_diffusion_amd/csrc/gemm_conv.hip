@@ -1643,6 +1643,8 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
         for (int u = 0; u < PER; ++u)
             if (tid + 512 * u < NSLOT) *reinterpret_cast<bf16x8_t*>(smem + (tid + 512 * u) * 16) = wv[u];
     }
+    float* sbias = reinterpret_cast<float*>(smem + W_BYTES) + 8 * (8 * EP_LD);      // the panel's bias (zeros without one), fast epilogues
+    if (EPI && tid < BN) sbias[tid] = p.bias ? p.bias[pbase + tid] : 0.f;
     __syncthreads();
     float* stage = reinterpret_cast<float*>(smem + W_BYTES) + wave * (8 * EP_LD);
     const int ttot = (int)((p.M + 31) / 32), nchunk = 8 * cpx, tpc = (ttot + nchunk - 1) / nchunk;
@@ -1651,32 +1653,43 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
     const int mlast = (int)p.M - 1;
     const bf16_t* abase = p.x0 + 8 * q;
     bf16x8_t areg[RING][2];
+    // With the straight-line epilogues the ring loads are issued and waited for by hand: the compiler answers loads carried
+    // around the tile loop with vmcnt(0) at the top of every tile.  vmcnt retires in order, so "slot kk has landed" = at most
+    // as many operations outstanding as were issued after it: the 18 other ring loads plus, when the slot was filled before
+    // the previous tile's epilogue, that epilogue's EOPS stores / residual loads (a fixed number: they are skipped only in the
+    // tile past M, which is the last one its wave runs).
+    constexpr int EOPS = EPI == 0 ? 0 : (EPI == 1 ? 4 : 8) * ((BN + 63) / 64);
     auto load_a = [&](int slot, int tile, int kk) {            // rows past M clamp to the last one (their results are never stored)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = min(tile * 32 + 16 * i + l15, mlast);
-            areg[slot][i] = *reinterpret_cast<const bf16x8_t*>(abase + (long long)m * K + 32 * kk);
+            const bf16_t* ap = abase + (long long)m * K + 32 * kk;
+            if (EPI)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(areg[slot][i]) : "v"(ap) : "memory");
+            else
+                areg[slot][i] = *reinterpret_cast<const bf16x8_t*>(ap);
         }
     };
     // fast epilogue: this lane's cells of an 8-row pass (cell = lane + 64 c over 8 rows x BN / 8 columns-of-eight)
     constexpr int NC8 = BN / 8, NCELL = (8 * NC8 + 63) / 64;
     int crow[NCELL], ccol[NCELL];
     bool cval[NCELL];
-    float cbias[NCELL][8];
 #pragma unroll
     for (int c = 0; c < NCELL; ++c) {
         const int cell = lane + 64 * c;
         cval[c] = cell < 8 * NC8;
         crow[c] = cval[c] ? cell / NC8 : 0;
         ccol[c] = cval[c] ? (cell % NC8) * 8 : 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cbias[c][e] = (EPI && p.bias) ? p.bias[pbase + ccol[c] + e] : 0.f;
     }
     int t = t_begin + wave;
     if (t >= t_end) return;
 #pragma unroll
     for (int s = 0; s < RING; ++s) load_a(s, t, s);
-    for (; t < t_end; t += 8) {
+    // one tile; FIRST: no epilogue lies between the prologue's loads and this tile's k-steps (separate instantiations, not a
+    // runtime flag: two wait statements tied to the same ring registers in two branches make the compiler copy those registers
+    // ahead of the wait)
+    auto tile_body = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const int tn = t + 8 < t_end ? t + 8 : t;              // the tile whose first k-steps refill the ring at the end of this one
         f32x4 acc[2][NJ];
 #pragma unroll
@@ -1686,6 +1699,12 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
 #pragma unroll
         for (int kk = 0; kk < KT; ++kk) {
             const int slot = kk % RING;
+            if (EPI) {
+                if (kk < RING && !FIRST)
+                    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(areg[slot][0]), "+v"(areg[slot][1]) : "n"(18 + EOPS) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(18)" : "+v"(areg[slot][0]), "+v"(areg[slot][1])::"memory");
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(smem + ((kk * NJ + j) * 64 + lane) * 16);
@@ -1696,6 +1715,19 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
                 load_a(slot, t, kk + RING);
             else
                 load_a(slot, tn, kk + RING - KT);
+            // W fragments: NJ / 2 - 1 reads ahead of the MFMAs that use them (left alone the scheduler keeps one pair in flight and
+            // waits for an LDS round trip every four MFMAs)
+            // (not with the residual double buffer: too few registers left, measured 47 -> 53 us with two reads ahead)
+            constexpr int AHEAD = NJ / 2 - 1;
+            if (!(EPI == 2 && NJ == 10)) {
+                __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+                for (int g = 0; g < NJ - AHEAD; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * AHEAD, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);                 // keep each refill where its slot frees up (the scheduler sinks them all
         }                                                      // below the last MFMA otherwise)
         // epilogue: four passes of 8 rows; lanes whose row lies in the pass write their 16 columns-of-four, then every lane
@@ -1725,11 +1757,12 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
                     if (!cval[c]) continue;
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + crow[c] * EP_LD + ccol[c]);
                     const f32x4 hi4 = *reinterpret_cast<const f32x4*>(stage + crow[c] * EP_LD + ccol[c] + 4);
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sbias + ccol[c]), b1 = *reinterpret_cast<const f32x4*>(sbias + ccol[c] + 4);
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = lo[e] + cbias[c][e];
-                        v[4 + e] = hi4[e] + cbias[c][4 + e];
+                        v[e] = lo[e] + b0[e];
+                        v[4 + e] = hi4[e] + b1[e];
                     }
                     if (EPI == 2) {
 #pragma unroll
@@ -1739,12 +1772,18 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(v[e]);
                     const int m = t * 32 + 8 * pass + crow[c];
-                    if (m <= mlast) *reinterpret_cast<bf16x8_t*>(p.out + (long long)m * p.ldo + pbase + ccol[c]) = o;
+                    // the store is hidden from the compiler's wait-count model: with stores and loads both pending it falls back to
+                    // vmcnt(0) before every use of the A ring; counting loads only it emits counted waits, which the hardware (whose
+                    // counter includes the stores, retiring in order) can only over-satisfy
+                    if (m <= mlast) {
+                        bf16_t* op = p.out + (long long)m * p.ldo + pbase + ccol[c];
+                        asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(op), "v"(o) : "memory");
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
-            continue;
+            return;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -1760,7 +1799,9 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
-    }
+    };
+    tile_body(std::true_type{});
+    for (t += 8; t < t_end; t += 8) tile_body(std::false_type{});
 }
 
 extern "C" {
@@ -1911,24 +1952,25 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     if (ws_mode < 0) {
         const char* e = getenv("VIDSEG_GEMM_WS");
         ws_mode = e ? atoi(e) : 1;
-        (void)hipFuncSetAttribute((const void*)k_gemm_ws<10, 10, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 1024 + 8 * 8 * 164 * 4);
-        (void)hipFuncSetAttribute((const void*)k_gemm_ws<10, 10, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 1024 + 8 * 8 * 164 * 4);
-        (void)hipFuncSetAttribute((const void*)k_gemm_ws<10, 10, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 1024 + 8 * 8 * 164 * 4);
-        (void)hipFuncSetAttribute((const void*)k_gemm_ws<5, 20, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 20 * 1024 + 8 * 8 * 84 * 4);
-        (void)hipFuncSetAttribute((const void*)k_gemm_ws<5, 20, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 20 * 1024 + 8 * 8 * 84 * 4);
-        (void)hipFuncSetAttribute((const void*)k_gemm_ws<5, 20, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 20 * 1024 + 8 * 8 * 84 * 4);
+        (void)hipFuncSetAttribute((const void*)k_gemm_ws<10, 10, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 1024 + 8 * 8 * 164 * 4 + 640);
+        (void)hipFuncSetAttribute((const void*)k_gemm_ws<10, 10, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 1024 + 8 * 8 * 164 * 4 + 640);
+        (void)hipFuncSetAttribute((const void*)k_gemm_ws<10, 10, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 1024 + 8 * 8 * 164 * 4 + 640);
+        (void)hipFuncSetAttribute((const void*)k_gemm_ws<5, 20, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 20 * 1024 + 8 * 8 * 84 * 4 + 320);
+        (void)hipFuncSetAttribute((const void*)k_gemm_ws<5, 20, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 20 * 1024 + 8 * 8 * 84 * 4 + 320);
+        (void)hipFuncSetAttribute((const void*)k_gemm_ws<5, 20, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 20 * 1024 + 8 * 8 * 84 * 4 + 320);
     }
     const int ws_bn = p.K == 320 ? 160 : 80;
     const int ws_np = p.N / ws_bn;
     const bool ws_ok = ws_mode && p.ksize == 1 && !p.x1 && p.C1 == 0 && p.C0 == p.K && (p.K == 320 || p.K == 640) && p.act != 2 &&
                        p.tmode == 0 && p.N % ws_bn == 0 && ws_np >= 1 && ws_np <= 32 && (32 % ws_np) <= 2 &&
-                       (ws_mode == 2 || p.M >= 16384);     // VIDSEG_GEMM_WS=2: whenever legal (tests)
+                       (ws_mode == 2 || (p.M >= 16384 && p.K == 320));     // VIDSEG_GEMM_WS=2: whenever legal (tests); K = 640 is
+                                                                            // slower than k_gemm_p7 so far (28672x640x640: 54 vs 44 us)
     if (ws_ok) {
         kind = 5;
         const int cpx = 32 / ws_np;
         const bool plain = p.out && !p.out_f32 && !p.rowvec && !p.rowadd && !p.tap && p.act == 0;
         const int epi = !plain ? 0 : (p.residual ? 2 : 1);
-        const size_t l320 = 10 * 10 * 1024 + 8 * 8 * 164 * 4, l640 = 5 * 20 * 1024 + 8 * 8 * 84 * 4;
+        const size_t l320 = 10 * 10 * 1024 + 8 * 8 * 164 * 4 + 640, l640 = 5 * 20 * 1024 + 8 * 8 * 84 * 4 + 320;
         if (p.K == 320) {
             if (epi == 0) k_gemm_ws<10, 10, 0><<<dim3(256), 512, l320, st>>>(p, ws_np, cpx);
             else if (epi == 1) k_gemm_ws<10, 10, 1><<<dim3(256), 512, l320, st>>>(p, ws_np, cpx);
