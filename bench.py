@@ -430,6 +430,8 @@ def main():
             tr = pmc_traffic(["--refine"] if args.refine else []) if os.environ.get("VIDSEG_BENCH_PMC", "1") != "0" else None
             dom = out["roofline"]["kernel"]
             key = "k_gemm_p7" if dom.startswith("k_gemm_p7") else ("k_gemm_ph<5>" if dom.startswith("k_gemm_ph") else "k_gemm_dma<2>")
+            if tr and key not in tr:                                 # template instances: k_gemm_p7<5>
+                key = next((k for k in sorted(tr) if k.startswith(key)), key)
             if tr and key in tr:
                 out["roofline"]["traffic"] = int(tr[key][1])
                 out["roofline"]["traffic_how"] = (f"this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over one window of "

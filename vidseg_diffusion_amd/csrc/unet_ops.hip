@@ -1713,8 +1713,8 @@ int vidseg_attention_a16(const void* q, int ldq, const void* k, int ldk, const v
     if (attn3 < 0) { const char* e = getenv("VIDSEG_ATTN3"); attn3 = e ? atoi(e) : 1; }
     static int minq = -1;                                                  // VIDSEG_ATTN2_MINQ: shortest sequence the 64-queries-per-wave kernels take
     if (minq < 0) { const char* e = getenv("VIDSEG_ATTN2_MINQ"); minq = e ? atoi(e) : 1024; }
-    static int attn4 = -1;                                                 // VIDSEG_ATTN4=0: k_attention3 (same softmax, not pipelined)
-    if (attn4 < 0) { const char* e = getenv("VIDSEG_ATTN4"); attn4 = e ? atoi(e) : 1; }
+    static int attn4 = -1;                                                 // VIDSEG_ATTN4=1 / 2: k_attention4 (software-pipelined; 2-4 % slower so far)
+    if (attn4 < 0) { const char* e = getenv("VIDSEG_ATTN4"); attn4 = e ? atoi(e) : 0; }
     if (attn2 && attn3 && attn4 && Nk % 64 == 0 && Nq >= minq)
         (attn4 == 2 ? k_attention4<1> : k_attention4<2>)<<<dim3((Nq + 255) / 256, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
                                                                      (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
