@@ -134,6 +134,29 @@ def mask_iou_vs_reference(labels, refine, k_masks):
                     "tools/gen_golden_c2_window.py)" + ("; Step 3b (correct_low_res_mask) included" if refine else "")}
 
 
+def more_windows_vs_reference(eng, dev, cfg, refine, k_masks):
+    """Windows 1.. of the headline clip for which the reference's labels are committed (tests/golden/c2_window_w<w>.npz):
+    one untimed segment_window each, matched IoU / identical fraction against the reference."""
+    from tools_metrics import matched_iou
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import segment_window
+    res = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "c2_window_w*.npz"))):
+        g = np.load(path)
+        w = int(g["window_id"])
+        lat, c, uc, noise = make_inputs(dev, w, cfg)
+        FE.FeatureStore.clear()
+        FE.MaskStore.clear()
+        labels, _ = segment_window(eng, lat, c, uc, num_masks=k_masks, num_steps=NUM_STEPS, t_start=22, seed=17, noise=noise,
+                                   is_refine_mask=refine, keep_all_steps=False, feature_folder="/nonexistent/bench_more", exp_name=f"w{w}")
+        ref = g["corrected_labels" if refine else "match_labels"].astype(np.int64)
+        iou, exact = matched_iou(np.asarray(labels).reshape(-1), ref.reshape(-1), k_masks)
+        res.append({"window": w, "iou": round(float(iou), 4), "identical_fraction": round(float(exact), 4)})
+    FE.FeatureStore.clear()
+    FE.MaskStore.clear()
+    return res
+
+
 def pmc_traffic(extra_args, timeout=240):
     """HBM-side bytes per launch of every GEMM kernel, measured now: two separate rocprofv3 --kernel-trace --pmc passes
     (FETCH_SIZE, then WRITE_SIZE) over one window of this workload in a child process.  rocprofv3 reports KB; on gfx950
@@ -382,6 +405,16 @@ def main():
             m = mask_iou_vs_reference(labels if world == 1 else np.asarray(labels)[0], refine, k_masks)
             if m is not None:
                 out["mask_iou_vs_reference"] = m
+                if world == 1 and k_masks == 20 and not args.masks_only and not args.fp8_attn:
+                    more = more_windows_vs_reference(eng, dev, cfg, refine, k_masks)      # untimed: windows 1.. of the clip
+                    if more:
+                        m["windows"] = [{"window": 0, "iou": m["iou"], "identical_fraction": m["identical_fraction"]}] + more
+                        m["mean_iou"] = round(float(np.mean([w["iou"] for w in m["windows"]])), 4)
+                        m["mean_identical_fraction"] = round(float(np.mean([w["identical_fraction"] for w in m["windows"]])), 4)
+                        m["note"] = ("best-of-10 K-means is not a continuous function of its input: between builds whose Q taps agree to "
+                                     "1.2e-3 with the reference, single windows have moved between IoU 0.96 and 0.9999 (one cluster "
+                                     "boundary settling differently, both clusterings within 1e-3 of each other in the K-means objective: "
+                                     "tests/test_gpu_c2_window.py); the mean over the fixture windows is the stable figure")
         if world == 1 and (args.masks_only or args.fp8_attn):        # outside the timed region: the same window on the plain path
             saved = (args.masks_only, args.fp8_attn)
             args.masks_only = False

@@ -20,3 +20,16 @@ def matched_iou(a, b, K):
         ious.append(inter / union)
         agree += inter
     return float(np.mean(ious)), float(agree / a.size)
+
+
+def clustering_objective(flat, labels):
+    """K-means objective of a labelling on given features: sum over tokens of the squared distance to the mean of the token's
+    cluster (float64).  Two labelings of the same features with (nearly) the same objective are equally good clusterings: which
+    one best-of-n_init K-means returns is decided by rounding."""
+    X = np.asarray(flat, dtype=np.float64)
+    lab = np.asarray(labels).reshape(-1)
+    tot = 0.0
+    for l in np.unique(lab):
+        m = X[lab == l]
+        tot += float(((m - m.mean(axis=0)) ** 2).sum())
+    return tot

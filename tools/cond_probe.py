@@ -23,12 +23,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from tools_metrics import matched_iou  # noqa: E402
 
 DESIGNS = [
-    ("reg20", dict(kind="region", R=20, amp=1.5, noise=0.05)),
-    ("lat20_a1.0", dict(kind="region", R=20, amp=1.0, noise=0.05, protos="lattice")),
-    ("lat20_a1.5", dict(kind="region", R=20, amp=1.5, noise=0.05, protos="lattice")),
     ("lat20_a2.0", dict(kind="region", R=20, amp=2.0, noise=0.05, protos="lattice")),
+    ("blk20_a2.0", dict(kind="region", R=20, amp=2.0, noise=0.05, protos="lattice", layout="blocks")),
+    ("blk20_a3.0", dict(kind="region", R=20, amp=3.0, noise=0.05, protos="lattice", layout="blocks")),
+    ("blk20_a2.0_n0", dict(kind="region", R=20, amp=2.0, noise=0.0, protos="lattice", layout="blocks")),
 ]
-ZERO_GAINS = [float(v) for v in os.environ.get("PROBE_ZERO_GAINS", "0.3,0.1").split(",")]
+ZERO_GAINS = [float(v) for v in os.environ.get("PROBE_ZERO_GAINS", "0.3").split(",")]
+TAG = os.environ.get("PROBE_TAG", "")
 
 
 def make_latent(d, F, lat):
@@ -39,8 +40,9 @@ def make_latent(d, F, lat):
         x = synthetic.scene_clip(F, lat, lat, num_objects=d["R"], cells=d["cells"], seed=1, amp=d["amp"], noise=d["noise"])
         gt = synthetic.scene_labels(F, lat, lat, d["R"], d["cells"], 1 + 4000)
     else:
-        x = synthetic.region_clip(F, lat, lat, num_regions=d["R"], seed=1, amp=d["amp"], noise=d["noise"], protos=d.get("protos", "random"))
-        gt = synthetic.region_labels(F, lat, lat, d["R"], 1 + 4000)
+        x = synthetic.region_clip(F, lat, lat, num_regions=d["R"], seed=1, amp=d["amp"], noise=d["noise"], protos=d.get("protos", "random"),
+                                  layout=d.get("layout", "voronoi"))
+        gt = (synthetic.block_labels if d.get("layout") == "blocks" else synthetic.region_labels)(F, lat, lat, d["R"], 1 + 4000)
     return x, gt[:, ::2, ::2].reshape(F, -1)                       # token grid = latent / 2 (top-left latent pixel of each token)
 
 
@@ -52,12 +54,20 @@ def main():
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     if args.compare:
-        a = np.load(os.path.join(out_dir, "cond_probe_f16.npz"))
-        b = np.load(os.path.join(out_dir, "cond_probe_bf16.npz"))
-        for key in a.files:
-            if key.endswith("_full") and key in b.files:
-                iou, ex = matched_iou(a[key], b[key], args.masks)
-                print(f"{key:30s} f16 vs bf16: IoU {iou:.4f} identical {ex:.4f}")
+        import glob
+        files = sorted(glob.glob(os.path.join(out_dir, "cond_probe_*.npz")))
+        data = {os.path.basename(f)[11:-4]: np.load(f) for f in files}
+        names = sorted(data)
+        for key in data[names[0]].files:
+            if not key.endswith("_full"):
+                continue
+            worst = (2.0, 2.0, "")
+            for i in range(len(names)):
+                for j in range(i + 1, len(names)):
+                    if key in data[names[j]].files:
+                        iou, ex = matched_iou(data[names[i]][key], data[names[j]][key], args.masks)
+                        worst = min(worst, (iou, ex, f"{names[i]} vs {names[j]}"))
+            print(f"{key:30s} worst pair over {names}: IoU {worst[0]:.4f} identical {worst[1]:.4f} ({worst[2]})")
         return
     from vidseg_diffusion_amd import feature_extraction as FE
     from vidseg_diffusion_amd import ops, synthetic
@@ -100,7 +110,7 @@ def main():
             print(line, flush=True)
         del net, eng
         torch.cuda.empty_cache()
-    np.savez_compressed(os.path.join(out_dir, f"cond_probe_{act}.npz"), **rec)
+    np.savez_compressed(os.path.join(out_dir, f"cond_probe_{act}{TAG}.npz"), **rec)
 
 
 if __name__ == "__main__":

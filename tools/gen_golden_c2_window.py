@@ -39,7 +39,10 @@ BLOCKS = ["output_block_8", "output_block_7", "output_block_6"]
 
 def main():
     zero_gain = float(os.environ.get("C2_ZERO_GAIN", synthetic.HEADLINE["zero_gain"]))
-    out_path = os.environ.get("C2_OUT", os.path.join(ROOT, "tests", "golden", "c2_window.npz"))
+    # C2_WINDOW=w > 0: window w of the headline clip (bench.py make_inputs: latent seed 1 + w, noise seed 100 + w, the same
+    # conditioning) -> tests/golden/c2_window_w<w>.npz holding the reference's labels and the input hashes only (no taps)
+    wid = int(os.environ.get("C2_WINDOW", "0"))
+    out_path = os.environ.get("C2_OUT", os.path.join(ROOT, "tests", "golden", "c2_window.npz" if wid == 0 else f"c2_window_w{wid}.npz"))
     fe = import_reference()
     from sgm.modules.diffusionmodules.denoiser import DiscreteDenoiser
     from sgm.modules.diffusionmodules.openaimodel import UNetModel
@@ -56,9 +59,10 @@ def main():
     rec = dict(state_dict_signature=synthetic.state_dict_signature(shapes), weight_seed=1234, zero_gain=zero_gain,
                F=F, lat=LAT, K=K, t_start=T_START, num_steps=NUM_STEPS, seed=17)
 
-    lat = synthetic.headline_latent(F, LAT, LAT, window_id=0)
+    lat = synthetic.headline_latent(F, LAT, LAT, window_id=wid)
     c, uc = synthetic.sd_conditioning(F, context_dim=cfg["context_dim"], seq=77, seed=1)
-    noise = torch.randn((F, 4, LAT, LAT), generator=torch.Generator().manual_seed(100))
+    noise = torch.randn((F, 4, LAT, LAT), generator=torch.Generator().manual_seed(100 + wid))
+    rec.update(window_id=wid)
     rec.update(latent_sha256=synthetic.sha256_of(lat), c_sha256=synthetic.sha256_of(c), noise_sha256=synthetic.sha256_of(noise.numpy()))
 
     # ---- batch-chunked network call (values identical to the batch-28 call, see module docstring) -------------------------
@@ -90,11 +94,11 @@ def main():
                           modulate_params=modulate_params)
 
     cond, ucond = {"crossattn": torch.from_numpy(c)}, {"crossattn": torch.from_numpy(uc)}
-    torch.manual_seed(100)                                   # add_noise draws torch.randn_like(x) (sampling.py:139): same stream
+    torch.manual_seed(100 + wid)                             # add_noise draws torch.randn_like(x) (sampling.py:139): same stream
     noised = sampler.add_noise(torch.from_numpy(lat).clone(), cond=cond, uc=ucond, num_steps=NUM_STEPS, noise_level=T_START)
     sig = sampler.discretization(NUM_STEPS, device="cpu")
     chk = (torch.from_numpy(lat) + noise * sig[T_START]) / torch.sqrt(1.0 + sig[0] ** 2.0)
-    assert torch.equal(noised, chk), "torch.randn_like under manual_seed(100) != Generator(100) draw"
+    assert torch.equal(noised, chk), "torch.randn_like under manual_seed != Generator draw"
 
     xs = []
 
@@ -142,7 +146,10 @@ def main():
     finally:
         os.chdir(cwd)
         shutil.rmtree(base, ignore_errors=True)
-    gt = synthetic.headline_partition(F, LAT, LAT, window_id=0)
+    if wid:                                                   # labels-only fixture
+        for k in [k for k in rec if k.startswith("q") or k.startswith("x_")]:
+            del rec[k]
+    gt = synthetic.headline_partition(F, LAT, LAT, window_id=wid)
     rec["generating_partition_agreement"] = np.float64(_agreement(rec["match_labels"], gt, K))
     import sklearn
     rec["versions"] = np.array([f"torch {torch.__version__}", f"sklearn {sklearn.__version__}", f"numpy {np.__version__}"])

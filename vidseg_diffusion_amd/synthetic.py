@@ -124,6 +124,31 @@ def region_labels(num_frames: int, h: int, w: int, num_regions: int, seed: int) 
     return out
 
 
+def block_labels(num_frames: int, h: int, w: int, num_regions: int, seed: int, align: int = 4) -> np.ndarray:
+    """Partition into a gy x gx grid of rectangles whose edges sit on multiples of `align` latent pixels (seeded jitter of the
+    cut positions), the whole pattern sliding right by `align` pixels every fourth frame (wrapping): int64 [F, h, w].  With an
+    even `align` no 2 x 2-pixel token of the UNet's first attention level ever straddles two regions, so no token is an exact
+    half-and-half mixture of two prototypes -- the tokens whose cluster a rounding error decides."""
+    g = _rng(seed)
+    gy = int(np.floor(np.sqrt(num_regions * h / w) + 0.5))
+    gy = max(1, min(gy, num_regions))
+    while num_regions % gy:
+        gy -= 1
+    gx = num_regions // gy
+
+    def cuts(n, parts):
+        base = np.round(np.arange(1, parts) * (n / parts) / align).astype(np.int64)
+        jit = g.integers(-1, 2, size=parts - 1)
+        c = np.clip(base + jit, 1, n // align - 1) * align
+        return np.concatenate([[0], np.maximum.accumulate(c), [n]])
+
+    cy, cx = cuts(h, gy), cuts(w, gx)
+    row = np.searchsorted(cy, np.arange(h), side="right") - 1
+    col = np.searchsorted(cx, np.arange(w), side="right") - 1
+    base = (np.clip(row, 0, gy - 1)[:, None] * gx + np.clip(col, 0, gx - 1)[None, :]).astype(np.int64)
+    return np.stack([np.roll(base, align * (t // 4), axis=1) for t in range(num_frames)])
+
+
 def region_prototypes(num_regions: int, channels: int, seed: int, min_dist: float = 1.2, kind: str = "random") -> np.ndarray:
     """`num_regions` prototype vectors, float64 [R, channels].  kind="random": unit-scale normal draws with pairwise Euclidean
     distance >= min_dist (rejection sampling on the seeded stream).  kind="lattice" (channels = 4, R <= 24): a seeded choice
@@ -145,13 +170,13 @@ def region_prototypes(num_regions: int, channels: int, seed: int, min_dist: floa
 
 
 def region_clip(num_frames: int, h: int, w: int, num_regions: int = 20, seed: int = 1, channels: int = 4, amp: float = 1.5,
-                noise: float = 0.05, protos: str = "random") -> np.ndarray:
+                noise: float = 0.05, protos: str = "random", layout: str = "voronoi") -> np.ndarray:
     """Seeded piecewise-constant latent: `num_regions` drifting Voronoi cells, each with its own well-separated prototype
     vector, + white noise; float32 [F, C, h, w] at the scale of an encode_first_stage output (std ~ 1).  The headline
     workload (bench.py, tests at BASELINE configs[1]) uses it with num_regions = the number of masks, so that the K-means
     problem Steps 3-3b solve has K natural clusters (a clip of K objects) instead of over-segmenting a 6-blob scene, whose
     partition is decided by the last bits of the features."""
-    lab = region_labels(num_frames, h, w, num_regions, seed + 4000)
+    lab = (block_labels if layout == "blocks" else region_labels)(num_frames, h, w, num_regions, seed + 4000)
     pv = region_prototypes(num_regions, channels, seed + 5000, kind=protos)
     g = _rng(seed)
     lat = pv[lab] * amp + noise * g.standard_normal((num_frames, h, w, channels))
