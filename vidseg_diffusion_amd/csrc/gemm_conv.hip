@@ -13,6 +13,7 @@
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 struct GemmParams {
     // A operand
@@ -1617,6 +1618,12 @@ static inline hipEvent_t prof_event() {
 // three 8-column cells of an 8-row pass sit at fixed columns, so their bias lives in registers, the residual of the NEXT pass is
 // requested before the stores of this one (vmcnt retires in order: a load queued behind stores waits for them), and the
 // compiler's counted waits do the rest.
+#ifdef VS_WS_STAMPS                                        /* experiment builds only (tools/build_exp.py): s_memtime at the phase boundaries */
+__device__ unsigned long long vs_ws_stamps[8 * 4 * 4];
+#define VS_WS_STAMP(i) do { if (blockIdx.x == 40 && lane == 0 && tile_no >= 1 && tile_no < 5) vs_ws_stamps[(wave * 4 + (tile_no - 1)) * 4 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define VS_WS_STAMP(i)
+#endif
 template <int NJ, int KT, int EPI>
 __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cpx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1629,6 +1636,11 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
     if (qx >= cpx * np) return;
     const int panel = qx % np, chunk = xcd * cpx + qx / np;
     const int pbase = panel * BN;
+    // Panel column behind row i of fragment j.  The direct epilogues pair fragments (2u, 2u+1): accumulator row 4g + r of the
+    // pair is column 32u + 8g + 4 (j & 1) + r, so a lane (g = lane >> 4) holds 8 consecutive columns = one 16-byte store and the
+    // four lane groups 64 contiguous bytes of a row (32-byte pieces, one fragment at a time, were store-issue bound: 5000-6000
+    // cycles per tile by the stamps).  An unpaired last fragment (NJ odd) and the shared epilogue keep the natural order.
+    auto pcol = [](int j, int i) { return (EPI && NJ != 10 && j < (NJ & ~1)) ? (j >> 1) * 32 + (i >> 2) * 8 + (j & 1) * 4 + (i & 3) : 16 * j + i; };
     // W panel -> LDS: slot (kk, j, g, n16) holds W[pbase + 16 j + n16][32 kk + 8 g .. +8]
     {
         constexpr int NSLOT = KT * NJ * 64, PER = (NSLOT + 511) / 512;      // 13 pieces per thread, all in flight before the first store
@@ -1637,7 +1649,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
         for (int u = 0; u < PER; ++u) {
             const int sidx = min(tid + 512 * u, NSLOT - 1);
             const int l = sidx & 63, f = sidx >> 6, j = f % NJ, kk = f / NJ;
-            wv[u] = *reinterpret_cast<const bf16x8_t*>(p.w + (long long)(pbase + 16 * j + (l & 15)) * K + 32 * kk + 8 * (l >> 4));
+            wv[u] = *reinterpret_cast<const bf16x8_t*>(p.w + (long long)(pbase + pcol(j, l & 15)) * K + 32 * kk + 8 * (l >> 4));
         }
 #pragma unroll
         for (int u = 0; u < PER; ++u)
@@ -1654,11 +1666,19 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
     const bf16_t* abase = p.x0 + 8 * q;
     bf16x8_t areg[RING][2];
     // With the straight-line epilogues the ring loads are issued and waited for by hand: the compiler answers loads carried
-    // around the tile loop with vmcnt(0) at the top of every tile.  vmcnt retires in order, so "slot kk has landed" = at most
-    // as many operations outstanding as were issued after it: the 18 other ring loads plus, when the slot was filled before
-    // the previous tile's epilogue, that epilogue's EOPS stores / residual loads (a fixed number: they are skipped only in the
-    // tile past M, which is the last one its wave runs).
-    constexpr int EOPS = EPI == 0 ? 0 : (EPI == 1 ? 4 : 8) * ((BN + 63) / 64);
+    // around the tile loop with vmcnt(0) at the top of every tile.  Loads retire in order, so "slot kk has landed" = at most
+    // as many operations outstanding as LOADS were issued after it: the 18 other ring loads plus, when the slot was filled
+    // before the previous tile's epilogue, that epilogue's EOPS residual loads.
+    // The two straight-line epilogues.  STAGED (160-column panels): 8-row passes through the per-wave fp32 buffer, every lane
+    // then writes 16-byte cells of whole rows (12 stores per tile, full lines).  Direct (80-column panels): fragment pairs as
+    // 16-byte stores straight from the accumulators (pcol), 64 contiguous bytes per row and instruction.  Measured per shape:
+    // 114688x320x320 39.7 / 38.5 us, + residual 47.4 / 56.8, x960 130 / 143; 28672x640x640 + residual 53.8 / 44.9.
+    constexpr bool STAGED = NJ == 10;
+    constexpr int EOPS = EPI != 2 ? 0 : (STAGED ? 4 * ((8 * (BN / 8) + 63) / 64) : 2 * ((NJ + 1) / 2));     // LOADS the epilogue issues (residual).  Its stores are NOT counted:
+                                                                // loads retire in order among loads, but a store may retire ahead of an
+                                                                // older load (seen: with stores in the count the ring was read too early
+                                                                // once the epilogue got short), so the count must hold with every store
+                                                                // already gone; while stores are pending it merely over-waits
     auto load_a = [&](int slot, int tile, int kk) {            // rows past M clamp to the last one (their results are never stored)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1670,7 +1690,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
                 areg[slot][i] = *reinterpret_cast<const bf16x8_t*>(ap);
         }
     };
-    // fast epilogue: this lane's cells of an 8-row pass (cell = lane + 64 c over 8 rows x BN / 8 columns-of-eight)
+    // staged epilogue: this lane's cells of an 8-row pass (cell = lane + 64 c over 8 rows x BN / 8 columns-of-eight)
     constexpr int NC8 = BN / 8, NCELL = (8 * NC8 + 63) / 64;
     int crow[NCELL], ccol[NCELL];
     bool cval[NCELL];
@@ -1688,8 +1708,10 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
     // one tile; FIRST: no epilogue lies between the prologue's loads and this tile's k-steps (separate instantiations, not a
     // runtime flag: two wait statements tied to the same ring registers in two branches make the compiler copy those registers
     // ahead of the wait)
+    int tile_no = 0;
     auto tile_body = [&](auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
+        VS_WS_STAMP(0);
         const int tn = t + 8 < t_end ? t + 8 : t;              // the tile whose first k-steps refill the ring at the end of this one
         f32x4 acc[2][NJ];
 #pragma unroll
@@ -1732,24 +1754,23 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
         }                                                      // below the last MFMA otherwise)
         // epilogue: four passes of 8 rows; lanes whose row lies in the pass write their 16 columns-of-four, then every lane
         // takes 8-column cells of the staged rows (bias, residual, taps ... exactly as the tiled kernels)
-        if (EPI) {
-            bf16x8_t rr[2][NCELL];
-            auto load_res = [&](int pass, int buf) {
-#pragma unroll
-                for (int c = 0; c < NCELL; ++c) {
-                    const int m = min(t * 32 + 8 * pass + crow[c], mlast);
-                    rr[buf][c] = *reinterpret_cast<const bf16x8_t*>(p.residual + (long long)m * p.ldr + pbase + ccol[c]);
-                }
-            };
-            if (EPI == 2) load_res(0, 0);
+        VS_WS_STAMP(1);
+        if (EPI && STAGED) {
+            bf16x8_t rr[NCELL];                                // the pass's residual cells, requested before its LDS round trip
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int i = pass >> 1, h = pass & 1;
+                if (EPI == 2) {
+#pragma unroll
+                    for (int c = 0; c < NCELL; ++c) {
+                        const int m = min(t * 32 + 8 * pass + crow[c], mlast);
+                        rr[c] = *reinterpret_cast<const bf16x8_t*>(p.residual + (long long)m * p.ldr + pbase + ccol[c]);
+                    }
+                }
                 if ((l15 >> 3) == h) {
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(stage + (l15 & 7) * EP_LD + 16 * j + 4 * q) = acc[i][j];
                 }
-                if (EPI == 2 && pass < 3) load_res(pass + 1, (pass + 1) & 1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1766,23 +1787,69 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
                     }
                     if (EPI == 2) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[pass & 1][c][e]);
+                        for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[c][e]);
                     }
-                    bf16x8_t o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(v[e]);
+                    const u32x4 o = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
                     const int m = t * 32 + 8 * pass + crow[c];
-                    // the store is hidden from the compiler's wait-count model: with stores and loads both pending it falls back to
-                    // vmcnt(0) before every use of the A ring; counting loads only it emits counted waits, which the hardware (whose
-                    // counter includes the stores, retiring in order) can only over-satisfy
-                    if (m <= mlast) {
-                        bf16_t* op = p.out + (long long)m * p.ldo + pbase + ccol[c];
-                        asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(op), "v"(o) : "memory");
-                    }
+                    // compiler-visible stores (see the direct epilogue below for what an asm store did)
+                    if (m <= mlast) *reinterpret_cast<u32x4*>(p.out + (long long)m * p.ldo + pbase + ccol[c]) = o;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
+            VS_WS_STAMP(2);
+            ++tile_no;
+            return;
+        }
+        if (EPI) {
+            // direct epilogue (no LDS round trip): fragment pairs as 16-byte stores, see pcol
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = t * 32 + 16 * i + l15;
+                const bf16_t* rrow = p.residual + (long long)min(m, mlast) * p.ldr + pbase;
+                bf16_t* orow = p.out + (long long)m * p.ldo + pbase;
+                constexpr int NP = NJ / 2;
+                u32x4 rr[NP];
+                u32x2 rl;
+                if (EPI == 2) {
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) rr[u] = *reinterpret_cast<const u32x4*>(rrow + 32 * u + 8 * q);
+                    if (NJ & 1) rl = *reinterpret_cast<const u32x2*>(rrow + 16 * (NJ - 1) + 4 * q);
+                }
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sbias + 32 * u + 8 * q), b1 = *reinterpret_cast<const f32x4*>(sbias + 32 * u + 8 * q + 4);
+                    f32x4 v0 = acc[i][2 * u] + b0, v1 = acc[i][2 * u + 1] + b1;
+                    if (EPI == 2) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            v0[2 * e] += bf16_to_f32((bf16_t)(rr[u][e] & 0xffffu));
+                            v0[2 * e + 1] += bf16_to_f32((bf16_t)(rr[u][e] >> 16));
+                            v1[2 * e] += bf16_to_f32((bf16_t)(rr[u][2 + e] & 0xffffu));
+                            v1[2 * e + 1] += bf16_to_f32((bf16_t)(rr[u][2 + e] >> 16));
+                        }
+                    }
+                    const u32x4 o = {pack2_bf16(v0[0], v0[1]), pack2_bf16(v0[2], v0[3]), pack2_bf16(v1[0], v1[1]), pack2_bf16(v1[2], v1[3])};
+                    // a compiler-visible store: issued from inline asm, the next LDS read reused its data registers and the rows
+                    // 12-15 of every fragment went out with the first word overwritten (32 wait states after the store cured it;
+                    // the compiler knows how long a store's data registers stay busy, an asm statement tells it nothing)
+                    if (m <= mlast) *reinterpret_cast<u32x4*>(orow + 32 * u + 8 * q) = o;
+                }
+                if (NJ & 1) {
+                    const f32x4 bj = *reinterpret_cast<const f32x4*>(sbias + 16 * (NJ - 1) + 4 * q);
+                    f32x4 v = acc[i][NJ - 1] + bj;
+                    if (EPI == 2) {
+                        v[0] += bf16_to_f32((bf16_t)(rl[0] & 0xffffu));
+                        v[1] += bf16_to_f32((bf16_t)(rl[0] >> 16));
+                        v[2] += bf16_to_f32((bf16_t)(rl[1] & 0xffffu));
+                        v[3] += bf16_to_f32((bf16_t)(rl[1] >> 16));
+                    }
+                    const u32x2 o = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+                    if (m <= mlast) *reinterpret_cast<u32x2*>(orow + 16 * (NJ - 1) + 4 * q) = o;
+                }
+            }
+            VS_WS_STAMP(2);
+            ++tile_no;
             return;
         }
 #pragma unroll
@@ -1804,6 +1871,11 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
     for (t += 8; t < t_end; t += 8) tile_body(std::false_type{});
 }
 
+#ifdef VS_WS_STAMPS
+extern "C" int vidseg_debug_ws_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vs_ws_stamps), sizeof(unsigned long long) * 8 * 4 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" {
 
 int vidseg_gemm_profile_begin(void) {
