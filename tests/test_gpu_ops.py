@@ -298,7 +298,8 @@ def test_attention_reference_moves(dev):
         ref = TF.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, N, C)
         out = ops.attention(q.to(dev), k.to(dev), v.to(dev), H).float().cpu()
         assert torch.isfinite(out).all()
-        tol = (2.0 ** -7) * ref.abs() + 2e-3 * ref.abs().max()
+        wide = 1.0 if ops.act_dtype() == torch.float16 else 4.0           # bf16 build: P carries 8 significand bits
+        tol = wide * ((2.0 ** -7) * ref.abs() + 2e-3 * ref.abs().max())
         assert ((out - ref).abs() <= tol).all(), f"{kind}: attention max err {(out - ref).abs().max():.4g}"
 
 
