@@ -1627,9 +1627,10 @@ __device__ unsigned long long vs_ws_stamps[8 * 4 * 4];
 template <int NJ, int KT, int EPI>
 __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cpx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BN = NJ * 16, K = KT * 32, EP_LD = BN + 4, RING = 10;
+    // ring depth: ten k-steps (3200 MFMA cycles of cover per wave); five where the residual double buffer needs the registers
+    constexpr int BN = NJ * 16, K = KT * 32, EP_LD = BN + 4, RING = (EPI == 2 && NJ == 10) ? 5 : 10;
     constexpr int W_BYTES = KT * NJ * 1024;                    // [k-step][fragment][lane] x 16 B: a fragment read is lane-linear
-    static_assert(KT % RING == 0, "the A ring is indexed by k-step mod 10");
+    static_assert(KT % RING == 0, "the A ring is indexed by k-step mod RING");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7, qx = blockIdx.x >> 3;
@@ -1723,9 +1724,9 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
             const int slot = kk % RING;
             if (EPI) {
                 if (kk < RING && !FIRST)
-                    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(areg[slot][0]), "+v"(areg[slot][1]) : "n"(18 + EOPS) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(areg[slot][0]), "+v"(areg[slot][1]) : "n"(2 * (RING - 1) + EOPS) : "memory");
                 else
-                    asm volatile("s_waitcnt vmcnt(18)" : "+v"(areg[slot][0]), "+v"(areg[slot][1])::"memory");
+                    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(areg[slot][0]), "+v"(areg[slot][1]) : "n"(2 * (RING - 1)) : "memory");
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -1739,7 +1740,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
                 load_a(slot, tn, kk + RING - KT);
             // W fragments: NJ / 2 - 1 reads ahead of the MFMAs that use them (left alone the scheduler keeps one pair in flight and
             // waits for an LDS round trip every four MFMAs)
-            // (not with the residual double buffer: too few registers left, measured 47 -> 53 us with two reads ahead)
+            // (not in the residual variant: no difference there, 48-52 us either way)
             constexpr int AHEAD = NJ / 2 - 1;
             if (!(EPI == 2 && NJ == 10)) {
                 __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
@@ -1756,20 +1757,36 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
         // takes 8-column cells of the staged rows (bias, residual, taps ... exactly as the tiled kernels)
         VS_WS_STAMP(1);
         if (EPI && STAGED) {
-            bf16x8_t rr[NCELL];                                // the pass's residual cells, requested before its LDS round trip
+            // residual cells: like the A ring, loaded and waited for by hand (a compiler-tracked load next to the stores makes
+            // every wait a vmcnt(0): PMC showed these waves parked 57 % of their cycles).  The next pass's cells are requested
+            // before this pass's stores; "pass p has landed" = at most the next pass's NCELL loads outstanding (loads retire in
+            // order; pending stores only make the wait longer), the last pass has no younger load and drains.
+            bf16x8_t rr[2][NCELL];
+            auto load_res = [&](int pass) {
+#pragma unroll
+                for (int c = 0; c < NCELL; ++c) {
+                    const bf16_t* rp = p.residual + (long long)min(t * 32 + 8 * pass + crow[c], mlast) * p.ldr + pbase + ccol[c];
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rr[pass & 1][c]) : "v"(rp) : "memory");
+                }
+            };
+            if (EPI == 2) load_res(0);
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int i = pass >> 1, h = pass & 1;
-                if (EPI == 2) {
-#pragma unroll
-                    for (int c = 0; c < NCELL; ++c) {
-                        const int m = min(t * 32 + 8 * pass + crow[c], mlast);
-                        rr[c] = *reinterpret_cast<const bf16x8_t*>(p.residual + (long long)m * p.ldr + pbase + ccol[c]);
-                    }
-                }
                 if ((l15 >> 3) == h) {
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(stage + (l15 & 7) * EP_LD + 16 * j + 4 * q) = acc[i][j];
+                }
+                if (EPI == 2) {
+                    if (pass < 3) {
+                        load_res(pass + 1);
+                        if (NCELL == 3)
+                            asm volatile("s_waitcnt vmcnt(3)" : "+v"(rr[pass & 1][0]), "+v"(rr[pass & 1][1]), "+v"(rr[pass & 1][NCELL - 1])::"memory");
+                        else
+                            asm volatile("s_waitcnt vmcnt(2)" : "+v"(rr[pass & 1][0]), "+v"(rr[pass & 1][NCELL - 1])::"memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rr[pass & 1][0]), "+v"(rr[pass & 1][NCELL > 1 ? 1 : 0]), "+v"(rr[pass & 1][NCELL - 1])::"memory");
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
@@ -1787,7 +1804,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
                     }
                     if (EPI == 2) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[c][e]);
+                        for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[pass & 1][c][e]);
                     }
                     const u32x4 o = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
                     const int m = t * 32 + 8 * pass + crow[c];
