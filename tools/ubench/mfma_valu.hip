@@ -9,7 +9,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int KIND, int N>
-__device__ __forceinline__ void fillers(float (&x)[8], f32x2 (&y)[8], unsigned (&w)[8]) {
+__device__ __forceinline__ void fillers(float (&x)[8], f32x2 (&y)[8], unsigned (&w)[8], unsigned& sreg) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         if (KIND == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
@@ -19,6 +19,9 @@ __device__ __forceinline__ void fillers(float (&x)[8], f32x2 (&y)[8], unsigned (
         if (KIND == 5) asm volatile("v_max3_f32 %0, %0, %0, %0" : "+v"(x[i]));
         if (KIND == 6) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(y[i]));
         if (KIND == 7) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x[i]));
+        if (KIND == 8) asm volatile("v_add_u32 %0, %0, %0" : "+v"(w[i]));
+        if (KIND == 9) asm volatile("s_add_u32 s20, s20, 1" ::: "s20", "scc");
+        if (KIND == 10) asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(w[i]));
     }
 }
 
@@ -31,18 +34,31 @@ __global__ void __launch_bounds__(512) k(float* out, int iters, f16x8 a, f16x8 b
     float x[8];
     f32x2 y[8];
     unsigned w[8];
+    unsigned sreg = 1;
     for (int i = 0; i < 8; ++i) { x[i] = -1.0f - i; y[i] = f32x2{1.f, 2.f}; w[i] = 0; }
-    const bool do_mfma = MODE == 0 || threadIdx.x < 256, do_fill = MODE == 0 || threadIdx.x >= 256;
-    for (int it = 0; it < iters; ++it) {
+    if (MODE == 0) {
+        for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (do_mfma) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c[i]) : "v"(a), "v"(b));
-            if (do_fill) fillers<KIND, N>(x, y, w);
+            for (int i = 0; i < 4; ++i) {
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c[i]) : "v"(a), "v"(b));
+                fillers<KIND, N>(x, y, w, sreg);
+            }
+        }
+    } else if (__builtin_amdgcn_readfirstlane(threadIdx.x) < 256) {      // one uniform branch, then two branch-free loops
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c[i]) : "v"(a), "v"(b));
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fillers<KIND, N>(x, y, w, sreg);
         }
     }
     float s = 0.f;
     for (int i = 0; i < 4; ++i) s += c[i][0] + c[i][5];
     for (int i = 0; i < 8; ++i) s += x[i] + y[i][0] + (float)w[i];
+    s += (float)sreg;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -76,6 +92,13 @@ void kind(float* d, const char* name, int iters) {
            run<KIND, 8, 1>(d, 512, iters) / base1);
 }
 
+template <int KIND>
+void split_small(float* d, const char* name, int iters) {
+    const float base1 = run<0, 0, 0>(d, 256, iters);
+    printf("%-14s split waves (4 MFMA waves + 4 filler waves), fillers per MFMA slot: N=1 %.2f  N=2 %.2f  N=4 %.2f\n", name,
+           run<KIND, 1, 1>(d, 512, iters) / base1, run<KIND, 2, 1>(d, 512, iters) / base1, run<KIND, 4, 1>(d, 512, iters) / base1);
+}
+
 int main() {
     float* d;
     hipMalloc(&d, 1 << 22);
@@ -90,5 +113,12 @@ int main() {
     kind<5>(d, "v_max3_f32", iters);
     kind<6>(d, "v_pk_fma_f32", iters);
     kind<7>(d, "v_fma_f32", iters);
+    kind<8>(d, "v_add_u32", iters);
+    kind<9>(d, "s_add_u32", iters);
+    kind<10>(d, "v_mul_lo_u32", iters);
+    split_small<2>(d, "v_add_f32", iters);
+    split_small<8>(d, "v_add_u32", iters);
+    split_small<9>(d, "s_add_u32", iters);
+    split_small<10>(d, "v_mul_lo_u32", iters);
     return 0;
 }

@@ -1141,10 +1141,10 @@ __global__ void __launch_bounds__(256, 2) k_attention3(const bf16_t* __restrict_
     }
 }
 
-// k_attention3 software-pipelined inside the wave.  The two waves a SIMD holds run the same phases and fall into step (the one
-// that lags gets the matrix pipe to itself and catches up), so MFMA and softmax VALU never overlapped across waves: MFMA-busy +
-// VALU-active was 93 % of the cycles.  Here the unit of work is a 32-key half tile u: while the matrix pipe computes S(u+1), the
-// VALU turns S(u) into P(u) in the same basic block (straight-line since k_attention3: exp2, row sum, conversion), then P(u) V(u).
+// k_attention3 software-pipelined inside the wave.  PMC on k_attention2 / k_attention3: MFMA-busy + VALU-active = 93 % of the
+// cycles -- the two waves a SIMD holds were hardly ever in complementary phases (the hardware would overlap them:
+// tools/ubench/mfma_valu.hip).  Here the unit of work is a 32-key half tile u: while the matrix pipe computes S(u+1), the VALU
+// turns S(u) into P(u) in the same basic block (straight-line since k_attention3: exp2, row sum, conversion), then P(u) V(u).
 // K is staged two tiles ahead (ring of 3) because S(t+1, first half) runs before the end-of-tile barrier of tile t; V one (ring of 2).
 #ifdef VS_ATTN_STAMPS                                      /* experiment builds only: s_memtime at the phase boundaries of tiles 8..11 */
 __device__ unsigned long long vs_attn_stamps[4 * 8 * 8];
