@@ -235,6 +235,13 @@ def test_conv_in_out(dev):
     ref2 = TF.conv2d(x2.permute(0, 3, 1, 2), w2, b2, padding=1)
     out2 = ops.conv_out4(x2.to(ops.act_dtype()).to(dev), ops.pack_conv_out(w2, dev), b2.to(dev))
     assert (out2.cpu() - ref2).abs().max() <= 1e-4 * ref2.abs().max() + 1e-5
+    # >= 4096 pixels: the register-resident-weights kernel (three / six 16-byte pieces per lane), ragged image edges
+    for (B, H, W, C) in ((2, 48, 50, 320), (3, 40, 37, 128), (2, 47, 45, 192)):
+        x3 = rnd((B, H, W, C), 7).to(ops.act_dtype()).float()
+        w3, b3 = rnd((4, C, 3, 3), 8, 0.05).to(ops.act_dtype()).float(), rnd((4,), 9)
+        ref3 = TF.conv2d(x3.permute(0, 3, 1, 2), w3, b3, padding=1)
+        out3 = ops.conv_out4(x3.to(ops.act_dtype()).to(dev), ops.pack_conv_out(w3, dev), b3.to(dev))
+        assert (out3.cpu() - ref3).abs().max() <= 1e-4 * ref3.abs().max() + 1e-5, (B, H, W, C)
 
 
 @pytest.mark.parametrize("B,HW,C0,C1,silu,eps", [(2, 64, 64, 0, True, 1e-5), (3, 100, 128, 64, True, 1e-5), (2, 256, 320, 0, False, 1e-6),

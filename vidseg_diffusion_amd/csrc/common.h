@@ -80,6 +80,15 @@ __device__ __forceinline__ f32x4 mfma_16x16x32(vs_s16x8 a, vs_s16x8 b, f32x4 c) 
 }
 #endif
 
+// acc + a.lo * b.lo + a.hi * b.hi on a packed pair of activations (one v_dot2c_f32_{f16,bf16})
+__device__ __forceinline__ float dot2_acc(unsigned a, unsigned b, float acc) {
+#if VIDSEG_ACT_IS_F16
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(vs_f16x2, a), __builtin_bit_cast(vs_f16x2, b), acc, false);
+#else
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(vs_bf16x2, a), __builtin_bit_cast(vs_bf16x2, b), acc, false);
+#endif
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

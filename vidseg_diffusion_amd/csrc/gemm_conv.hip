@@ -1573,6 +1573,69 @@ __global__ void __launch_bounds__(256) k_conv_out4(const bf16_t* __restrict__ x,
         for (int co = 0; co < 4; ++co) out_nchw[(((long long)b * 4 + co) * H + oh) * W + ow] = acc[co] + (bias ? bias[co] : 0.f);
 }
 
+// The same with the weights held in registers: a wave keeps its lanes' 16-byte pieces of all four filters (NP pieces per lane,
+// 9 * Cin / 8 <= 64 NP) and walks a strided list of output pixels, so the 23 KB of weights are read once per wave instead of once
+// per pixel (k_conv_out4 at 28 x 64 x 64 x 320: 175 -> 106 us for a 73 MB input); products on v_dot2c_f32_{f16,bf16} (v_fma_mix_f32: 122 us).
+// What is left is L2 traffic: neighbouring pixels run on different CUs, so the 9 taps of a pixel are 9 L2 reads of its 640-byte rows;
+// an LDS-tiled version (8 x 8 pixels + halo per block) would cut that to ~1.6x.
+template <int NP>
+__global__ void __launch_bounds__(256) k_conv_out4_ws(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ bias,
+                                                      int B, int H, int W, int Cin, float* __restrict__ out_nchw) {
+    const int lane = threadIdx.x & 63;
+    const long long npix = (long long)B * H * W;
+    const int c8 = Cin / 8, np = 9 * c8;
+    u32x4 wreg[NP][4];
+    int dh[NP], dw[NP], cofs[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int t = min(lane + 64 * k, np - 1), tap = t / c8;
+        dh[k] = tap / 3 - 1;
+        dw[k] = tap % 3 - 1;
+        cofs[k] = (t - tap * c8) * 8;
+        if (lane + 64 * k >= np) dh[k] = 1 << 20;              // no such piece: always out of range
+#pragma unroll
+        for (int co = 0; co < 4; ++co) wreg[k][co] = *reinterpret_cast<const u32x4*>(w + ((long long)co * 9 + tap) * Cin + cofs[k]);
+    }
+    const float b_lane = (bias && lane < 4) ? bias[lane] : 0.f;
+    const long long stride = (long long)gridDim.x * 4;
+    // two pixels per iteration: both pixels' pieces are requested before either's products (a wave has one SIMD partner: 170+ registers)
+    u32x4 xv[2][NP];
+    bool ok[2][NP];
+    for (long long pix0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); pix0 < npix; pix0 += 2 * stride) {
+        int ow[2], oh[2], bb[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long pc = pix0 + u * stride < npix ? pix0 + u * stride : pix0;
+            ow[u] = (int)(pc % W);
+            oh[u] = (int)((pc / W) % H);
+            bb[u] = (int)(pc / ((long long)W * H));
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int ih = oh[u] + dh[k], iw = ow[u] + dw[k];
+                ok[u][k] = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                const long long off = ok[u][k] ? (((long long)bb[u] * H + ih) * W + iw) * Cin + cofs[k] : 0;
+                xv[u][k] = *reinterpret_cast<const u32x4*>(x + off);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if (!ok[u][k]) continue;
+#pragma unroll
+                for (int co = 0; co < 4; ++co)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[co] = dot2_acc(xv[u][k][e], wreg[k][co][e], acc[co]);
+            }
+#pragma unroll
+            for (int co = 0; co < 4; ++co) acc[co] = wave_sum_f32(acc[co]);
+            const float v = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+            if (lane < 4 && (u == 0 || pix0 + stride < npix)) out_nchw[(((long long)bb[u] * 4 + lane) * H + oh[u]) * W + ow[u]] = v + b_lane;
+        }
+    }
+}
+
 // ---- live HIP-event timing of this kernel family (bench.py roofline) -------------------------------------
 // When enabled, every k_gemm_conv launch is bracketed by two events recorded on the launch stream; collect()
 // synchronises, sums the elapsed times and the algorithmic FLOPs (2*M*N*K per launch).
@@ -2404,7 +2467,16 @@ int vidseg_conv_out4(const void* x, const void* w, const float* bias, int B, int
     VS_REQUIRE(Cin % 8 == 0, "conv_out4: Cin=%d must be a multiple of 8", Cin);
     const long long pix = (long long)B * H * W;
     if (pix == 0) return VS_OK;
-    k_conv_out4<<<dim3((unsigned)((pix + 3) / 4)), 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, B, H, W, Cin, out_f32_nchw);
+    static int ws4 = -1;                                       // VIDSEG_CONV_OUT_WS=0: one wave per pixel, weights re-read per pixel
+    if (ws4 < 0) { const char* e = getenv("VIDSEG_CONV_OUT_WS"); ws4 = e ? atoi(e) : 1; }
+    const int npieces = 9 * (Cin / 8);
+    const unsigned nblk = (unsigned)((pix + 3) / 4 < 2048 ? (pix + 3) / 4 : 2048);      // 8 blocks per CU walk the pixel list
+    if (ws4 && pix >= 4096 && npieces <= 64 * 3)
+        k_conv_out4_ws<3><<<dim3(nblk), 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, B, H, W, Cin, out_f32_nchw);
+    else if (ws4 && pix >= 4096 && npieces <= 64 * 6)
+        k_conv_out4_ws<6><<<dim3(nblk), 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, B, H, W, Cin, out_f32_nchw);
+    else
+        k_conv_out4<<<dim3((unsigned)((pix + 3) / 4)), 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, B, H, W, Cin, out_f32_nchw);
     VS_CHECK_LAUNCH("conv_out4");
     return VS_OK;
 }
