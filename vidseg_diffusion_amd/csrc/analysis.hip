@@ -364,20 +364,25 @@ __global__ void __launch_bounds__(256) k_kpp_dist(RowsF16 X, const double* __res
 __global__ void __launch_bounds__(1024) k_kpp_pick(int64_t n, int R, int K, int c, int Tprev, int Tnext, const double* __restrict__ u,
                                                    int ustride, double* __restrict__ closest, const double* __restrict__ dcand,
                                                    const double* __restrict__ part, int ntiles, double* __restrict__ pot,
-                                                   int32_t* __restrict__ cand, int32_t* __restrict__ center_ids, int Tmax) {
+                                                   int32_t* __restrict__ cand, int32_t* __restrict__ center_ids, int Tmax, int staged) {
     // one block per restart r.  Finalises centre c-1 from the Tprev trial results, then (if c < K)
-    // draws Tnext candidates for centre c.
+    // draws Tnext candidates for centre c.  staged: the winning trial's n distances go through LDS (one coalesced read) and the
+    // two per-thread segment walks read them there -- the same per-thread arithmetic as the direct walk (whose 112-byte-strided
+    // global reads were the rest of this kernel's time).
+    extern __shared__ double s_src[];
     const int r = blockIdx.x;
     __shared__ double s_pots[16];
     __shared__ int s_best;
     __shared__ double s_seg[1024];
     __shared__ int s_cnt[16];
     const int t = threadIdx.x;
-    if (t < Tprev) {
+    if ((t >> 6) < Tprev) {                           // wave k sums trial k's tile partials: lane-strided, then a butterfly
+        const int k = t >> 6;                         // (four threads walking 224 partials one load at a time was a third of the kernel)
         double s = 0.0;
-        const double* p = part + (int64_t)(r * Tprev + t) * ntiles;
-        for (int i = 0; i < ntiles; ++i) s += p[i];
-        s_pots[t] = s;
+        const double* p = part + (int64_t)(r * Tprev + k) * ntiles;
+        for (int i = t & 63; i < ntiles; i += 64) s += p[i];
+        s = wave_sum_f64(s);
+        if ((t & 63) == 0) s_pots[k] = s;
     }
     __syncthreads();
     if (t == 0) {
@@ -396,21 +401,46 @@ __global__ void __launch_bounds__(1024) k_kpp_pick(int64_t n, int R, int K, int 
     const int64_t seg = (n + 1023) / 1024;
     const int64_t i0 = (int64_t)t * seg, i1 = min(n, i0 + seg);
     double tot = 0.0;
-    for (int64_t i = i0; i < i1; ++i) {
-        double v = src[i];
-        dst[i] = v;
-        tot += v;
+    if (staged) {
+        for (int64_t i = t; i < n; i += 1024) {
+            const double v = src[i];
+            s_src[i] = v;
+            dst[i] = v;
+        }
+        __syncthreads();
+        for (int64_t i = i0; i < i1; ++i) tot += s_src[i];
+    } else {
+        for (int64_t i = i0; i < i1; ++i) {
+            double v = src[i];
+            dst[i] = v;
+            tot += v;
+        }
     }
     if (c >= K) return;
     s_seg[t] = tot;
     __syncthreads();
-    if (t == 0) {                                     // exclusive scan of segment totals, sequential order
+    if (t < 64) {
+        // exclusive scan of the 1024 segment totals by one wave: 16 consecutive totals per lane in order, the lane totals by a
+        // log-step scan, the lane's offset added to its 16 prefixes.  (One thread walking all 1024 through LDS took most of this
+        // kernel's 73 us.  Like the segment split itself this is another association of the same float64 sum than numpy's
+        // sequential cumsum -- differences of one ulp of the running total, against thresholds u * pot drawn from a continuous
+        // distribution; every reference fixture still picks the same candidates.)
+        double loc[16];
         double run = 0.0;
-        for (int k = 0; k < 1024; ++k) {
-            double v = s_seg[k];
-            s_seg[k] = run;
-            run += v;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            loc[k] = run;
+            run += s_seg[t * 16 + k];
         }
+        double incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(incl, o, 64);
+            if (t >= o) incl += up;
+        }
+        const double base = incl - run;               // sum of the lanes before this one
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s_seg[t * 16 + k] = base + loc[k];
     }
     __syncthreads();
     const double potr = s_pots[best];
@@ -422,7 +452,7 @@ __global__ void __launch_bounds__(1024) k_kpp_pick(int64_t n, int R, int K, int 
     }
     double run = s_seg[t];
     for (int64_t i = i0; i < i1; ++i) {
-        run += src[i];
+        run += staged ? s_src[i] : src[i];
         for (int k = 0; k < Tnext; ++k) cnt[k] += (run < rv[k]) ? 1 : 0;
     }
     for (int k = 0; k < Tnext; ++k)
@@ -1411,8 +1441,14 @@ int vidseg_kpp_round(const void* x16, const double* mean, const double* xsq, int
     const int ntiles = (int)cdiv64(n, TS);
     RowsF16 X{(const f16*)x16, nullptr, mean, n, C};
     if (c > 0) {
-        k_kpp_pick<<<dim3(R), 1024, 0, st>>>(n, R, K, c, Tprev, Tnext, u, ustride, closest, dcand, part, ntiles, pot, cand, center_ids,
-                                             Tmax);
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)k_kpp_pick, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+            attr = true;
+        }
+        const int staged = n * 8 <= 120 * 1024;                        // 14336 tokens: 112 KB
+        k_kpp_pick<<<dim3(R), 1024, staged ? (size_t)n * 8 : 0, st>>>(n, R, K, c, Tprev, Tnext, u, ustride, closest, dcand, part, ntiles, pot, cand,
+                                                                   center_ids, Tmax, staged);
         VS_CHECK_LAUNCH("kpp_pick");
     }
     if (c < K) {
