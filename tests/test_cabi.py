@@ -115,3 +115,24 @@ def test_png_mask_folder_round_trip(tmp_path):
             assert a.numel() == (base * (4 if block == 7 else 8)) ** 2
     same_res = load_feature_masks(folder, 5, num_frames=F, modulate_block_idx=7, base_height=2, base_width=2, frame_name_list=names, device=cpu)
     assert torch.equal(same_res[0], torch.from_numpy((lab[0] == 5).astype(np.float64).reshape(-1)))
+
+
+def test_hand_counted_kernels_have_no_scratch(tmp_path):
+    """k_gemm_ws waits for its ring loads with hand-written `s_waitcnt vmcnt(N)` counts; a register spill would put scratch loads
+    (VMEM operations the counts do not know about) into its loop and the ring would be read too early.  Cross-compile the GEMM
+    file to assembly for both builds and require: no private segment, no scratch instruction in any k_gemm_ws instantiation."""
+    import re
+    import subprocess
+    import __graft_entry__ as G
+    src = os.path.join(G.CSRC, "gemm_conv.hip")
+    for defines in ([], ["-DVIDSEG_ACT_BF16"]):
+        out = str(tmp_path / ("gemm" + ("_bf16" if defines else "") + ".s"))
+        subprocess.check_call([G.HIPCC, *[f for f in G.FLAGS if f != "-fPIC"], *defines, "-I", os.path.join(G.ROOT, "include"),
+                               "--cuda-device-only", "-S", "-o", out, src], stderr=subprocess.DEVNULL)
+        text = open(out).read()
+        bodies = re.findall(r"^(_Z9k_gemm_wsILi\d+ELi\d+ELi\d+EEv\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, flags=re.S | re.M)
+        assert len(bodies) >= 6, [b[0] for b in bodies]
+        for name, body in bodies:
+            assert "scratch_" not in body, (name, defines)
+        for name, size in re.findall(r"\.amdhsa_kernel (_Z9k_gemm_ws\S+).*?\.amdhsa_private_segment_fixed_size (\d+)", text, flags=re.S):
+            assert int(size) == 0, (name, size, defines)
