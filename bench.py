@@ -375,21 +375,39 @@ def main():
     ap.add_argument("--masks", type=int, default=None, help="number of masks K (default 20; configs[4] uses 50)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the chained-window figure, the in-run PMC passes and the SVD secondary")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # one window under rocprofv3 --pmc (see pmc_traffic)
+    ap.add_argument("--launch-dry-run", action="store_true",
+                    help="start the N ranks, form the process group, all-reduce a one per rank and print {n_gpus, rccl_ranks} -- no GPU "
+                         "work (CPU test of the launcher: VIDSEG_DIST_BACKEND=gloo)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` called directly: become the launcher -- one rank per GPU through torch.distributed.run, exactly
+        # the command the driver's contract names; rank 0 of the children prints the JSON line on the inherited stdout.
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("VIDSEG_DIST_BACKEND", "nccl")       # "gloo" + VIDSEG_ONE_GPU=1: dry-run of the N > 1 path on a 1-GPU box
     if os.environ.get("VIDSEG_ONE_GPU") == "1":
         local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
+    if args.launch_dry_run:
+        return launch_dry_run(rank, world, backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if os.environ.get("VIDSEG_ONE_GPU") != "1" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+        ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)                                        # every rank really is in the group: the sum is the group's size
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == dist.get_world_size() == args.gpus, (rccl_ranks, dist.get_world_size(), args.gpus)
 
     from vidseg_diffusion_amd import ops
     svd = args.config == "svd"
@@ -399,6 +417,8 @@ def main():
     out, sd_cpu, cfg, eng, labels, run_steps = run_config(args, svd, rank, world, dev, args.steps, args.warmup)
 
     if out is not None:
+        out["rccl_ranks"] = rccl_ranks
+        out["dist_backend"] = (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from tools_metrics import matched_iou
         if not svd and not args.narrow:
@@ -494,6 +514,36 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """Re-exec this script as N ranks of one node: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port <free> bench.py <same flags>.  Returns the launcher's exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                # dmabuf IPC (RCCL needs it on this host driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def launch_dry_run(rank, world, backend):
+    """The launcher and the process group without any GPU work (tests/test_parallel_gloo.py::test_bench_self_launch)."""
+    ranks = 1
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend)
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        ranks = int(ones.item())
+        assert ranks == dist.get_world_size()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "rccl_ranks": ranks, "dist_backend": backend, "dry_run": True}))
 
 
 def first_stage_timing(dev, svd):

@@ -88,3 +88,22 @@ def test_two_ranks_equal_sequential_windows():
     seq = np.stack(seq)
     for r in range(2):
         assert np.array_equal(res[r], seq), f"rank {r}: sharded labels differ from the sequential window loop"
+
+
+def test_bench_gpus_flag_starts_the_ranks():
+    """`python bench.py --gpus 2` called directly (the driver's call) on a one-GPU box: both ranks on cuda:0, gloo collectives.
+    The line must say n_gpus = 2 = the size of the group that was formed, and count two windows per step."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VIDSEG_DIST_BACKEND="gloo", VIDSEG_ONE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--narrow", "--steps", "2", "--warmup", "1",
+                        "--no-secondary", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["scaling"] == "weak"
+    assert abs(out["value"] - 2 * 14 * 2 / (out["ms_per_step"] * 2 / 1e3)) / out["value"] < 1e-2      # frames of BOTH ranks / max-rank time

@@ -96,3 +96,24 @@ def test_window_slices_match_reference_loop():
     assert window_slices(28, 14) == [(0, 14), (14, 28), (14, 28)]
     assert window_slices(30, 14) == [(0, 14), (14, 28), (16, 30)]
     assert window_slices(5, 14) == [(0, 5)]
+
+
+def test_bench_self_launch():
+    """`python bench.py --gpus 2` called DIRECTLY (no torchrun around it, WORLD_SIZE unset -- how the driver calls it) must start two
+    ranks itself and report n_gpus = 2 = the size of the process group it really formed; --gpus disagreeing with an inherited
+    WORLD_SIZE must fail instead of printing a line for the wrong N."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VIDSEG_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-dry-run"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["rccl_ranks"] == 2, r.stdout
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-dry-run"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "disagree" in (r.stderr + r.stdout)

@@ -16,7 +16,14 @@ The fixture stores: the reference's labels (Step 3) and corrected labels (Step 3
 step-24 Q taps (every 16th token, every 2nd channel, conditional half of blocks 6/7/8 in fp16) with the full-tensor norms, plus
 sha256 of every input so the tests can detect drift of the generators.
 
-    python tools/gen_golden_c2_window.py
+Round 3: `--windows 0-15` runs several windows in one process (the network is built once) and every fixture also holds the
+labels, inertia and iteration count of ALL TEN restarts of the reference's `KMeans(n_init=10)` (captured by wrapping
+sklearn.cluster._kmeans._kmeans_single_lloyd while the reference's own `feature_extraction_main` runs -- the reference's
+arithmetic, observed, not restated): `restart_labels` int8 [10, F*N], `restart_inertia` f64 [10], `restart_n_iter`, `restart_best`.
+With C2_TAP_CACHE=<dir> the full fp32 step-24 Q taps (conditional half, blocks 6/7/8) are also written there (110 MB per window,
+never committed) for tools/mask_knee_study.py.
+
+    python tools/gen_golden_c2_window.py [--windows 0-15]
 """
 import os
 import shutil
@@ -38,12 +45,46 @@ BLOCKS = ["output_block_8", "output_block_7", "output_block_6"]
 
 
 def main():
-    zero_gain = float(os.environ.get("C2_ZERO_GAIN", synthetic.HEADLINE["zero_gain"]))
-    # C2_WINDOW=w > 0: window w of the headline clip (bench.py make_inputs: latent seed 1 + w, noise seed 100 + w, the same
-    # conditioning) -> tests/golden/c2_window_w<w>.npz holding the reference's labels and the input hashes only (no taps)
-    wid = int(os.environ.get("C2_WINDOW", "0"))
-    out_path = os.environ.get("C2_OUT", os.path.join(ROOT, "tests", "golden", "c2_window.npz" if wid == 0 else f"c2_window_w{wid}.npz"))
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--windows", default=os.environ.get("C2_WINDOW", "0"), help="e.g. 0 or 0-15 or 3,7,9")
+    args = ap.parse_args()
+    wids = []
+    for part in args.windows.split(","):
+        a, _, b = part.partition("-")
+        wids += list(range(int(a), int(b or a) + 1))
     fe = import_reference()
+    state = {}
+    for wid in wids:
+        run_window(fe, wid, state)
+
+
+class RestartRecorder:
+    """Observe every restart of the reference's KMeans(n_init=10).fit: sklearn/cluster/_kmeans.py:1497-1531 calls the module-level
+    `_kmeans_single_lloyd` once per restart and keeps the best by inertia; the wrapper records what each call returned."""
+
+    def __init__(self):
+        import sklearn.cluster._kmeans as km
+        self.km, self.orig, self.runs = km, km._kmeans_single_lloyd, []
+
+    def __enter__(self):
+        def wrapped(*a, **kw):
+            out = self.orig(*a, **kw)
+            labels, inertia, centers, n_iter = out
+            self.runs.append((np.asarray(labels).astype(np.int8).copy(), float(inertia), int(n_iter)))
+            return out
+        self.km._kmeans_single_lloyd = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        self.km._kmeans_single_lloyd = self.orig
+
+
+def run_window(fe, wid, state):
+    zero_gain = float(os.environ.get("C2_ZERO_GAIN", synthetic.HEADLINE["zero_gain"]))
+    # window w > 0 of the headline clip (bench.py make_inputs: latent seed 1 + w, noise seed 100 + w, the same
+    # conditioning) -> tests/golden/c2_window_w<w>.npz holding the reference's labels and the input hashes only (no taps)
+    out_path = os.environ.get("C2_OUT", os.path.join(ROOT, "tests", "golden", "c2_window.npz" if wid == 0 else f"c2_window_w{wid}.npz"))
     from sgm.modules.diffusionmodules.denoiser import DiscreteDenoiser
     from sgm.modules.diffusionmodules.openaimodel import UNetModel
     from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
@@ -51,11 +92,14 @@ def main():
     torch.set_grad_enabled(False)
     t_all = time.time()
     cfg = dict(synthetic.SD21_FULL)
-    net = UNetModel(use_checkpoint=False, **cfg).eval()
-    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
-    sd = synthetic.fill_state_dict(shapes, seed=1234, zero_gain=zero_gain)
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    del sd
+    if "net" not in state:
+        net = UNetModel(use_checkpoint=False, **cfg).eval()
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        sd = synthetic.fill_state_dict(shapes, seed=1234, zero_gain=zero_gain)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        del sd
+        state["net"], state["shapes"], state["orig_forward"] = net, shapes, net.forward
+    net, shapes = state["net"], state["shapes"]
     rec = dict(state_dict_signature=synthetic.state_dict_signature(shapes), weight_seed=1234, zero_gain=zero_gain,
                F=F, lat=LAT, K=K, t_start=T_START, num_steps=NUM_STEPS, seed=17)
 
@@ -67,7 +111,7 @@ def main():
 
     # ---- batch-chunked network call (values identical to the batch-28 call, see module docstring) -------------------------
     taps = {}
-    orig_forward = net.forward
+    orig_forward = state["orig_forward"]
     attn = {b: net.output_blocks[b][1].transformer_blocks[0].attn1 for b in (6, 7, 8)}
 
     def chunked_forward(x, timesteps=None, context=None, y=None, **kw):
@@ -108,6 +152,10 @@ def main():
         if i == NUM_STEPS - 1:
             for b, a in attn.items():
                 taps[b] = a.q.half()
+            if os.environ.get("C2_TAP_CACHE"):
+                os.makedirs(os.environ["C2_TAP_CACHE"], exist_ok=True)
+                np.savez(os.path.join(os.environ["C2_TAP_CACHE"], f"taps_w{wid}.npz"),
+                         **{f"q{b}": a.q[F:].numpy().astype(np.float32) for b, a in attn.items()})
 
     final = sampler(denoiser, noised.clone(), cond=cond, uc=ucond, img_callback=cb, t_start=T_START)
     rec.update(x_final=final.numpy().astype(np.float32), x_step_norms=np.array([np.linalg.norm(x.astype(np.float64)) for x in xs]),
@@ -130,10 +178,16 @@ def main():
     os.chdir(REF)
     try:
         np.random.seed(17)                                    # seed_everything(seed) of the window, SDP:255
-        ul, ref_mask, ref_fm = fe.feature_extraction_main(
-            "match_gt_mask", K, T_START, ",".join(BLOCKS), exp, exp, "spatial_self_attn_q", LAT // 2, LAT // 2, "24",
-            frame_name_list=names, base_folder=base, num_frames=F, ref_mask=None, ref_feature_map=None, ref_unique_labels=None,
-            gt_mask_path=None)
+        with RestartRecorder() as recd:
+            ul, ref_mask, ref_fm = fe.feature_extraction_main(
+                "match_gt_mask", K, T_START, ",".join(BLOCKS), exp, exp, "spatial_self_attn_q", LAT // 2, LAT // 2, "24",
+                frame_name_list=names, base_folder=base, num_frames=F, ref_mask=None, ref_feature_map=None, ref_unique_labels=None,
+                gt_mask_path=None)
+        assert len(recd.runs) == 10, len(recd.runs)
+        rec["restart_labels"] = np.stack([r[0] for r in recd.runs])
+        rec["restart_inertia"] = np.array([r[1] for r in recd.runs], dtype=np.float64)
+        rec["restart_n_iter"] = np.array([r[2] for r in recd.runs], dtype=np.int32)
+        rec["restart_best"] = np.int32(np.argmin(rec["restart_inertia"]))
         rec["unique_labels"] = np.asarray(ul)
         rec["match_labels"] = np.asarray(ref_mask).astype(np.int16)
         rec["ref_feature_sha256"] = synthetic.sha256_of(np.asarray(ref_fm))
