@@ -44,8 +44,9 @@ def _worker(rank, world, port, refine, q):
     from vidseg_diffusion_amd.parallel import ChainOps, resolve_windows
     feat, tracks = _window_inputs(rank)
 
-    def first(feat0):
-        np.random.seed(17)
+    def first(feat0, seed0):
+        assert seed0 == 17                                          # rank 0's seed, whatever this rank was given
+        np.random.seed(seed0)
         f0 = feat0.numpy()
         centers, _, _ = OA.kmeans_fit(f0, K, np.random.mtrand._rand)
         fake = OA.kmeans_predict(f0[:N], centers)
@@ -57,7 +58,8 @@ def _worker(rank, world, port, refine, q):
                    refine=(lambda t, l: torch.from_numpy(
                        OA.correct_low_res_mask(l.numpy().reshape(F, H, W), t.numpy() // W, t.numpy() % W)[0].astype(np.int32)).view(F, N))
                    if refine else None)
-    labels = resolve_windows(torch.from_numpy(feat), torch.from_numpy(tracks) if refine else None, ops, rank, world, F)
+    labels = resolve_windows(torch.from_numpy(feat), torch.from_numpy(tracks) if refine else None, ops, rank, world, F,
+                             seed=17 + 5 * rank, check=True)       # ranks > 0 hold OTHER seeds: window 0 must still use rank 0's
     q.put((rank, labels.numpy()))
     dist.barrier()
     dist.destroy_process_group()

@@ -32,7 +32,7 @@ import torch
 @dataclass
 class ChainOps:
     """Compute callbacks of the cross-window stage (HIP-backed in the product, oracle-backed in CPU tests)."""
-    first_window_labels: Callable      # feat0 [F*N, C] -> labels int32 [F*N]      (K-means + predict + 4-NN vs frame 0)
+    first_window_labels: Callable      # (feat0 [F*N, C], seed) -> labels int32 [F*N]  (K-means + predict + 4-NN vs frame 0)
     knn_top4: Callable                 # (ref_feat, query_feat) -> int32 [nq, 4]
     vote4: Callable                    # (nn_idx [nq,4], ref_labels [nref]) -> int32 [nq]
     refine: Optional[Callable] = None  # (tracks [F,N] int32, labels [F,N] int32) -> int32 [F,N]
@@ -53,18 +53,32 @@ def _all_gather(t: torch.Tensor, world: int):
     return out.view((world,) + tuple(t.shape))
 
 
-def resolve_windows(feat: torch.Tensor, tracks: Optional[torch.Tensor], ops: ChainOps, rank: int, world: int, num_frames: int):
-    """feat: this rank's normalised tokens fp16 [F*N, C]; tracks: this rank's dense tracks int32 [F, N] or None.
-    Returns final labels of ALL windows, int32 [world, F*N], identical on every rank."""
+def resolve_windows(feat: torch.Tensor, tracks: Optional[torch.Tensor], ops: ChainOps, rank: int, world: int, num_frames: int,
+                    seed: int = 17, check: Optional[bool] = None):
+    """feat: this rank's normalised tokens fp16 [F*N, C]; tracks: this rank's dense tracks int32 [F, N] or None; seed: this rank's
+    window seed (sd_pipeline_vspw.py:255).  Returns final labels of ALL windows, int32 [world, F*N], identical on every rank.
+
+    Window 0's K-means runs redundantly on every rank and must be seeded with WINDOW 0's seed, i.e. rank 0's: each rank's seed
+    travels as one extra row of the int32 all-gather and every rank reads row 0's.  check (default: VIDSEG_CHECK_RANKS=1): one more
+    tiny all-gather of a checksum of labels0, so a kernel that is not bit-deterministic across devices is detected, not assumed."""
+    import os
     import torch.distributed as dist
     FN = feat.shape[0]
     all_feat = _all_gather(feat, world)                               # [W, F*N, C]   <- the RCCL all-gather over xGMI
-    if rank == 0:
-        nn_idx = torch.full((FN, 4), -1, dtype=torch.int32, device=feat.device)
-    else:
-        nn_idx = ops.knn_top4(all_feat[rank - 1], feat).to(torch.int32)
-    all_idx = _all_gather(nn_idx, world)                              # [W, F*N, 4]   (issued before the K-means so it overlaps it)
-    labels0 = ops.first_window_labels(all_feat[0]).to(torch.int32)    # every rank, same bits (see module docstring)
+    nn_idx = torch.full((FN + 1, 4), -1, dtype=torch.int32, device=feat.device)
+    if rank != 0:
+        nn_idx[:FN] = ops.knn_top4(all_feat[rank - 1], feat).to(torch.int32)
+    nn_idx[FN, 0] = int(seed)
+    all_idx = _all_gather(nn_idx, world)                              # [W, F*N + 1, 4] (issued before the K-means so it overlaps it)
+    seed0 = int(all_idx[0, FN, 0].item())
+    all_idx = all_idx[:, :FN]
+    labels0 = ops.first_window_labels(all_feat[0], seed0).to(torch.int32)    # every rank, same bits (see module docstring)
+    if os.environ.get("VIDSEG_CHECK_RANKS") == "1" if check is None else check:
+        w = torch.arange(1, FN + 1, dtype=torch.int64, device=labels0.device)
+        digest = ((labels0.to(torch.int64) + 1) * w).sum().reshape(1)
+        alld = _all_gather(digest, world).reshape(-1)
+        if not bool((alld == alld[0]).all()):
+            raise RuntimeError(f"rank {rank}: window 0's redundantly computed labels differ between ranks (checksums {alld.tolist()})")
     all_tracks = _all_gather(tracks, world) if tracks is not None else None
     out = []
     prev = labels0
@@ -127,15 +141,15 @@ def sharded_resolve(engine, h, *, num_masks=20, is_aggre_attn=True, is_refine_ma
         q7 = store[f"output_block_7_spatial_self_attn_q_time_{ts}"]
         tracks, _ = A.dense_tracking(q7[F:2 * F].contiguous(), F, fh, fw)
 
-    def first_window(feat0):
-        np.random.seed(seed)                                              # window 0's seed_everything (SDP:255)
+    def first_window(feat0, seed0):
+        np.random.seed(seed0)                                             # window 0's seed_everything (SDP:255) = rank 0's seed
         km = A.kmeans_fit(feat0, num_masks, n_init=10)
         fake = A.kmeans_predict(feat0[:N], km.centers)                    # identity cluster->label map (no GT mask, FE:586-595)
         return A.knn_predict(feat0[:N].contiguous(), fake, feat0)
 
     ops = ChainOps(first_window_labels=first_window, knn_top4=A.knn_top4, vote4=A.vote4,
                    refine=(lambda t, l: A.trajectory_vote(t.contiguous(), l.contiguous(), fw)) if is_refine_mask else None)
-    labels = resolve_windows(feat, tracks, ops, rank, world, F)
+    labels = resolve_windows(feat, tracks, ops, rank, world, F, seed=seed)
     out = labels.view(world, F, N).cpu().numpy().astype(np.int64)
     FE.FeatureStore.clear(h["feature_folder"], h["exp_name"])
     return out
@@ -163,7 +177,9 @@ class ShardedPipeline:
         if lane is None:
             h = sharded_feature_pass(self.engine, latent, c, uc, rank=self.rank, **feature_kw)
         else:
+            from .pipeline import hand_to_stream
             lane.wait_stream(torch.cuda.current_stream())
+            hand_to_stream(lane, latent, c, uc, feature_kw.get("noise"))
             with torch.cuda.stream(lane):
                 h = sharded_feature_pass(self.engine, latent, c, uc, rank=self.rank, **feature_kw)
         self.pending.append(h)

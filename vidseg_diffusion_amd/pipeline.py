@@ -245,6 +245,16 @@ def segment_window(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, n
                           frame_names=frame_names, gt_mask_path=gt_mask_path)
 
 
+def hand_to_stream(lane, *things):
+    """The caller allocated these tensors (dicts of tensors) on ITS stream; a lane reads them later, possibly after the caller has
+    dropped them.  record_stream tells the caching allocator not to reuse their blocks before the lane's queued work is done."""
+    for t in things:
+        if isinstance(t, dict):
+            hand_to_stream(lane, *t.values())
+        elif torch.is_tensor(t) and t.is_cuda:
+            t.record_stream(lane)
+
+
 class WindowPipeline:
     """Software pipeline over windows: the UNet feature pass of window w+1 is enqueued BEFORE the analysis of window w runs on
     a second HIP stream, so the latency-bound K-means / 4-NN / tracking kernels (and their host polls) of one window hide
@@ -286,6 +296,7 @@ class WindowPipeline:
             h = feature_pass(self.engine, latent, c, uc, **feature_kw)               # enqueue first: the GPU never waits for the host
         else:
             lane.wait_stream(torch.cuda.current_stream())                            # the inputs were produced on the caller's stream
+            hand_to_stream(lane, latent, c, uc, feature_kw.get("noise"))
             with torch.cuda.stream(lane):
                 h = feature_pass(self.engine, latent, c, uc, **feature_kw)
         self.pending.append(h)

@@ -167,9 +167,9 @@ class CrossAttention(nn.Module):
                     t = torch.empty((B, L, C), dtype=F16, device=dev)
                     return ops.linear(context, self.w_kv, tap=t, tap_cols=C), t
 
-                kv, tk = ops.window_cached(self, "_kv_tap", (context,), make_kv)
+                kv, tk = ops.window_cached(self, "_kv_tap", (context, self.w_kv), make_kv)
             else:
-                kv = ops.window_cached(self, "_kv", (context,), lambda: ops.linear(context, self.w_kv))
+                kv = ops.window_cached(self, "_kv", (context, self.w_kv), lambda: ops.linear(context, self.w_kv))
             if inj_q is not None:
                 q = ops.f16_to_bf16(inj_q)
             k = ops.f16_to_bf16(inj_k) if inj_k is not None else kv[..., :C]
