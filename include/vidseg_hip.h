@@ -134,6 +134,12 @@ int vidseg_linear_a16(const void* a0, const void* a1, int C0, int C1, long long 
 int vidseg_conv3x3_a16(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up,
                         const void* w, int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual,
                         void* out, int pad, float* out_f32 /*opt*/, vidseg_stream_t stream);
+/* The same convolution with an fp16 [M][Cout] copy of the value inside the epilogue: tap_early = 1 after conv + bias, before the
+ * per-sample emb vector = ResBlock.in_layers_features (OAI:349-350); tap_early = 0 after them, before the residual =
+ * ResBlock.out_layers_features (OAI:367-368).  The reference stashes both on every ResBlock forward ("mid-block spatial features"). */
+int vidseg_conv3x3_a16_tap(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up,
+                            const void* w, int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual,
+                            void* out, int pad, void* tap_f16, int tap_early, vidseg_stream_t stream);
 /* First stage (VAE encoder, model.py:487-600): row softmax of fp32 logits (the single-head dim-512 mid attention runs as
  * GEMM -> softmax -> GEMM, model.py:161-202) and DiagonalGaussianDistribution.sample * scale_factor
  * (distributions.py:24-41, sgm/models/diffusion.py:138-151); moments NHWC [B][HW][2Z] fp32, noise / out NCHW [B][Z][HW]. */

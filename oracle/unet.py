@@ -41,6 +41,7 @@ class UNetOracle:
         self.hc = num_head_channels
         self.rb = round_bf16
         self.taps = {}
+        self.rb_feats = {}
         self.n_in = 1 + max(int(m.group(1)) for k in self.sd if (m := re.match(r"input_blocks\.(\d+)\.", k)))
         self.n_out = 1 + max(int(m.group(1)) for k in self.sd if (m := re.match(r"output_blocks\.(\d+)\.", k)))
 
@@ -64,14 +65,18 @@ class UNetOracle:
     # ---- blocks -------------------------------------------------------------------------------
     def resblock(self, x, emb_silu, p):
         h = _bf(F.silu(self.gn(x, p + ".in_layers.0", 1e-5)), self.rb)
-        h = self.conv(h, p + ".in_layers.2") + self.lin(emb_silu, p + ".emb_layers.1")[:, :, None, None]
+        h = self.conv(h, p + ".in_layers.2")
+        feat_in = h                                                    # ResBlock.in_layers_features (openaimodel.py:349-350)
+        h = h + self.lin(emb_silu, p + ".emb_layers.1")[:, :, None, None]
         h = _bf(h, self.rb)
         h = _bf(F.silu(self.gn(h, p + ".out_layers.0", 1e-5)), self.rb)
         if self.has(p + ".skip_connection."):
             skip = _bf(self.conv(x, p + ".skip_connection", pad=0), self.rb)
         else:
             skip = x
-        out = _bf(self.conv(h, p + ".out_layers.3") + skip, self.rb)
+        h = self.conv(h, p + ".out_layers.3")
+        self.rb_feats[p] = (feat_in, h)                                # (.., ResBlock.out_layers_features, openaimodel.py:367-368)
+        out = _bf(h + skip, self.rb)
         if self.has(p + ".time_stack."):
             out = self.video_resblock_tail(out, emb_silu, p)
         return out

@@ -46,7 +46,21 @@ def test_unet_forward_vs_reference(env):
     from oracle.unet import UNetOracle
     dev, g, net, sd = env
     x, t, ctx = (torch.from_numpy(g[k]) for k in ("fw_x", "fw_t", "fw_ctx"))
-    out = net(x.to(dev), timesteps=t.to(dev), context=ctx.to(dev)).cpu().numpy()
+    plain = net(x.to(dev), timesteps=t.to(dev), context=ctx.to(dev)).cpu().numpy()
+    net.stash_resblock_features(True)                                    # the reference's ResBlock stash, off by default
+    try:
+        out = net(x.to(dev), timesteps=t.to(dev), context=ctx.to(dev)).cpu().numpy()
+        assert np.array_equal(out, plain), "the feature stash must not change the network's output"
+        for name in synthetic.RESBLOCK_FEATURE_PROBES:                   # openaimodel.py:349-350 (before the emb add), 367-368 (before the skip)
+            rb = net.get_submodule(name)
+            for which, got in (("in", rb.in_layers_features), ("out", rb.out_layers_features)):
+                ref = g[f"fw_rb_{name}_{which}"].astype(np.float32)
+                assert got.dtype == torch.float16 and tuple(got.shape) == ref.shape, (name, which, got.shape, ref.shape)
+                e = nrms(got.float().cpu().numpy(), ref)
+                assert e < act_mode()[1], (name, which, e)
+    finally:
+        net.stash_resblock_features(False)
+    assert net.get_submodule("middle_block.0").in_layers_features is None
     fmt = nrms(UNetOracle(sd, round_bf16=act_mode()[0]).forward(x, t, ctx).numpy(), g["fw_out"])      # what bf16 alone costs
     err = nrms(out, g["fw_out"])
     assert err < act_mode()[1] and err <= 1.5 * fmt + 1e-3, (err, fmt)

@@ -50,6 +50,11 @@ def test_unet_forward_matches_reference(gold, narrow_sd):
         if k.startswith("fw_output_block_"):
             got = o.taps[k[3:]].float().numpy()
             assert np.abs(got - v.astype(np.float32)).max() <= 2e-3 * np.abs(v.astype(np.float32)).max(), k   # fp16 taps
+    from vidseg_diffusion_amd import synthetic
+    for name in synthetic.RESBLOCK_FEATURE_PROBES:                       # openaimodel.py:349-350, 367-368
+        for which, got in zip(("in", "out"), o.rb_feats[name]):
+            v = gold[f"fw_rb_{name}_{which}"].astype(np.float32)
+            assert got.shape == v.shape and np.abs(got.numpy() - v).max() <= 2e-3 * np.abs(v).max(), (name, which)
 
 
 def test_sigmas_match_reference(gold):

@@ -46,6 +46,13 @@ def main():
                 rec[f"fw_output_block_{i}_spatial_{an}_attn_q"] = a.q.half().numpy()
                 rec[f"fw_output_block_{i}_spatial_{an}_attn_k"] = a.k.half().numpy()
 
+    # the "mid-block spatial features" every ResBlock leaves behind (openaimodel.py:349-350, 367-368): in_layers(x) before the emb
+    # add, out_layers(h) before the skip add -- NCHW, stored in fp16 for six blocks across the levels
+    for name in synthetic.RESBLOCK_FEATURE_PROBES:
+        rb = net.get_submodule(name)
+        rec[f"fw_rb_{name}_in"] = rb.in_layers_features.half().numpy()
+        rec[f"fw_rb_{name}_out"] = rb.out_layers_features.half().numpy()
+
     # --- sampler: add_noise + Euler steps 22..24 with CFG ------------------------------------
     Fn = 2
     lat = synthetic.latent_clip(Fn, 16, 16, seed=9)

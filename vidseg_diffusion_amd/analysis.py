@@ -51,7 +51,12 @@ def mean_normalize(blocks, row0: int, rows: int, want_mean: bool = False):
 # sklearn KMeans(n_clusters, n_init=10) on the GPU, restarts batched
 # --------------------------------------------------------------------------------------
 class KMeansResult:
-    __slots__ = ("centers", "labels", "inertia", "n_iter", "best_restart", "total_lloyd_iters")
+    """all_labels int32 [R, n] (device) / all_inertia float64 [R] (host) / all_n_iter: every restart, not only the winner -- what
+    sklearn's fit loop sees before it keeps the best (_kmeans.py:1497-1531); read by the restart-equivalence parity test."""
+    __slots__ = ("centers", "labels", "inertia", "n_iter", "best_restart", "total_lloyd_iters", "all_labels", "all_inertia", "all_n_iter")
+
+
+LAST_KMEANS = None          # the most recent KMeansResult of this process (diagnostics / parity tests; never read by the product path)
 
 
 def _draw_kpp_uniforms(n, K, R, random_state):
@@ -203,6 +208,9 @@ def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: i
     res.n_iter = n_iter[best]
     res.best_restart = best
     res.total_lloyd_iters = total
+    res.all_labels, res.all_inertia, res.all_n_iter = labels, h_inertia, n_iter
+    global LAST_KMEANS
+    LAST_KMEANS = res
     return res
 
 

@@ -42,6 +42,8 @@ struct GemmParams {
     f16* tap;                // fp16 copy of columns [0, tap_cols) with leading dim tap_ld, or nullptr
     f16* tap2;               // fp16 copy of columns [tap_cols, 2*tap_cols) (same leading dim), or nullptr
     int tap_cols, tap_ld;
+    int tap_early;           // 1: the tap is taken after the bias, BEFORE the per-sample vector / activation (ResBlock.in_layers_features,
+                             // openaimodel.py:349-350: in_layers(x) before `h + emb_out`); 0: after them, before the residual
     int act;                 // 0 none, 1 SiLU, 2 GEGLU (32-column interleaved x|gate groups)
     int ksplit;              // >1: K range split over `ksplit` blocks per tile, fp32 partials in ws[split][M][N]
     float* ws;
@@ -177,6 +179,12 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
                     v[4 + e] += b1[e];
                 }
             }
+            if (p.tap && p.tap_early && n < p.tap_cols) {
+                f16x8 t;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
+                *reinterpret_cast<f16x8*>(p.tap + (long long)m * p.tap_ld + n) = t;
+            }
             if (p.rowvec) {
                 const float* rvp = p.rowvec + (long long)(m / rps) * p.rv_stride + n;
                 const f32x4 r0v = *reinterpret_cast<const f32x4*>(rvp), r1v = *reinterpret_cast<const f32x4*>(rvp + 4);
@@ -196,7 +204,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += ra;
         }
-        if (p.tap && n < 2 * p.tap_cols) {
+        if (p.tap && !p.tap_early && n < 2 * p.tap_cols) {
             f16x8 t;
 #pragma unroll
             for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
@@ -1421,6 +1429,12 @@ __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
             v[4 + e] += b1[e];
         }
     }
+    if (p.tap && p.tap_early && n < p.tap_cols) {
+        f16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
+        *reinterpret_cast<f16x8*>(p.tap + (long long)m * p.tap_ld + n) = t;
+    }
     if (p.rowvec) {
         const float* rvp = p.rowvec + (long long)(m / p.rows_per_sample) * p.rv_stride + n;
         const f32x4 r0 = *reinterpret_cast<const f32x4*>(rvp), r1 = *reinterpret_cast<const f32x4*>(rvp + 4);
@@ -1439,7 +1453,7 @@ __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += ra;
     }
-    if (p.tap && n < p.tap_cols) {
+    if (p.tap && !p.tap_early && n < p.tap_cols) {
         f16x8 t;
 #pragma unroll
         for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
@@ -2406,9 +2420,9 @@ int vidseg_conv_temporal3_a16(const void* x, int C, int BT, int HW, int T, const
 }
 
 // 3x3 convolution, padding 1, NHWC bf16 activations, weight packed [Cout][c/64][kh*3+kw][c%64] (chunk-major K order).
-int vidseg_conv3x3_a16(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up, const void* w,
+static int conv3x3_impl(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up, const void* w,
                         int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual, void* out,
-                        int pad, float* out_f32, hipStream_t st) {
+                        int pad, float* out_f32, void* tap, int tap_early, hipStream_t st) {
     VS_REQUIRE((stride == 1 || stride == 2) && (up == 1 || up == 2) && (pad == 0 || pad == 1), "conv3x3: stride=%d up=%d pad=%d", stride,
                up, pad);
     GemmParams p{};
@@ -2439,7 +2453,30 @@ int vidseg_conv3x3_a16(const void* x0, const void* x1, int C0, int C1, int B, in
     p.ldr = Cout;
     p.out = (bf16_t*)out;
     p.ldo = Cout;
+    if (tap) {
+        p.tap = (f16*)tap;
+        p.tap_cols = Cout;
+        p.tap_ld = Cout;
+        p.tap_early = tap_early ? 1 : 0;
+    }
     return launch_gemm(p, st);
+}
+
+int vidseg_conv3x3_a16(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up, const void* w,
+                        int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual, void* out,
+                        int pad, float* out_f32, hipStream_t st) {
+    return conv3x3_impl(x0, x1, C0, C1, B, Hin, Win, stride, up, w, Cout, bias, rowvec, rv_stride, residual, out, pad, out_f32, nullptr, 0, st);
+}
+
+// The same convolution with an fp16 copy of the result taken inside the epilogue: tap_early = 1 after the bias and before the
+// per-sample vector (ResBlock.in_layers_features, openaimodel.py:349-350), 0 after it and before the residual
+// (ResBlock.out_layers_features, openaimodel.py:367-368).
+int vidseg_conv3x3_a16_tap(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up, const void* w,
+                            int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual, void* out,
+                            int pad, void* tap_f16, int tap_early, hipStream_t st) {
+    VS_REQUIRE(tap_f16 != nullptr, "conv3x3_tap: tap buffer is null");
+    return conv3x3_impl(x0, x1, C0, C1, B, Hin, Win, stride, up, w, Cout, bias, rowvec, rv_stride, residual, out, pad, nullptr, tap_f16,
+                        tap_early, st);
 }
 
 // Tiny-channel 3x3 convs.  conv_in: x NHWC fp32 [B][H][W][Cin], w fp32 [3][3][Cin][Cout] -> bf16 NHWC.

@@ -19,6 +19,7 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 _lib.register({
     "vidseg_linear_a16": [_P, _P, _I, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P],
     "vidseg_conv3x3_a16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P],
+    "vidseg_conv3x3_a16_tap": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P],
     "vidseg_softmax_rows_a16": [_P, _L, _I, _F, _P, _P],
     "vidseg_gaussian_sample": [_P, _P, _I, _I, _I, _F, _P, _P],
     "vidseg_conv_in": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
@@ -133,11 +134,25 @@ def linear(a, w, bias=None, *, a1=None, rowvec=None, rows_per_sample=0, residual
     return out
 
 
-def conv3x3(x0, w, bias, *, x1=None, stride=1, up=1, rowvec=None, residual=None, pad=1, want_f32=False):
+def conv3x3(x0, w, bias, *, x1=None, stride=1, up=1, rowvec=None, residual=None, pad=1, want_f32=False, tap=None):
     """3x3 conv, padding 1, on NHWC bf16 [B, H, W, C0] (+ channel-concat x1), optional fused nearest-2x
     upsample of the input (openaimodel.py:149-167) or stride 2 (openaimodel.py:202-217).  pad=0: the first stage's
-    (0,1,0,1)-padded Downsample (model.py:84-91).  want_f32: also return the result in fp32 (same shape)."""
+    (0,1,0,1)-padded Downsample (model.py:84-91).  want_f32: also return the result in fp32 (same shape).
+    tap = "early" | "late": also return an fp16 NHWC copy taken inside the epilogue after conv + bias -- before the per-sample
+    vector ("early": ResBlock.in_layers_features, openaimodel.py:349-350) or after it and before the residual ("late":
+    ResBlock.out_layers_features, openaimodel.py:367-368)."""
     workspace(x0.device)
+    if tap is not None:
+        assert tap in ("early", "late") and not want_f32
+        B, H, W, C0 = x0.shape
+        Cout = w.shape[0]
+        Ho, Wo = (H * up + 2 - 3) // stride + 1, (W * up + 2 - 3) // stride + 1
+        out = torch.empty((B, Ho, Wo, Cout), dtype=act_dtype(), device=x0.device)
+        t16 = torch.empty((B, Ho, Wo, Cout), dtype=torch.float16, device=x0.device)
+        call("vidseg_conv3x3_a16_tap", ptr(x0), ptr(x1), C0, x1.shape[-1] if x1 is not None else 0, B, H, W, stride, up, ptr(w), Cout,
+             ptr(bias), ptr(rowvec), rowvec.stride(0) if rowvec is not None else 0, ptr(residual), ptr(out), pad, ptr(t16),
+             1 if tap == "early" else 0, stream())
+        return out, t16
     B, H, W, C0 = x0.shape
     C1 = x1.shape[-1] if x1 is not None else 0
     Cout = w.shape[0]

@@ -290,3 +290,7 @@ SVD_FULL = dict(in_channels=8, out_channels=4, model_channels=320, attention_res
                 channel_mult=[1, 2, 4, 4], num_head_channels=64, use_linear_in_transformer=True, transformer_depth=1,
                 context_dim=1024, adm_in_channels=768, num_classes="sequential", extra_ff_mix_layer=True, use_spatial_context=True,
                 merge_strategy="learned_with_images", video_kernel_size=[3, 1, 1])   # configs/inference/svd.yaml:16-34
+
+
+# ResBlocks whose in_layers_features / out_layers_features (openaimodel.py:349-350, 367-368) the goldens hold (tools/gen_golden_unet.py)
+RESBLOCK_FEATURE_PROBES = ("input_blocks.1.0", "input_blocks.4.0", "middle_block.0", "middle_block.2", "output_blocks.2.0", "output_blocks.11.0")

@@ -83,6 +83,11 @@ class ResBlock(nn.Module):
         else:
             self.skip_connection = _meta(nn.Conv2d, channels, self.out_channels, 1)
         self.emb_offset = None                                     # column offset into the batched emb GEMM
+        # openaimodel.py:326-327, 349-350, 367-368: the "mid-block spatial features" the reference leaves on every ResBlock after a
+        # forward -- in_layers(x) BEFORE the emb add and out_layers(h) BEFORE the skip add.  Nothing downstream reads them, so they
+        # are produced only when `stash_features` is set (UNetModel.stash_resblock_features(True)): fp16 copies taken inside the two
+        # conv epilogues, exposed NCHW-shaped like the reference's tensors (a permuted view of the NHWC buffer).
+        self.stash_features = False
         self.in_layers_features = None
         self.out_layers_features = None
 
@@ -100,8 +105,11 @@ class ResBlock(nn.Module):
         emb_all: fp32 [B, sum(Cout)] = every block's emb_layers output from one batched GEMM."""
         h = ops.groupnorm(x0, self.g1, self.b1, x1=x1, eps=1e-5, silu=True)
         rv = emb_all[:, self.emb_offset:self.emb_offset + self.out_channels]
-        h = ops.conv3x3(h, self.w1, self.cb1, rowvec=rv)                               # conv + bias + emb_out (OAI:353-365)
-        self.in_layers_features = h
+        if self.stash_features:
+            h, t = ops.conv3x3(h, self.w1, self.cb1, rowvec=rv, tap="early")           # tap = in_layers(x), OAI:349-350
+            self.in_layers_features = t.permute(0, 3, 1, 2)
+        else:
+            h = ops.conv3x3(h, self.w1, self.cb1, rowvec=rv)                           # conv + bias + emb_out (OAI:353-365)
         h = ops.groupnorm(h, self.g2, self.b2, eps=1e-5, silu=True)
         if isinstance(self.skip_connection, nn.Identity):
             if x1 is not None:
@@ -109,9 +117,11 @@ class ResBlock(nn.Module):
             res = x0
         else:
             res = ops.linear(x0, self.ws, self.bs, a1=x1)
-        out = ops.conv3x3(h, self.w2, self.cb2, residual=res)                          # OAI:369
-        self.out_layers_features = out
-        return out
+        if self.stash_features:
+            out, t = ops.conv3x3(h, self.w2, self.cb2, residual=res, tap="late")       # tap = out_layers(h), OAI:367-368
+            self.out_layers_features = t.permute(0, 3, 1, 2)
+            return out
+        return ops.conv3x3(h, self.w2, self.cb2, residual=res)                         # OAI:369
 
 
 class CrossAttention(nn.Module):
@@ -418,6 +428,14 @@ class UNetModel(nn.Module):
 
     def _resblocks(self):
         return [m for m in self.modules() if isinstance(m, ResBlock)]
+
+    def stash_resblock_features(self, on=True):
+        """Make every ResBlock leave `in_layers_features` / `out_layers_features` (openaimodel.py:349-350, 367-368) after a forward.
+        Off by default: nothing on the path reads them and they cost two fp16 stores per ResBlock."""
+        for rb in self._resblocks():
+            rb.stash_features = bool(on)
+            if not on:
+                rb.in_layers_features = rb.out_layers_features = None
 
     def pack(self, device):
         """One-time weight packing into the layouts the kernels read (bf16 K-contiguous matrices)."""
