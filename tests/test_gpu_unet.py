@@ -288,6 +288,69 @@ def test_inversion_vs_reference(env):
     assert err <= 1.5 * fmt + 1e-2
 
 
+def test_inversion_window_vs_reference(env):
+    """`--inversion_type inversion` through the harness (sd_pipeline_vspw.py:233-236, 340-345, 357): sampler.inversion, then the
+    feature pass from t_start = 0 with the dump callback at all 25 steps, Steps 3 / 3b on the step-24 dumps -- against ONE window the
+    reference itself ran that way (tests/golden/sd_inversion_window_narrow.npz, tools/gen_golden_inversion_window.py).  49 network
+    evaluations with random weights amplify rounding, so the latent / tap bars are relative to what the storage format alone costs
+    (the oracle in its rounding mode); given the device's taps the masks are the oracle's bit for bit."""
+    from oracle import analysis as OA
+    from oracle.unet import UNetOracle, euler_inversion, euler_sample
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import build_sd_engine, segment_window
+    dev, _, net, sd = env
+    z = np.load(os.path.join(os.path.dirname(G), "sd_inversion_window_narrow.npz"))
+    g = {k: z[k] for k in z.files}
+    Fn, LAT, K = int(g["F"]), int(g["lat"]), int(g["K"])
+    eng = build_sd_engine(net, num_steps=25, scale=5.0)
+    c = {"crossattn": torch.from_numpy(g["c"]).to(dev)}
+    uc = {"crossattn": torch.zeros_like(c["crossattn"])}
+    FE.FeatureStore.clear()
+    FE.MaskStore.clear()
+    labels, _ = segment_window(eng, torch.from_numpy(g["latent"]).to(dev), c, uc, num_masks=K, num_steps=25, t_start=22, seed=17,
+                               is_refine_mask=True, feature_folder="/nonexistent/inv", exp_name="w", keep_all_steps=True,
+                               inversion_type="inversion")
+    store = FE.FeatureStore.folder("/nonexistent/inv", "w")
+    for i in range(25):                                                  # t_start = 0: the callback dumps at EVERY step (SDP:235-236, 103-105)
+        assert f"xt_time_{i}" in store and f"output_block_7_spatial_self_attn_q_time_{i}" in store, i
+    # the storage format's own cost on this 49-evaluation trajectory (CPU oracle with every operand / activation rounded)
+    cc = torch.from_numpy(g["c"])
+    o = UNetOracle(sd, round_bf16=act_mode()[0])
+    inv, _ = euler_inversion(o, torch.from_numpy(g["latent"]), cc, torch.zeros_like(cc))
+    fx, ft = {}, {}
+
+    def cb(x, i, t):
+        if i in (0, 12, 24):
+            fx[i] = x.numpy().copy()
+        if i == 24:
+            for b in (6, 7, 8):
+                ft[b] = t[f"output_block_{b}_spatial_self_attn_q"].float().numpy().copy()
+
+    euler_sample(o, inv, cc, torch.zeros_like(cc), t_start=0, noise=None, callback=cb)
+    for i in (0, 12, 24):
+        err, fmt = nrms(store[f"xt_time_{i}"].cpu().numpy(), g[f"x_step{i}"]), nrms(fx[i], g[f"x_step{i}"])
+        print(f"inversion window: x after step {i}: nrms {err:.3e} (16-bit format alone {fmt:.3e})")
+        assert err <= 1.5 * fmt + 1e-2, (i, err, fmt)
+    taps = {}
+    for b in (6, 7, 8):
+        taps[b] = store[f"output_block_{b}_spatial_self_attn_q_time_24"].cpu().numpy()
+        err, fmt = nrms(taps[b].astype(np.float32), g[f"q{b}"].astype(np.float32)), nrms(ft[b], g[f"q{b}"].astype(np.float32))
+        print(f"inversion window: block {b} step-24 Q tap: nrms {err:.3e} (16-bit format alone {fmt:.3e})")
+        assert err <= 1.5 * fmt + 1e-2, (b, err, fmt)
+    from tools_metrics import matched_iou
+    iou = matched_iou(labels, g["corrected_labels"].astype(np.int64), K)
+    print(f"inversion window: masks vs reference IoU {iou[0]:.4f} identical {iou[1]:.4f}")
+    np.random.seed(17)                                                   # bit-exact part: the analysis of the device's own taps
+    _, lab, _ = OA.match_gt_mask(OA.aggregate_blocks([taps[8], taps[7], taps[6]]), K, np.random.mtrand._rand)
+    th, tw = OA.dense_tracking(taps[7], Fn, LAT // 2, LAT // 2)
+    corr, _ = OA.correct_low_res_mask(lab.reshape(Fn, LAT // 2, LAT // 2), th, tw)
+    assert np.array_equal(np.asarray(labels).reshape(-1), corr)
+    FE.FeatureStore.clear()
+    FE.MaskStore.clear()
+    with pytest.raises(ValueError, match="Unknown inversion type"):      # SDP:345
+        segment_window(eng, torch.from_numpy(g["latent"]).to(dev), c, uc, num_masks=K, inversion_type="ddim")
+
+
 def test_smooth_latent_schedule(env):
     """is_smooth_latent (sampling.py:117-125, 199-212): at steps 23 / 24 the denoised latent is decoded, frames with
     (frame_id - {1, 2}) % 3 == 0 are replaced by the mean of their neighbours, and the result is encoded again.  Checked with a

@@ -168,6 +168,58 @@ def test_inversion_matches_reference(gold, narrow_sd):
         assert np.abs(got.numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
 
 
+def test_inversion_window_matches_reference(narrow_sd):
+    """The inversion variant of the harness (sd_pipeline_vspw.py:233-236, 340-345): sampler.inversion, feature pass from
+    t_start = 0, Steps 3 / 3b on the step-24 dumps -- oracle vs the window the reference ran that way (49 narrow evaluations)."""
+    import os
+    from oracle import analysis as OA
+    from oracle.unet import euler_inversion, euler_sample
+    _, sd = narrow_sd
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sd_inversion_window_narrow.npz"))
+    g = {k: z[k] for k in z.files}
+    Fn, LAT, K = int(g["F"]), int(g["lat"]), int(g["K"])
+    o = UNetOracle(sd)
+    c = torch.from_numpy(g["c"])
+    inv, _ = euler_inversion(o, torch.from_numpy(g["latent"]), c, torch.zeros_like(c))
+    assert np.abs(inv.numpy() - g["inverted"]).max() <= 5e-4 * np.abs(g["inverted"]).max()
+    xs, taps = {}, {}
+
+    def cb(x, i, t):
+        xs[i] = x.numpy().copy()
+        if i == 24:
+            for b in (6, 7, 8):
+                taps[b] = t[f"output_block_{b}_spatial_self_attn_q"].numpy().copy()
+
+    slow = os.environ.get("VIDSEG_SLOW_TESTS", "0") not in ("", "0")   # default: the first feature step only (the other 24 take a minute)
+    if not slow:
+        class _Stop(Exception):
+            pass
+
+        def cb1(x, i, t):
+            xs[i] = x.numpy().copy()
+            raise _Stop
+        try:
+            euler_sample(o, inv, c, torch.zeros_like(c), t_start=0, noise=None, callback=cb1)
+        except _Stop:
+            pass
+        assert np.abs(xs[0] - g["x_step0"]).max() <= 2e-3 * np.abs(g["x_step0"]).max()
+    else:
+        final = euler_sample(o, inv, c, torch.zeros_like(c), t_start=0, noise=None, callback=cb)
+        assert sorted(xs) == list(range(25))
+        for i in (0, 12, 24):
+            assert np.abs(xs[i] - g[f"x_step{i}"]).max() <= 2e-3 * np.abs(g[f"x_step{i}"]).max(), i
+        assert np.abs(final.numpy() - g["x_final"]).max() <= 2e-3 * np.abs(g["x_final"]).max()
+        for b in (6, 7, 8):
+            ref = g[f"q{b}"].astype(np.float32)
+            assert np.abs(taps[b].astype(np.float32) - ref).max() <= 4e-3 * np.abs(ref).max(), b
+    np.random.seed(17)
+    _, lab, _ = OA.match_gt_mask(OA.aggregate_blocks([g["q8"], g["q7"], g["q6"]]), K, np.random.mtrand._rand)
+    assert np.array_equal(lab, g["match_labels"].astype(np.int64).reshape(-1))
+    th, tw = OA.dense_tracking(g["q7"], Fn, LAT // 2, LAT // 2)
+    corr, _ = OA.correct_low_res_mask(lab.reshape(Fn, LAT // 2, LAT // 2), th, tw)
+    assert np.array_equal(corr, g["corrected_labels"].astype(np.int64).reshape(-1))
+
+
 def _oracle_svd_modulated(o, g, lam, t_start=22):
     from oracle.unet import euler_sample_svd
     lat, noise = torch.from_numpy(g["latent"]), torch.from_numpy(g["noise"])

@@ -92,20 +92,22 @@ def resolve_windows(feat: torch.Tensor, tracks: Optional[torch.Tensor], ops: Cha
 
 
 def sharded_feature_pass(engine, latent, c, uc, *, noise=None, num_steps=25, t_start=22, seed=17, rank=0,
-                         feature_folder="features_outputs_VSPW", exp_name=None, masks_only=False, feature_timestep=None):
+                         feature_folder="features_outputs_VSPW", exp_name=None, masks_only=False, feature_timestep=None,
+                         inversion_type="add_noise"):
     """This rank's UNet feature pass (Steps 1-2), enqueued on the current stream; only the taps the cross-window stage reads
     are kept (decoder blocks 6-8 at sampler step `feature_timestep`, default the last one, num_steps - 1 -- the drivers'
     `feature_timestep="24"` for their 25 steps, sd_pipeline_vspw.py:633-645).  Returns the handle for `sharded_resolve`."""
-    from .pipeline import make_denoiser, save_feature_maps, seed_everything
+    from .pipeline import first_latent, make_denoiser, save_feature_maps, seed_everything
     exp_name = exp_name or f"rank{rank}"
     F, _, lh, lw = latent.shape
     want = num_steps - 1 if feature_timestep is None else int(feature_timestep)
-    if not t_start <= want < num_steps:
+    if not (0 if inversion_type == "inversion" else t_start) <= want < num_steps:
         raise ValueError(f"feature_timestep {want} is outside the sampled steps [{t_start}, {num_steps})")
     if masks_only:                                      # opt-in pruning of the last step, see pipeline.feature_pass
         from .pipeline import feature_pass
         h = feature_pass(engine, latent, c, uc, num_steps=num_steps, t_start=t_start, feature_timestep=str(want), seed=seed,
-                         feature_folder=feature_folder, exp_name=exp_name, noise=noise, keep_all_steps=False, masks_only=True)
+                         feature_folder=feature_folder, exp_name=exp_name, noise=noise, keep_all_steps=False, masks_only=True,
+                         inversion_type=inversion_type)
         return dict(F=F, fh=lh // 2, fw=lw // 2, seed=seed, feature_folder=feature_folder, exp_name=exp_name, done=h["done"],
                     feature_timestep=want)
     from . import ops
@@ -113,9 +115,20 @@ def sharded_feature_pass(engine, latent, c, uc, *, noise=None, num_steps=25, t_s
     seed_everything(seed)
     sampler = engine.sampler
     denoiser = make_denoiser(engine, F)
-    x = sampler.add_noise(latent, cond=c, uc=uc, num_steps=num_steps, noise_level=t_start, noise=noise)
-    sampler(denoiser, x, cond=c, uc=uc, t_start=t_start,
-            img_callback=lambda xt, i: save_feature_maps(engine, feature_folder, exp_name, i, xt=xt, block_filter=(6, 7, 8)) if i == want else None)
+    x, t_start = first_latent(engine, denoiser, latent, c, uc, num_steps, t_start, noise, inversion_type)
+    net = engine.model.diffusion_model
+    hook, mode0 = None, getattr(net, "tap_mode", None)
+    if mode0 is not None:                               # Q/K taps only at the step that is dumped (see pipeline.feature_pass)
+        def hook(i):
+            net.tap_mode = mode0 if i == want else "none"
+            net._set_taps()
+    try:
+        sampler(denoiser, x, cond=c, uc=uc, t_start=t_start, step_hook=hook,
+                img_callback=lambda xt, i: save_feature_maps(engine, feature_folder, exp_name, i, xt=xt, block_filter=(6, 7, 8)) if i == want else None)
+    finally:
+        if hook is not None:
+            net.tap_mode = mode0
+            net._set_taps()
     done = torch.cuda.Event()
     done.record(torch.cuda.current_stream())
     return dict(F=F, fh=lh // 2, fw=lw // 2, seed=seed, feature_folder=feature_folder, exp_name=exp_name, done=done,
@@ -198,7 +211,7 @@ class ShardedPipeline:
 
 def segment_windows_sharded(engine, latent, c, uc, *, noise=None, num_masks=20, num_steps=25, t_start=22, is_aggre_attn=True,
                             is_refine_mask=False, seed=17, rank=0, world=1, feature_folder="features_outputs_VSPW", exp_name=None,
-                            masks_only=False, feature_timestep=None):
+                            masks_only=False, feature_timestep=None, inversion_type="add_noise"):
     """Each rank segments its own window (`latent` is THIS rank's [F,4,h,w]); returns int64 labels:
     world == 1 -> [F, N] (exactly pipeline.segment_window); world > 1 -> [world, F, N], same on every rank."""
     from .pipeline import segment_window
@@ -207,9 +220,11 @@ def segment_windows_sharded(engine, latent, c, uc, *, noise=None, num_masks=20, 
         labels, _ = segment_window(engine, latent, c, uc, num_masks=num_masks, num_steps=num_steps, t_start=t_start,
                                    is_aggre_attn=is_aggre_attn, is_refine_mask=is_refine_mask, seed=seed, noise=noise,
                                    feature_folder=feature_folder, exp_name=exp_name, keep_all_steps=False, masks_only=masks_only,
-                                   feature_timestep=str(num_steps - 1 if feature_timestep is None else int(feature_timestep)))
+                                   feature_timestep=str(num_steps - 1 if feature_timestep is None else int(feature_timestep)),
+                                   inversion_type=inversion_type)
         return labels
     h = sharded_feature_pass(engine, latent, c, uc, noise=noise, num_steps=num_steps, t_start=t_start, seed=seed, rank=rank,
-                             feature_folder=feature_folder, exp_name=exp_name, masks_only=masks_only, feature_timestep=feature_timestep)
+                             feature_folder=feature_folder, exp_name=exp_name, masks_only=masks_only, feature_timestep=feature_timestep,
+                             inversion_type=inversion_type)
     return sharded_resolve(engine, h, num_masks=num_masks, is_aggre_attn=is_aggre_attn, is_refine_mask=is_refine_mask, rank=rank,
                            world=world)

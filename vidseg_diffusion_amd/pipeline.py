@@ -89,6 +89,8 @@ def save_feature_maps(engine, store_folder, exp_name, i, xt=None, block_filter=N
     pad_uncond: the taps come from a conditional-half-only evaluation ([F, N, C]); they are stored as the second half of a
     [2F, N, C] tensor whose first (unconditional) half is never read by Steps 3-3b (FE:550-551 keeps `feature_maps[num_frames:]`)."""
     def put(name, t):
+        if t is None:
+            raise FE.VidsegError(f"save_feature_maps: {name} has no tap at step {i} (taps were off for this evaluation)")
         if pad_uncond:
             full = torch.empty((2 * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             full[t.shape[0]:] = t
@@ -125,10 +127,36 @@ def make_denoiser(engine: Engine, num_frames: int):
     return denoiser
 
 
+def first_latent(engine: Engine, denoiser, latent, c, uc, num_steps, t_start, noise, inversion_type):
+    """Step 1 of sample() (sd_pipeline_vspw.py:233-236, 340-345): returns (x at the first sampled step, t_start)."""
+    sampler, net = engine.sampler, engine.model.diffusion_model
+    if inversion_type == "add_noise":
+        return sampler.add_noise(latent, cond=c, uc=uc, num_steps=num_steps, noise_level=t_start, noise=noise), t_start   # SDP:341
+    if inversion_type != "inversion":
+        raise ValueError(f"Unknown inversion type: {inversion_type}")                # SDP:345
+    mode0 = getattr(net, "tap_mode", None)
+    if mode0 is not None:                                                           # nothing reads the inversion's own Q/K
+        net.tap_mode = "none"
+        net._set_taps()
+    try:
+        x, _ = sampler.inversion(denoiser, latent, cond=c, uc=uc, num_steps=num_steps)            # SDP:343
+    finally:
+        if mode0 is not None:
+            net.tap_mode = mode0
+            net._set_taps()
+    return x, 0                                                                     # SDP:235-236: t_start = 0
+
+
 def feature_pass(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, num_steps=25, t_start=22, feature_timestep="24", seed=17,
-                 feature_folder="features_outputs_VSPW", exp_name="exp", noise=None, keep_all_steps=True, masks_only=False):
+                 feature_folder="features_outputs_VSPW", exp_name="exp", noise=None, keep_all_steps=True, masks_only=False,
+                 inversion_type="add_noise"):
     """Steps 1-2 of one window (sd_pipeline_vspw.py:255, 336-357): reseed, add_noise, the Euler steps of the UNet with the dump
     callback.  Everything is enqueued on the current HIP stream; returns the handle `analyse_window` needs.
+
+    inversion_type (sd_pipeline_vspw.py:233-236, 340-345; svd_pipeline_vspw.py likewise): "add_noise" (the drivers' default) noises
+    the latent to step `t_start`; "inversion" runs the EDM-form DDIM inversion `sampler.inversion` over all num_steps sigma pairs
+    (sampling.py:264-296; num_steps - 1 network evaluations, the first pair skips the network) and then the feature pass from
+    t_start = 0 -- num_steps more evaluations, the callback firing at every step.
 
     masks_only=True (opt-in, not the reference's schedule): the evaluation at `feature_timestep` -- whose only consumers in
     Steps 3-3b are the conditional half's Q taps of decoder blocks 6-8 -- runs on the conditional half alone and stops after
@@ -142,7 +170,8 @@ def feature_pass(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, num
     seed_everything(seed)                                                           # SDP:255
     sampler = engine.sampler
     denoiser = make_denoiser(engine, F)
-    x = sampler.add_noise(latent, cond=c, uc=uc, num_steps=num_steps, noise_level=t_start, noise=noise)   # Step 1, SDP:341
+    net = engine.model.diffusion_model
+    x, t_start = first_latent(engine, denoiser, latent, c, uc, num_steps, t_start, noise, inversion_type)     # Step 1
     want = int(feature_timestep)
 
     def callback(xt, i):                                                            # SDP:103-105
@@ -160,24 +189,18 @@ def feature_pass(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, num
         _taps_only_eval(engine, sampler, x, c, F, num_steps, want)
         save_feature_maps(engine, feature_folder, exp_name, want, xt=None, block_filter=(6, 7, 8), pad_uncond=True)
     else:
-        net = engine.model.diffusion_model
-        if keep_all_steps or not hasattr(net, "tap_mode"):
-            den = denoiser
-        else:
+        hook, mode0 = None, getattr(net, "tap_mode", None)
+        if not keep_all_steps and mode0 is not None:
             # only step `want` is dumped: the fp16 Q/K tap copies of the other steps (1.5 GB per evaluation at config 2) would be
-            # written and never read.  The network's outputs do not depend on the taps.
-            calls, mode0 = [0], net.tap_mode
-
-            def den(inp, sigma, cc, **kw):
-                net.tap_mode = mode0 if t_start + calls[0] == want else "none"
+            # written and never read.  The network's outputs do not depend on the taps.  Keyed on the sampler's own loop index.
+            def hook(i):
+                net.tap_mode = mode0 if i == want else "none"
                 net._set_taps()
-                calls[0] += 1
-                return denoiser(inp, sigma, cc, **kw)
         try:
-            sampler(den, x, cond=c, uc=uc, img_callback=callback, is_modulate=False, modulate_params=None, uc_list=None,
-                    t_start=t_start, is_latent_blending=False)                      # Step 2, SDP:357
+            sampler(denoiser, x, cond=c, uc=uc, img_callback=callback, is_modulate=False, modulate_params=None, uc_list=None,
+                    t_start=t_start, is_latent_blending=False, step_hook=hook)      # Step 2, SDP:357
         finally:
-            if den is not denoiser:
+            if hook is not None:
                 net.tap_mode = mode0
                 net._set_taps()
     done = torch.cuda.Event()
@@ -232,7 +255,7 @@ def analyse_window(engine: Engine, h: dict, *, num_masks=20, is_aggre_attn=True,
 def segment_window(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, num_masks=20, num_steps=25, t_start=22,
                    feature_timestep="24", is_aggre_attn=True, is_refine_mask=False, seed=17, state: WindowState = None,
                    frame_names=None, feature_folder="features_outputs_VSPW", exp_name="exp", gt_mask_path=None, noise=None,
-                   keep_all_steps=True, masks_only=False):
+                   keep_all_steps=True, masks_only=False, inversion_type="add_noise"):
     """One 14-frame window: latent [F,4,h,w] fp32 (VAE output * 0.18215) -> cluster-id masks int64 [F, h/2 * w/2].
     masks_only: see feature_pass (opt-in pruning of the work Steps 3-3b never read; implies keep_all_steps=False).
 
@@ -240,7 +263,7 @@ def segment_window(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, n
     next window exactly like the driver's loop variables."""
     h = feature_pass(engine, latent, c, uc, num_steps=num_steps, t_start=t_start, feature_timestep=feature_timestep, seed=seed,
                      feature_folder=feature_folder, exp_name=exp_name, noise=noise, keep_all_steps=keep_all_steps and not masks_only,
-                     masks_only=masks_only)
+                     masks_only=masks_only, inversion_type=inversion_type)
     return analyse_window(engine, h, num_masks=num_masks, is_aggre_attn=is_aggre_attn, is_refine_mask=is_refine_mask, state=state,
                           frame_names=frame_names, gt_mask_path=gt_mask_path)
 
@@ -314,7 +337,8 @@ class WindowPipeline:
         return out[-1] if out else None
 
 
-_FEATURE_KEYS = ("num_steps", "t_start", "feature_timestep", "seed", "feature_folder", "noise", "keep_all_steps", "masks_only")
+_FEATURE_KEYS = ("num_steps", "t_start", "feature_timestep", "seed", "feature_folder", "noise", "keep_all_steps", "masks_only",
+                 "inversion_type")
 
 
 def segment_clip(engine, latents, c_fn, *, batch_size=14, overlap=True, lanes=1, exp_name="exp", **kw):

@@ -296,7 +296,9 @@ class EDMSampler(SingleStepDiffusionSampler):
 
     def __call__(self, denoiser, x, cond, uc=None, num_steps=None, callback=None, img_callback=None, is_modulate=False,
                  modulate_params=None, uc_list=None, t_start=None, t_end=None, is_latent_blending=False, feature_height=None,
-                 feature_width=None, is_smooth_latent=False, model=None):
+                 feature_width=None, is_smooth_latent=False, model=None, step_hook=None):
+        """step_hook(i) (not in the reference): called with the loop index BEFORE step i's network evaluation(s) -- the feature pass
+        switches the Q/K taps on for exactly the step it dumps, whatever the number of denoiser calls a step makes."""
         x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
         if is_modulate:
             if len(modulate_params["modulate_timestep_frames"]) == 0:
@@ -324,6 +326,8 @@ class EDMSampler(SingleStepDiffusionSampler):
             if uc_list is not None:
                 uc = uc_list[i]
             smooth_step = is_smooth_latent and i in (23, 24)                   # SAM:199-212: steps 23 / 24 with offsets 1 / 2
+            if step_hook is not None:
+                step_hook(i)
             x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc, gamma,
                                   is_modulate_step=is_modulate_step, is_injected_step=is_injected_step,
                                   modulate_params=modulate_params, is_smooth_latent=smooth_step, model=model,
