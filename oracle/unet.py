@@ -36,10 +36,15 @@ def _bf(x, on):
 
 
 class UNetOracle:
-    def __init__(self, state_dict, num_head_channels=64, round_bf16=False):
+    def __init__(self, state_dict, num_head_channels=64, round_bf16=False, round_spec=None):
+        """round_spec (studies only, tools/tap_error_study.py): overrides of the rounding mode for classes of values --
+        {"w": matrices / conv kernels, "ln": LayerNorm outputs, "res": the residual stream (ResBlock / attention / FF / transformer
+        outputs after the skip add)}; a class set to False stays fp32 while everything else follows `round_bf16`."""
         self.sd = {k: v.float() for k, v in state_dict.items()}
         self.hc = num_head_channels
         self.rb = round_bf16
+        spec = round_spec or {}
+        self.rb_w, self.rb_ln, self.rb_res = (spec.get(k, round_bf16) for k in ("w", "ln", "res"))
         self.taps = {}
         self.rb_feats = {}
         self.n_in = 1 + max(int(m.group(1)) for k in self.sd if (m := re.match(r"input_blocks\.(\d+)\.", k)))
@@ -48,7 +53,7 @@ class UNetOracle:
     # ---- primitives ---------------------------------------------------------------------------
     def w(self, name):
         t = self.sd[name]
-        return _bf(t, self.rb) if (t.dim() >= 2) else t                # matrices/conv kernels are bf16 operands
+        return _bf(t, self.rb_w) if (t.dim() >= 2) else t              # matrices/conv kernels are bf16 operands
 
     def has(self, prefix):
         return any(k.startswith(prefix) for k in self.sd)
@@ -76,7 +81,7 @@ class UNetOracle:
             skip = x
         h = self.conv(h, p + ".out_layers.3")
         self.rb_feats[p] = (feat_in, h)                                # (.., ResBlock.out_layers_features, openaimodel.py:367-368)
-        out = _bf(h + skip, self.rb)
+        out = _bf(h + skip, self.rb_res)
         if self.has(p + ".time_stack."):
             out = self.video_resblock_tail(out, emb_silu, p)
         return out
@@ -116,7 +121,7 @@ class UNetOracle:
         return out
 
     def ln(self, x, p):
-        return _bf(F.layer_norm(x, (x.shape[-1],), self.sd[p + ".weight"], self.sd[p + ".bias"], 1e-5), self.rb)
+        return _bf(F.layer_norm(x, (x.shape[-1],), self.sd[p + ".weight"], self.sd[p + ".bias"], 1e-5), self.rb_ln)
 
     def transformer(self, x, context, p, tapname):
         B, C, H, W = x.shape
@@ -140,22 +145,22 @@ class UNetOracle:
             pick = lambda sub: next((v for kk, v in inj.items() if sub in kk), None)           # noqa: E731
             n1 = self.ln(t, b + ".norm1")
             t = _bf(self.attention(n1, n1, b + ".attn1", tn and tn + "_spatial_self_attn", pick("spatial_self_attn_q"),
-                                   pick("spatial_self_attn_k"), ra.get("self_attn")) + t, self.rb)
+                                   pick("spatial_self_attn_k"), ra.get("self_attn")) + t, self.rb_res)
             t = _bf(self.attention(self.ln(t, b + ".norm2"), context, b + ".attn2", tn and tn + "_spatial_cross_attn",
-                                   pick("spatial_cross_attn_q"), pick("spatial_cross_attn_k"), ra.get("cross_attn")) + t, self.rb)
+                                   pick("spatial_cross_attn_q"), pick("spatial_cross_attn_k"), ra.get("cross_attn")) + t, self.rb_res)
             y = self.lin(self.ln(t, b + ".norm3"), b + ".ff.net.0.proj")
             val, gate = y.chunk(2, dim=-1)
             ffo = self.lin(_bf(val * F.gelu(gate), self.rb), b + ".ff.net.2")
             if ra.get("ff_out") is not None:
                 ffo = ffo + ra["ff_out"][:, :, None]
-            t = _bf(ffo + t, self.rb)
+            t = _bf(ffo + t, self.rb_res)
             if video:
                 tm = self.video_block(_bf(t + temb, self.rb), tctx, f"{p}.time_stack.{d}", tn, H * W, inj, ra_t)
                 alpha = torch.sigmoid(self.sd[p + ".time_mixer.mix_factor"])
                 t = _bf(alpha * t + (1.0 - alpha) * tm, self.rb)
             d += 1
         t = self.lin(t, p + ".proj_out")
-        return _bf(t.reshape(B, H, W, C).permute(0, 3, 1, 2) + x, self.rb)
+        return _bf(t.reshape(B, H, W, C).permute(0, 3, 1, 2) + x, self.rb_res)
 
     def geglu_ff(self, x, p):
         y = self.lin(x, p + ".net.0.proj")
