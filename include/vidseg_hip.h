@@ -251,6 +251,26 @@ int vidseg_gemm_profile_kinds(double* out);
 /* algorithmic HBM bytes of the same region per kernel, out[6] (every operand and result once; no split-K partials) */
 int vidseg_gemm_profile_bytes(double* out);
 
+/* ---- "exact" mode of the UNet path (fp16 build; csrc/exact_ops.hip): every value is carried in fp32 and handed to the 16-bit MFMA
+ * GEMM / conv entry points above as the operand image [hi | lo | hi] (hi = fp16(x), lo = fp16(x - hi)) against weights packed as
+ * [w_hi | w_hi | w_lo], i.e. one ordinary GEMM over a three-fold K axis with fp32 accumulation = a_hi w_hi + a_lo w_hi + a_hi w_lo.
+ * Replaces, at fp32 accuracy, the same reference operators as the 16-bit entry points: GroupNorm32 (+SiLU) DU:276-278 /
+ * OAI:267-271, 302-315; LayerNorm ATT:609-759; GEGLU ATT:89-96; scaled-dot-product attention ATT:352-356.  The bf16 build exports
+ * the symbols and returns VS_ERR_UNSUPPORTED. */
+int vidseg_x_split3(const float* x, long long M, int C, int silu, void* out_f16 /* [M][3C] */, vidseg_stream_t stream);
+int vidseg_x_geglu_split3(const float* y /* [M][2*inner]: value | gate */, long long M, int inner, void* out_f16 /* [M][3*inner] */,
+                          vidseg_stream_t stream);
+int vidseg_x_groupnorm_split3(const float* x0, const float* x1 /* opt: channel concat */, int C0, int C1, int B, int HW, int G,
+                              const float* gamma, const float* beta, float eps, int silu, float* stats /* scratch [B][2][C] */,
+                              int stats_floats, void* out_f16 /* [B][HW][3C] */, vidseg_stream_t stream);
+int vidseg_x_layernorm_split3(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
+                              void* out_f16 /* [M][3C] */, vidseg_stream_t stream);
+int vidseg_x_attention_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int B, int H,
+                           int Nq, int Nk, float scale, vidseg_stream_t stream);
+/* input conv (OAI:638-644) with the fp32 accumulators stored as they are: fp32 NHWC [B][H][W][Cin] -> fp32 NHWC [B][H][W][Cout] */
+int vidseg_conv_in_f32(const float* x, const float* w, const float* bias, int B, int H, int W, int Cin, int Cout, float* out_f32_nhwc,
+                       vidseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

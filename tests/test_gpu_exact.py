@@ -1,0 +1,156 @@
+"""The "exact" precision mode (vidseg_diffusion_amd/exact.py, csrc/exact_ops.hip): fp32-accurate evaluation of the SD UNet on the
+16-bit MFMA kernels over split (hi, lo) operands.
+
+Bars (fp16 build only; floating point, stated against float64 evaluations of the same fp32 inputs):
+    glue operators (split3, GroupNorm, LayerNorm, GEGLU, attention)   |err| <= 2e-6 * max|ref|   (fp32 arithmetic)
+    split GEMM / conv (one MFMA GEMM over the 3-fold K axis)             |err| <= 5e-6 * max|ref|   (22-bit operands, fp32 accumulation)
+    narrow UNet forward + taps vs the REFERENCE golden                   normalised rms <= 5e-5 (output), fp16 taps: at most 1 ulp apart
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from conftest import act_mode
+from vidseg_diffusion_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden", "unet_sd_narrow.npz")
+
+
+@pytest.fixture(scope="module")
+def X():
+    assert torch.cuda.is_available()
+    from vidseg_diffusion_amd import _lib, exact
+    _lib.lib()
+    if act_mode()[0] != "f16":
+        pytest.skip("the exact mode exists in the fp16 build only")
+    return exact
+
+
+def rel(got, ref):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float(np.abs(got - ref).max() / np.abs(ref).max())
+
+
+def rnd(shape, seed, scale=1.0):
+    return (torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal(shape).astype(np.float32)) * scale)
+
+
+def test_split3_reconstructs_22_bits(X):
+    dev = torch.device("cuda:0")
+    for scale in (1.0, 1e-2, 30.0):                              # incl. values whose lo part is an fp16 subnormal
+        x = rnd((37, 320), 1, scale)
+        s = X.split3(x.to(dev)).cpu()
+        assert s.dtype == torch.float16 and tuple(s.shape) == (37, 960)
+        hi, lo, hi2 = s[:, :320], s[:, 320:640], s[:, 640:]
+        assert torch.equal(hi, hi2) and torch.equal(hi, x.half())
+        rec = hi.double() + lo.double()
+        assert float((rec - x.double()).abs().max()) <= max(2.0 ** -21 * scale * 6, 2.0 ** -24), scale
+    y = X.split3(rnd((5, 64), 2).to(dev), silu=True).cpu()
+    ref = TF.silu(rnd((5, 64), 2).double())
+    assert rel(y[:, :64].double() + y[:, 64:128].double(), ref) <= 2e-6
+
+
+def test_split_gemm_is_fp32_accurate(X):
+    """linear_x / conv3x3_x = ONE call of the 16-bit MFMA GEMM over [hi|lo|hi] x [hi|hi|lo]: compare with float64."""
+    from vidseg_diffusion_amd import ops
+    dev = torch.device("cuda:0")
+    for (M, K, N), sa, sw in (((300, 320, 640), 1.0, 0.02), ((4096, 1280, 320), 3.0, 0.02), ((28, 320, 1280), 1e-2, 1e-3)):
+        a, w, b = rnd((M, K), 3, sa), rnd((N, K), 4, sw), rnd((N,), 5)
+        out = X.linear_x(X.split3(a.to(dev)), X.pack_linear_x(w, dev), ops.f32(b, dev)).cpu()
+        ref = a.double() @ w.double().t() + b.double()
+        e = rel(out, ref)
+        e16 = rel(a.half().double() @ w.half().double().t() + b.double(), ref)      # what plain fp16 operands cost on the same data
+        print(f"split GEMM {M}x{N}x{K} (scales {sa}, {sw}): max err {e:.2e} of max|ref| (fp16 operands alone: {e16:.2e})")
+        assert e <= 5e-6, (M, K, N, e)
+    x, w, b = rnd((2, 64, 12, 20), 6), rnd((128, 64, 3, 3), 7, 0.05), rnd((128,), 8)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    for kw, ref in ((dict(), TF.conv2d(x.double(), w.double(), b.double(), padding=1)),
+                    (dict(stride=2), TF.conv2d(x.double(), w.double(), b.double(), padding=1, stride=2)),
+                    (dict(up=2), TF.conv2d(TF.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1))):
+        out = X.conv3x3_x(X.split3(xn), X.pack_conv3x3_x(w, dev), ops.f32(b, dev), **kw).cpu().permute(0, 3, 1, 2)
+        e = rel(out, ref)
+        print(f"split conv3x3 {kw}: max err {e:.2e}")
+        assert e <= 5e-6, (kw, e)
+
+
+def test_fp32_glue_operators(X):
+    from vidseg_diffusion_amd import ops
+    dev = torch.device("cuda:0")
+
+    def join(s, C):
+        s = s.cpu().double()
+        return s[..., :C] + s[..., C:2 * C]
+
+    x0, x1 = rnd((3, 8, 10, 64), 11) + 0.7, rnd((3, 8, 10, 128), 12, 2.0)
+    g, b = rnd((192,), 13) * 0.3 + 1.0, rnd((192,), 14) * 0.2
+    for silu in (True, False):
+        for two in (True, False):
+            xs = torch.cat([x0, x1], -1) if two else x0
+            C = xs.shape[-1]
+            out = join(X.groupnorm_split3(x0.to(dev), ops.f32(g[:C], dev), ops.f32(b[:C], dev), x1=x1.to(dev) if two else None, eps=1e-5,
+                                          silu=silu), C)
+            ref = TF.group_norm(xs.double().permute(0, 3, 1, 2), 32, g[:C].double(), b[:C].double(), 1e-5).permute(0, 2, 3, 1)
+            ref = TF.silu(ref) if silu else ref
+            assert rel(out, ref) <= 2e-6, (silu, two, rel(out, ref))
+    for C in (320, 640, 1280):
+        x, gg, bb = rnd((77, C), 15) * 2 + 0.3, rnd((C,), 16) * 0.3 + 1.0, rnd((C,), 17) * 0.1
+        out = join(X.layernorm_split3(x.to(dev), ops.f32(gg, dev), ops.f32(bb, dev)), C)
+        assert rel(out, TF.layer_norm(x.double(), (C,), gg.double(), bb.double(), 1e-5)) <= 2e-6, C
+    y = rnd((50, 2 * 256), 18, 1.5)
+    out = join(X.geglu_split3(y.to(dev)), 256)
+    v, gt = y.double().chunk(2, dim=-1)
+    assert rel(out, v * TF.gelu(gt)) <= 2e-6
+    for (B, H, Nq, Nk) in ((2, 5, 200, 200), (3, 2, 64, 77), (1, 10, 1024, 1024)):
+        q, k, vv = rnd((B, Nq, H * 64), 19), rnd((B, Nk, H * 64), 20), rnd((B, Nk, H * 64), 21)
+        qkv = torch.cat([q, q, q], -1).to(dev)                                   # q as a column slice of a wider buffer (stride 3C)
+        out = X.attention_f32(qkv[..., H * 64:2 * H * 64], k.to(dev), vv.to(dev), H, B, Nq, Nk).cpu()
+        hd = lambda t, n: t.double().view(B, n, H, 64).transpose(1, 2)            # noqa: E731
+        ref = TF.scaled_dot_product_attention(hd(q, Nq), hd(k, Nk), hd(vv, Nk)).transpose(1, 2).reshape(B, Nq, H * 64)
+        e = rel(out, ref)
+        print(f"attention_f32 B={B} H={H} Nq={Nq} Nk={Nk}: max err {e:.2e}")
+        assert e <= 2e-6, (B, H, Nq, Nk, e)
+
+
+def test_exact_unet_forward_vs_reference(X):
+    """Narrow SD UNet in the exact mode against the REFERENCE's fp32 forward (tests/golden/unet_sd_narrow.npz): output and every
+    dumped Q/K tap -- and the 16-bit mode of the same object on the same inputs, for the ratio."""
+    from vidseg_diffusion_amd.unet import UNetModel
+    dev = torch.device("cuda:0")
+    z = np.load(G)
+    g = {k: z[k] for k in z.files}
+    net = UNetModel(**synthetic.SD21_NARROW)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, 1234).items()})
+    x, t, ctx = (torch.from_numpy(g[k]).to(dev) for k in ("fw_x", "fw_t", "fw_ctx"))
+
+    def nrms(a, b):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+    out16 = net(x, timesteps=t, context=ctx).cpu().numpy()
+    net.set_precision("exact")
+    out = net(x, timesteps=t, context=ctx).cpu().numpy()
+    e, e16 = nrms(out, g["fw_out"]), nrms(out16, g["fw_out"])
+    print(f"narrow UNet output vs reference: exact mode nrms {e:.2e}, 16-bit mode {e16:.2e}")
+    assert e <= 5e-5, e
+    worst = 0.0
+    for b in range(3, 12):
+        tb = net.output_blocks[b][1].transformer_blocks[0]
+        for nm, a in (("self", tb.attn1), ("cross", tb.attn2)):
+            for w in ("q", "k"):
+                ref = g[f"fw_output_block_{b}_spatial_{nm}_attn_{w}"]
+                got = getattr(a, w).cpu().numpy()
+                assert got.dtype == np.float16 and got.shape == ref.shape
+                # both are fp16 roundings of fp32 values 1e-5 apart: identical except where a value sits on a rounding boundary
+                d = np.abs(got.astype(np.float32) - ref.astype(np.float32))
+                assert float(d.max()) <= 2.0 ** -10 * float(np.abs(ref.astype(np.float32)).max()), (b, nm, w)
+                worst = max(worst, nrms(got.astype(np.float32), ref.astype(np.float32)))
+                assert np.mean(got != ref) <= 0.05, (b, nm, w, float(np.mean(got != ref)))
+    print(f"exact mode: worst fp16 tap nrms vs reference {worst:.2e}")
+    assert worst <= 1e-4
+    net.set_precision("fp16")
+    assert np.array_equal(net(x, timesteps=t, context=ctx).cpu().numpy(), out16)

@@ -384,3 +384,49 @@ def test_linear_weight_stationary_fast_epilogues(dev, M, K, N):
     check(ops.linear(ad, wd, b.to(dev)), a @ w.T + b, "ws linear+bias")
     check(ops.linear(ad, wd, None), a @ w.T, "ws linear")
     check(ops.linear(ad, wd, b.to(dev), residual=res.to(ops.act_dtype()).to(dev)), a @ w.T + b + res, "ws linear+bias+residual")
+
+
+# ---- the time stack of the VideoUNet at the benchmarked frame count T = 14 (BASELINE configs[2]), each kernel on its own -----------
+@pytest.mark.parametrize("Bv,T,S,H", [(2, 14, 150, 5), (1, 14, 64, 10), (2, 3, 40, 2)])
+def test_temporal_attention_T14(dev, Bv, T, S, H):
+    """k_temporal_attention: attention across the T frames of every (video, location) -- VideoTransformerBlock's attn1 after
+    `(b t) s c -> (b s) t c` (video_attention.py:171-196) -- on rows kept in the spatial order (b t) s."""
+    from vidseg_diffusion_amd import ops
+    C = H * 64
+    q, k, v = rnd((Bv * T, S, C), 31), rnd((Bv * T, S, C), 32), rnd((Bv * T, S, C), 33)
+    ad = ops.act_dtype()
+    out = ops.temporal_attention(q.to(ad).to(dev), k.to(ad).to(dev), v.to(ad).to(dev), H, Bv, T, S)
+    assert tuple(out.shape) == (Bv * T, S, C)
+    tl = lambda t: t.view(Bv, T, S, H, 64).permute(0, 2, 3, 1, 4).reshape(Bv * S, H, T, 64)          # noqa: E731  -> (b s) h t d
+    ref = TF.scaled_dot_product_attention(tl(q), tl(k), tl(v))                                       # [(b s), h, t, d]
+    ref = ref.view(Bv, S, H, T, 64).permute(0, 3, 1, 2, 4).reshape(Bv * T, S, C)
+    check(out, ref, f"temporal attention T={T}")
+
+
+@pytest.mark.parametrize("Bv,T,HW,Cin,Cout", [(2, 14, (6, 10), 128, 128), (1, 14, (4, 4), 320, 320), (2, 5, (3, 5), 64, 192)])
+def test_conv_temporal3_T14(dev, Bv, T, HW, Cin, Cout):
+    """vidseg_conv_temporal3_a16: Conv3d kernel [3,1,1] over the frame axis (video_model.py:45-58) as a 3-tap implicit GEMM with the
+    per-(b t) emb vector and the residual in the epilogue; the first / last frame of every video see zero padding, and frames of
+    different videos never mix."""
+    from vidseg_diffusion_amd import ops
+    Hh, Ww = HW
+    x, w, b = rnd((Bv * T, Hh, Ww, Cin), 41), rnd((Cout, Cin, 3, 1, 1), 42, 0.05), rnd((Cout,), 43)
+    rv, res = rnd((Bv * T, Cout), 44), rnd((Bv * T, Hh, Ww, Cout), 45)
+    ad = ops.act_dtype()
+    out = ops.conv_temporal3(x.to(ad).to(dev), ops.pack_conv_temporal3(w, dev), b.to(dev), T, rowvec=rv.to(dev), residual=res.to(ad).to(dev))
+    x5 = x.view(Bv, T, Hh, Ww, Cin).permute(0, 4, 1, 2, 3)                                           # b c t h w
+    ref = TF.conv3d(x5, w, b, padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(Bv * T, Hh, Ww, Cout)
+    ref = ref + rv[:, None, None, :] + res
+    check(out, ref, f"conv_temporal3 T={T}")
+
+
+def test_alpha_blend(dev):
+    """AlphaBlender 'learned_with_images' with image_only_indicator = 0 (diffusionmodules/util.py:343-380): sigmoid(mix) * spatial +
+    (1 - sigmoid(mix)) * temporal."""
+    from vidseg_diffusion_amd import ops
+    a, b = rnd((28, 36, 640), 51), rnd((28, 36, 640), 52)
+    ad = ops.act_dtype()
+    for mix in (0.3, -1.2, 4.0):
+        out = ops.alpha_blend(a.to(ad).to(dev), b.to(ad).to(dev), torch.tensor([mix], dtype=torch.float32, device=dev))
+        al = torch.sigmoid(torch.tensor(mix))
+        check(out, al * a + (1 - al) * b, f"alpha_blend mix={mix}")

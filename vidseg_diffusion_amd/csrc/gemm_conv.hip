@@ -1500,7 +1500,7 @@ __device__ __forceinline__ float ld_in<bf16_t>(const bf16_t* p, long long i) { r
 // weight vector for the 4 pixels -- 96 FMAs per 6 LDS reads, VALU-bound.  The bf16 result leaves as 16-byte stores.
 #define CONV_IN_QUADS 32
 __global__ void __launch_bounds__(256) k_conv_in(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                 int B, int H, int W, int Cin, int Cout, bf16_t* __restrict__ out) {
+                                                 int B, int H, int W, int Cin, int Cout, bf16_t* __restrict__ out, float* __restrict__ out32) {
     extern __shared__ __attribute__((aligned(16))) float wl[];           // [9*Cin][Cout]
     const int K = 9 * Cin;
     for (int i = threadIdx.x; i < K * Cout / 4; i += 256) reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(w)[i];
@@ -1548,6 +1548,15 @@ __global__ void __launch_bounds__(256) k_conv_in(const float* __restrict__ x, co
                         }
                 }
             }
+        }
+        if (out32) {                                           // exact mode: the fp32 accumulators as they are
+            float* op32 = out32 + (((long long)b * H + oh) * W + ow0) * Cout + co;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                *reinterpret_cast<f32x4*>(op32 + (long long)p * Cout) = f32x4{acc[p][0], acc[p][1], acc[p][2], acc[p][3]};
+                *reinterpret_cast<f32x4*>(op32 + (long long)p * Cout + 4) = f32x4{acc[p][4], acc[p][5], acc[p][6], acc[p][7]};
+            }
+            continue;
         }
         bf16_t* op = out + (((long long)b * H + oh) * W + ow0) * Cout + co;
 #pragma unroll
@@ -2480,8 +2489,8 @@ int vidseg_conv3x3_a16_tap(const void* x0, const void* x1, int C0, int C1, int B
 }
 
 // Tiny-channel 3x3 convs.  conv_in: x NHWC fp32 [B][H][W][Cin], w fp32 [3][3][Cin][Cout] -> bf16 NHWC.
-int vidseg_conv_in(const float* x, const float* w, const float* bias, int B, int H, int W, int Cin, int Cout, void* out_bf16_nhwc,
-                   hipStream_t st) {
+static int conv_in_impl(const float* x, const float* w, const float* bias, int B, int H, int W, int Cin, int Cout, void* out_bf16_nhwc,
+                        float* out_f32_nhwc, hipStream_t st) {
     const long long npix = (long long)B * H * W;
     if (npix == 0 || Cout == 0) return VS_OK;
     VS_REQUIRE(Cout % 8 == 0 && Cout <= 2048 && 9 * Cin * Cout * 4 <= 160 * 1024 && W % 4 == 0, "conv_in: Cin=%d Cout=%d W=%d", Cin, Cout, W);
@@ -2493,9 +2502,19 @@ int vidseg_conv_in(const float* x, const float* w, const float* bias, int B, int
     }
     const long long nquad = npix / 4;
     k_conv_in<<<dim3((unsigned)((nquad + CONV_IN_QUADS - 1) / CONV_IN_QUADS)), 256, lds, st>>>(x, w, bias, B, H, W, Cin, Cout,
-                                                                                                (bf16_t*)out_bf16_nhwc);
+                                                                                                (bf16_t*)out_bf16_nhwc, out_f32_nhwc);
     VS_CHECK_LAUNCH("conv_in");
     return VS_OK;
+}
+
+int vidseg_conv_in(const float* x, const float* w, const float* bias, int B, int H, int W, int Cin, int Cout, void* out_bf16_nhwc,
+                   hipStream_t st) {
+    return conv_in_impl(x, w, bias, B, H, W, Cin, Cout, out_bf16_nhwc, nullptr, st);
+}
+// the same convolution with the fp32 accumulators stored as they are (exact mode, exact_ops.hip)
+int vidseg_conv_in_f32(const float* x, const float* w, const float* bias, int B, int H, int W, int Cin, int Cout, float* out_f32_nhwc,
+                       hipStream_t st) {
+    return conv_in_impl(x, w, bias, B, H, W, Cin, Cout, nullptr, out_f32_nhwc, st);
 }
 
 // conv_out: x NHWC bf16 [B][H][W][Cin], w bf16 [4][3][3][Cin] -> fp32 NCHW [B][4][H][W].

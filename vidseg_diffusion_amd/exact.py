@@ -1,0 +1,290 @@
+"""`UNetModel.set_precision("exact")`: the SD UNet forward at fp32 accuracy on the 16-bit MFMA kernels (fp16 build only).
+
+Why: Step 3 of the drivers is best-of-10 K-means++ on the dumped Q taps (scripts/sampling/feature_extraction.py:562-572), and
+K-means++ seeding is chaotic in its input: measured on the REFERENCE's own taps with the reference's own sklearn call
+(tools/mask_knee_study.py -> profiles/r03_mask_knee_study.txt), white noise of normalised rms 1e-3 -- what fp16 storage of the
+activations costs, on any device, the reference's CUDA autocast included -- re-rolls about half of the ten restarts and only
+3 of 8 windows keep the reference's masks (IoU >= 0.99); at 1e-4 every window does.  The 16-bit path (unet.py) sits at 1.2e-3.
+This mode carries every activation in fp32 and evaluates each conv / linear as ONE call of the same MFMA kernels over a
+three-fold K axis, operands split as hi = fp16(x), lo = fp16(x - hi):
+
+    [ a_hi | a_lo | a_hi ] . [ w_hi | w_hi | w_lo ]^T  =  a_hi w_hi + a_lo w_hi + a_hi w_lo      (fp32 accumulation in the MFMA)
+
+GroupNorm / LayerNorm / SiLU / GEGLU / softmax run in fp32 (csrc/exact_ops.hip) and write the split operand image directly.
+3x the MFMA work + fp32 glue; taps land within ~1e-5 of the fp32 reference.  It mirrors the same reference operators as unet.py
+(openaimodel.py:341-369 ResBlock, :831-954 forward; attention.py:609-759 transformer block, :286-364 attention with the q/k
+capture at :330-331, :889-927 SpatialTransformer) and writes the same taps onto the same attention modules, so the drivers'
+dump protocol is unchanged.  Feature-dump path only: no modulation / injection, SD UNet only.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from ._lib import VidsegError, call, ptr, stream
+
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+_lib.register({
+    "vidseg_x_split3": [_P, _L, _I, _I, _P, _P],
+    "vidseg_x_geglu_split3": [_P, _L, _I, _P, _P],
+    "vidseg_x_groupnorm_split3": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _P],
+    "vidseg_x_layernorm_split3": [_P, _L, _I, _P, _P, _F, _P, _P],
+    "vidseg_x_attention_f32": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
+    "vidseg_conv_in_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+})
+
+F32, F16 = torch.float32, torch.float16
+
+
+# ----------------------------------------------------------------------------- weights: [w_hi | w_hi | w_lo] along K
+def _hl(w):
+    w = w.detach().to(F32)
+    hi = w.to(F16)
+    return hi, (w - hi.to(F32)).to(F16)
+
+
+def pack_linear_x(weight, device):
+    hi, lo = _hl(weight)
+    return torch.cat([hi, hi, lo], dim=1).to(device).contiguous()
+
+
+def pack_conv3x3_x(weight, device):
+    """[Cout, Cin, 3, 3] -> the chunk-major packing of ops.pack_conv3x3 over the 3*Cin input channels [hi | hi | lo]."""
+    hi, lo = _hl(weight)
+    return ops.pack_conv3x3(torch.cat([hi, hi, lo], dim=1), device)
+
+
+def pack_conv_out_x(weight, device):
+    hi, lo = _hl(weight)
+    return ops.pack_conv_out(torch.cat([hi, hi, lo], dim=1), device)
+
+
+# ----------------------------------------------------------------------------- fp32 glue operators
+def split3(x, silu=False):
+    C = x.shape[-1]
+    out = torch.empty(x.shape[:-1] + (3 * C,), dtype=F16, device=x.device)
+    call("vidseg_x_split3", ptr(x), x.numel() // C, C, int(silu), ptr(out), stream())
+    return out
+
+
+def geglu_split3(y):
+    inner = y.shape[-1] // 2
+    out = torch.empty(y.shape[:-1] + (3 * inner,), dtype=F16, device=y.device)
+    call("vidseg_x_geglu_split3", ptr(y), y.numel() // (2 * inner), inner, ptr(out), stream())
+    return out
+
+
+def groupnorm_split3(x0, gamma, beta, *, x1=None, eps=1e-5, silu=True):
+    B, C0 = x0.shape[0], x0.shape[-1]
+    C1 = x1.shape[-1] if x1 is not None else 0
+    HW = x0.numel() // (B * C0)
+    stats = torch.empty(B * 2 * (C0 + C1), dtype=F32, device=x0.device)
+    out = torch.empty(x0.shape[:-1] + (3 * (C0 + C1),), dtype=F16, device=x0.device)
+    call("vidseg_x_groupnorm_split3", ptr(x0), ptr(x1), C0, C1, B, HW, 32, ptr(gamma), ptr(beta), eps, int(silu), ptr(stats), stats.numel(),
+         ptr(out), stream())
+    return out
+
+
+def layernorm_split3(x, gamma, beta, eps=1e-5):
+    C = x.shape[-1]
+    out = torch.empty(x.shape[:-1] + (3 * C,), dtype=F16, device=x.device)
+    call("vidseg_x_layernorm_split3", ptr(x), x.numel() // C, C, ptr(gamma), ptr(beta), eps, ptr(out), stream())
+    return out
+
+
+def attention_f32(q, k, v, heads, B, Nq, Nk):
+    """softmax(q k^T / 8) v per 64-wide head; q / k / v: fp32 column slices [B, N, >= heads*64] of row-major buffers."""
+    out = torch.empty((B, Nq, heads * 64), dtype=F32, device=q.device)
+    call("vidseg_x_attention_f32", q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), v.data_ptr(), v.stride(1), ptr(out), heads * 64,
+         B, heads, Nq, Nk, 0.125, stream())
+    return out
+
+
+def linear_x(a3, w3, bias=None, *, rowvec=None, rows_per_sample=0, act=ops.ACT_NONE, tap=None, tap2=None, tap_cols=0):
+    """fp32 out = act(a . w^T + bias + rowvec[sample]) on split operands (a3: [.., 3K] fp16, w3: [N, 3K] fp16)."""
+    ops.workspace(a3.device)
+    K3 = a3.shape[-1]
+    M = a3.numel() // K3
+    N = w3.shape[0]
+    out = torch.empty(a3.shape[:-1] + (N,), dtype=F32, device=a3.device)
+    call("vidseg_linear_a16", ptr(a3), None, K3, 0, M, ptr(w3), N, ptr(bias), ptr(rowvec), rowvec.stride(0) if rowvec is not None else 0,
+         rows_per_sample, None, 0, None, ptr(out), N, ptr(tap), ptr(tap2), tap_cols, tap.shape[-1] if tap is not None else 0, None, act,
+         stream())
+    return out
+
+
+def conv3x3_x(x3, w3, bias, *, stride=1, up=1, rowvec=None):
+    """fp32 NHWC out of the 3x3 conv on the split image x3 [B, H, W, 3Cin]."""
+    ops.workspace(x3.device)
+    B, H, W, C3 = x3.shape
+    Cout = w3.shape[0]
+    Ho, Wo = (H * up + 2 - 3) // stride + 1, (W * up + 2 - 3) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cout), dtype=F32, device=x3.device)
+    call("vidseg_conv3x3_a16", ptr(x3), None, C3, 0, B, H, W, stride, up, ptr(w3), Cout, ptr(bias), ptr(rowvec),
+         rowvec.stride(0) if rowvec is not None else 0, None, None, 1, ptr(out), stream())
+    return out
+
+
+def add(a, b):
+    return ops.axpy(a, b, 1.0)
+
+
+# ----------------------------------------------------------------------------- the network
+class ExactRunner:
+    """Walks the module tree of a loaded `unet.UNetModel` (fp32 parameters) and evaluates it in the exact mode."""
+
+    def __init__(self, net, device):
+        if ops.act_dtype() != F16:
+            raise VidsegError("the exact mode needs the fp16 build of libvidseg_hip.so (VIDSEG_ACT=f16)")
+        from . import unet as U
+        self.U, self.net, self.dev = U, net, torch.device(device)
+        if net.num_classes is not None:
+            raise NotImplementedError("exact mode: SD UNet only (no label embedding / video layers)")
+        d = self.dev
+        f = lambda t: ops.f32(t, d)                                          # noqa: E731
+        self.w = {}
+        for name, m in net.named_modules():
+            if isinstance(m, U.ResBlock):
+                if type(m) is not U.ResBlock:
+                    raise NotImplementedError("exact mode: VideoResBlock is not supported")
+                e = dict(g1=f(m.in_layers[0].weight), b1=f(m.in_layers[0].bias), w1=pack_conv3x3_x(m.in_layers[2].weight, d),
+                         cb1=f(m.in_layers[2].bias), g2=f(m.out_layers[0].weight), b2=f(m.out_layers[0].bias),
+                         w2=pack_conv3x3_x(m.out_layers[3].weight, d), cb2=f(m.out_layers[3].bias))
+                if not isinstance(m.skip_connection, nn.Identity):
+                    e["ws"] = pack_linear_x(m.skip_connection.weight.reshape(m.out_channels, m.channels), d)
+                    e["bs"] = f(m.skip_connection.bias)
+                self.w[name] = e
+            elif isinstance(m, U.SpatialTransformer):
+                if type(m) is not U.SpatialTransformer:
+                    raise NotImplementedError("exact mode: SpatialVideoTransformer is not supported")
+                e = dict(g=f(m.norm.weight), b=f(m.norm.bias), w_in=pack_linear_x(m.proj_in.weight, d), b_in=f(m.proj_in.bias),
+                         w_out=pack_linear_x(m.proj_out.weight, d), b_out=f(m.proj_out.bias), blocks=[])
+                for blk in m.transformer_blocks:
+                    a1, a2, ff = blk.attn1, blk.attn2, blk.ff
+                    e["blocks"].append(dict(
+                        ln=[(f(n.weight), f(n.bias)) for n in (blk.norm1, blk.norm2, blk.norm3)],
+                        w_qkv=pack_linear_x(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0), d),
+                        w_o1=pack_linear_x(a1.to_out[0].weight, d), b_o1=f(a1.to_out[0].bias),
+                        w_q=pack_linear_x(a2.to_q.weight, d), w_kv=pack_linear_x(torch.cat([a2.to_k.weight, a2.to_v.weight], 0), d),
+                        w_o2=pack_linear_x(a2.to_out[0].weight, d), b_o2=f(a2.to_out[0].bias),
+                        w_ff1=pack_linear_x(ff.net[0].proj.weight, d), b_ff1=f(ff.net[0].proj.bias),
+                        w_ff2=pack_linear_x(ff.net[2].weight, d), b_ff2=f(ff.net[2].bias)))
+                self.w[name] = e
+            elif isinstance(m, U.Upsample):
+                self.w[name] = dict(w=pack_conv3x3_x(m.conv.weight, d), b=f(m.conv.bias))
+            elif isinstance(m, U.Downsample):
+                self.w[name] = dict(w=pack_conv3x3_x(m.op.weight, d), b=f(m.op.bias))
+        te = net.time_embed
+        self.te = (pack_linear_x(te[0].weight, d), f(te[0].bias), pack_linear_x(te[2].weight, d), f(te[2].bias))
+        rbs = net._resblocks()
+        off = 0
+        self.emb_off = {}
+        for rb in rbs:
+            self.emb_off[id(rb)] = off
+            off += rb.out_channels
+        self.emb_w = pack_linear_x(torch.cat([rb.emb_layers[1].weight for rb in rbs], 0), d)
+        self.emb_b = f(torch.cat([rb.emb_layers[1].bias for rb in rbs], 0))
+        cin = net.input_blocks[0][0]
+        self.cin_w, self.cin_b = ops.pack_conv_in(cin.weight, d), f(cin.bias)
+        self.out_g, self.out_beta = f(net.out[0].weight), f(net.out[0].bias)
+        self.out_w, self.out_b = pack_conv_out_x(net.out[2].weight, d), f(net.out[2].bias)
+        self.names = {id(m): n for n, m in net.named_modules()}
+
+    # ---- blocks -------------------------------------------------------------------------------------------------------
+    def resblock(self, m, x0, x1, emb_all):
+        e = self.w[self.names[id(m)]]
+        h = groupnorm_split3(x0, e["g1"], e["b1"], x1=x1, eps=1e-5, silu=True)
+        off = self.emb_off[id(m)]
+        rv = emb_all[:, off:off + m.out_channels]
+        h = conv3x3_x(h, e["w1"], e["cb1"], rowvec=rv)                              # conv + bias + emb_out (OAI:353-365)
+        h = groupnorm_split3(h, e["g2"], e["b2"], eps=1e-5, silu=True)
+        h = conv3x3_x(h, e["w2"], e["cb2"])
+        if "ws" in e:
+            xin = x0 if x1 is None else torch.cat([x0, x1], dim=-1)
+            res = linear_x(split3(xin), e["ws"], e["bs"])                           # 1x1 skip conv on the concat (OAI:912, 369)
+        else:
+            if x1 is not None:
+                raise VidsegError("ResBlock: identity skip with a concatenated input")
+            res = x0
+        return add(h, res)
+
+    def transformer(self, m, x, ctx3, tap):
+        e = self.w[self.names[id(m)]]
+        B, H, W, C = x.shape
+        N = H * W
+        t = groupnorm_split3(x, e["g"], e["b"], eps=1e-6, silu=False).view(B, N, 3 * C)              # ATT:897-903
+        t = linear_x(t, e["w_in"], e["b_in"])
+        for i, (blk, bw) in enumerate(zip(m.transformer_blocks, e["blocks"])):
+            heads, Ci = blk.attn1.heads, blk.attn1.inner
+            dump = tap and i == 0
+            # self-attention (ATT:636-672); q / k taps = fp16 of the fp32 projections (ATT:330-331)
+            tq = torch.empty((B, N, Ci), dtype=F16, device=x.device) if dump else None
+            tk = torch.empty((B, N, Ci), dtype=F16, device=x.device) if dump else None
+            qkv = linear_x(layernorm_split3(t, *bw["ln"][0]), bw["w_qkv"], tap=tq, tap2=tk, tap_cols=Ci)
+            a = attention_f32(qkv[..., :Ci], qkv[..., Ci:2 * Ci], qkv[..., 2 * Ci:], heads, B, N, N)
+            t = add(linear_x(split3(a), bw["w_o1"], bw["b_o1"]), t)
+            if dump:
+                blk.attn1.q, blk.attn1.k = tq, tk
+            # cross-attention to the (step-constant) context (ATT:689-726)
+            L = ctx3.shape[1]
+            tq = torch.empty((B, N, Ci), dtype=F16, device=x.device) if dump else None
+            q = linear_x(layernorm_split3(t, *bw["ln"][1]), bw["w_q"], tap=tq, tap_cols=Ci)
+            tk = torch.empty((B, L, Ci), dtype=F16, device=x.device) if dump else None
+            kv = linear_x(ctx3, bw["w_kv"], tap=tk, tap_cols=Ci)
+            a = attention_f32(q, kv[..., :Ci], kv[..., Ci:], heads, B, N, L)
+            t = add(linear_x(split3(a), bw["w_o2"], bw["b_o2"]), t)
+            if dump:
+                blk.attn2.q, blk.attn2.k = tq, tk
+            # GEGLU feed-forward (ATT:728-757, :89-115)
+            y = linear_x(layernorm_split3(t, *bw["ln"][2]), bw["w_ff1"], bw["b_ff1"])
+            t = add(linear_x(geglu_split3(y), bw["w_ff2"], bw["b_ff2"]), t)
+        out = add(linear_x(split3(t), e["w_out"], e["b_out"]), x.view(B, N, C))                        # ATT:921-927
+        return out.view(B, H, W, C)
+
+    def block(self, blk, x, x_skip, emb_all, ctx3):
+        U = self.U
+        for layer in blk:
+            if isinstance(layer, U.ResBlock):
+                x = self.resblock(layer, x, x_skip, emb_all)
+                x_skip = None
+            elif isinstance(layer, U.SpatialTransformer):
+                x = self.transformer(layer, x, ctx3, layer.tap)
+            elif isinstance(layer, U.Upsample):
+                e = self.w[self.names[id(layer)]]
+                x = conv3x3_x(split3(x), e["w"], e["b"], up=2)
+            elif isinstance(layer, U.Downsample):
+                e = self.w[self.names[id(layer)]]
+                x = conv3x3_x(split3(x), e["w"], e["b"], stride=2)
+            else:
+                raise VidsegError(f"unexpected layer {type(layer)}")
+        return x
+
+    def forward(self, x_nchw, timesteps, context):
+        net, dev = self.net, self.dev
+        mc = net.model_channels
+        half = mc // 2                                                                                # timestep_embedding, DU:209-233 (host fp32)
+        ts = timesteps.detach().float().cpu()
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=F32) / half)
+        args = ts[:, None] * freqs[None]
+        t_emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(dev)
+        w1, b1, w2, b2 = self.te
+        emb = linear_x(split3(linear_x(split3(t_emb), w1, b1, act=ops.ACT_SILU)), w2, b2)
+        emb_all = linear_x(split3(emb, silu=True), self.emb_w, self.emb_b)                              # every ResBlock's emb_layers
+        ctx3 = ops.window_cached(self, "_ctx3", (context,), lambda: split3(context.float().contiguous()))
+        xn = x_nchw.float().permute(0, 2, 3, 1).contiguous()
+        B, H, W, Cin = xn.shape
+        h = torch.empty((B, H, W, mc), dtype=F32, device=dev)
+        call("vidseg_conv_in_f32", ptr(xn), ptr(self.cin_w), ptr(self.cin_b), B, H, W, Cin, mc, ptr(h), stream())
+        hs = [h]
+        for blk in list(net.input_blocks)[1:]:
+            h = self.block(blk, h, None, emb_all, ctx3)
+            hs.append(h)
+        h = self.block(net.middle_block, h, None, emb_all, ctx3)
+        for blk in net.output_blocks:
+            h = self.block(blk, h, hs.pop(), emb_all, ctx3)                                            # OAI:911-948
+        h3 = groupnorm_split3(h, self.out_g, self.out_beta, eps=1e-5, silu=True)
+        return ops.conv_out4(h3, self.out_w, self.out_b)

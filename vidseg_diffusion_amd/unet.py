@@ -419,15 +419,29 @@ class UNetModel(nn.Module):
         self.out = nn.Sequential(_meta(GroupNorm32, 32, ch), nn.SiLU(), _meta(nn.Conv2d, model_channels, out_channels, 3, padding=1))
         self._packed_on = None
         self.tap_mode = "output"                                    # "output" (reference dumps), "all", "none"
+        self.precision = "fp16"                                     # "fp16" (16-bit activations, this file) or "exact" (exact.py)
+        self._exact = None
 
     # ------------------------------------------------------------------ parameters
     def load_state_dict(self, state_dict, strict=True, assign=True):
         r = super().load_state_dict(state_dict, strict=strict, assign=True)
         self._packed_on = None
+        self._exact = None
         return r
 
     def _resblocks(self):
         return [m for m in self.modules() if isinstance(m, ResBlock)]
+
+    def set_precision(self, mode):
+        """"fp16": the 16-bit path of this file (activations stored in the library's 16-bit format; taps ~1.2e-3 from an fp32
+        evaluation).  "exact": exact.ExactRunner -- fp32 activations, every conv / linear on the same MFMA kernels over split
+        (hi, lo) operands, taps ~1e-5 from fp32: what best-of-10 K-means++ needs to return the reference's masks (3x the MFMA
+        work; feature-dump path of the SD UNet only)."""
+        if mode not in ("fp16", "exact"):
+            raise ValueError(f"unknown precision {mode!r}")
+        self.precision = mode
+        if mode == "fp16":
+            self._exact = None
 
     def stash_resblock_features(self, on=True):
         """Make every ResBlock leave `in_layers_features` / `out_layers_features` (openaimodel.py:349-350, 367-368) after a forward.
@@ -535,6 +549,17 @@ class UNetModel(nn.Module):
             raise AssertionError("must specify y if and only if the model is class-conditional")
         if not x.is_cuda:
             raise VidsegError("UNetModel runs on a HIP device only (no CPU fallback)")
+        if self.precision == "exact":
+            if is_modulate_step or is_injected_step or stop_after_block is not None:
+                raise NotImplementedError("exact precision covers the feature-dump pass (no modulation / injection / early stop)")
+            if self._exact is None:
+                from .exact import ExactRunner
+                for p in self.parameters():
+                    if p.is_meta:
+                        raise VidsegError("UNetModel has no weights: call load_state_dict() first")
+                self._set_taps()
+                self._exact = ExactRunner(self, x.device)
+            return self._exact.forward(x, timesteps, context)
         xn = x.float().permute(0, 2, 3, 1).contiguous()
         ctx = context if context.dtype == ops.act_dtype() else \
             ops.window_cached(self, "_ctx16", (context,), lambda: ops.to_bf16(context.float().contiguous()))
