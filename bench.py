@@ -283,6 +283,8 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False):
     t_start = 17 if svd else 22
     refine = True if svd else args.refine
     eng, cfg, sd_cpu, n_params = build(svd, args.narrow, dev)
+    if args.precision == "exact" and not svd:
+        eng.model.diffusion_model.set_precision("exact")
     # The timed steps CYCLE over the windows of the synthetic clip (step i of rank r = window (i * world + r) mod n): K-means
     # iteration counts, restarts and tie replays are data dependent, so one repeated window would time -- and score -- a single
     # draw.  SD headline: the windows for which the reference's labels are committed (tests/golden/c2_window*.npz), so that
@@ -360,6 +362,7 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False):
             dist.barrier()
         torch.cuda.synchronize()
 
+    run_steps.record, run_steps.windows = record, win_ids             # the secondary timings of main() read the masks they produced
     if warmup:
         run_steps(warmup)
     barrier()
@@ -402,7 +405,8 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False):
     out = {
         "metric": metric, "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16" if ops.act_dtype() == torch.float16 else "bf16", "data": "synthetic",
+        "dtype": ("f16" if ops.act_dtype() == torch.float16 else "bf16") if (args.precision == "fp16" or svd) else
+                 "f32 carried as split f16 pairs (22-bit operands on the f16 MFMA, f32 accumulation)", "data": "synthetic",
         "config": {"workload": workload, "frames_per_gpu": F_WIN, "num_masks": k_masks, "unet_evals_per_step": evals,
                    "parallelism": f"window-per-gpu x{world}",
                    "overlap": (f"{lanes} feature pass(es) in flight on their own HIP streams; the analysis of a finished window runs on another "
@@ -436,6 +440,10 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False):
         out["dtype"] += " + e4m3 attention (q, k, v, P; >= 1024 keys)"
         out["config"]["workload"] += "; BASELINE configs[4] attention path: OCP e4m3 MFMA on the spatial self-attentions"
     out["config"]["windows_cycled"] = win_ids
+    if args.precision == "exact" and not svd:
+        out["metric"] += " [precision=exact]"
+        out["config"]["workload"] += ("; PRECISION MODE exact (exact.py): fp32 activations, conv / linear on the 16-bit MFMA kernels over split "
+                                      "(hi, lo) operands -- 3x the MFMA work of the headline's 16-bit mode")
     if args.inversion:
         out["metric"] += " [inversion_type=inversion: 49 UNet evaluations per window]"
         out["config"]["workload"] += ("; INVERSION VARIANT (sd_pipeline_vspw.py:233-236, 340-345): EulerEDMSampler.inversion over 25 sigma pairs "
@@ -470,6 +478,10 @@ def main():
     ap.add_argument("--masks", type=int, default=None, help="number of masks K (default 20; configs[4] uses 50)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the chained-window figure, the in-run PMC passes and the SVD secondary")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # one window under rocprofv3 --pmc (see pmc_traffic)
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "exact"],
+                    help="fp16 (headline): 16-bit activations, the reference's CUDA-autocast dtype.  exact: UNetModel.set_precision('exact') -- "
+                         "fp32 activations, every conv / linear on the same MFMA kernels over split (hi, lo) operands (3x the MFMA work); the mode "
+                         "whose masks ARE the reference's.  The default run reports it as `exact_mode` beside the headline")
     ap.add_argument("--one-window", action="store_true", help="every step runs window 0 (the pre-round-3 behaviour) instead of cycling the fixture windows")
     ap.add_argument("--inversion", action="store_true",
                     help="the `--inversion_type inversion` variant of the drivers (sd_pipeline_vspw.py:233-236, 340-345): sampler.inversion "
@@ -573,6 +585,32 @@ def main():
                                         "HIP streams (same launches, same masks: tests/test_gpu_unet.py::test_overlapped_clip_equals_sequential); "
                                         "a second window's kernels take the CUs a launch leaves idle (28 = 4*7 samples fill 7/8 of a round of "
                                         "256 CUs with power-of-two tiles)"}
+        if plain and not svd and args.precision == "fp16" and ops.act_dtype() == torch.float16 and os.environ.get("VIDSEG_BENCH_EXACT", "1") != "0":
+            # the precision mode whose masks ARE the reference's (exact.py), timed on the same windows outside the headline timing
+            net = eng.model.diffusion_model
+            net.set_precision("exact")
+            try:
+                run_steps(1)
+                torch.cuda.synchronize()
+                del run_steps.record[:]
+                n = len(run_steps.windows)
+                t0 = time.perf_counter()
+                run_steps(n)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                mm = timed_masks_vs_reference(list(run_steps.record), refine, k_masks)
+                out["exact_mode"] = {"value": round(F_WIN * n / dt, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n, 3), "steps": n,
+                                     "mask_iou_vs_reference": {k: mm[k] for k in ("mean_iou", "min_iou", "windows_at_0.99", "n_windows",
+                                                                                  "mean_identical_fraction")} if mm else None,
+                                     "note": "UNetModel.set_precision('exact'): every activation in fp32, every conv / linear ONE call of the same "
+                                             "16-bit MFMA kernels over a three-fold K axis ([a_hi|a_lo|a_hi] x [w_hi|w_hi|w_lo], fp32 accumulation), "
+                                             "fp32 GroupNorm / LayerNorm / GEGLU / attention (csrc/exact_ops.hip).  Taps 4e-5 from the fp32 reference: "
+                                             "K-means++ then draws the reference's seeds and the masks are the reference's.  Same windows, same "
+                                             "pipeline, outside the headline timing"}
+            except Exception as e:
+                out["exact_mode"] = {"error": repr(e)[:300]}
+            finally:
+                net.set_precision("fp16")
         if args.vae:                                                 # outside the timed region, never part of `value`
             out["first_stage"] = first_stage_timing(dev, svd)
         if plain and not svd:

@@ -20,8 +20,9 @@ def golden_dir():
 
 
 def act_mode():
-    """("f16" | "bf16", whole-network tolerance) of the library under test: the default fp16 build must stay within 4e-3
-    normalised rms of the fp32 reference (taps, UNet outputs, sampler trajectories), a -DVIDSEG_ACT_BF16 build within 4e-2."""
+    """("f16" | "bf16", whole-network tolerance) of the library under test: the default fp16 build must stay within 2.5e-3
+    normalised rms of the fp32 reference (taps, UNet outputs, sampler trajectories; measured 1.2e-3 ... 2.0e-3), a
+    -DVIDSEG_ACT_BF16 build within 2.5e-2 (measured 1.2e-2 ... 1.6e-2)."""
     import torch
     from vidseg_diffusion_amd import ops
-    return ("f16", 4e-3) if ops.act_dtype() == torch.float16 else ("bf16", 4e-2)
+    return ("f16", 2.5e-3) if ops.act_dtype() == torch.float16 else ("bf16", 2.5e-2)

@@ -189,83 +189,122 @@ __global__ void __launch_bounds__(256) k_x_layernorm_split3(const float* __restr
     }
 }
 
-// fp32 attention, head dim 64: one thread per query, keys / values staged through LDS 64 at a time (every lane reads the same
-// key element: broadcast), the tile's 64 scores of a query parked in LDS (column t of `ss`), tile-wise online softmax (one rescale
-// per 64 keys).  q, k, v: fp32 with row strides ld* (column slices of wider buffers), head h at columns [64 h, 64 h + 64).
-// grid (ceil(Nq / 64), H, B), 64 threads, 48 KB of LDS.
-__global__ void __launch_bounds__(64) k_x_attention_f32(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
-                                                        const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo, int Nq, int Nk,
-                                                        float scale) {
-    __shared__ float ks[64][64];
-    __shared__ float vs[64][64];
-    __shared__ float ss[64][64];
-    const int t = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int qi = blockIdx.x * 64 + t;
-    const bool live = qi < Nq;
-    float qr[64], o[64];
-    {
-        const float* qp = q + ((long long)b * Nq + (live ? qi : 0)) * ldq + h * 64;
+// fp32 attention, head dim 64, on the vector FMA pipe (packed fp32): a 256-thread block owns 64 queries of one (sample, head) and
+// walks the keys 64 at a time.  Both contractions are register-blocked outer products -- thread (ty, tx) holds the 4 x 4 block
+// S[4ty.., 4tx..] of the scores and the 4 x 4 block O[4ty.., 4tx..] of the output -- so one pair of 16-byte LDS reads feeds 16
+// FMAs (Q and K are staged transposed, [d][token], P goes through LDS transposed, [key][query]).  Online softmax per tile: the 64
+// scores of a query live in the 16 lanes that share ty (consecutive lanes of one wave), row max / row sum by four xor-shuffles.
+// q, k, v: fp32, row strides ld* (column slices of wider buffers), head h at columns [64 h, 64 h + 64).  grid (ceil(Nq/64), H, B).
+typedef __attribute__((ext_vector_type(2))) float xf2;
+#define XA_LD 68                                               // row stride of the LDS tiles (floats): 16-byte aligned rows, 4-bank skew
+__global__ void __launch_bounds__(256) k_x_attention_f32(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                         const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo, int Nq, int Nk,
+                                                         float scale) {
+    __shared__ __attribute__((aligned(16))) float Qt[64 * XA_LD];      // [d][query]
+    __shared__ __attribute__((aligned(16))) float Kt[64 * XA_LD];      // [d][key]
+    __shared__ __attribute__((aligned(16))) float Vs[64 * XA_LD];      // [key][d]
+    __shared__ __attribute__((aligned(16))) float Pt[64 * XA_LD];      // [key][query]
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 64;
 #pragma unroll
-        for (int d = 0; d < 64; d += 4) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(qp + d);
-            qr[d] = a[0] * scale;
-            qr[d + 1] = a[1] * scale;
-            qr[d + 2] = a[2] * scale;
-            qr[d + 3] = a[3] * scale;
-        }
+    for (int i = 0; i < 4; ++i) {                              // Q tile, transposed and pre-scaled; rows beyond Nq are zeros
+        const int idx = tid + i * 256, r = idx >> 4, c4 = (idx & 15) * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (q0 + r < Nq) a = *reinterpret_cast<const f32x4*>(q + ((long long)b * Nq + q0 + r) * ldq + h * 64 + c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Qt[(c4 + j) * XA_LD + r] = a[j] * scale;
     }
+    xf2 o[4][2];
+    float mrun[4], lrun[4];
 #pragma unroll
-    for (int d = 0; d < 64; ++d) o[d] = 0.f;
-    float mrun = -INFINITY, lrun = 0.f;
+    for (int i = 0; i < 4; ++i) {
+        o[i][0] = o[i][1] = xf2{0.f, 0.f};
+        mrun[i] = -INFINITY;
+        lrun[i] = 0.f;
+    }
     for (int k0 = 0; k0 < Nk; k0 += 64) {
-        const int nk = min(64, Nk - k0);
-        __syncthreads();
-        for (int r = 0; r < nk; ++r) {                         // thread t stages column t of every key / value row of the tile
-            ks[r][t] = k[((long long)b * Nk + k0 + r) * ldk + h * 64 + t];
-            vs[r][t] = v[((long long)b * Nk + k0 + r) * ldv + h * 64 + t];
-        }
-        __syncthreads();
-        float mt = -INFINITY;
-#pragma nounroll
-        for (int j = 0; j < nk; ++j) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        __syncthreads();                                       // the previous tile's readers of Kt / Vs / Pt are done (and Qt is written)
 #pragma unroll
-            for (int d = 0; d < 64; d += 4) {
-                const f32x4 kk = *reinterpret_cast<const f32x4*>(&ks[j][d]);
-                a0 = fmaf(qr[d], kk[0], a0);
-                a1 = fmaf(qr[d + 1], kk[1], a1);
-                a2 = fmaf(qr[d + 2], kk[2], a2);
-                a3 = fmaf(qr[d + 3], kk[3], a3);
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256, r = idx >> 4, c4 = (idx & 15) * 4;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + r < Nk) {
+                a = *reinterpret_cast<const f32x4*>(k + ((long long)b * Nk + k0 + r) * ldk + h * 64 + c4);
+                w = *reinterpret_cast<const f32x4*>(v + ((long long)b * Nk + k0 + r) * ldv + h * 64 + c4);
             }
-            const float acc = (a0 + a1) + (a2 + a3);
-            ss[j][t] = acc;
-            mt = fmaxf(mt, acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Kt[(c4 + j) * XA_LD + r] = a[j];
+            *reinterpret_cast<f32x4*>(&Vs[r * XA_LD + c4]) = w;
         }
-        const float mnew = fmaxf(mrun, mt);
-        const float corr = expf(mrun - mnew);                  // exp(-inf) = 0 on the first tile
-        lrun *= corr;
+        __syncthreads();
+        xf2 s[4][2];
 #pragma unroll
-        for (int d = 0; d < 64; ++d) o[d] *= corr;
-#pragma nounroll
-        for (int j = 0; j < nk; ++j) {
-            const float p = expf(ss[j][t] - mnew);
-            lrun += p;
+        for (int i = 0; i < 4; ++i) s[i][0] = s[i][1] = xf2{0.f, 0.f};
+#pragma unroll 8
+        for (int d = 0; d < 64; ++d) {
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(&Qt[d * XA_LD + 4 * ty]);
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(&Kt[d * XA_LD + 4 * tx]);
+            const xf2 k01 = {kv[0], kv[1]}, k23 = {kv[2], kv[3]};
 #pragma unroll
-            for (int d = 0; d < 64; d += 4) {
-                const f32x4 vv = *reinterpret_cast<const f32x4*>(&vs[j][d]);
-                o[d] = fmaf(p, vv[0], o[d]);
-                o[d + 1] = fmaf(p, vv[1], o[d + 1]);
-                o[d + 2] = fmaf(p, vv[2], o[d + 2]);
-                o[d + 3] = fmaf(p, vv[3], o[d + 3]);
+            for (int i = 0; i < 4; ++i) {
+                const xf2 qq = {qv[i], qv[i]};
+                s[i][0] = qq * k01 + s[i][0];
+                s[i][1] = qq * k23 + s[i][1];
             }
         }
-        mrun = mnew;
+        float p[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            p[i][0] = s[i][0][0];
+            p[i][1] = s[i][0][1];
+            p[i][2] = s[i][1][0];
+            p[i][3] = s[i][1][1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + 4 * tx + j >= Nk) p[i][j] = -INFINITY;
+            float mt = fmaxf(fmaxf(p[i][0], p[i][1]), fmaxf(p[i][2], p[i][3]));
+#pragma unroll
+            for (int sh = 8; sh > 0; sh >>= 1) mt = fmaxf(mt, __shfl_xor(mt, sh, 64));
+            const float mnew = fmaxf(mrun[i], mt);
+            const float corr = expf(mrun[i] - mnew);           // exp(-inf) = 0 on the first tile
+            float ls = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p[i][j] = expf(p[i][j] - mnew);
+                ls += p[i][j];
+            }
+#pragma unroll
+            for (int sh = 8; sh > 0; sh >>= 1) ls += __shfl_xor(ls, sh, 64);
+            lrun[i] = lrun[i] * corr + ls;
+            mrun[i] = mnew;
+            o[i][0] *= corr;
+            o[i][1] *= corr;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(&Pt[(4 * tx + j) * XA_LD + 4 * ty]) = f32x4{p[0][j], p[1][j], p[2][j], p[3][j]};
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 64; ++kk) {
+            const f32x4 pq = *reinterpret_cast<const f32x4*>(&Pt[kk * XA_LD + 4 * ty]);
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(&Vs[kk * XA_LD + 4 * tx]);
+            const xf2 v01 = {vv[0], vv[1]}, v23 = {vv[2], vv[3]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const xf2 pp = {pq[i], pq[i]};
+                o[i][0] = pp * v01 + o[i][0];
+                o[i][1] = pp * v23 + o[i][1];
+            }
+        }
     }
-    if (live) {
-        const float inv = 1.0f / lrun;
-        float* op = out + ((long long)b * Nq + qi) * ldo + h * 64;
 #pragma unroll
-        for (int d = 0; d < 64; d += 4) *reinterpret_cast<f32x4*>(op + d) = f32x4{o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
+    for (int i = 0; i < 4; ++i) {
+        const int qi = q0 + 4 * ty + i;
+        if (qi < Nq) {
+            const float inv = 1.0f / lrun[i];
+            *reinterpret_cast<f32x4*>(out + ((long long)b * Nq + qi) * ldo + h * 64 + 4 * tx) =
+                f32x4{o[i][0][0] * inv, o[i][0][1] * inv, o[i][1][0] * inv, o[i][1][1] * inv};
+        }
     }
 }
 
@@ -318,7 +357,8 @@ int vidseg_x_attention_f32(const float* q, int ldq, const float* k, int ldk, con
                            int Nq, int Nk, float scale, hipStream_t st) {
     VS_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && Nk > 0, "x_attention: ldq=%d ldo=%d Nk=%d", ldq, ldo, Nk);
     if (B * H * Nq == 0) return VS_OK;
-    k_x_attention_f32<<<dim3((unsigned)((Nq + 63) / 64), H, B), 64, 0, st>>>(q, ldq, k, ldk, v, ldv, out, ldo, Nq, Nk, scale);
+    VS_REQUIRE(ldk % 4 == 0 && ldv % 4 == 0, "x_attention: ldk=%d ldv=%d", ldk, ldv);
+    k_x_attention_f32<<<dim3((unsigned)((Nq + 63) / 64), H, B), 256, 0, st>>>(q, ldq, k, ldk, v, ldv, out, ldo, Nq, Nk, scale);
     VS_CHECK_LAUNCH("x_attention_f32");
     return VS_OK;
 }
