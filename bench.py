@@ -440,6 +440,44 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False):
         out["dtype"] += " + e4m3 attention (q, k, v, P; >= 1024 keys)"
         out["config"]["workload"] += "; BASELINE configs[4] attention path: OCP e4m3 MFMA on the spatial self-attentions"
     out["config"]["windows_cycled"] = win_ids
+    if svd and world == 1 and not args.narrow and not args.masks_only:
+        # BASELINE configs[2] names "is_refine_mask + latent blending": the blending lives in Step 4's modulated sampler passes
+        # (sampling.py:229-250; svd_pipeline_vspw.py:396-487 -- 2*K of them per window).  One label's +lambda / -lambda pair is run and
+        # timed here with the SVD driver's defaults (block 8, spatial + temporal self-attention rows, modulate_timestep 17 = t_start,
+        # latent blending on, no feature injection), after an untimed window that keeps the x_t of every step in HBM for it.
+        try:
+            from vidseg_diffusion_amd.pipeline import modulation_sweep, segment_window
+            FE.FeatureStore.clear()
+            FE.MaskStore.clear()
+            lat, cw, ucw, noise = inputs[win_ids[0]]
+            base, exp = "/nonexistent/bench_step4", "w0"
+            lab, _ = segment_window(eng, lat, cw, ucw, num_masks=k_masks, num_steps=NUM_STEPS, t_start=t_start, seed=17, noise=noise,
+                                    is_refine_mask=refine, feature_folder=base, exp_name=exp, keep_all_steps=True)
+            folder = os.path.join(base, exp, "match_gt_mask", f"output_block_8_output_block_7_output_block_6_spatial_self_attn_q_masks_{k_masks}"
+                                  + ("_corrected" if refine else ""))
+            if FE.MaskStore.get(folder) is None:
+                folder = folder.replace("_corrected", "")
+            label = int(np.unique(lab)[0])
+            kw = dict(t_start=t_start, num_steps=NUM_STEPS, modulate_block_idx=(8,), modulate_layer_type=("spatial", "temporal"),
+                      modulate_attn_type=("self_attn",), is_injected_features=False, is_latent_blending=True, feature_folder=base, exp_name=exp,
+                      noise=noise, seed=17)
+            modulation_sweep(eng, lat, cw, ucw, [label], folder, **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = modulation_sweep(eng, lat, cw, ucw, [label], folder, **kw)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out["step4_latent_blending"] = {"ms_per_modulated_pass": round(1e3 * dt / 2, 2), "passes_per_window": 2 * k_masks,
+                                            "finite": bool(all(torch.isfinite(v).all().item() for v in res.values())),
+                                            "note": "one label's +lambda / -lambda modulated sampler passes (8 CFG evaluations each, lambda*mask added "
+                                                    "to the spatial and temporal self-attention rows of decoder block 8 at step 17, latents blended "
+                                                    "with the feature pass's x_t outside the mask at every step): the Step 4 unit of configs[2]; "
+                                                    "outside `value` (Steps 1-3b), which the metric is quoted on"}
+        except Exception as e:
+            out["step4_latent_blending"] = {"error": repr(e)[:300]}
+        finally:
+            FE.FeatureStore.clear()
+            FE.MaskStore.clear()
     if args.precision == "exact" and not svd:
         out["metric"] += " [precision=exact]"
         out["config"]["workload"] += ("; PRECISION MODE exact (exact.py): fp32 activations, conv / linear on the 16-bit MFMA kernels over split "
@@ -642,7 +680,8 @@ def main():
             try:
                 args.inversion = False
                 sec, *_ = run_config(args, True, rank, world, dev, steps=3, warmup=1, secondary=True)
-                out["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "unique_labels")}
+                out["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "unique_labels",
+                                                       "step4_latent_blending") if k in sec}
                 out["secondary"]["roofline"] = {k: sec["roofline"][k] for k in ("achieved", "frac", "kernel", "family")}
             except Exception as e:                                   # never lose the headline line to the secondary
                 out["secondary"] = {"error": repr(e)[:200]}

@@ -285,7 +285,7 @@ def test_inversion_vs_reference(env):
     fmt = nrms(xo.numpy(), g["inv_final"])
     err = nrms(x.cpu().numpy(), g["inv_final"])
     print("inversion nrms", err, "16-bit format", fmt)
-    assert err <= 1.5 * fmt + 1e-2
+    assert err <= 1.3 * fmt + 2e-3, (err, fmt)                       # measured (fp16 build): 2.33e-2 against 1.95e-2 for the format alone
 
 
 def test_inversion_window_vs_reference(env):
@@ -330,13 +330,13 @@ def test_inversion_window_vs_reference(env):
     for i in (0, 12, 24):
         err, fmt = nrms(store[f"xt_time_{i}"].cpu().numpy(), g[f"x_step{i}"]), nrms(fx[i], g[f"x_step{i}"])
         print(f"inversion window: x after step {i}: nrms {err:.3e} (16-bit format alone {fmt:.3e})")
-        assert err <= 1.5 * fmt + 1e-2, (i, err, fmt)
+        assert err <= 1.2 * fmt + 2e-3, (i, err, fmt)                 # measured: 0.95e-2 / 2.73e-2 / 2.85e-2, each just below the format's own
     taps = {}
     for b in (6, 7, 8):
         taps[b] = store[f"output_block_{b}_spatial_self_attn_q_time_24"].cpu().numpy()
         err, fmt = nrms(taps[b].astype(np.float32), g[f"q{b}"].astype(np.float32)), nrms(ft[b], g[f"q{b}"].astype(np.float32))
         print(f"inversion window: block {b} step-24 Q tap: nrms {err:.3e} (16-bit format alone {fmt:.3e})")
-        assert err <= 1.5 * fmt + 1e-2, (b, err, fmt)
+        assert err <= 1.2 * fmt + 2e-3, (b, err, fmt)                 # measured 3.0e-2 against 3.1e-2
     from tools_metrics import matched_iou
     iou = matched_iou(labels, g["corrected_labels"].astype(np.int64), K)
     print(f"inversion window: masks vs reference IoU {iou[0]:.4f} identical {iou[1]:.4f}")
