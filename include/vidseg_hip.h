@@ -267,6 +267,12 @@ int vidseg_x_layernorm_split3(const float* x, long long M, int C, const float* g
                               void* out_f16 /* [M][3C] */, vidseg_stream_t stream);
 int vidseg_x_attention_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int B, int H,
                            int Nq, int Nk, float scale, vidseg_stream_t stream);
+/* x + vec[sample % nvec] per row (the frame-index embedding add of SpatialVideoTransformer, VA:417-431), fp32 */
+int vidseg_x_add_rowvec_f32(const float* x, const float* vec, long long M, int C, int rows_per_sample, int nvec, float* out,
+                            vidseg_stream_t stream);
+/* vidseg_conv_temporal3_a16 with the fp32 accumulators (+ bias + per-(b t) vector) stored as they are */
+int vidseg_conv_temporal3_a16_f32(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
+                                   const float* rowvec, int rv_stride, float* out_f32, vidseg_stream_t stream);
 /* input conv (OAI:638-644) with the fp32 accumulators stored as they are: fp32 NHWC [B][H][W][Cin] -> fp32 NHWC [B][H][W][Cout] */
 int vidseg_conv_in_f32(const float* x, const float* w, const float* bias, int B, int H, int W, int Cin, int Cout, float* out_f32_nhwc,
                        vidseg_stream_t stream);

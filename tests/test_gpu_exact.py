@@ -154,3 +154,46 @@ def test_exact_unet_forward_vs_reference(X):
     assert worst <= 1e-4
     net.set_precision("fp16")
     assert np.array_equal(net(x, timesteps=t, context=ctx).cpu().numpy(), out16)
+
+
+def test_exact_video_unet_forward_vs_reference(X):
+    """The SVD VideoUNet (narrow, T = 3) in the exact mode against the REFERENCE's fp32 forward (tests/golden/unet_svd_narrow.npz):
+    output, spatial taps and the temporal taps in the reference's [(b s), t, c] layout -- the time stack (3-D ResBlock on the
+    [3,1,1] temporal conv, AlphaBlender, frame-index embedding, ff_in, temporal self-attention, cross-attention to the first frame's
+    context) on split operands too."""
+    from vidseg_diffusion_amd.video_unet import VideoUNet
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(os.path.dirname(G), "unet_svd_narrow.npz"))
+    g = {k: z[k] for k in z.files}
+    net = VideoUNet(**synthetic.SVD_NARROW)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=4321).items()})
+    T = int(g["T"])
+    x, t, ctx, y = (torch.from_numpy(g[k]).to(dev) for k in ("fw_x", "fw_t", "fw_ctx", "fw_y"))
+
+    def nrms(a, b):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+    kw = dict(timesteps=t, context=ctx, y=y, num_video_frames=T, image_only_indicator=torch.zeros(2, T))
+    out16 = net(x, **kw).cpu().numpy()
+    net.set_precision("exact")
+    out = net(x, **kw).cpu().numpy()
+    e, e16 = nrms(out, g["fw_out"]), nrms(out16, g["fw_out"])
+    print(f"narrow VideoUNet output vs reference: exact mode nrms {e:.2e}, 16-bit mode {e16:.2e}")
+    assert e <= 5e-5, e
+    worst = 0.0
+    for i in (3, 7, 8, 11):
+        blk = net.output_blocks[i]
+        pairs = [("spatial_self_attn_q", blk[1].transformer_blocks[0].attn1.q), ("temporal_self_attn_q", blk[1].time_stack[0].attn1.q),
+                 ("temporal_self_attn_k", blk[1].time_stack[0].attn1.k), ("temporal_cross_attn_k", blk[1].time_stack[0].attn2.k)]
+        for name, got in pairs:
+            ref = g[f"fw_output_block_{i}_{name}"]
+            got = got.cpu().numpy()
+            assert got.dtype == np.float16 and got.shape == ref.shape, (i, name, got.shape, ref.shape)
+            worst = max(worst, nrms(got.astype(np.float32), ref.astype(np.float32)))
+            assert np.mean(got != ref) <= 0.05, (i, name, float(np.mean(got != ref)))
+    print(f"exact VideoUNet: worst fp16 tap nrms vs reference {worst:.2e}")
+    assert worst <= 1e-4
+    net.set_precision("fp16")
+    assert np.array_equal(net(x, **kw).cpu().numpy(), out16)

@@ -71,6 +71,20 @@ __global__ void __launch_bounds__(256) k_x_geglu_split3(const float* __restrict_
     *reinterpret_cast<f16x4*>(o + 2 * I) = h;
 }
 
+// out[(sample, row)][c] = x[(sample, row)][c] + vec[sample % nvec][c]   (the frame-index embedding of SpatialVideoTransformer,
+// video_attention.py:417-431: x + time_pos_embed(timestep_embedding(arange(T)))[t]); fp32, C % 4 == 0
+__global__ void __launch_bounds__(256) k_x_add_rowvec(const float* __restrict__ x, const float* __restrict__ vec, long long M, int C,
+                                                      int rows_per_sample, int nvec, float* __restrict__ out) {
+    const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c4n = C / 4;
+    if (i4 >= M * c4n) return;
+    const long long m = i4 / c4n;
+    const int c = (int)(i4 - m * c4n) * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + m * C + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(vec + (long long)((m / rows_per_sample) % nvec) * C + c);
+    *reinterpret_cast<f32x4*>(out + m * C + c) = f32x4{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
+}
+
 // ---- GroupNorm over the channel concat of two fp32 NHWC sources: statistics in float64, one block per (group, sample) ----------
 __device__ __forceinline__ float ld_cat(const float* x0, const float* x1, int C0, int C1, long long row, int c) {
     return c < C0 ? x0[row * C0 + c] : x1[row * C1 + (c - C0)];
@@ -323,6 +337,14 @@ int vidseg_x_split3(const float* x, long long M, int C, int silu, void* out16, h
     return VS_OK;
 }
 
+int vidseg_x_add_rowvec_f32(const float* x, const float* vec, long long M, int C, int rows_per_sample, int nvec, float* out, hipStream_t st) {
+    VS_REQUIRE(C % 4 == 0 && rows_per_sample > 0 && nvec > 0, "x_add_rowvec: C=%d rows_per_sample=%d nvec=%d", C, rows_per_sample, nvec);
+    if (M * C == 0) return VS_OK;
+    k_x_add_rowvec<<<X_GRID(M * (C / 4)), 256, 0, st>>>(x, vec, M, C, rows_per_sample, nvec, out);
+    VS_CHECK_LAUNCH("x_add_rowvec_f32");
+    return VS_OK;
+}
+
 int vidseg_x_geglu_split3(const float* y, long long M, int inner, void* out16, hipStream_t st) {
     VS_REQUIRE(inner % 4 == 0, "x_geglu_split3: inner=%d must be a multiple of 4", inner);
     if (M * inner == 0) return VS_OK;
@@ -368,6 +390,7 @@ int vidseg_x_attention_f32(const float* q, int ldq, const float* k, int ldk, con
 #define X_UNSUPPORTED(name) VS_FAIL(VS_ERR_UNSUPPORTED, name ": the exact (split-fp16) mode needs the fp16 build of the library")
 int vidseg_x_split3(const float*, long long, int, int, void*, hipStream_t) { X_UNSUPPORTED("x_split3"); }
 int vidseg_x_geglu_split3(const float*, long long, int, void*, hipStream_t) { X_UNSUPPORTED("x_geglu_split3"); }
+int vidseg_x_add_rowvec_f32(const float*, const float*, long long, int, int, int, float*, hipStream_t) { X_UNSUPPORTED("x_add_rowvec_f32"); }
 int vidseg_x_groupnorm_split3(const float*, const float*, int, int, int, int, int, const float*, const float*, float, int, float*, int, void*,
                               hipStream_t) {
     X_UNSUPPORTED("x_groupnorm_split3");

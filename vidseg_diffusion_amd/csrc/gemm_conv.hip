@@ -2399,8 +2399,8 @@ int vidseg_linear_a16_ttap(const void* a0, long long M, int C0, const void* w, i
 
 // Conv3d with kernel [3,1,1], padding [1,0,0] over frames (video_model.py:45-58): x NHWC bf16 [(b t)][HW][C],
 // w packed [Cout][c/64][dt][c%64] (chunk-major K order, see GemmParams), + bias + per-sample emb vector + residual.
-int vidseg_conv_temporal3_a16(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
-                               const float* rowvec, int rv_stride, const void* residual, void* out, hipStream_t st) {
+static int conv_temporal3_impl(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
+                               const float* rowvec, int rv_stride, const void* residual, void* out, float* out_f32, hipStream_t st) {
     VS_REQUIRE(T >= 1 && BT % T == 0, "conv_temporal3: BT=%d T=%d", BT, T);
     GemmParams p{};
     p.x0 = (const bf16_t*)x;
@@ -2424,8 +2424,20 @@ int vidseg_conv_temporal3_a16(const void* x, int C, int BT, int HW, int T, const
     p.residual = (const bf16_t*)residual;
     p.ldr = Cout;
     p.out = (bf16_t*)out;
+    p.out_f32 = out_f32;
     p.ldo = Cout;
     return launch_gemm(p, st);
+}
+
+int vidseg_conv_temporal3_a16(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
+                               const float* rowvec, int rv_stride, const void* residual, void* out, hipStream_t st) {
+    return conv_temporal3_impl(x, C, BT, HW, T, w, Cout, bias, rowvec, rv_stride, residual, out, nullptr, st);
+}
+// the same temporal convolution with the fp32 accumulators (+ bias + per-(b t) vector) stored as they are (exact mode, exact_ops.hip)
+int vidseg_conv_temporal3_a16_f32(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
+                                   const float* rowvec, int rv_stride, float* out_f32, hipStream_t st) {
+    VS_REQUIRE(out_f32 != nullptr, "conv_temporal3_f32: output is null");
+    return conv_temporal3_impl(x, C, BT, HW, T, w, Cout, bias, rowvec, rv_stride, nullptr, nullptr, out_f32, st);
 }
 
 // 3x3 convolution, padding 1, NHWC bf16 activations, weight packed [Cout][c/64][kh*3+kw][c%64] (chunk-major K order).

@@ -1,4 +1,4 @@
-"""`UNetModel.set_precision("exact")`: the SD UNet forward at fp32 accuracy on the 16-bit MFMA kernels (fp16 build only).
+"""`UNetModel.set_precision("exact")`: the SD UNet / SVD VideoUNet forward at fp32 accuracy on the 16-bit MFMA kernels (fp16 build only).
 
 Why: Step 3 of the drivers is best-of-10 K-means++ on the dumped Q taps (scripts/sampling/feature_extraction.py:562-572), and
 K-means++ seeding is chaotic in its input: measured on the REFERENCE's own taps with the reference's own sklearn call
@@ -14,7 +14,9 @@ GroupNorm / LayerNorm / SiLU / GEGLU / softmax run in fp32 (csrc/exact_ops.hip) 
 3x the MFMA work + fp32 glue; taps land within ~1e-5 of the fp32 reference.  It mirrors the same reference operators as unet.py
 (openaimodel.py:341-369 ResBlock, :831-954 forward; attention.py:609-759 transformer block, :286-364 attention with the q/k
 capture at :330-331, :889-927 SpatialTransformer) and writes the same taps onto the same attention modules, so the drivers'
-dump protocol is unchanged.  Feature-dump path only: no modulation / injection, SD UNet only.
+dump protocol is unchanged.  The VideoUNet's time stack is covered the same way (video_model.py:15-89 VideoResBlock on the [3,1,1]
+temporal conv with split operands, video_attention.py:145-285 / :378-489 temporal transformer block, frame-index embedding and
+AlphaBlender in fp32; temporal taps in the reference's [(b s), t, c] layout).  Feature-dump path only: no modulation / injection.
 """
 from __future__ import annotations
 
@@ -35,6 +37,8 @@ _lib.register({
     "vidseg_x_layernorm_split3": [_P, _L, _I, _P, _P, _F, _P, _P],
     "vidseg_x_attention_f32": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     "vidseg_conv_in_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "vidseg_x_add_rowvec_f32": [_P, _P, _L, _I, _I, _I, _P, _P],
+    "vidseg_conv_temporal3_a16_f32": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P],
 })
 
 F32, F16 = torch.float32, torch.float16
@@ -56,6 +60,12 @@ def pack_conv3x3_x(weight, device):
     """[Cout, Cin, 3, 3] -> the chunk-major packing of ops.pack_conv3x3 over the 3*Cin input channels [hi | hi | lo]."""
     hi, lo = _hl(weight)
     return ops.pack_conv3x3(torch.cat([hi, hi, lo], dim=1), device)
+
+
+def pack_conv_temporal3_x(weight, device):
+    """Conv3d [Cout, Cin, 3, 1, 1] -> ops.pack_conv_temporal3 over the 3*Cin input channels [hi | hi | lo]."""
+    hi, lo = _hl(weight)
+    return ops.pack_conv_temporal3(torch.cat([hi, hi, lo], dim=1), device)
 
 
 def pack_conv_out_x(weight, device):
@@ -129,8 +139,32 @@ def conv3x3_x(x3, w3, bias, *, stride=1, up=1, rowvec=None):
     return out
 
 
+def conv_temporal3_x(x3, w3, bias, T, *, rowvec=None):
+    """fp32 NHWC out of the [3,1,1] temporal conv on the split image x3 [(b t), H, W, 3C]."""
+    ops.workspace(x3.device)
+    BT, H, W, C3 = x3.shape
+    Cout = w3.shape[0]
+    out = torch.empty((BT, H, W, Cout), dtype=F32, device=x3.device)
+    call("vidseg_conv_temporal3_a16_f32", ptr(x3), C3, BT, H * W, T, ptr(w3), Cout, ptr(bias), ptr(rowvec),
+         rowvec.stride(0) if rowvec is not None else 0, ptr(out), stream())
+    return out
+
+
+def add_rowvec(x, vec, rows_per_sample):
+    """x[(sample, row), :] + vec[sample % len(vec), :] in fp32."""
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    call("vidseg_x_add_rowvec_f32", ptr(x), ptr(vec), x.numel() // C, C, rows_per_sample, vec.shape[0], ptr(out), stream())
+    return out
+
+
 def add(a, b):
     return ops.axpy(a, b, 1.0)
+
+
+def blend(a, b, alpha):
+    """alpha * a + (1 - alpha) * b (AlphaBlender with image_only_indicator = 0, diffusionmodules/util.py:343-380), fp32."""
+    return ops.axpy(a, b, (1.0 - alpha) / alpha, alpha)
 
 
 # ----------------------------------------------------------------------------- the network
@@ -142,25 +176,29 @@ class ExactRunner:
             raise VidsegError("the exact mode needs the fp16 build of libvidseg_hip.so (VIDSEG_ACT=f16)")
         from . import unet as U
         self.U, self.net, self.dev = U, net, torch.device(device)
-        if net.num_classes is not None:
-            raise NotImplementedError("exact mode: SD UNet only (no label embedding / video layers)")
+        self.video = net.num_classes is not None
+        if self.video:
+            from . import video_unet as V
+            self.V = V
         d = self.dev
         f = lambda t: ops.f32(t, d)                                          # noqa: E731
         self.w = {}
         for name, m in net.named_modules():
             if isinstance(m, U.ResBlock):
-                if type(m) is not U.ResBlock:
-                    raise NotImplementedError("exact mode: VideoResBlock is not supported")
                 e = dict(g1=f(m.in_layers[0].weight), b1=f(m.in_layers[0].bias), w1=pack_conv3x3_x(m.in_layers[2].weight, d),
                          cb1=f(m.in_layers[2].bias), g2=f(m.out_layers[0].weight), b2=f(m.out_layers[0].bias),
                          w2=pack_conv3x3_x(m.out_layers[3].weight, d), cb2=f(m.out_layers[3].bias))
                 if not isinstance(m.skip_connection, nn.Identity):
                     e["ws"] = pack_linear_x(m.skip_connection.weight.reshape(m.out_channels, m.channels), d)
                     e["bs"] = f(m.skip_connection.bias)
+                if self.video and isinstance(m, self.V.VideoResBlock):                # video_model.py:15-89
+                    ts = m.time_stack
+                    e["ts"] = dict(g1=f(ts.in_layers[0].weight), b1=f(ts.in_layers[0].bias), w1=pack_conv_temporal3_x(ts.in_layers[2].weight, d),
+                                   cb1=f(ts.in_layers[2].bias), g2=f(ts.out_layers[0].weight), b2=f(ts.out_layers[0].bias),
+                                   w2=pack_conv_temporal3_x(ts.out_layers[3].weight, d), cb2=f(ts.out_layers[3].bias))
+                    e["alpha"] = float(torch.sigmoid(m.time_mixer.mix_factor.detach().float()).item())
                 self.w[name] = e
             elif isinstance(m, U.SpatialTransformer):
-                if type(m) is not U.SpatialTransformer:
-                    raise NotImplementedError("exact mode: SpatialVideoTransformer is not supported")
                 e = dict(g=f(m.norm.weight), b=f(m.norm.bias), w_in=pack_linear_x(m.proj_in.weight, d), b_in=f(m.proj_in.bias),
                          w_out=pack_linear_x(m.proj_out.weight, d), b_out=f(m.proj_out.bias), blocks=[])
                 for blk in m.transformer_blocks:
@@ -173,6 +211,24 @@ class ExactRunner:
                         w_o2=pack_linear_x(a2.to_out[0].weight, d), b_o2=f(a2.to_out[0].bias),
                         w_ff1=pack_linear_x(ff.net[0].proj.weight, d), b_ff1=f(ff.net[0].proj.bias),
                         w_ff2=pack_linear_x(ff.net[2].weight, d), b_ff2=f(ff.net[2].bias)))
+                if self.video and isinstance(m, self.V.SpatialVideoTransformer):     # video_attention.py:291-489
+                    e["time"] = []
+                    for tb in m.time_stack:
+                        a1, a2 = tb.attn1, tb.attn2
+                        e["time"].append(dict(
+                            ln={n: (f(getattr(tb, n).weight), f(getattr(tb, n).bias)) for n in ("norm_in", "norm1", "norm2", "norm3")},
+                            w_fi1=pack_linear_x(tb.ff_in.net[0].proj.weight, d), b_fi1=f(tb.ff_in.net[0].proj.bias),
+                            w_fi2=pack_linear_x(tb.ff_in.net[2].weight, d), b_fi2=f(tb.ff_in.net[2].bias),
+                            w_qkv=pack_linear_x(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0), d),
+                            w_o1=pack_linear_x(a1.to_out[0].weight, d), b_o1=f(a1.to_out[0].bias),
+                            w_q=pack_linear_x(a2.to_q.weight, d), w_kv=pack_linear_x(torch.cat([a2.to_k.weight, a2.to_v.weight], 0), d),
+                            w_o2=pack_linear_x(a2.to_out[0].weight, d), b_o2=f(a2.to_out[0].bias),
+                            w_ff1=pack_linear_x(tb.ff.net[0].proj.weight, d), b_ff1=f(tb.ff.net[0].proj.bias),
+                            w_ff2=pack_linear_x(tb.ff.net[2].weight, d), b_ff2=f(tb.ff.net[2].bias)))
+                    tp = m.time_pos_embed
+                    e["tp"] = (pack_linear_x(tp[0].weight, d), f(tp[0].bias), pack_linear_x(tp[2].weight, d), f(tp[2].bias))
+                    e["alpha"] = float(torch.sigmoid(m.time_mixer.mix_factor.detach().float()).item())
+                    e["period"] = float(m.max_time_embed_period)
                 self.w[name] = e
             elif isinstance(m, U.Upsample):
                 self.w[name] = dict(w=pack_conv3x3_x(m.conv.weight, d), b=f(m.conv.bias))
@@ -180,6 +236,10 @@ class ExactRunner:
                 self.w[name] = dict(w=pack_conv3x3_x(m.op.weight, d), b=f(m.op.bias))
         te = net.time_embed
         self.te = (pack_linear_x(te[0].weight, d), f(te[0].bias), pack_linear_x(te[2].weight, d), f(te[2].bias))
+        if self.video:
+            le = net.label_emb[0]
+            self.le = (pack_linear_x(le[0].weight, d), f(le[0].bias), pack_linear_x(le[2].weight, d), f(le[2].bias))
+        self._temb = {}
         rbs = net._resblocks()
         off = 0
         self.emb_off = {}
@@ -210,7 +270,62 @@ class ExactRunner:
             if x1 is not None:
                 raise VidsegError("ResBlock: identity skip with a concatenated input")
             res = x0
-        return add(h, res)
+        out = add(h, res)
+        if "ts" in e:                                                               # VideoResBlock.forward, video_model.py:66-89
+            out = self.video_resblock_tail(m, e, out, emb_all)
+        return out
+
+    def video_resblock_tail(self, m, e, x, emb_all):
+        """3-D ResBlock (kernel [3,1,1]) over the frames of each video with the per-(b t) emb vector, then AlphaBlender."""
+        T, ts = self.T, e["ts"]
+        BT, H, W, C = x.shape
+        off = self.emb_off[id(m.time_stack)]
+        rv = emb_all[:, off:off + C]
+        h = groupnorm_split3(x.view(BT // T, T * H, W, C), ts["g1"], ts["b1"], eps=1e-5, silu=True).view(BT, H, W, 3 * C)
+        h = conv_temporal3_x(h, ts["w1"], ts["cb1"], T, rowvec=rv)
+        h = groupnorm_split3(h.view(BT // T, T * H, W, C), ts["g2"], ts["b2"], eps=1e-5, silu=True).view(BT, H, W, 3 * C)
+        h = add(conv_temporal3_x(h, ts["w2"], ts["cb2"], T), x)
+        return blend(x, h, e["alpha"])
+
+    def frame_emb(self, m, e, T):
+        """time_pos_embed(timestep_embedding(arange(T))) (video_attention.py:417-427), fp32."""
+        key = (id(m), T)
+        if key not in self._temb:
+            C = m.in_channels
+            half = C // 2
+            freqs = torch.exp(-math.log(e["period"]) * torch.arange(half, dtype=F32) / half)
+            args = torch.arange(T, dtype=F32)[:, None] * freqs[None]
+            te = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(self.dev)
+            w1, b1, w2, b2 = e["tp"]
+            self._temb[key] = linear_x(split3(linear_x(split3(te), w1, b1, act=ops.ACT_SILU)), w2, b2)
+        return self._temb[key]
+
+    def time_block(self, tb, bw, x, tctx3, T, dump):
+        """VideoTransformerBlock._forward (video_attention.py:145-285) on rows kept in the spatial order (b t) s: ff_in, temporal
+        self-attention over the T frames of every (video, location), cross-attention to the first frame's context, ff."""
+        BT, S, C = x.shape
+        b = BT // T
+        heads = tb.attn1.heads
+        y = linear_x(layernorm_split3(x, *bw["ln"]["norm_in"]), bw["w_fi1"], bw["b_fi1"])            # VA:155-159
+        x = add(linear_x(geglu_split3(y), bw["w_fi2"], bw["b_fi2"]), x)
+        qkv = linear_x(layernorm_split3(x, *bw["ln"]["norm1"]), bw["w_qkv"])                          # [(b t), S, 3C]
+        tqkv = qkv.view(b, T, S, 3 * C).permute(0, 2, 1, 3).reshape(b * S, T, 3 * C)                 # (b t) s c -> (b s) t c (VA:171)
+        a = attention_f32(tqkv[..., :C], tqkv[..., C:2 * C], tqkv[..., 2 * C:], heads, b * S, T, T)
+        a = a.view(b, S, T, C).permute(0, 2, 1, 3).reshape(BT, S, C)
+        if dump:
+            tb.attn1.q, tb.attn1.k = tqkv[..., :C].half(), tqkv[..., C:2 * C].half()                  # the reference's [(b s), t, c] layout
+        x = add(linear_x(split3(a), bw["w_o1"], bw["b_o1"]), x)                                      # VA:197-218
+        L = tctx3.shape[1]
+        q2 = linear_x(layernorm_split3(x, *bw["ln"]["norm2"]), bw["w_q"])
+        tk = torch.empty((b, L, C), dtype=F16, device=x.device) if dump else None
+        kv = linear_x(tctx3, bw["w_kv"], tap=tk, tap_cols=C)
+        a2 = attention_f32(q2.view(b, T * S, C), kv[..., :C], kv[..., C:], heads, b, T * S, L)       # VA:224-250
+        x = add(linear_x(split3(a2.view(BT, S, C)), bw["w_o2"], bw["b_o2"]), x)
+        if dump:
+            tb.attn2.q = q2.view(b, T, S, C).permute(0, 2, 1, 3).reshape(b * S, T, C).half()
+            tb.attn2.k = tk[:, None].expand(b, S, L, C).reshape(b * S, L, C)
+        y = linear_x(layernorm_split3(x, *bw["ln"]["norm3"]), bw["w_ff1"], bw["b_ff1"])               # VA:252-281
+        return add(linear_x(geglu_split3(y), bw["w_ff2"], bw["b_ff2"]), x)
 
     def transformer(self, m, x, ctx3, tap):
         e = self.w[self.names[id(m)]]
@@ -242,6 +357,10 @@ class ExactRunner:
             # GEGLU feed-forward (ATT:728-757, :89-115)
             y = linear_x(layernorm_split3(t, *bw["ln"][2]), bw["w_ff1"], bw["b_ff1"])
             t = add(linear_x(geglu_split3(y), bw["w_ff2"], bw["b_ff2"]), t)
+            if "time" in e:                                                                            # VA:429-476
+                T = self.T
+                tm = self.time_block(m.time_stack[i], e["time"][i], add_rowvec(t, self.frame_emb(m, e, T), N), self.tctx3, T, dump)
+                t = blend(t, tm, e["alpha"])
         out = add(linear_x(split3(t), e["w_out"], e["b_out"]), x.view(B, N, C))                        # ATT:921-927
         return out.view(B, H, W, C)
 
@@ -263,8 +382,11 @@ class ExactRunner:
                 raise VidsegError(f"unexpected layer {type(layer)}")
         return x
 
-    def forward(self, x_nchw, timesteps, context):
+    def forward(self, x_nchw, timesteps, context, y=None, num_video_frames=None):
         net, dev = self.net, self.dev
+        self.T = int(num_video_frames) if num_video_frames is not None else None
+        if self.video and (y is None or self.T is None):
+            raise VidsegError("exact VideoUNet needs y and num_video_frames")
         mc = net.model_channels
         half = mc // 2                                                                                # timestep_embedding, DU:209-233 (host fp32)
         ts = timesteps.detach().float().cpu()
@@ -273,8 +395,13 @@ class ExactRunner:
         t_emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(dev)
         w1, b1, w2, b2 = self.te
         emb = linear_x(split3(linear_x(split3(t_emb), w1, b1, act=ops.ACT_SILU)), w2, b2)
+        if self.video:                                                                                # label_emb(y), OAI:851-853
+            l1, lb1, l2, lb2 = self.le
+            emb = add(emb, linear_x(split3(linear_x(split3(y.float().contiguous()), l1, lb1, act=ops.ACT_SILU)), l2, lb2))
         emb_all = linear_x(split3(emb, silu=True), self.emb_w, self.emb_b)                              # every ResBlock's emb_layers
         ctx3 = ops.window_cached(self, "_ctx3", (context,), lambda: split3(context.float().contiguous()))
+        if self.video:                                                                                # first frame's context per video, VA:400-404
+            self.tctx3 = ops.window_cached(self, "_tctx3", (context,), lambda: split3(context[::self.T].float().contiguous()))
         xn = x_nchw.float().permute(0, 2, 3, 1).contiguous()
         B, H, W, Cin = xn.shape
         h = torch.empty((B, H, W, mc), dtype=F32, device=dev)

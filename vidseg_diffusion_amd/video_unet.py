@@ -314,6 +314,8 @@ class VideoUNet(UNetModel):
         self.out = nn.Sequential(_meta(GroupNorm32, 32, ch), nn.SiLU(), _meta(nn.Conv2d, model_channels, out_channels, 3, padding=1))
         self._packed_on = None
         self.tap_mode = "output"
+        self.precision = "fp16"
+        self._exact = None
 
     def _resblocks(self):
         # every emb_layers user, spatial and temporal, shares one batched GEMM
@@ -374,6 +376,14 @@ class VideoUNet(UNetModel):
             raise NotImplementedError("image_only_indicator != 0 (image batches) is not on the path")
         if not x.is_cuda:
             raise VidsegError("VideoUNet runs on a HIP device only (no CPU fallback)")
+        if self.precision == "exact":                                 # UNetModel.set_precision: exact.ExactRunner (fp32-accurate, 3x MFMA work)
+            if is_modulate_step or is_injected_step or stop_after_block is not None:
+                raise NotImplementedError("exact precision covers the feature-dump pass (no modulation / injection / early stop)")
+            if self._exact is None:
+                from .exact import ExactRunner
+                self._set_taps()
+                self._exact = ExactRunner(self, x.device)
+            return self._exact.forward(x, timesteps, context, y=y, num_video_frames=num_video_frames)
         xn = x.float().permute(0, 2, 3, 1).contiguous()
         ctx = context if context.dtype == ops.act_dtype() else ops.to_bf16(context.float().contiguous())
         return self.forward_nhwc(xn, timesteps, ctx, y, num_video_frames, is_modulate_step, is_injected_step, modulate_params,
