@@ -223,6 +223,18 @@ def workspace(device) -> Workspace:
     return _ws[key]
 
 
+_side = {}
+
+
+def side_stream(device):
+    """One helper HIP stream per (device, caller stream): independent branches of the network (the ResBlock's 1x1 skip conv) are
+    queued there and joined with wait_stream; keyed on the caller's stream so that two window lanes never share one."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=device)
+    return _side[key]
+
+
 # ----------------------------------------------------------------------------- per-window caches
 # Values that are constant over the sampler steps of ONE window (the CFG-stacked conditioning, its 16-bit copy, the cross-attention
 # K/V projections of that context: attention.py:317-322 recomputes to_k(context) / to_v(context) in every block of every step) are

@@ -22,6 +22,9 @@ from . import ops
 from ._lib import VidsegError
 
 F16 = torch.float16
+# VIDSEG_SIDE_SKIP=1: queue the ResBlock's 1x1 skip conv on a second HIP stream beside the in_layers chain.  Measured (round 3, same-box
+# A/B, two repeats): 147.0 vs 148.6 frames/s WITHOUT it -- the two event hand-overs per block cost more than the idle CUs it fills; off.
+_SIDE_SKIP = __import__("os").environ.get("VIDSEG_SIDE_SKIP", "0") == "1"
 
 
 def _meta(factory, *a, **k):
@@ -103,6 +106,20 @@ class ResBlock(nn.Module):
     def run(self, x0, x1, emb_all):
         """x0 (+ x1: skip tensor to concatenate on channels, openaimodel.py:912) NHWC bf16;
         emb_all: fp32 [B, sum(Cout)] = every block's emb_layers output from one batched GEMM."""
+        side = skip = None
+        if _SIDE_SKIP and not isinstance(self.skip_connection, nn.Identity):
+            # the 1x1 skip conv (OAI:369 `self.skip_connection(x)`) depends on the block's input only: it is queued on a second HIP
+            # stream and fills the CUs the GroupNorm passes and the conv tails of the main chain leave idle.  Same kernel, same split-K
+            # choice, same bits; its scratch is that stream's own (ops.workspace is per stream).
+            main = torch.cuda.current_stream()
+            side = ops.side_stream(x0.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                skip = ops.linear(x0, self.ws, self.bs, a1=x1)
+            skip.record_stream(main)
+            x0.record_stream(side)
+            if x1 is not None:
+                x1.record_stream(side)
         h = ops.groupnorm(x0, self.g1, self.b1, x1=x1, eps=1e-5, silu=True)
         rv = emb_all[:, self.emb_offset:self.emb_offset + self.out_channels]
         if self.stash_features:
@@ -115,6 +132,9 @@ class ResBlock(nn.Module):
             if x1 is not None:
                 raise VidsegError("ResBlock: identity skip with a concatenated input")
             res = x0
+        elif side is not None:
+            torch.cuda.current_stream().wait_stream(side)                              # the 1x1 skip conv ran beside in_layers / GroupNorm
+            res = skip
         else:
             res = ops.linear(x0, self.ws, self.bs, a1=x1)
         if self.stash_features:
