@@ -125,15 +125,6 @@ int vidseg_linear_a16(const void* a0, const void* a1, int C0, int C1, long long 
                        float* out_f32, int ldo, void* tap, void* tap2, int tap_cols, int tap_ld,
                        const float* rowadd /* per-row scalar: modulation lambda*mask[:,None], ATT:646-663, 697-719 */, int act,
                        vidseg_stream_t stream);
-/* LayerNorm folded into the projection that consumes it (ATT:609-759: norm1 -> to_q/to_k/to_v, norm2 -> to_q, norm3 -> GEGLU proj):
- * vidseg_layernorm_stats writes (mean, rstd) per row of x (same two-pass fp32 arithmetic as vidseg_layernorm_a16, eps inside rstd);
- * vidseg_linear_ln_a16 multiplies the RAW rows by w = gamma o W and forms rstd * (acc - mean * lns[n]) + bias[n] in its epilogue, with
- * lns[n] = sum_k w[n][k] and bias = W beta (+ the layer's bias): LN(x) W^T + b without the normalised copy being written or rounded.
- * act / taps / residual / rowadd as vidseg_linear_a16. */
-int vidseg_layernorm_stats(const void* x, long long M, int C, float eps, float* stat /* [M][2] */, vidseg_stream_t stream);
-int vidseg_linear_ln_a16(const void* a0, int C0, long long M, const void* w, int N, const float* bias, const float* lnstat, const float* lns,
-                          const void* residual, int ldr, void* out, int ldo, void* tap, void* tap2, int tap_cols, int tap_ld,
-                          const float* rowadd, int act, vidseg_stream_t stream);
 /* 3x3 conv, padding 1 (OAI:267-271, 302-315 ResBlock convs; OAI:202-217 Downsample stride 2; OAI:149-167
  * Upsample = nearest x2 folded into the addressing) over the channel concat of x0 and x1 (skip connection,
  * OAI:912), + bias + per-sample emb vector (OAI:353-365) + residual (OAI:369).  pad = 1, or 0 for the first stage's

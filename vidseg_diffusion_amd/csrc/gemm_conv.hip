@@ -52,10 +52,6 @@ struct GemmParams {
     int tap_T, tap_S;        // >0: taps are written in the reference's temporal layout [(b s), t, c] (row permutation)
     const float* rowadd;     // per-row scalar added to every column before the residual (attention-output modulation
                              // lambda*mask[:,None], attention.py:646-663, 697-719) or nullptr
-    const float* lnstat;     // LayerNorm folded into this GEMM (ATT:609-759 norm1/2/3 -> the projection that consumes it): per-row
-    const float* lns;        // (mean, rstd) pairs [M][2] and per-column s_n = sum_k W'[n][k]; the A operand is the RAW row x, the weight
-                             // is W' = gamma o W, and the epilogue forms rstd * (acc - mean * s_n) + c_n (c_n = W beta + bias in `bias`):
-                             // = LN(x) W^T + bias without the normalised copy ever being written or rounded
     int gn;                  // tile columns per panel of the launch order (map_tile)
     int taps, kchunk;        // K order of a conv weight row: k = (c / kchunk) * taps * kchunk + tap * kchunk + c % kchunk.
                              // kchunk = 64 (channel-chunk major: the taps of one 64-channel chunk are consecutive K-tiles, so the
@@ -175,15 +171,6 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
             continue;
         }
         if (pre) {
-            if (p.lnstat) {                                     // folded LayerNorm: rstd * (acc - mean * s_n)
-                const float mu = p.lnstat[2 * m], rs = p.lnstat[2 * m + 1];
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.lns + n), s1 = *reinterpret_cast<const f32x4*>(p.lns + n + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = rs * fmaf(-mu, s0[e], v[e]);
-                    v[4 + e] = rs * fmaf(-mu, s1[e], v[4 + e]);
-                }
-            }
             if (p.bias) {                                       // 32 bytes per lane, L1-resident after the first pass
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
@@ -272,14 +259,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         const int wcol0 = wcol_base + g * 64;                  // first GEMM column of this 64-column group
         const int mrow0 = (int)mrow_base + i * 32;
         // ---- phase 1: accumulators -> LDS fp32 [32][ncols]
-        float bx = 0.f, bg = 0.f, sx = 0.f, sg = 0.f;
+        float bx = 0.f, bg = 0.f;
         if (geglu && p.bias && (wcol0 + 32 + l31) < p.N) {
             bx = p.bias[wcol0 + l31];
             bg = p.bias[wcol0 + 32 + l31];
-        }
-        if (geglu && p.lnstat && (wcol0 + 32 + l31) < p.N) {
-            sx = p.lns[wcol0 + l31];
-            sg = p.lns[wcol0 + 32 + l31];
         }
 #pragma unroll
         for (int k = 0; k < MI * NG; ++k) {
@@ -292,14 +275,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        float ax = acc[ki][2 * kg][r], ag = acc[ki][2 * kg + 1][r];
-                        if (p.lnstat) {                         // folded LayerNorm (rows beyond M are never stored: clamp the address)
-                            const long long mm = min((long long)mrow0 + row, p.M - 1);
-                            const float mu = p.lnstat[2 * mm], rs = p.lnstat[2 * mm + 1];
-                            ax = rs * fmaf(-mu, sx, ax);
-                            ag = rs * fmaf(-mu, sg, ag);
-                        }
-                        stage[row * EP_LD + l31] = (ax + bx) * gelu_erf(ag + bg);
+                        stage[row * EP_LD + l31] = (acc[ki][2 * kg][r] + bx) * gelu_erf(acc[ki][2 * kg + 1][r] + bg);
                     }
                 }
             } else {
@@ -1445,15 +1421,6 @@ __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
             v[4 + e] += b[e];
         }
     }
-    if (p.lnstat) {
-        const float mu = p.lnstat[2 * m], rs = p.lnstat[2 * m + 1];
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.lns + n), s1 = *reinterpret_cast<const f32x4*>(p.lns + n + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] = rs * fmaf(-mu, s0[e], v[e]);
-            v[4 + e] = rs * fmaf(-mu, s1[e], v[4 + e]);
-        }
-    }
     if (p.bias) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
@@ -2176,7 +2143,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     if (ws_ok) {
         kind = 5;
         const int cpx = 32 / ws_np;
-        const bool plain = p.out && !p.out_f32 && !p.rowvec && !p.rowadd && !p.tap && p.act == 0 && !p.lnstat;
+        const bool plain = p.out && !p.out_f32 && !p.rowvec && !p.rowadd && !p.tap && p.act == 0;
         const int epi = !plain ? 0 : (p.residual ? 2 : 1);
         const size_t l320 = 10 * 10 * 1024 + 8 * 8 * 164 * 4 + 640, l640 = 5 * 20 * 1024 + 8 * 8 * 84 * 4 + 320;
         if (p.K == 320) {
@@ -2400,42 +2367,6 @@ int vidseg_linear_a16(const void* a0, const void* a1, int C0, int C1, long long 
     p.rowadd = rowadd;
     p.act = act;
     if (act == 2) VS_REQUIRE(N % 64 == 0 && out, "linear: GEGLU needs N %% 64 == 0 and a bf16 output");
-    return launch_gemm(p, st);
-}
-
-// vidseg_linear_a16 with a LayerNorm folded in (see GemmParams::lnstat): a0 = the RAW rows, w = gamma o W, bias = W beta (+ bias),
-// lnstat = per-row (mean, rstd) from vidseg_layernorm_stats, lns = per-column sums of the packed weight.
-int vidseg_linear_ln_a16(const void* a0, int C0, long long M, const void* w, int N, const float* bias, const float* lnstat, const float* lns,
-                          const void* residual, int ldr, void* out, int ldo, void* tap, void* tap2, int tap_cols, int tap_ld,
-                          const float* rowadd, int act, hipStream_t st) {
-    VS_REQUIRE(lnstat && lns, "linear_ln: row statistics / column sums are null");
-    GemmParams p{};
-    p.x0 = (const bf16_t*)a0;
-    p.C0 = C0;
-    p.ksize = 1;
-    p.stride = 1;
-    p.up = 1;
-    p.Hin = p.Win = p.Hout = p.Wout = 1;
-    p.w = (const bf16_t*)w;
-    p.N = N;
-    p.K = C0;
-    p.M = M;
-    p.x0_bytes = M * p.C0 * 2;
-    p.bias = bias;
-    p.rows_per_sample = 1;
-    p.lnstat = lnstat;
-    p.lns = lns;
-    p.residual = (const bf16_t*)residual;
-    p.ldr = ldr;
-    p.out = (bf16_t*)out;
-    p.ldo = ldo;
-    p.tap = (f16*)tap;
-    p.tap2 = (f16*)tap2;
-    p.tap_cols = tap_cols;
-    p.tap_ld = tap_ld;
-    p.rowadd = rowadd;
-    p.act = act;
-    if (act == 2) VS_REQUIRE(N % 64 == 0 && out, "linear_ln: GEGLU needs N %% 64 == 0 and a 16-bit output");
     return launch_gemm(p, st);
 }
 

@@ -143,49 +143,6 @@ __global__ void __launch_bounds__(1024) k_gn_apply(const bf16_t* __restrict__ x0
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row statistics of a LayerNorm that is folded into the GEMM consuming it (gemm_conv.hip, GemmParams::lnstat): (mean, rstd) per
-// row, the same two-pass fp32 arithmetic as k_layernorm; reads the row once, writes 8 bytes.  C <= 2048.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_layernorm_stats(const bf16_t* __restrict__ x, long long M, int C, float eps, float* __restrict__ stat) {
-    const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    constexpr int MAXCH = 4;
-    float v[MAXCH][8];
-    float s = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch) {
-        const int c = lane * 8 + ch * 512;
-        if (c < C) {
-            const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(x + row * C + c);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                v[ch][j] = bf16_to_f32((bf16_t)t[j]);
-                s += v[ch][j];
-            }
-        }
-    }
-    const float mean = wave_sum_f32(s) / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch) {
-        const int c = lane * 8 + ch * 512;
-        if (c < C) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float d = v[ch][j] - mean;
-                q = fmaf(d, d, q);
-            }
-        }
-    }
-    const float var = wave_sum_f32(q) / (float)C;
-    if (lane == 0) {
-        stat[2 * row] = mean;
-        stat[2 * row + 1] = rsqrtf(var + eps);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // LayerNorm over the last dim (eps 1e-5), one wave per row, fp32 two-pass in registers.  C <= 2048.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_layernorm(const bf16_t* __restrict__ x, long long M, int C, const float* __restrict__ gamma,
@@ -1723,14 +1680,6 @@ int vidseg_groupnorm_nhwc_a16(const void* x0, const void* x1, int C0, int C1, in
     k_gn_apply<<<dim3(nchunk, B), nthr, 0, st>>>((const bf16_t*)x0, (const bf16_t*)x1, C0, x1 ? C1 : 0, HW, rpb, rows_per_chunk, stats, silu,
                                                  (bf16_t*)out);
     VS_CHECK_LAUNCH("groupnorm");
-    return VS_OK;
-}
-
-int vidseg_layernorm_stats(const void* x, long long M, int C, float eps, float* stat, hipStream_t st) {
-    VS_REQUIRE(C % 8 == 0 && C <= 2048, "layernorm_stats: C=%d", C);
-    if (M == 0) return VS_OK;
-    k_layernorm_stats<<<dim3((unsigned)((M + 3) / 4)), 256, 0, st>>>((const bf16_t*)x, M, C, eps, stat);
-    VS_CHECK_LAUNCH("layernorm_stats");
     return VS_OK;
 }
 

@@ -20,8 +20,6 @@ _lib.register({
     "vidseg_linear_a16": [_P, _P, _I, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P],
     "vidseg_conv3x3_a16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P],
     "vidseg_conv3x3_a16_tap": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P],
-    "vidseg_layernorm_stats": [_P, _L, _I, _F, _P, _P],
-    "vidseg_linear_ln_a16": [_P, _I, _L, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P],
     "vidseg_softmax_rows_a16": [_P, _L, _I, _F, _P, _P],
     "vidseg_gaussian_sample": [_P, _P, _I, _I, _I, _F, _P, _P],
     "vidseg_conv_in": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
@@ -111,47 +109,6 @@ def pack_geglu(weight: torch.Tensor, bias: torch.Tensor, device):
     w = weight.detach().view(2, inner // 32, 32, K).permute(1, 0, 2, 3).reshape(two_inner, K)
     b = bias.detach().view(2, inner // 32, 32).permute(1, 0, 2).reshape(two_inner)
     return w.to(device=device, dtype=act_dtype()).contiguous(), b.to(device=device, dtype=F32).contiguous()
-
-
-def pack_linear_ln(weight, gamma, beta, bias, device, geglu=False):
-    """A LayerNorm (gamma, beta) folded into the linear that consumes it: returns (w' = gamma o W in the activation dtype, c = W beta +
-    bias in fp32, lns = row sums of the ROUNDED w' in fp32) for ops.linear_ln.  geglu: rows interleaved like pack_geglu."""
-    W = weight.detach().double()
-    Wg = (W * gamma.detach().double()[None, :]).float()
-    c = (W @ beta.detach().double())
-    if bias is not None:
-        c = c + bias.detach().double()
-    c = c.float()
-    if geglu:
-        w16, c = pack_geglu(Wg, c, device)
-    else:
-        w16, c = Wg.to(device=device, dtype=act_dtype()).contiguous(), c.to(device).contiguous()
-    lns = w16.double().sum(dim=1).float().contiguous()
-    return w16, c, lns
-
-
-def layernorm_stats(x, eps=1e-5):
-    """(mean, rstd) per row of x [.., C] -> fp32 [M, 2] for ops.linear_ln."""
-    C = x.shape[-1]
-    M = x.numel() // C
-    stat = torch.empty((M, 2), dtype=F32, device=x.device)
-    call("vidseg_layernorm_stats", ptr(x), M, C, eps, ptr(stat), stream())
-    return stat
-
-
-def linear_ln(a, w, c, lns, stat, *, residual=None, act=ACT_NONE, tap=None, tap2=None, tap_cols=0, rowadd=None):
-    """LayerNorm(a) @ W.T + bias with the LayerNorm folded into the GEMM: a = RAW rows, (w, c, lns) from pack_linear_ln, stat from
-    layernorm_stats(a)."""
-    workspace(a.device)
-    C0 = a.shape[-1]
-    M = a.numel() // C0
-    N = w.shape[0]
-    n_out = N // 2 if act == ACT_GEGLU else N
-    out = torch.empty(a.shape[:-1] + (n_out,), dtype=act_dtype(), device=a.device)
-    call("vidseg_linear_ln_a16", ptr(a), C0, M, ptr(w), N, ptr(c), ptr(stat), ptr(lns), ptr(residual),
-         residual.shape[-1] if residual is not None else 0, ptr(out), n_out, ptr(tap), ptr(tap2), tap_cols,
-         tap.shape[-1] if tap is not None else 0, ptr(rowadd), act, stream())
-    return out
 
 
 def f32(t: torch.Tensor, device) -> torch.Tensor:

@@ -25,9 +25,6 @@ F16 = torch.float16
 # VIDSEG_SIDE_SKIP=1: queue the ResBlock's 1x1 skip conv on a second HIP stream beside the in_layers chain.  Measured (round 3, same-box
 # A/B, two repeats): 147.0 vs 148.6 frames/s WITHOUT it -- the two event hand-overs per block cost more than the idle CUs it fills; off.
 _SIDE_SKIP = __import__("os").environ.get("VIDSEG_SIDE_SKIP", "0") == "1"
-# LayerNorm folded into the consuming projection (ops.linear_ln): norm1 -> fused q,k,v, norm2 -> to_q, norm3 -> GEGLU proj of every
-# BasicTransformerBlock; VIDSEG_LN_FOLD=0 restores the separate k_layernorm pass (A/B, tests)
-_LN_FOLD = __import__("os").environ.get("VIDSEG_LN_FOLD", "1") != "0"
 
 
 def _meta(factory, *a, **k):
@@ -175,32 +172,17 @@ class CrossAttention(nn.Module):
             self.w_kv = ops.pack_linear(torch.cat([self.to_k.weight, self.to_v.weight], 0), dev)
         self.w_o = ops.pack_linear(self.to_out[0].weight, dev)
         self.b_o = ops.f32(self.to_out[0].bias, dev)
-        self.ln_pack = None
 
-    def pack_ln(self, dev, gamma, beta):
-        """Fold the LayerNorm that feeds this attention's x-side projection(s) into them (ops.pack_linear_ln)."""
-        if self.is_self:
-            self.ln_pack = ops.pack_linear_ln(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0), gamma, beta, None, dev)
-        else:
-            self.ln_pack = ops.pack_linear_ln(self.to_q.weight, gamma, beta, None, dev)
-
-    def run(self, x, context, residual, tap, inj_q=None, inj_k=None, rowadd=None, ln_stat=None):
-        """x: normed tokens bf16 [B, N, C] -- or, with ln_stat (ops.layernorm_stats of x), the RAW tokens whose LayerNorm is folded
-        into the projection; returns to_out(attn) + rowadd[row] + residual.
+    def run(self, x, context, residual, tap, inj_q=None, inj_k=None, rowadd=None):
+        """x: normed tokens bf16 [B, N, C]; returns to_out(attn) + rowadd[row] + residual.
         inj_q / inj_k: fp16 dumps that replace the computed projections (attention.py:305-315)."""
         B, N, _ = x.shape
         C = self.inner
         dev = x.device
-
-        def proj(w_plain, **kw):
-            if ln_stat is not None:
-                return ops.linear_ln(x, *self.ln_pack, ln_stat, **kw)
-            return ops.linear(x, w_plain, **kw)
-
         if self.is_self:
             tq = torch.empty((B, N, C), dtype=F16, device=dev) if tap else None
             tk = torch.empty((B, N, C), dtype=F16, device=dev) if tap else None
-            qkv = proj(self.w_qkv, tap=tq, tap2=tk, tap_cols=C)
+            qkv = ops.linear(x, self.w_qkv, tap=tq, tap2=tk, tap_cols=C)
             q = ops.f16_to_bf16(inj_q) if inj_q is not None else qkv[..., :C]
             k = ops.f16_to_bf16(inj_k) if inj_k is not None else qkv[..., C:2 * C]
             a = ops.attention(q, k, qkv[..., 2 * C:], self.heads)
@@ -208,7 +190,7 @@ class CrossAttention(nn.Module):
             L = context.shape[1]
             tq = torch.empty((B, N, C), dtype=F16, device=dev) if tap else None
             tk = torch.empty((B, L, C), dtype=F16, device=dev) if tap else None
-            q = proj(self.w_q, tap=tq, tap_cols=C)
+            q = ops.linear(x, self.w_q, tap=tq, tap_cols=C)
             if tap:                                                              # the context is constant over a window's steps
 
                 def make_kv():
@@ -247,16 +229,9 @@ class FeedForward(nn.Module):
     def pack(self, dev):
         self.w1, self.b1 = ops.pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias, dev)
         self.w2, self.b2 = ops.pack_linear(self.net[2].weight, dev), ops.f32(self.net[2].bias, dev)
-        self.ln_pack = None
 
-    def pack_ln(self, dev, gamma, beta):
-        self.ln_pack = ops.pack_linear_ln(self.net[0].proj.weight, gamma, beta, self.net[0].proj.bias, dev, geglu=True)
-
-    def run(self, x, residual, rowadd=None, ln_stat=None):
-        if ln_stat is not None:                                   # x = RAW tokens, LayerNorm folded into the GEGLU projection
-            g = ops.linear_ln(x, *self.ln_pack, ln_stat, act=ops.ACT_GEGLU)
-        else:
-            g = ops.linear(x, self.w1, self.b1, act=ops.ACT_GEGLU)
+    def run(self, x, residual, rowadd=None):
+        g = ops.linear(x, self.w1, self.b1, act=ops.ACT_GEGLU)
         return ops.linear(g, self.w2, self.b2, residual=residual, rowadd=rowadd)
 
 
@@ -276,10 +251,6 @@ class BasicTransformerBlock(nn.Module):
         for m in (self.attn1, self.attn2, self.ff):
             m.pack(dev)
         self.ln = [(ops.f32(n.weight, dev), ops.f32(n.bias, dev)) for n in (self.norm1, self.norm2, self.norm3)]
-        self.fold = _LN_FOLD
-        if self.fold:
-            for m, n in ((self.attn1, self.norm1), (self.attn2, self.norm2), (self.ff, self.norm3)):
-                m.pack_ln(dev, n.weight, n.bias)
 
     def run(self, x, context, tap, mod=None):
         """mod: None, or (inject: dict|None, rowadd: dict attn_type -> fp32 [B*N]) for the modulated pass
@@ -293,12 +264,6 @@ class BasicTransformerBlock(nn.Module):
                     return v
             return None
 
-        if self.fold:                                                                   # LayerNorms folded into the projections
-            x = self.attn1.run(x, None, x, tap, pick("spatial_self_attn_q"), pick("spatial_self_attn_k"), ra.get("self_attn"),
-                               ln_stat=ops.layernorm_stats(x))                          # ATT:636-672
-            x = self.attn2.run(x, context, x, tap, pick("spatial_cross_attn_q"), pick("spatial_cross_attn_k"), ra.get("cross_attn"),
-                               ln_stat=ops.layernorm_stats(x))                          # ATT:689-726
-            return self.ff.run(x, x, ra.get("ff_out"), ln_stat=ops.layernorm_stats(x))  # ATT:728-757
         x = self.attn1.run(ops.layernorm(x, *self.ln[0]), None, x, tap, pick("spatial_self_attn_q"), pick("spatial_self_attn_k"),
                            ra.get("self_attn"))                                         # ATT:636-672
         x = self.attn2.run(ops.layernorm(x, *self.ln[1]), context, x, tap, pick("spatial_cross_attn_q"),
