@@ -136,3 +136,10 @@ def test_hand_counted_kernels_have_no_scratch(tmp_path):
             assert "scratch_" not in body, (name, defines)
         for name, size in re.findall(r"\.amdhsa_kernel (_Z9k_gemm_ws\S+).*?\.amdhsa_private_segment_fixed_size (\d+)", text, flags=re.S):
             assert int(size) == 0, (name, size, defines)
+        # and, as a performance invariant, no MFMA GEMM kernel of the family may spill at all: every one of them sits at 200-256 VGPRs,
+        # and an epilogue addition that tips one over costs every launch (round 3: a LayerNorm-folding epilogue put k_gemm_dma<2> /
+        # <3> and the 128x320 tiles 92-340 bytes into scratch -- 148 -> 133 frames/s, folded or not; reverted)
+        sizes = re.findall(r"\.amdhsa_kernel (_Z\d+k_gemm_\w+).*?\.amdhsa_private_segment_fixed_size (\d+)", text, flags=re.S)
+        assert len(sizes) >= 15, len(sizes)
+        for name, size in sizes:
+            assert int(size) == 0, (name, size, defines)
