@@ -267,6 +267,12 @@ int vidseg_x_layernorm_split3(const float* x, long long M, int C, const float* g
                               void* out_f16 /* [M][3C] */, vidseg_stream_t stream);
 int vidseg_x_attention_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int B, int H,
                            int Nq, int Nk, float scale, vidseg_stream_t stream);
+/* the same attention on the matrix pipe: three fp16 MFMA products of split operands per contraction (fp32 accuracy).  q fp32; k / v as
+ * fp16 hi / lo planes with one row stride (vidseg_x_split_planes makes them from fp32 column blocks) */
+int vidseg_x_split_planes(const float* x, int ld, long long rows, int cols, void* hi_f16 /* [rows][cols] */, void* lo_f16 /* [rows][cols] */,
+                          vidseg_stream_t stream);
+int vidseg_x_attention_mfma(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* v_hi, const void* v_lo, int ldkv,
+                            float* out, int ldo, int B, int H, int Nq, int Nk, float scale, vidseg_stream_t stream);
 /* x + vec[sample % nvec] per row (the frame-index embedding add of SpatialVideoTransformer, VA:417-431), fp32 */
 int vidseg_x_add_rowvec_f32(const float* x, const float* vec, long long M, int C, int rows_per_sample, int nvec, float* out,
                             vidseg_stream_t stream);

@@ -115,6 +115,58 @@ def test_fp32_glue_operators(X):
         assert e <= 2e-6, (B, H, Nq, Nk, e)
 
 
+def test_attention_mfma_split_operands(X):
+    """k_x_attention_mfma (both contractions as three fp16 MFMA products of hi / lo operands, P split in registers) against float64
+    attention of the same fp32 inputs: self-attention sizes, the ragged 77-key context, a query count that is no multiple of the
+    128-query block, large score ranges (the running maximum moves and the accumulators are rescaled) and inputs of small magnitude
+    (lo parts in the fp16 subnormal range)."""
+    dev = torch.device("cuda:0")
+    cases = ((2, 5, 256, 256, 1.0), (3, 2, 200, 77, 1.0), (1, 10, 1024, 1024, 1.0), (1, 5, 4096, 4096, 1.0), (2, 3, 384, 320, 4.0),
+             (2, 3, 128, 192, 0.02))
+    for (B, H, Nq, Nk, s) in cases:
+        C = H * 64
+        q, k, vv = rnd((B, Nq, C), 19, s), rnd((B, Nk, C), 20, s), rnd((B, Nk, C), 21, s)
+        qq = torch.cat([q, q], -1).to(dev)                                       # q as a column slice of a wider buffer
+        kv = torch.cat([torch.full((B, Nk, C), 7.0), k, vv], -1).to(dev)          # k | v as columns [C, 3C) of a [.., 3C] buffer
+        out = X.attention_mfma(qq[..., C:], kv[..., C:], H, B, Nq, Nk).cpu()
+        hd = lambda t, n: t.double().view(B, n, H, 64).transpose(1, 2)            # noqa: E731
+        ref = TF.scaled_dot_product_attention(hd(q, Nq), hd(k, Nk), hd(vv, Nk)).transpose(1, 2).reshape(B, Nq, C)
+        e = rel(out, ref)
+        f32 = X.attention_f32(qq[..., C:], kv[..., C:2 * C], kv[..., 2 * C:], H, B, Nq, Nk).cpu()
+        print(f"attention_mfma B={B} H={H} Nq={Nq} Nk={Nk} scale={s}: max err {e:.2e} (fp32 vector kernel {rel(f32, ref):.2e})")
+        # scores grow with s^2 and with them the fp32 spacing of the exponent's argument: the bar follows (the fp32 vector kernel
+        # reads 5.3e-6 at s = 4 where this one reads 2.8e-6)
+        assert e <= 2e-6 * max(1.0, s * s / 4), (B, H, Nq, Nk, s, e)
+
+
+def test_split_survives_rounding_ties(X):
+    """hi + lo must reconstruct x when x sits EXACTLY on an fp16 rounding tie and is the product of two fp32 values (the case in
+    which hipcc fused the conversion with the multiply differently per use: hi of the operand image from the rounded fp32 product,
+    lo against the singly-rounded exact product -- one fp16 ulp apart on ties, csrc/exact_ops.hip:split_hl).  The attention
+    prologue multiplies q by dim_head^-0.5 log2 e before the split: feed q values whose scaled fp32 product is a tie."""
+    dev = torch.device("cuda:0")
+    sc = np.float32(0.125 * 1.44269504088896340736)
+    rs = np.random.Generator(np.random.PCG64(5))
+    # candidates: fp32 q with fp32(q * sc) = (2 m + 1) 2^-13 for odd numerators in [0.25, 0.5), found by search around the quotient
+    ties = []
+    while len(ties) < 64 * 128:
+        m = int(rs.integers(1024, 2048))
+        target = np.float32((2 * m + 1) * 2.0 ** -13)                     # midpoint between two fp16 values in [0.25, 0.5)
+        q0 = np.float32(target / sc)
+        for cand in (q0, np.nextafter(q0, np.float32(1)), np.nextafter(q0, np.float32(-1))):
+            if np.float32(cand * sc) == target:
+                ties.append(float(cand) * (1 if rs.integers(2) else -1))
+                break
+    B, H, Nq, Nk = 1, 1, 128, 256
+    q = torch.tensor(ties[:Nq * 64], dtype=torch.float32).view(B, Nq, 64)
+    k, vv = rnd((B, Nk, 64), 31), rnd((B, Nk, 64), 32)
+    out = X.attention_mfma(q.to(dev), torch.cat([k, vv], -1).to(dev), H, B, Nq, Nk).cpu()
+    ref = TF.scaled_dot_product_attention(q.double()[:, None], k.double()[:, None], vv.double()[:, None])[:, 0]
+    e = rel(out, ref)
+    print(f"attention_mfma on {Nq * 64} tie-valued q entries: max err {e:.2e}")
+    assert e <= 2e-6, e
+
+
 def test_exact_unet_forward_vs_reference(X):
     """Narrow SD UNet in the exact mode against the REFERENCE's fp32 forward (tests/golden/unet_sd_narrow.npz): output and every
     dumped Q/K tap -- and the 16-bit mode of the same object on the same inputs, for the ratio."""

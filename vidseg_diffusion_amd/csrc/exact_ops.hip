@@ -19,7 +19,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned int xu32x4;
 
 #if VIDSEG_ACT_IS_F16
 
+// x must be ONE fp32 value for both lines.  Without the barrier hipcc (-ffp-contract=fast) fuses the conversion with x's producer
+// per use: for x = a * s it emitted hi = v_cvt_pk_f16_f32(v_mul_f32(a, s)) for the operand image (two roundings) but
+// v_fma_mixlo_f16(a, s, 0) (one rounding of the exact product) as the hi that lo is taken against -- the two differ when the fp32
+// product sits on an fp16 rounding tie, and hi + lo is then one fp16 ulp (2^-12 relative) off: 6 of 10240 query rows of a
+// 1024-token attention came out 5e-5 wrong (tools/x_attn_diag2.py), every one holding such a tie.
 __device__ __forceinline__ void split_hl(float x, f16& hi, f16& lo) {
+    asm volatile("" : "+v"(x));
     hi = (f16)x;
     lo = (f16)(x - (float)hi);
 }
@@ -322,6 +328,243 @@ __global__ void __launch_bounds__(256) k_x_attention_f32(const float* __restrict
     }
 }
 
+// fp32 columns [0, cols) of rows with stride ld  ->  fp16 planes hi = fp16(x), lo = fp16(x - hi), [rows][cols] each (cols % 4 == 0).
+// The K / V operands of k_x_attention_mfma: every key row is re-read by Nq / 128 query blocks, so it is split once here.
+__global__ void __launch_bounds__(256) k_x_split_planes(const float* __restrict__ x, int ld, long long rows, int cols, f16* __restrict__ hi,
+                                                        f16* __restrict__ lo) {
+    const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c4n = cols / 4;
+    if (i4 >= rows * c4n) return;
+    const long long m = i4 / c4n;
+    const int c = (int)(i4 - m * c4n) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + m * ld + c);
+    f16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f16 a, b;
+        split_hl(v[j], a, b);
+        h[j] = a;
+        l[j] = b;
+    }
+    *reinterpret_cast<f16x4*>(hi + m * cols + c) = h;
+    *reinterpret_cast<f16x4*>(lo + m * cols + c) = l;
+}
+
+// fp32-accurate attention on the matrix pipe, head dim 64: both contractions as three fp16 MFMA products of split operands,
+//     S^T = K_hi Q_hi^T + K_hi Q_lo^T + K_lo Q_hi^T,      O^T += V_hi^T P_hi^T + V_hi^T P_lo^T + V_lo^T P_hi^T      (fp32 accumulation)
+// with Q split in the prologue (pre-multiplied by dim_head^-0.5 log2 e in fp32), K / V split once per call by k_x_split_planes and P
+// split in registers (p' = exp2(s - m + 8) <= 2^8, so the lo part of small probabilities stays clear of the fp16 subnormal quantum:
+// 2^-24 against a row sum >= 2^8).  The tile schedule is k_attention's (unet_ops.hip): block = 4 waves x 32 queries, 64-key tiles,
+// S computed transposed so a lane owns one query column and the softmax statistics are lane-local plus one lane <-> lane + 32
+// exchange; K tiles [key][d] with the 16-byte-slot XOR swizzle; V tiles stay row-major [key][d] (16-byte stores) and the V^T
+// fragments come from ds_read_b64_tr_b16 (lane mapping as in k_attention3), rows 128 bytes with bit 6 of the byte column flipped on
+// rows 2, 3 (mod 4) so the 4 rows x 2 d-groups a 32-lane half reads cover all 64 banks once.  Double-buffered: 64 KB of LDS.
+// 48 MFMAs (32x32x16) per wave and tile against ~300 VALU instructions.  q: fp32 rows (stride ldq), head h at columns 64 h ..;
+// kh / kl / vh / vl: fp16 planes, row stride ldkv; out fp32.  grid (ceil(Nq / 128), B * H).
+typedef __attribute__((ext_vector_type(4))) short xs16x4;
+__device__ __forceinline__ f32x16 xmfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+template <bool RAGGED, bool FLUSH>
+__global__ void __launch_bounds__(256, 2) k_x_attention_mfma(const float* __restrict__ q, int ldq, const f16* __restrict__ kh,
+                                                             const f16* __restrict__ kl, const f16* __restrict__ vh,
+                                                             const f16* __restrict__ vl, int ldkv, float* __restrict__ out, int ldo, int Nq,
+                                                             int Nk, int H, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) char smem[2][4][64 * 128];      // [buffer][K hi, K lo, V hi, V lo][64 keys x 128 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int bh, qb;
+    attn_block(bh, qb);
+    const int b = bh / H, h = bh % H;
+    const int q0 = qb * 128 + wave * 32;
+    const float* qp = q + (long long)b * Nq * ldq + h * 64;
+    const long long kvoff = (long long)b * Nk * ldkv + h * 64;
+
+    // Q^T (scaled, split) as the MFMA B operand: lane holds query q0 + l31, d = s*16 + hi*8 .. +8
+    f16x8 fqh[4], fql[4];
+    {
+        const int qi = min(q0 + l31, Nq - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float* p = qp + (long long)qi * ldq + s * 16 + hi * 8;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p), c = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f16 x, y;
+                split_hl(a[e] * scale_log2e, x, y);
+                fqh[s][e] = x;
+                fql[s][e] = y;
+                split_hl(c[e] * scale_log2e, x, y);
+                fqh[s][4 + e] = x;
+                fql[s][4 + e] = y;
+            }
+        }
+    }
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (Nk + 63) / 64;
+    xu32x4 rg[2][4];                                            // next tile's 16-byte pieces: [row half][K hi, K lo, V hi, V lo]
+    const int st_ch = tid & 7, st_r = tid >> 3;
+    auto stage_load = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = min(t * 64 + st_r + 32 * i, Nk - 1);
+            const long long off = kvoff + (long long)key * ldkv + st_ch * 8;
+            rg[i][0] = *reinterpret_cast<const xu32x4*>(kh + off);
+            rg[i][1] = *reinterpret_cast<const xu32x4*>(kl + off);
+            rg[i][2] = *reinterpret_cast<const xu32x4*>(vh + off);
+            rg[i][3] = *reinterpret_cast<const xu32x4*>(vl + off);
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = st_r + 32 * i;
+            const int ko = r * 128 + ((st_ch ^ (r & 7)) << 4), vo = r * 128 + ((st_ch << 4) ^ (((r >> 1) & 1) << 6));
+            *reinterpret_cast<xu32x4*>(smem[buf][0] + ko) = rg[i][0];
+            *reinterpret_cast<xu32x4*>(smem[buf][1] + ko) = rg[i][1];
+            *reinterpret_cast<xu32x4*>(smem[buf][2] + vo) = rg[i][2];
+            *reinterpret_cast<xu32x4*>(smem[buf][3] + vo) = rg[i][3];
+        }
+    };
+    // transpose read of V: lane passes row 4 hi + ((lane & 15) >> 2) (+ 16-key slice, + 8), byte column ((lane >> 4) & 1) 32 + 8 (lane & 3) (+ 64 i)
+    const int vtr_base = (4 * hi + ((lane & 15) >> 2)) * 128 + ((lane >> 4) & 1) * 32 + 8 * (lane & 3);
+    const int vtr_swz = ((lane >> 3) & 1) << 6;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * 64;
+        const char* sKh = smem[t & 1][0];
+        const char* sKl = smem[t & 1][1];
+        const char* sVh = smem[t & 1][2];
+        const char* sVl = smem[t & 1][3];
+        stage_load(t + 1);                                      // unconditional (keys clamp to Nk - 1)
+        f32x16 sacc[2];                                         // S^T[j]: rows = keys j*32 + .., columns = queries; log2 units
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f16x8 fkh[2], fkl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = j * 32 + l31, off = r * 128 + (((s * 2 + hi) ^ (r & 7)) << 4);
+                fkh[j] = *reinterpret_cast<const f16x8*>(sKh + off);
+                fkl[j] = *reinterpret_cast<const f16x8*>(sKl + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                sacc[j] = xmfma(fkl[j], fqh[s], s == 0 ? f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f} : sacc[j]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) sacc[j] = xmfma(fkh[j], fql[s], sacc[j]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) sacc[j] = xmfma(fkh[j], fqh[s], sacc[j]);
+        }
+        // online softmax for this lane's query; key of sacc[j][r] = k0 + j*32 + (r&3) + 8*(r>>2) + 4*hi
+        if (RAGGED && k0 + 64 > Nk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= Nk) sacc[j][r] = -INFINITY;
+                }
+        }
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float mref = m_new - 8.0f;                        // p' = 2^8 p
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+        unsigned pkh[2][8], pkl[2][8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(sacc[j][r] - mref), p1 = __builtin_amdgcn_exp2f(sacc[j][r + 1] - mref);
+                ps4[(r >> 1) & 1] += p0;
+                ps4[2 + ((r >> 1) & 1)] += p1;
+                f16 h0, h1, l0, l1;
+                split_hl(p0, h0, l0);
+                split_hl(p1, h1, l1);
+                pkh[j][r >> 1] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                pkl[j][r >> 1] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+            }
+        float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+        psum += __shfl_xor(psum, 32, 64);
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // 0 on the first tile (m_run = -inf)
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            m_run = m_new;
+        }
+        l_run += psum;
+        // O^T[i] += V^T[d-block i] P^T: k-slices of 16 keys, the lane's 8 k-slots = keys base + {0..3, 8..11} + 4*hi
+        f32x16 otile[2];                                        // FLUSH: the tile's own product, added to oacc by the vector pipe
+        if (FLUSH) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) otile[i][r] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const xu32x4 ph = {pkh[j][s * 4 + 0], pkh[j][s * 4 + 1], pkh[j][s * 4 + 2], pkh[j][s * 4 + 3]};
+                const xu32x4 pl = {pkl[j][s * 4 + 0], pkl[j][s * 4 + 1], pkl[j][s * 4 + 2], pkl[j][s * 4 + 3]};
+                const f16x8 fph = __builtin_bit_cast(f16x8, ph), fpl = __builtin_bit_cast(f16x8, pl);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    typedef __attribute__((address_space(3))) xs16x4* lds4_t;
+                    const int a0 = vtr_base + (j * 32 + s * 16) * 128 + ((i * 64) ^ vtr_swz);
+                    struct { xs16x4 a, b; } th = {__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(sVh + a0)),
+                                                  __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(sVh + a0 + 8 * 128))};
+                    struct { xs16x4 a, b; } tl = {__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(sVl + a0)),
+                                                  __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(sVl + a0 + 8 * 128))};
+                    const f16x8 fvh = __builtin_bit_cast(f16x8, th), fvl = __builtin_bit_cast(f16x8, tl);
+                    if (FLUSH) {
+                        otile[i] = xmfma(fvl, fph, otile[i]);
+                        otile[i] = xmfma(fvh, fpl, otile[i]);
+                        otile[i] = xmfma(fvh, fph, otile[i]);
+                    } else {
+                        oacc[i] = xmfma(fvl, fph, oacc[i]);
+                        oacc[i] = xmfma(fvh, fpl, oacc[i]);
+                        oacc[i] = xmfma(fvh, fph, oacc[i]);
+                    }
+                }
+            }
+        if (FLUSH) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] += otile[i][r];
+        }
+        stage_store((t + 1) & 1);
+        __syncthreads();
+    }
+    // write O: lane owns query q0 + l31; oacc[i][r] is d = i*32 + (r&3) + 8*(r>>2) + 4*hi
+    const int qi = q0 + l31;
+    if (qi < Nq) {
+        const float inv = 1.0f / l_run;
+        float* op = out + ((long long)b * Nq + qi) * ldo + h * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(op + i * 32 + 8 * g + 4 * hi) =
+                    f32x4{oacc[i][g * 4 + 0] * inv, oacc[i][g * 4 + 1] * inv, oacc[i][g * 4 + 2] * inv, oacc[i][g * 4 + 3] * inv};
+    }
+}
+
 #endif  // VIDSEG_ACT_IS_F16
 
 extern "C" {
@@ -385,6 +628,31 @@ int vidseg_x_attention_f32(const float* q, int ldq, const float* k, int ldk, con
     return VS_OK;
 }
 
+int vidseg_x_split_planes(const float* x, int ld, long long rows, int cols, void* hi16, void* lo16, hipStream_t st) {
+    VS_REQUIRE(cols % 4 == 0 && ld % 4 == 0 && cols <= ld, "x_split_planes: cols=%d ld=%d", cols, ld);
+    if (rows * cols == 0) return VS_OK;
+    k_x_split_planes<<<X_GRID(rows * (cols / 4)), 256, 0, st>>>(x, ld, rows, cols, (f16*)hi16, (f16*)lo16);
+    VS_CHECK_LAUNCH("x_split_planes");
+    return VS_OK;
+}
+
+int vidseg_x_attention_mfma(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* v_hi, const void* v_lo, int ldkv,
+                            float* out, int ldo, int B, int H, int Nq, int Nk, float scale, hipStream_t st) {
+    VS_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ldkv % 8 == 0 && Nk > 0, "x_attention_mfma: ldq=%d ldo=%d ldkv=%d Nk=%d", ldq, ldo, ldkv, Nk);
+    if (B * H * Nq == 0) return VS_OK;
+    const float scale_log2e = scale * 1.44269504088896340736f;
+    const dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)(B * H));
+    static int flush = -1;                                   // VIDSEG_X_ATTN_FLUSH=0: the PV products accumulate across tiles inside the MFMA
+    if (flush < 0) { const char* e = getenv("VIDSEG_X_ATTN_FLUSH"); flush = e ? atoi(e) : 1; }
+#define XA_LAUNCH(R, F) k_x_attention_mfma<R, F><<<grid, 256, 0, st>>>(q, ldq, (const f16*)k_hi, (const f16*)k_lo, (const f16*)v_hi, \
+                                                                        (const f16*)v_lo, ldkv, out, ldo, Nq, Nk, H, scale_log2e)
+    if (Nk % 64 == 0) { if (flush) XA_LAUNCH(false, true); else XA_LAUNCH(false, false); }
+    else { if (flush) XA_LAUNCH(true, true); else XA_LAUNCH(true, false); }
+#undef XA_LAUNCH
+    VS_CHECK_LAUNCH("x_attention_mfma");
+    return VS_OK;
+}
+
 #else   // bf16 build: a two-term bf16 split carries 16 bits only; the exact mode exists in the fp16 build
 
 #define X_UNSUPPORTED(name) VS_FAIL(VS_ERR_UNSUPPORTED, name ": the exact (split-fp16) mode needs the fp16 build of the library")
@@ -400,6 +668,11 @@ int vidseg_x_layernorm_split3(const float*, long long, int, const float*, const 
 }
 int vidseg_x_attention_f32(const float*, int, const float*, int, const float*, int, float*, int, int, int, int, int, float, hipStream_t) {
     X_UNSUPPORTED("x_attention_f32");
+}
+int vidseg_x_split_planes(const float*, int, long long, int, void*, void*, hipStream_t) { X_UNSUPPORTED("x_split_planes"); }
+int vidseg_x_attention_mfma(const float*, int, const void*, const void*, const void*, const void*, int, float*, int, int, int, int, int, float,
+                            hipStream_t) {
+    X_UNSUPPORTED("x_attention_mfma");
 }
 #endif
 }

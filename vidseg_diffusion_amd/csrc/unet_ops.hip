@@ -191,17 +191,7 @@ __global__ void __launch_bounds__(256) k_layernorm(const bf16_t* __restrict__ x,
     }
 }
 
-// Blocks reach the 8 XCDs round-robin by linear block id; give every XCD one contiguous chunk of the (head, query block) space so
-// the query blocks of a (sample, head) share its K/V through one L2 instead of fetching it on all eight.
-__device__ __forceinline__ void attn_block(int& bh, int& qb) {
-    const int gx = gridDim.x;
-    const long long tot = (long long)gx * gridDim.y;
-    const long long lin = (long long)blockIdx.y * gx + blockIdx.x;
-    const long long q = tot / 8, r = tot % 8, xcd = lin % 8, idx = lin / 8;
-    const long long id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    bh = (int)(id / gx);
-    qb = (int)(id % gx);
-}
+// attn_block (XCD-aware (head, query block) order) lives in common.h: exact_ops.hip shares it.
 
 // ---------------------------------------------------------------------------------------------
 // Attention, head dim 64 (sgm/modules/attention.py:352-356: softmax(q k^T / sqrt(64)) v per head).

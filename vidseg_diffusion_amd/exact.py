@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -36,6 +37,8 @@ _lib.register({
     "vidseg_x_groupnorm_split3": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _P],
     "vidseg_x_layernorm_split3": [_P, _L, _I, _P, _P, _F, _P, _P],
     "vidseg_x_attention_f32": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
+    "vidseg_x_split_planes": [_P, _I, _L, _I, _P, _P, _P],
+    "vidseg_x_attention_mfma": [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     "vidseg_conv_in_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "vidseg_x_add_rowvec_f32": [_P, _P, _L, _I, _I, _I, _P, _P],
     "vidseg_conv_temporal3_a16_f32": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P],
@@ -112,6 +115,38 @@ def attention_f32(q, k, v, heads, B, Nq, Nk):
     call("vidseg_x_attention_f32", q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), v.data_ptr(), v.stride(1), ptr(out), heads * 64,
          B, heads, Nq, Nk, 0.125, stream())
     return out
+
+
+def split_planes(x):
+    """fp32 [.., cols] (a column slice of a row-major buffer) -> fp16 planes hi = fp16(x), lo = fp16(x - hi), contiguous [.., cols]."""
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    hi = torch.empty(x.shape, dtype=F16, device=x.device)
+    lo = torch.empty(x.shape, dtype=F16, device=x.device)
+    call("vidseg_x_split_planes", x.data_ptr(), x.stride(-2), rows, cols, ptr(hi), ptr(lo), stream())
+    return hi, lo
+
+
+def attention_mfma(q, kv, heads, B, Nq, Nk):
+    """softmax(q k^T / 8) v per 64-wide head at fp32 accuracy on the matrix pipe (three fp16 MFMA products of split operands per
+    contraction).  q: fp32 column slice [B, Nq, heads*64]; kv: fp32 [B, Nk, 2*heads*64] column slice holding k | v side by side."""
+    C = heads * 64
+    hi, lo = split_planes(kv)
+    out = torch.empty((B, Nq, C), dtype=F32, device=q.device)
+    call("vidseg_x_attention_mfma", q.data_ptr(), q.stride(1), hi.data_ptr(), lo.data_ptr(), hi.data_ptr() + 2 * C, lo.data_ptr() + 2 * C, 2 * C,
+         ptr(out), C, B, heads, Nq, Nk, 0.125, stream())
+    return out
+
+
+_MFMA_MIN_Q = int(os.environ.get("VIDSEG_X_ATTN_MFMA_MINQ", "128"))   # below: k_x_attention_f32 (the 14-frame temporal attention); 0 disables
+
+
+def attention_x(q, kv, heads, B, Nq, Nk):
+    """The exact mode's attention: the MFMA kernel from 128 queries up (a block owns 128), the fp32 vector kernel below that."""
+    C = heads * 64
+    if _MFMA_MIN_Q and Nq >= _MFMA_MIN_Q:
+        return attention_mfma(q, kv, heads, B, Nq, Nk)
+    return attention_f32(q, kv[..., :C], kv[..., C:], heads, B, Nq, Nk)
 
 
 def linear_x(a3, w3, bias=None, *, rowvec=None, rows_per_sample=0, act=ops.ACT_NONE, tap=None, tap2=None, tap_cols=0):
@@ -310,7 +345,7 @@ class ExactRunner:
         x = add(linear_x(geglu_split3(y), bw["w_fi2"], bw["b_fi2"]), x)
         qkv = linear_x(layernorm_split3(x, *bw["ln"]["norm1"]), bw["w_qkv"])                          # [(b t), S, 3C]
         tqkv = qkv.view(b, T, S, 3 * C).permute(0, 2, 1, 3).reshape(b * S, T, 3 * C)                 # (b t) s c -> (b s) t c (VA:171)
-        a = attention_f32(tqkv[..., :C], tqkv[..., C:2 * C], tqkv[..., 2 * C:], heads, b * S, T, T)
+        a = attention_x(tqkv[..., :C], tqkv[..., C:], heads, b * S, T, T)
         a = a.view(b, S, T, C).permute(0, 2, 1, 3).reshape(BT, S, C)
         if dump:
             tb.attn1.q, tb.attn1.k = tqkv[..., :C].half(), tqkv[..., C:2 * C].half()                  # the reference's [(b s), t, c] layout
@@ -319,7 +354,7 @@ class ExactRunner:
         q2 = linear_x(layernorm_split3(x, *bw["ln"]["norm2"]), bw["w_q"])
         tk = torch.empty((b, L, C), dtype=F16, device=x.device) if dump else None
         kv = linear_x(tctx3, bw["w_kv"], tap=tk, tap_cols=C)
-        a2 = attention_f32(q2.view(b, T * S, C), kv[..., :C], kv[..., C:], heads, b, T * S, L)       # VA:224-250
+        a2 = attention_x(q2.view(b, T * S, C), kv, heads, b, T * S, L)       # VA:224-250
         x = add(linear_x(split3(a2.view(BT, S, C)), bw["w_o2"], bw["b_o2"]), x)
         if dump:
             tb.attn2.q = q2.view(b, T, S, C).permute(0, 2, 1, 3).reshape(b * S, T, C).half()
@@ -340,7 +375,7 @@ class ExactRunner:
             tq = torch.empty((B, N, Ci), dtype=F16, device=x.device) if dump else None
             tk = torch.empty((B, N, Ci), dtype=F16, device=x.device) if dump else None
             qkv = linear_x(layernorm_split3(t, *bw["ln"][0]), bw["w_qkv"], tap=tq, tap2=tk, tap_cols=Ci)
-            a = attention_f32(qkv[..., :Ci], qkv[..., Ci:2 * Ci], qkv[..., 2 * Ci:], heads, B, N, N)
+            a = attention_x(qkv[..., :Ci], qkv[..., Ci:], heads, B, N, N)
             t = add(linear_x(split3(a), bw["w_o1"], bw["b_o1"]), t)
             if dump:
                 blk.attn1.q, blk.attn1.k = tq, tk
@@ -350,7 +385,7 @@ class ExactRunner:
             q = linear_x(layernorm_split3(t, *bw["ln"][1]), bw["w_q"], tap=tq, tap_cols=Ci)
             tk = torch.empty((B, L, Ci), dtype=F16, device=x.device) if dump else None
             kv = linear_x(ctx3, bw["w_kv"], tap=tk, tap_cols=Ci)
-            a = attention_f32(q, kv[..., :Ci], kv[..., Ci:], heads, B, N, L)
+            a = attention_x(q, kv, heads, B, N, L)
             t = add(linear_x(split3(a), bw["w_o2"], bw["b_o2"]), t)
             if dump:
                 blk.attn2.q, blk.attn2.k = tq, tk
