@@ -262,17 +262,27 @@ int vidseg_x_geglu_split3(const float* y /* [M][2*inner]: value | gate */, long 
                           vidseg_stream_t stream);
 int vidseg_x_groupnorm_split3(const float* x0, const float* x1 /* opt: channel concat */, int C0, int C1, int B, int HW, int G,
                               const float* gamma, const float* beta, float eps, int silu, float* stats /* scratch [B][2][C] */,
-                              int stats_floats, void* out_f16 /* [B][HW][3C] */, vidseg_stream_t stream);
+                              int stats_floats, double* part /* scratch [B][ceil(HW / rows_per_chunk)][2][C] */, long long part_doubles,
+                              void* out_f16 /* [B][HW][3C] */, vidseg_stream_t stream);
+int vidseg_x_groupnorm_rows_per_chunk(int HW); /* rows per block of the statistics pass (sizes `part`) */
 int vidseg_x_layernorm_split3(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
                               void* out_f16 /* [M][3C] */, vidseg_stream_t stream);
 int vidseg_x_attention_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int B, int H,
                            int Nq, int Nk, float scale, vidseg_stream_t stream);
+/* linear / 3x3 conv of the exact mode with the fp32 residual added in the epilogue (ATT:636-757, 921-927; OAI:369): split operand
+ * image in, fp32 out, `residual_f32` [M][ldr] / NHWC [B][Ho][Wo][Cout] or NULL */
+int vidseg_linear_a16_rf32(const void* a, int K, long long M, const void* w, int N, const float* bias, const float* rowvec, int rv_stride,
+                           int rows_per_sample, const float* residual_f32, int ldr, float* out_f32, int ldo, void* tap_f16, void* tap2_f16,
+                           int tap_cols, int tap_ld, int act, vidseg_stream_t stream);
+int vidseg_conv3x3_a16_rf32(const void* x, int C, int B, int Hin, int Win, int stride, int up, const void* w, int Cout, const float* bias,
+                            const float* rowvec, int rv_stride, const float* residual_f32, float* out_f32, vidseg_stream_t stream);
 /* the same attention on the matrix pipe: three fp16 MFMA products of split operands per contraction (fp32 accuracy).  q fp32; k / v as
  * fp16 hi / lo planes with one row stride (vidseg_x_split_planes makes them from fp32 column blocks) */
 int vidseg_x_split_planes(const float* x, int ld, long long rows, int cols, void* hi_f16 /* [rows][cols] */, void* lo_f16 /* [rows][cols] */,
                           vidseg_stream_t stream);
 int vidseg_x_attention_mfma(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* v_hi, const void* v_lo, int ldkv,
-                            float* out, int ldo, int B, int H, int Nq, int Nk, float scale, vidseg_stream_t stream);
+                            float* out /* fp32 [B][Nq][ldo], or NULL */, void* out_split3 /* f16 [B][Nq][3 ldo] = [hi | lo | hi], or NULL */,
+                            int ldo, int B, int H, int Nq, int Nk, float scale, vidseg_stream_t stream);
 /* x + vec[sample % nvec] per row (the frame-index embedding add of SpatialVideoTransformer, VA:417-431), fp32 */
 int vidseg_x_add_rowvec_f32(const float* x, const float* vec, long long M, int C, int rows_per_sample, int nvec, float* out,
                             vidseg_stream_t stream);

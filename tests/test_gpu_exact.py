@@ -139,6 +139,49 @@ def test_attention_mfma_split_operands(X):
         assert e <= 2e-6 * max(1.0, s * s / 4), (B, H, Nq, Nk, s, e)
 
 
+def test_fused_residual_and_split_outputs(X):
+    """The exact mode's fused forms: fp32 residual inside the GEMM / conv epilogue (incl. a split-K shape, whose finish kernel adds
+    it), the attention kernel writing the consumer's [hi | lo | hi] image, GroupNorm statistics over the coalesced two-pass kernels
+    at the window's channel counts (80 / 640 four-channel columns, two sources)."""
+    from vidseg_diffusion_amd import ops
+    dev = torch.device("cuda:0")
+    for (M, K, N) in ((300, 320, 640), (7168, 5120, 1280), (1792, 1280, 1280)):
+        a, w, b, r = rnd((M, K), 41), rnd((N, K), 42, 0.02), rnd((N,), 43), rnd((M, N), 44, 2.0)
+        out = X.linear_x(X.split3(a.to(dev)), X.pack_linear_x(w, dev), ops.f32(b, dev), residual=r.to(dev)).cpu()
+        ref = a.double() @ w.double().t() + b.double() + r.double()
+        e = rel(out, ref)
+        print(f"linear_x + fp32 residual {M}x{N}x{K}: max err {e:.2e}")
+        assert e <= 5e-6, (M, K, N, e)
+    x, w, b = rnd((2, 64, 12, 20), 45), rnd((128, 64, 3, 3), 46, 0.05), rnd((128,), 47)
+    r = rnd((2, 12, 20, 128), 48, 3.0)
+    out = X.conv3x3_x(X.split3(x.permute(0, 2, 3, 1).contiguous().to(dev)), X.pack_conv3x3_x(w, dev), ops.f32(b, dev), residual=r.to(dev)).cpu()
+    ref = TF.conv2d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1) + r.double()
+    assert rel(out, ref) <= 5e-6, rel(out, ref)
+    B, H, Nq, Nk = 2, 5, 256, 192
+    C = H * 64
+    q, kv = rnd((B, Nq, C), 49), rnd((B, Nk, 2 * C), 50)
+    o32 = X.attention_mfma(q.to(dev), kv.to(dev), H, B, Nq, Nk).cpu()
+    o3 = X.attention_mfma(q.to(dev), kv.to(dev), H, B, Nq, Nk, split_out=True).cpu()
+    assert tuple(o3.shape) == (B, Nq, 3 * C) and torch.equal(o3[..., :C], o3[..., 2 * C:]) and torch.equal(o3[..., :C], o32.half())
+    assert float((o3[..., :C].double() + o3[..., C:2 * C].double() - o32.double()).abs().max()) <= 2.0 ** -21 * float(o32.abs().max())
+
+    def join(s, C):
+        s = s.cpu().double()
+        return s[..., :C] + s[..., C:2 * C]
+
+    for (B, Hh, Ww, C0, C1) in ((2, 64, 64, 320, 0), (2, 16, 16, 1280, 1280), (3, 8, 8, 192, 0), (1, 32, 32, 640, 320)):
+        C = C0 + C1
+        x0 = rnd((B, Hh, Ww, C0), 51) * 1.5 + 0.4
+        x1 = rnd((B, Hh, Ww, C1), 52, 0.7) if C1 else None
+        g, bt = rnd((C,), 53) * 0.3 + 1.0, rnd((C,), 54) * 0.2
+        out = join(X.groupnorm_split3(x0.to(dev), ops.f32(g, dev), ops.f32(bt, dev), x1=x1.to(dev) if C1 else None, eps=1e-5, silu=True), C)
+        xs = torch.cat([x0, x1], -1) if C1 else x0
+        ref = TF.silu(TF.group_norm(xs.double().permute(0, 3, 1, 2), 32, g.double(), bt.double(), 1e-5).permute(0, 2, 3, 1))
+        e = rel(out, ref)
+        print(f"groupnorm_split3 B={B} {Hh}x{Ww} C={C0}+{C1}: max err {e:.2e}")
+        assert e <= 2e-6, (B, Hh, Ww, C0, C1, e)
+
+
 def test_split_survives_rounding_ties(X):
     """hi + lo must reconstruct x when x sits EXACTLY on an fp16 rounding tie and is the product of two fp32 values (the case in
     which hipcc fused the conversion with the multiply differently per use: hi of the operand image from the rounded fp32 product,

@@ -91,23 +91,73 @@ __global__ void __launch_bounds__(256) k_x_add_rowvec(const float* __restrict__ 
     *reinterpret_cast<f32x4*>(out + m * C + c) = f32x4{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
 }
 
-// ---- GroupNorm over the channel concat of two fp32 NHWC sources: statistics in float64, one block per (group, sample) ----------
-__device__ __forceinline__ float ld_cat(const float* x0, const float* x1, int C0, int C1, long long row, int c) {
-    return c < C0 ? x0[row * C0 + c] : x1[row * C1 + (c - C0)];
+// ---- GroupNorm over the channel concat of two fp32 NHWC sources: statistics in float64 ----------------------------------------
+// Statistics in two coalesced passes (the first version ran one block per (group, sample) over that group's 10..80-channel runs of
+// every row: 40..320-byte pieces, 61 us on average).  Pass 1: grid (row chunk, sample); thread (ry, c4) owns the four channels
+// 4 c4 .. of the rows ry, ry + RY, .. of its chunk (a wave reads 1 KB of one row per instruction), float64 sums and sums of squares,
+// the RY row lanes reduced through LDS in lane order -> part[sample][chunk][2][C].  Pass 2: one block per (group, sample) adds the
+// chunks x channels of its group in a fixed order and writes scale = rstd * gamma, shift = beta - mean * scale.
+__global__ void __launch_bounds__(256) k_x_gn_partial(const float* __restrict__ x0, const float* __restrict__ x1, int C0, int C1, int HW,
+                                                      int rpc, double* __restrict__ part) {
+    __shared__ double red[256 * 8];
+    const int C = C0 + C1, c4n = C / 4, chunk = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x, tid = threadIdx.x;
+    const int cols = c4n < 256 ? c4n : 256, ryn = 256 / cols, ry = tid / cols, cl = tid - ry * cols;
+    const int r0 = chunk * rpc, r1 = min(HW, r0 + rpc);
+    double* po = part + ((long long)b * nchunk + chunk) * 2 * C;
+    for (int cb = 0; cb < c4n; cb += cols) {
+        const int c = (cb + cl) * 4;
+        const bool live = ry < ryn && cb + cl < c4n;
+        double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+        if (live) {
+            const float* src = c < C0 ? x0 + c : x1 + (c - C0);
+            const int ld = c < C0 ? C0 : C1;
+            for (int r = r0 + ry; r < r1; r += ryn) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((long long)b * HW + r) * ld);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double f = (double)v[j];
+                    s[j] += f;
+                    q[j] += f * f;
+                }
+            }
+        }
+        if (ryn > 1) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                red[tid * 8 + j] = s[j];
+                red[tid * 8 + 4 + j] = q[j];
+            }
+            __syncthreads();
+            if (live && ry == 0) {
+                for (int y = 1; y < ryn; ++y)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        s[j] += red[(y * cols + cl) * 8 + j];
+                        q[j] += red[(y * cols + cl) * 8 + 4 + j];
+                    }
+            }
+        }
+        if (live && ry == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                po[c + j] = s[j];
+                po[C + c + j] = q[j];
+            }
+        }
+    }
 }
 
-__global__ void __launch_bounds__(256) k_x_gn_stats(const float* __restrict__ x0, const float* __restrict__ x1, int C0, int C1, int HW, int G,
-                                                    float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    float* __restrict__ stats) {
+__global__ void __launch_bounds__(256) k_x_gn_finish(const double* __restrict__ part, int C, int HW, int G, int nchunk, float eps,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ stats) {
     __shared__ double red[2][4];
-    const int C = C0 + C1, cpg = C / G, g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const long long total = (long long)HW * cpg;
+    const int cpg = C / G, g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const double* pb = part + (long long)b * nchunk * 2 * C;
     double s = 0.0, q = 0.0;
-    for (long long i = tid; i < total; i += 256) {
-        const long long r = i / cpg;
-        const double f = (double)ld_cat(x0, x1, C0, C1, (long long)b * HW + r, g * cpg + (int)(i - r * cpg));
-        s += f;
-        q += f * f;
+    for (int i = tid; i < nchunk * cpg; i += 256) {
+        const int ch = i / cpg, c = g * cpg + (i - ch * cpg);
+        s += pb[(long long)ch * 2 * C + c];
+        q += pb[(long long)ch * 2 * C + C + c];
     }
     s = wave_sum_f64(s);
     q = wave_sum_f64(q);
@@ -118,7 +168,7 @@ __global__ void __launch_bounds__(256) k_x_gn_stats(const float* __restrict__ x0
     __syncthreads();
     s = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
     q = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
-    const double n = (double)total, mean = s / n, var = fmax(q / n - mean * mean, 0.0);
+    const double n = (double)HW * cpg, mean = s / n, var = fmax(q / n - mean * mean, 0.0);
     const double rstd = 1.0 / sqrt(var + (double)eps);
     float* o = stats + (long long)b * 2 * C;
     for (int i = tid; i < cpg; i += 256) {
@@ -367,8 +417,8 @@ __device__ __forceinline__ f32x16 xmfma(f16x8 a, f16x8 b, f32x16 c) { return __b
 template <bool RAGGED, bool FLUSH>
 __global__ void __launch_bounds__(256, 2) k_x_attention_mfma(const float* __restrict__ q, int ldq, const f16* __restrict__ kh,
                                                              const f16* __restrict__ kl, const f16* __restrict__ vh,
-                                                             const f16* __restrict__ vl, int ldkv, float* __restrict__ out, int ldo, int Nq,
-                                                             int Nk, int H, float scale_log2e) {
+                                                             const f16* __restrict__ vl, int ldkv, float* __restrict__ out, int ldo,
+                                                             f16* __restrict__ out3, int Nq, int Nk, int H, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) char smem[2][4][64 * 128];      // [buffer][K hi, K lo, V hi, V lo][64 keys x 128 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -555,13 +605,34 @@ __global__ void __launch_bounds__(256, 2) k_x_attention_mfma(const float* __rest
     const int qi = q0 + l31;
     if (qi < Nq) {
         const float inv = 1.0f / l_run;
-        float* op = out + ((long long)b * Nq + qi) * ldo + h * 64;
+        if (out3) {                                             // the consumer's split operand image [hi | lo | hi], row stride 3 ldo
+            f16* op = out3 + ((long long)b * Nq + qi) * 3 * ldo + h * 64;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<f32x4*>(op + i * 32 + 8 * g + 4 * hi) =
-                    f32x4{oacc[i][g * 4 + 0] * inv, oacc[i][g * 4 + 1] * inv, oacc[i][g * 4 + 2] * inv, oacc[i][g * 4 + 3] * inv};
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 vh4, vl4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        f16 a, c;
+                        split_hl(oacc[i][g * 4 + e] * inv, a, c);
+                        vh4[e] = a;
+                        vl4[e] = c;
+                    }
+                    f16* o = op + i * 32 + 8 * g + 4 * hi;
+                    *reinterpret_cast<f16x4*>(o) = vh4;
+                    *reinterpret_cast<f16x4*>(o + ldo) = vl4;
+                    *reinterpret_cast<f16x4*>(o + 2 * ldo) = vh4;
+                }
+        } else {
+            float* op = out + ((long long)b * Nq + qi) * ldo + h * 64;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(op + i * 32 + 8 * g + 4 * hi) =
+                        f32x4{oacc[i][g * 4 + 0] * inv, oacc[i][g * 4 + 1] * inv, oacc[i][g * 4 + 2] * inv, oacc[i][g * 4 + 3] * inv};
+        }
     }
 }
 
@@ -596,13 +667,20 @@ int vidseg_x_geglu_split3(const float* y, long long M, int inner, void* out16, h
     return VS_OK;
 }
 
+int vidseg_x_groupnorm_rows_per_chunk(int HW) { return HW / 64 < 4 ? 4 : (HW / 64 > 64 ? 64 : HW / 64); }
+
 int vidseg_x_groupnorm_split3(const float* x0, const float* x1, int C0, int C1, int B, int HW, int G, const float* gamma, const float* beta,
-                              float eps, int silu, float* stats, int stats_floats, void* out16, hipStream_t st) {
+                              float eps, int silu, float* stats, int stats_floats, double* part, long long part_doubles, void* out16,
+                              hipStream_t st) {
     const int C = C0 + (x1 ? C1 : 0);
     VS_REQUIRE(C % G == 0 && C0 % 4 == 0 && (!x1 || C1 % 4 == 0), "x_groupnorm: C0=%d C1=%d G=%d", C0, C1, G);
     VS_REQUIRE((long long)B * 2 * C <= stats_floats, "x_groupnorm: scale/shift buffer too small");
     if (B * HW == 0) return VS_OK;
-    k_x_gn_stats<<<dim3(G, B), 256, 0, st>>>(x0, x1, C0, x1 ? C1 : 0, HW, G, eps, gamma, beta, stats);
+    const int rpc = vidseg_x_groupnorm_rows_per_chunk(HW), nchunk = (HW + rpc - 1) / rpc;
+    VS_REQUIRE((long long)B * nchunk * 2 * C <= part_doubles, "x_groupnorm: partial-sum buffer too small (%lld doubles needed)",
+               (long long)B * nchunk * 2 * C);
+    k_x_gn_partial<<<dim3(nchunk, B), 256, 0, st>>>(x0, x1, C0, x1 ? C1 : 0, HW, rpc, part);
+    k_x_gn_finish<<<dim3(G, B), 256, 0, st>>>(part, C, HW, G, nchunk, eps, gamma, beta, stats);
     const long long rows = (long long)B * HW;
     k_x_gn_apply_split3<<<X_GRID(rows * (C / 4)), 256, 0, st>>>(x0, x1, C0, x1 ? C1 : 0, HW, rows, stats, silu, (f16*)out16);
     VS_CHECK_LAUNCH("x_groupnorm_split3");
@@ -637,15 +715,16 @@ int vidseg_x_split_planes(const float* x, int ld, long long rows, int cols, void
 }
 
 int vidseg_x_attention_mfma(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* v_hi, const void* v_lo, int ldkv,
-                            float* out, int ldo, int B, int H, int Nq, int Nk, float scale, hipStream_t st) {
+                            float* out, void* out_split3, int ldo, int B, int H, int Nq, int Nk, float scale, hipStream_t st) {
     VS_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ldkv % 8 == 0 && Nk > 0, "x_attention_mfma: ldq=%d ldo=%d ldkv=%d Nk=%d", ldq, ldo, ldkv, Nk);
+    VS_REQUIRE((out != nullptr) != (out_split3 != nullptr), "x_attention_mfma: exactly one of out / out_split3");
     if (B * H * Nq == 0) return VS_OK;
     const float scale_log2e = scale * 1.44269504088896340736f;
     const dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)(B * H));
     static int flush = -1;                                   // VIDSEG_X_ATTN_FLUSH=0: the PV products accumulate across tiles inside the MFMA
     if (flush < 0) { const char* e = getenv("VIDSEG_X_ATTN_FLUSH"); flush = e ? atoi(e) : 1; }
 #define XA_LAUNCH(R, F) k_x_attention_mfma<R, F><<<grid, 256, 0, st>>>(q, ldq, (const f16*)k_hi, (const f16*)k_lo, (const f16*)v_hi, \
-                                                                        (const f16*)v_lo, ldkv, out, ldo, Nq, Nk, H, scale_log2e)
+                                                                        (const f16*)v_lo, ldkv, out, ldo, (f16*)out_split3, Nq, Nk, H, scale_log2e)
     if (Nk % 64 == 0) { if (flush) XA_LAUNCH(false, true); else XA_LAUNCH(false, false); }
     else { if (flush) XA_LAUNCH(true, true); else XA_LAUNCH(true, false); }
 #undef XA_LAUNCH
@@ -659,8 +738,9 @@ int vidseg_x_attention_mfma(const float* q, int ldq, const void* k_hi, const voi
 int vidseg_x_split3(const float*, long long, int, int, void*, hipStream_t) { X_UNSUPPORTED("x_split3"); }
 int vidseg_x_geglu_split3(const float*, long long, int, void*, hipStream_t) { X_UNSUPPORTED("x_geglu_split3"); }
 int vidseg_x_add_rowvec_f32(const float*, const float*, long long, int, int, int, float*, hipStream_t) { X_UNSUPPORTED("x_add_rowvec_f32"); }
-int vidseg_x_groupnorm_split3(const float*, const float*, int, int, int, int, int, const float*, const float*, float, int, float*, int, void*,
-                              hipStream_t) {
+int vidseg_x_groupnorm_rows_per_chunk(int HW) { return HW / 64 < 4 ? 4 : (HW / 64 > 64 ? 64 : HW / 64); }
+int vidseg_x_groupnorm_split3(const float*, const float*, int, int, int, int, int, const float*, const float*, float, int, float*, int, double*,
+                              long long, void*, hipStream_t) {
     X_UNSUPPORTED("x_groupnorm_split3");
 }
 int vidseg_x_layernorm_split3(const float*, long long, int, const float*, const float*, float, void*, hipStream_t) {
@@ -670,8 +750,8 @@ int vidseg_x_attention_f32(const float*, int, const float*, int, const float*, i
     X_UNSUPPORTED("x_attention_f32");
 }
 int vidseg_x_split_planes(const float*, int, long long, int, void*, void*, hipStream_t) { X_UNSUPPORTED("x_split_planes"); }
-int vidseg_x_attention_mfma(const float*, int, const void*, const void*, const void*, const void*, int, float*, int, int, int, int, int, float,
-                            hipStream_t) {
+int vidseg_x_attention_mfma(const float*, int, const void*, const void*, const void*, const void*, int, float*, void*, int, int, int, int, int,
+                            float, hipStream_t) {
     X_UNSUPPORTED("x_attention_mfma");
 }
 #endif

@@ -36,6 +36,7 @@ struct GemmParams {
     int rv_stride, rows_per_sample;
     const bf16_t* residual;  // [M][ldr] or nullptr
     int ldr;
+    int res_f32;             // 1: `residual` points to fp32 values (the exact mode's fp32 residual stream, *_rf32 entry points)
     bf16_t* out;             // [M][ldo] or nullptr
     int ldo;
     float* out_f32;          // [M][ldo] or nullptr
@@ -215,9 +216,19 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
                 *reinterpret_cast<f16x8*>(p.tap2 + tr + (n - p.tap_cols)) = t;
         }
         if (p.residual) {
-            const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + (long long)m * p.ldr + n);
+            if (p.res_f32) {
+                const float* rp = reinterpret_cast<const float*>(p.residual) + (long long)m * p.ldr + n;
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
+                for (int e = 0; e < 4; ++e) {
+                    v[e] += r0[e];
+                    v[4 + e] += r1[e];
+                }
+            } else {
+                const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + (long long)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
+            }
         }
         const long long oo = (long long)m * p.ldo + n;
         if (p.out) {
@@ -1465,7 +1476,15 @@ __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
         for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
         *reinterpret_cast<f16x8*>(p.tap2 + tap_row(p, m) * p.tap_ld + (n - p.tap_cols)) = t;
     }
-    if (p.residual) {
+    if (p.residual && p.res_f32) {
+        const float* rp = reinterpret_cast<const float*>(p.residual) + (long long)m * p.ldr + n;
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] += r0[e];
+            v[4 + e] += r1[e];
+        }
+    } else if (p.residual) {
         const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + (long long)m * p.ldr + n);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
@@ -2321,7 +2340,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         (void)hipEventRecord(prof_event(), st);
         const double n_out = p.act == 2 ? p.N / 2 : p.N;
         double ab = (double)p.x0_bytes + (double)p.x1_bytes + 2.0 * (double)p.N * (double)p.K;
-        if (p.residual) ab += 2.0 * (double)p.M * n_out;
+        if (p.residual) ab += (p.res_f32 ? 4.0 : 2.0) * (double)p.M * n_out;
         if (p.out) ab += 2.0 * (double)p.M * n_out;
         if (p.out_f32) ab += 4.0 * (double)p.M * n_out;
         if (p.tap) ab += 2.0 * (double)p.M * (double)p.tap_cols * (p.tap2 ? 2.0 : 1.0);
@@ -2367,6 +2386,41 @@ int vidseg_linear_a16(const void* a0, const void* a1, int C0, int C1, long long 
     p.rowadd = rowadd;
     p.act = act;
     if (act == 2) VS_REQUIRE(N % 64 == 0 && out, "linear: GEGLU needs N %% 64 == 0 and a bf16 output");
+    return launch_gemm(p, st);
+}
+
+// The exact mode's linear: vidseg_linear_a16 on a split operand image with an fp32 result and an fp32 residual added in the epilogue
+// (t + to_out(attn(..)), x + proj_out(..): attention.py:636-757, 921-927 -- the residual stream stays fp32, no separate add pass).
+int vidseg_linear_a16_rf32(const void* a, int K, long long M, const void* w, int N, const float* bias, const float* rowvec, int rv_stride,
+                           int rows_per_sample, const float* residual_f32, int ldr, float* out_f32, int ldo, void* tap, void* tap2,
+                           int tap_cols, int tap_ld, int act, hipStream_t st) {
+    VS_REQUIRE(out_f32 != nullptr && act != 2 && (!residual_f32 || ldr % 8 == 0), "linear_rf32: needs an fp32 output, act != GEGLU, ldr %% 8 == 0");
+    GemmParams p{};
+    p.x0 = (const bf16_t*)a;
+    p.C0 = K;
+    p.ksize = 1;
+    p.stride = 1;
+    p.up = 1;
+    p.Hin = p.Win = p.Hout = p.Wout = 1;
+    p.w = (const bf16_t*)w;
+    p.N = N;
+    p.K = K;
+    p.M = M;
+    p.x0_bytes = M * K * 2;
+    p.bias = bias;
+    p.rowvec = rowvec;
+    p.rv_stride = rv_stride;
+    p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+    p.residual = (const bf16_t*)residual_f32;
+    p.res_f32 = 1;
+    p.ldr = ldr;
+    p.out_f32 = out_f32;
+    p.ldo = ldo;
+    p.tap = (f16*)tap;
+    p.tap2 = (f16*)tap2;
+    p.tap_cols = tap_cols;
+    p.tap_ld = tap_ld;
+    p.act = act;
     return launch_gemm(p, st);
 }
 
@@ -2443,7 +2497,7 @@ int vidseg_conv_temporal3_a16_f32(const void* x, int C, int BT, int HW, int T, c
 // 3x3 convolution, padding 1, NHWC bf16 activations, weight packed [Cout][c/64][kh*3+kw][c%64] (chunk-major K order).
 static int conv3x3_impl(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up, const void* w,
                         int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual, void* out,
-                        int pad, float* out_f32, void* tap, int tap_early, hipStream_t st) {
+                        int pad, float* out_f32, void* tap, int tap_early, hipStream_t st, int res_f32 = 0) {
     VS_REQUIRE((stride == 1 || stride == 2) && (up == 1 || up == 2) && (pad == 0 || pad == 1), "conv3x3: stride=%d up=%d pad=%d", stride,
                up, pad);
     GemmParams p{};
@@ -2471,6 +2525,7 @@ static int conv3x3_impl(const void* x0, const void* x1, int C0, int C1, int B, i
     p.rv_stride = rv_stride;
     p.rows_per_sample = p.Hout * p.Wout;
     p.residual = (const bf16_t*)residual;
+    p.res_f32 = res_f32;
     p.ldr = Cout;
     p.out = (bf16_t*)out;
     p.ldo = Cout;
@@ -2487,6 +2542,15 @@ int vidseg_conv3x3_a16(const void* x0, const void* x1, int C0, int C1, int B, in
                         int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual, void* out,
                         int pad, float* out_f32, hipStream_t st) {
     return conv3x3_impl(x0, x1, C0, C1, B, Hin, Win, stride, up, w, Cout, bias, rowvec, rv_stride, residual, out, pad, out_f32, nullptr, 0, st);
+}
+
+// The exact mode's 3x3 conv: split operand image in, fp32 out, fp32 residual (the ResBlock's `skip_connection(x) + h`, openaimodel.py:369)
+// added in the epilogue.
+int vidseg_conv3x3_a16_rf32(const void* x, int C, int B, int Hin, int Win, int stride, int up, const void* w, int Cout, const float* bias,
+                            const float* rowvec, int rv_stride, const float* residual_f32, float* out_f32, hipStream_t st) {
+    VS_REQUIRE(out_f32 != nullptr, "conv3x3_rf32: needs an fp32 output");
+    return conv3x3_impl(x, nullptr, C, 0, B, Hin, Win, stride, up, w, Cout, bias, rowvec, rv_stride, residual_f32, nullptr, 1, out_f32, nullptr, 0,
+                        st, 1);
 }
 
 // The same convolution with an fp16 copy of the result taken inside the epilogue: tap_early = 1 after the bias and before the

@@ -34,11 +34,14 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 _lib.register({
     "vidseg_x_split3": [_P, _L, _I, _I, _P, _P],
     "vidseg_x_geglu_split3": [_P, _L, _I, _P, _P],
-    "vidseg_x_groupnorm_split3": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _P],
+    "vidseg_x_groupnorm_split3": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _L, _P, _P],
+    "vidseg_x_groupnorm_rows_per_chunk": [_I],
+    "vidseg_linear_a16_rf32": [_P, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
+    "vidseg_conv3x3_a16_rf32": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
     "vidseg_x_layernorm_split3": [_P, _L, _I, _P, _P, _F, _P, _P],
     "vidseg_x_attention_f32": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     "vidseg_x_split_planes": [_P, _I, _L, _I, _P, _P, _P],
-    "vidseg_x_attention_mfma": [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
+    "vidseg_x_attention_mfma": [_P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "vidseg_conv_in_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "vidseg_x_add_rowvec_f32": [_P, _P, _L, _I, _I, _I, _P, _P],
     "vidseg_conv_temporal3_a16_f32": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P],
@@ -96,9 +99,11 @@ def groupnorm_split3(x0, gamma, beta, *, x1=None, eps=1e-5, silu=True):
     C1 = x1.shape[-1] if x1 is not None else 0
     HW = x0.numel() // (B * C0)
     stats = torch.empty(B * 2 * (C0 + C1), dtype=F32, device=x0.device)
+    rpc = _lib.lib().vidseg_x_groupnorm_rows_per_chunk(HW)                  # rows per block of the statistics pass
+    part = torch.empty(B * (-(-HW // rpc)) * 2 * (C0 + C1), dtype=torch.float64, device=x0.device)
     out = torch.empty(x0.shape[:-1] + (3 * (C0 + C1),), dtype=F16, device=x0.device)
     call("vidseg_x_groupnorm_split3", ptr(x0), ptr(x1), C0, C1, B, HW, 32, ptr(gamma), ptr(beta), eps, int(silu), ptr(stats), stats.numel(),
-         ptr(out), stream())
+         ptr(part), part.numel(), ptr(out), stream())
     return out
 
 
@@ -127,48 +132,64 @@ def split_planes(x):
     return hi, lo
 
 
-def attention_mfma(q, kv, heads, B, Nq, Nk):
+def attention_mfma(q, kv, heads, B, Nq, Nk, split_out=False):
     """softmax(q k^T / 8) v per 64-wide head at fp32 accuracy on the matrix pipe (three fp16 MFMA products of split operands per
-    contraction).  q: fp32 column slice [B, Nq, heads*64]; kv: fp32 [B, Nk, 2*heads*64] column slice holding k | v side by side."""
+    contraction).  q: fp32 column slice [B, Nq, heads*64]; kv: fp32 [B, Nk, 2*heads*64] column slice holding k | v side by side.
+    split_out: return the consumer's split operand image [B, Nq, 3*heads*64] (fp16 [hi | lo | hi]) instead of the fp32 result."""
     C = heads * 64
     hi, lo = split_planes(kv)
-    out = torch.empty((B, Nq, C), dtype=F32, device=q.device)
+    out = torch.empty((B, Nq, 3 * C), dtype=F16, device=q.device) if split_out else torch.empty((B, Nq, C), dtype=F32, device=q.device)
     call("vidseg_x_attention_mfma", q.data_ptr(), q.stride(1), hi.data_ptr(), lo.data_ptr(), hi.data_ptr() + 2 * C, lo.data_ptr() + 2 * C, 2 * C,
-         ptr(out), C, B, heads, Nq, Nk, 0.125, stream())
+         None if split_out else ptr(out), ptr(out) if split_out else None, C, B, heads, Nq, Nk, 0.125, stream())
     return out
 
 
 _MFMA_MIN_Q = int(os.environ.get("VIDSEG_X_ATTN_MFMA_MINQ", "128"))   # below: k_x_attention_f32 (the 14-frame temporal attention); 0 disables
 
 
-def attention_x(q, kv, heads, B, Nq, Nk):
+def attention_x(q, kv, heads, B, Nq, Nk, split_out=False):
     """The exact mode's attention: the MFMA kernel from 128 queries up (a block owns 128), the fp32 vector kernel below that."""
     C = heads * 64
     if _MFMA_MIN_Q and Nq >= _MFMA_MIN_Q:
-        return attention_mfma(q, kv, heads, B, Nq, Nk)
-    return attention_f32(q, kv[..., :C], kv[..., C:], heads, B, Nq, Nk)
+        return attention_mfma(q, kv, heads, B, Nq, Nk, split_out)
+    a = attention_f32(q, kv[..., :C], kv[..., C:], heads, B, Nq, Nk)
+    return split3(a) if split_out else a
 
 
-def linear_x(a3, w3, bias=None, *, rowvec=None, rows_per_sample=0, act=ops.ACT_NONE, tap=None, tap2=None, tap_cols=0):
-    """fp32 out = act(a . w^T + bias + rowvec[sample]) on split operands (a3: [.., 3K] fp16, w3: [N, 3K] fp16)."""
+def linear_x(a3, w3, bias=None, *, rowvec=None, rows_per_sample=0, act=ops.ACT_NONE, tap=None, tap2=None, tap_cols=0, residual=None):
+    """fp32 out = act(a . w^T + bias + rowvec[sample]) + residual on split operands (a3: [.., 3K] fp16, w3: [N, 3K] fp16; residual
+    fp32 [.., N], added inside the GEMM epilogue)."""
     ops.workspace(a3.device)
     K3 = a3.shape[-1]
     M = a3.numel() // K3
     N = w3.shape[0]
     out = torch.empty(a3.shape[:-1] + (N,), dtype=F32, device=a3.device)
+    if residual is not None:
+        if residual.dtype != F32 or residual.numel() != M * N or not residual.is_contiguous():
+            raise VidsegError("linear_x: residual must be a contiguous fp32 [.., N] tensor")
+        call("vidseg_linear_a16_rf32", ptr(a3), K3, M, ptr(w3), N, ptr(bias), ptr(rowvec), rowvec.stride(0) if rowvec is not None else 0,
+             rows_per_sample, ptr(residual), N, ptr(out), N, ptr(tap), ptr(tap2), tap_cols, tap.shape[-1] if tap is not None else 0, act,
+             stream())
+        return out
     call("vidseg_linear_a16", ptr(a3), None, K3, 0, M, ptr(w3), N, ptr(bias), ptr(rowvec), rowvec.stride(0) if rowvec is not None else 0,
          rows_per_sample, None, 0, None, ptr(out), N, ptr(tap), ptr(tap2), tap_cols, tap.shape[-1] if tap is not None else 0, None, act,
          stream())
     return out
 
 
-def conv3x3_x(x3, w3, bias, *, stride=1, up=1, rowvec=None):
-    """fp32 NHWC out of the 3x3 conv on the split image x3 [B, H, W, 3Cin]."""
+def conv3x3_x(x3, w3, bias, *, stride=1, up=1, rowvec=None, residual=None):
+    """fp32 NHWC out of the 3x3 conv on the split image x3 [B, H, W, 3Cin] (+ fp32 NHWC residual inside the epilogue)."""
     ops.workspace(x3.device)
     B, H, W, C3 = x3.shape
     Cout = w3.shape[0]
     Ho, Wo = (H * up + 2 - 3) // stride + 1, (W * up + 2 - 3) // stride + 1
     out = torch.empty((B, Ho, Wo, Cout), dtype=F32, device=x3.device)
+    if residual is not None:
+        if residual.dtype != F32 or tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous():
+            raise VidsegError("conv3x3_x: residual must be a contiguous fp32 tensor of the output's shape")
+        call("vidseg_conv3x3_a16_rf32", ptr(x3), C3, B, H, W, stride, up, ptr(w3), Cout, ptr(bias), ptr(rowvec),
+             rowvec.stride(0) if rowvec is not None else 0, ptr(residual), ptr(out), stream())
+        return out
     call("vidseg_conv3x3_a16", ptr(x3), None, C3, 0, B, H, W, stride, up, ptr(w3), Cout, ptr(bias), ptr(rowvec),
          rowvec.stride(0) if rowvec is not None else 0, None, None, 1, ptr(out), stream())
     return out
@@ -297,7 +318,6 @@ class ExactRunner:
         rv = emb_all[:, off:off + m.out_channels]
         h = conv3x3_x(h, e["w1"], e["cb1"], rowvec=rv)                              # conv + bias + emb_out (OAI:353-365)
         h = groupnorm_split3(h, e["g2"], e["b2"], eps=1e-5, silu=True)
-        h = conv3x3_x(h, e["w2"], e["cb2"])
         if "ws" in e:
             xin = x0 if x1 is None else torch.cat([x0, x1], dim=-1)
             res = linear_x(split3(xin), e["ws"], e["bs"])                           # 1x1 skip conv on the concat (OAI:912, 369)
@@ -305,7 +325,7 @@ class ExactRunner:
             if x1 is not None:
                 raise VidsegError("ResBlock: identity skip with a concatenated input")
             res = x0
-        out = add(h, res)
+        out = conv3x3_x(h, e["w2"], e["cb2"], residual=res.view(h.shape[0], h.shape[1], h.shape[2], -1))   # skip + h in the epilogue
         if "ts" in e:                                                               # VideoResBlock.forward, video_model.py:66-89
             out = self.video_resblock_tail(m, e, out, emb_all)
         return out
@@ -342,25 +362,25 @@ class ExactRunner:
         b = BT // T
         heads = tb.attn1.heads
         y = linear_x(layernorm_split3(x, *bw["ln"]["norm_in"]), bw["w_fi1"], bw["b_fi1"])            # VA:155-159
-        x = add(linear_x(geglu_split3(y), bw["w_fi2"], bw["b_fi2"]), x)
+        x = linear_x(geglu_split3(y), bw["w_fi2"], bw["b_fi2"], residual=x)
         qkv = linear_x(layernorm_split3(x, *bw["ln"]["norm1"]), bw["w_qkv"])                          # [(b t), S, 3C]
         tqkv = qkv.view(b, T, S, 3 * C).permute(0, 2, 1, 3).reshape(b * S, T, 3 * C)                 # (b t) s c -> (b s) t c (VA:171)
         a = attention_x(tqkv[..., :C], tqkv[..., C:], heads, b * S, T, T)
         a = a.view(b, S, T, C).permute(0, 2, 1, 3).reshape(BT, S, C)
         if dump:
             tb.attn1.q, tb.attn1.k = tqkv[..., :C].half(), tqkv[..., C:2 * C].half()                  # the reference's [(b s), t, c] layout
-        x = add(linear_x(split3(a), bw["w_o1"], bw["b_o1"]), x)                                      # VA:197-218
+        x = linear_x(split3(a), bw["w_o1"], bw["b_o1"], residual=x)                                  # VA:197-218
         L = tctx3.shape[1]
         q2 = linear_x(layernorm_split3(x, *bw["ln"]["norm2"]), bw["w_q"])
         tk = torch.empty((b, L, C), dtype=F16, device=x.device) if dump else None
         kv = linear_x(tctx3, bw["w_kv"], tap=tk, tap_cols=C)
-        a2 = attention_x(q2.view(b, T * S, C), kv, heads, b, T * S, L)       # VA:224-250
-        x = add(linear_x(split3(a2.view(BT, S, C)), bw["w_o2"], bw["b_o2"]), x)
+        a23 = attention_x(q2.view(b, T * S, C), kv, heads, b, T * S, L, split_out=True)       # VA:224-250
+        x = linear_x(a23.view(BT, S, 3 * C), bw["w_o2"], bw["b_o2"], residual=x)
         if dump:
             tb.attn2.q = q2.view(b, T, S, C).permute(0, 2, 1, 3).reshape(b * S, T, C).half()
             tb.attn2.k = tk[:, None].expand(b, S, L, C).reshape(b * S, L, C)
         y = linear_x(layernorm_split3(x, *bw["ln"]["norm3"]), bw["w_ff1"], bw["b_ff1"])               # VA:252-281
-        return add(linear_x(geglu_split3(y), bw["w_ff2"], bw["b_ff2"]), x)
+        return linear_x(geglu_split3(y), bw["w_ff2"], bw["b_ff2"], residual=x)
 
     def transformer(self, m, x, ctx3, tap):
         e = self.w[self.names[id(m)]]
@@ -375,8 +395,8 @@ class ExactRunner:
             tq = torch.empty((B, N, Ci), dtype=F16, device=x.device) if dump else None
             tk = torch.empty((B, N, Ci), dtype=F16, device=x.device) if dump else None
             qkv = linear_x(layernorm_split3(t, *bw["ln"][0]), bw["w_qkv"], tap=tq, tap2=tk, tap_cols=Ci)
-            a = attention_x(qkv[..., :Ci], qkv[..., Ci:], heads, B, N, N)
-            t = add(linear_x(split3(a), bw["w_o1"], bw["b_o1"]), t)
+            a3 = attention_x(qkv[..., :Ci], qkv[..., Ci:], heads, B, N, N, split_out=True)
+            t = linear_x(a3, bw["w_o1"], bw["b_o1"], residual=t)
             if dump:
                 blk.attn1.q, blk.attn1.k = tq, tk
             # cross-attention to the (step-constant) context (ATT:689-726)
@@ -385,18 +405,18 @@ class ExactRunner:
             q = linear_x(layernorm_split3(t, *bw["ln"][1]), bw["w_q"], tap=tq, tap_cols=Ci)
             tk = torch.empty((B, L, Ci), dtype=F16, device=x.device) if dump else None
             kv = linear_x(ctx3, bw["w_kv"], tap=tk, tap_cols=Ci)
-            a = attention_x(q, kv, heads, B, N, L)
-            t = add(linear_x(split3(a), bw["w_o2"], bw["b_o2"]), t)
+            a3 = attention_x(q, kv, heads, B, N, L, split_out=True)
+            t = linear_x(a3, bw["w_o2"], bw["b_o2"], residual=t)
             if dump:
                 blk.attn2.q, blk.attn2.k = tq, tk
             # GEGLU feed-forward (ATT:728-757, :89-115)
             y = linear_x(layernorm_split3(t, *bw["ln"][2]), bw["w_ff1"], bw["b_ff1"])
-            t = add(linear_x(geglu_split3(y), bw["w_ff2"], bw["b_ff2"]), t)
+            t = linear_x(geglu_split3(y), bw["w_ff2"], bw["b_ff2"], residual=t)
             if "time" in e:                                                                            # VA:429-476
                 T = self.T
                 tm = self.time_block(m.time_stack[i], e["time"][i], add_rowvec(t, self.frame_emb(m, e, T), N), self.tctx3, T, dump)
                 t = blend(t, tm, e["alpha"])
-        out = add(linear_x(split3(t), e["w_out"], e["b_out"]), x.view(B, N, C))                        # ATT:921-927
+        out = linear_x(split3(t), e["w_out"], e["b_out"], residual=x.view(B, N, C))                    # ATT:921-927
         return out.view(B, H, W, C)
 
     def block(self, blk, x, x_skip, emb_all, ctx3):
