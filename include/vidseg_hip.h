@@ -258,6 +258,8 @@ int vidseg_gemm_profile_bytes(double* out);
  * OAI:267-271, 302-315; LayerNorm ATT:609-759; GEGLU ATT:89-96; scaled-dot-product attention ATT:352-356.  The bf16 build exports
  * the symbols and returns VS_ERR_UNSUPPORTED. */
 int vidseg_x_split3(const float* x, long long M, int C, int silu, void* out_f16 /* [M][3C] */, vidseg_stream_t stream);
+int vidseg_x_split3_cat(const float* x0 /* [M][C0] */, const float* x1 /* [M][C1] */, long long M, int C0, int C1,
+                        void* out_f16 /* [M][3 (C0 + C1)]: split3 of the channel concat */, vidseg_stream_t stream);
 int vidseg_x_geglu_split3(const float* y /* [M][2*inner]: value | gate */, long long M, int inner, void* out_f16 /* [M][3*inner] */,
                           vidseg_stream_t stream);
 int vidseg_x_groupnorm_split3(const float* x0, const float* x1 /* opt: channel concat */, int C0, int C1, int B, int HW, int G,

@@ -49,6 +49,8 @@ def test_split3_reconstructs_22_bits(X):
         assert torch.equal(hi, hi2) and torch.equal(hi, x.half())
         rec = hi.double() + lo.double()
         assert float((rec - x.double()).abs().max()) <= max(2.0 ** -21 * scale * 6, 2.0 ** -24), scale
+    a, b = rnd((9, 7, 128), 3), rnd((9, 7, 64), 4, 20.0)
+    assert torch.equal(X.split3_cat(a.to(dev), b.to(dev)).cpu(), X.split3(torch.cat([a, b], -1).to(dev)).cpu())
     y = X.split3(rnd((5, 64), 2).to(dev), silu=True).cpu()
     ref = TF.silu(rnd((5, 64), 2).double())
     assert rel(y[:, :64].double() + y[:, 64:128].double(), ref) <= 2e-6

@@ -1441,12 +1441,12 @@ int vidseg_kpp_round(const void* x16, const double* mean, const double* xsq, int
     const int ntiles = (int)cdiv64(n, TS);
     RowsF16 X{(const f16*)x16, nullptr, mean, n, C};
     if (c > 0) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)k_kpp_pick, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-            attr = true;
+        static int lds_ok = -1;                                        // 0: the device refused 120 KB of dynamic LDS -> distances stay in global memory
+        if (lds_ok < 0) {
+            lds_ok = hipFuncSetAttribute((const void*)k_kpp_pick, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
+            (void)hipGetLastError();
         }
-        const int staged = n * 8 <= 120 * 1024;                        // 14336 tokens: 112 KB
+        const int staged = lds_ok && n * 8 <= 120 * 1024;              // 14336 tokens: 112 KB
         k_kpp_pick<<<dim3(R), 1024, staged ? (size_t)n * 8 : 0, st>>>(n, R, K, c, Tprev, Tnext, u, ustride, closest, dcand, part, ntiles, pot, cand,
                                                                    center_ids, Tmax, staged);
         VS_CHECK_LAUNCH("kpp_pick");

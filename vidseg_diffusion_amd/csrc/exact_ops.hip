@@ -54,6 +54,30 @@ __global__ void __launch_bounds__(256) k_x_split3(const float* __restrict__ x, l
     *reinterpret_cast<f16x4*>(o + 2 * C) = h;
 }
 
+// the same for the channel concat of two sources (the ResBlock skip convolution's input, openaimodel.py:912): x0 [M][C0], x1 [M][C1]
+// -> [M][3 (C0 + C1)] without materialising the concat
+__global__ void __launch_bounds__(256) k_x_split3_cat(const float* __restrict__ x0, const float* __restrict__ x1, long long M, int C0, int C1,
+                                                      f16* __restrict__ out) {
+    const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int C = C0 + C1, c4n = C / 4;
+    if (i4 >= M * c4n) return;
+    const long long m = i4 / c4n;
+    const int c = (int)(i4 - m * c4n) * 4;
+    const f32x4 v = c < C0 ? *reinterpret_cast<const f32x4*>(x0 + m * C0 + c) : *reinterpret_cast<const f32x4*>(x1 + m * C1 + (c - C0));
+    f16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f16 a, b;
+        split_hl(v[j], a, b);
+        h[j] = a;
+        l[j] = b;
+    }
+    f16* o = out + m * 3 * C + c;
+    *reinterpret_cast<f16x4*>(o) = h;
+    *reinterpret_cast<f16x4*>(o + C) = l;
+    *reinterpret_cast<f16x4*>(o + 2 * C) = h;
+}
+
 // GEGLU (attention.py:89-96): y [M][2I] fp32, value = y[:, :I], gate = y[:, I:]  ->  split3(value * gelu_erf(gate)) [M][3I]
 __global__ void __launch_bounds__(256) k_x_geglu_split3(const float* __restrict__ y, long long M, int I, f16* __restrict__ out) {
     const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -651,6 +675,14 @@ int vidseg_x_split3(const float* x, long long M, int C, int silu, void* out16, h
     return VS_OK;
 }
 
+int vidseg_x_split3_cat(const float* x0, const float* x1, long long M, int C0, int C1, void* out16, hipStream_t st) {
+    VS_REQUIRE(C0 % 4 == 0 && C1 % 4 == 0 && x0 && x1, "x_split3_cat: C0=%d C1=%d", C0, C1);
+    if (M * (C0 + C1) == 0) return VS_OK;
+    k_x_split3_cat<<<X_GRID(M * ((C0 + C1) / 4)), 256, 0, st>>>(x0, x1, M, C0, C1, (f16*)out16);
+    VS_CHECK_LAUNCH("x_split3_cat");
+    return VS_OK;
+}
+
 int vidseg_x_add_rowvec_f32(const float* x, const float* vec, long long M, int C, int rows_per_sample, int nvec, float* out, hipStream_t st) {
     VS_REQUIRE(C % 4 == 0 && rows_per_sample > 0 && nvec > 0, "x_add_rowvec: C=%d rows_per_sample=%d nvec=%d", C, rows_per_sample, nvec);
     if (M * C == 0) return VS_OK;
@@ -737,6 +769,7 @@ int vidseg_x_attention_mfma(const float* q, int ldq, const void* k_hi, const voi
 #define X_UNSUPPORTED(name) VS_FAIL(VS_ERR_UNSUPPORTED, name ": the exact (split-fp16) mode needs the fp16 build of the library")
 int vidseg_x_split3(const float*, long long, int, int, void*, hipStream_t) { X_UNSUPPORTED("x_split3"); }
 int vidseg_x_geglu_split3(const float*, long long, int, void*, hipStream_t) { X_UNSUPPORTED("x_geglu_split3"); }
+int vidseg_x_split3_cat(const float*, const float*, long long, int, int, void*, hipStream_t) { X_UNSUPPORTED("x_split3_cat"); }
 int vidseg_x_add_rowvec_f32(const float*, const float*, long long, int, int, int, float*, hipStream_t) { X_UNSUPPORTED("x_add_rowvec_f32"); }
 int vidseg_x_groupnorm_rows_per_chunk(int HW) { return HW / 64 < 4 ? 4 : (HW / 64 > 64 ? 64 : HW / 64); }
 int vidseg_x_groupnorm_split3(const float*, const float*, int, int, int, int, int, const float*, const float*, float, int, float*, int, double*,

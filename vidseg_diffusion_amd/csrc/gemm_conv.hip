@@ -2146,16 +2146,26 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     if (ws_mode < 0) {
         const char* e = getenv("VIDSEG_GEMM_WS");
         ws_mode = e ? atoi(e) : 1;
-        (void)hipFuncSetAttribute((const void*)k_gemm_ws<10, 10, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 1024 + 8 * 8 * 164 * 4 + 640);
-        (void)hipFuncSetAttribute((const void*)k_gemm_ws<10, 10, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 1024 + 8 * 8 * 164 * 4 + 640);
-        (void)hipFuncSetAttribute((const void*)k_gemm_ws<10, 10, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 1024 + 8 * 8 * 164 * 4 + 640);
-        (void)hipFuncSetAttribute((const void*)k_gemm_ws<5, 20, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 20 * 1024 + 8 * 8 * 84 * 4 + 320);
-        (void)hipFuncSetAttribute((const void*)k_gemm_ws<5, 20, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 20 * 1024 + 8 * 8 * 84 * 4 + 320);
-        (void)hipFuncSetAttribute((const void*)k_gemm_ws<5, 20, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 20 * 1024 + 8 * 8 * 84 * 4 + 320);
+    }
+    // k_gemm_ws is written for this chip: a fixed grid of 256 persistent blocks laid out over 8 XCDs and ~142 KB of dynamic LDS.  On
+    // a device that does not offer that (fewer CUs, less LDS per block) or when the attribute call is refused, the launch goes to
+    // the tiled kernels instead of failing (or idling half a larger chip).
+    static int ws_fits = -1;
+    if (ws_fits < 0) {
+        int dev = 0, cus = 0, lds = 0;
+        ws_fits = hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+                  hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && cus == 256 &&
+                  lds >= 10 * 10 * 1024 + 8 * 8 * 164 * 4 + 640;
+        const size_t l320 = 10 * 10 * 1024 + 8 * 8 * 164 * 4 + 640, l640 = 5 * 20 * 1024 + 8 * 8 * 84 * 4 + 320;
+        const void* fns[6] = {(const void*)k_gemm_ws<10, 10, 0>, (const void*)k_gemm_ws<10, 10, 1>, (const void*)k_gemm_ws<10, 10, 2>,
+                              (const void*)k_gemm_ws<5, 20, 0>,  (const void*)k_gemm_ws<5, 20, 1>,  (const void*)k_gemm_ws<5, 20, 2>};
+        for (int i = 0; i < 6 && ws_fits; ++i)
+            if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(i < 3 ? l320 : l640)) != hipSuccess) ws_fits = 0;
+        (void)hipGetLastError();                                 // a refused attribute must not surface as this launch's error
     }
     const int ws_bn = p.K == 320 ? 160 : 80;
     const int ws_np = p.N / ws_bn;
-    const bool ws_ok = ws_mode && p.ksize == 1 && !p.x1 && p.C1 == 0 && p.C0 == p.K && (p.K == 320 || p.K == 640) && p.act != 2 &&
+    const bool ws_ok = ws_mode && ws_fits && p.ksize == 1 && !p.x1 && p.C1 == 0 && p.C0 == p.K && (p.K == 320 || p.K == 640) && p.act != 2 &&
                        p.tmode == 0 && p.N % ws_bn == 0 && ws_np >= 1 && ws_np <= 32 && (32 % ws_np) <= 2 &&
                        (ws_mode == 2 || (p.M >= 16384 && p.K == 320));     // VIDSEG_GEMM_WS=2: whenever legal (tests); K = 640 is
                                                                             // slower than k_gemm_p7 so far (28672x640x640: 54 vs 44 us)

@@ -34,6 +34,7 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 _lib.register({
     "vidseg_x_split3": [_P, _L, _I, _I, _P, _P],
     "vidseg_x_geglu_split3": [_P, _L, _I, _P, _P],
+    "vidseg_x_split3_cat": [_P, _P, _L, _I, _I, _P, _P],
     "vidseg_x_groupnorm_split3": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _L, _P, _P],
     "vidseg_x_groupnorm_rows_per_chunk": [_I],
     "vidseg_linear_a16_rf32": [_P, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
@@ -84,6 +85,14 @@ def split3(x, silu=False):
     C = x.shape[-1]
     out = torch.empty(x.shape[:-1] + (3 * C,), dtype=F16, device=x.device)
     call("vidseg_x_split3", ptr(x), x.numel() // C, C, int(silu), ptr(out), stream())
+    return out
+
+
+def split3_cat(x0, x1):
+    """split3 of the channel concat [x0 | x1] (fp32 [.., C0], [.., C1]) without materialising the concat."""
+    C0, C1 = x0.shape[-1], x1.shape[-1]
+    out = torch.empty(x0.shape[:-1] + (3 * (C0 + C1),), dtype=F16, device=x0.device)
+    call("vidseg_x_split3_cat", ptr(x0), ptr(x1), x0.numel() // C0, C0, C1, ptr(out), stream())
     return out
 
 
@@ -319,8 +328,7 @@ class ExactRunner:
         h = conv3x3_x(h, e["w1"], e["cb1"], rowvec=rv)                              # conv + bias + emb_out (OAI:353-365)
         h = groupnorm_split3(h, e["g2"], e["b2"], eps=1e-5, silu=True)
         if "ws" in e:
-            xin = x0 if x1 is None else torch.cat([x0, x1], dim=-1)
-            res = linear_x(split3(xin), e["ws"], e["bs"])                           # 1x1 skip conv on the concat (OAI:912, 369)
+            res = linear_x(split3(x0) if x1 is None else split3_cat(x0, x1), e["ws"], e["bs"])   # 1x1 skip conv on the concat (OAI:912, 369)
         else:
             if x1 is not None:
                 raise VidsegError("ResBlock: identity skip with a concatenated input")
