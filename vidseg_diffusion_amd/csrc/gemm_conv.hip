@@ -145,13 +145,42 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 // consecutive columns of one row per pass, 64 cells per pass in row-major cell order (NC8 = 4 / 8: 16 / 8 rows per pass, the
 // original layout; NC8 = 10: the 80-column wave tile of k_gemm_p7).
 // `pre` = the staged values still need bias / per-sample vector / SiLU (everything but GEGLU, which is lane-local in phase 1).
-template <int NC8, int EP_LD>
+// The 16-bit residual cells of all U cells a lane owns in one staged group (U = 5 for the 32 x 80 group of k_gemm_p7, 4 / 2 for the
+// 64- / 32-column groups) are requested before the first cell is worked on; the cell loop itself stays rolled (unrolled it spilled
+// next to the 140 live accumulators) and picks its cell's registers by the uniform loop counter.  One cell at a time, every cell
+// paid its own residual round trip (the load sits behind the tap stores, which the compiler must assume may alias it) -- with the 8
+// waves of a CU all in the epilogue nothing else covered those ~1000 cycles, 20 times per tile.
+#ifndef VS_EPI_PRELOAD
+#define VS_EPI_PRELOAD 1                                       // 0: A/B builds without the residual preload (tools/build_exp.py)
+#endif
+template <int NC8, int EP_LD, int U_ = (32 * NC8 + 63) / 64, bool PRELOAD = (VS_EPI_PRELOAD != 0)>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* stage, int mrow0, int nrows, int ocol0, int nout, int lane,
                                               int split, bool fin, bool pre) {
+    constexpr int U = PRELOAD ? U_ : 1;                        // without the preload: the plain one-cell-at-a-time loop
+    static_assert(U <= 5, "epilogue_rows: five residual register sets");
     const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
     const int ncell = nrows * NC8;
+    const bool res16 = PRELOAD && fin && p.residual && !p.res_f32;    // PRELOAD = false: kernels capped at 128 registers (4 blocks per CU)
 #pragma nounroll
-    for (int cell = lane; cell < ncell; cell += 64) {
+    for (int cell0 = lane; cell0 < ncell; cell0 += 64 * U) {
+        bf16x8_t rr0 = {0, 0, 0, 0, 0, 0, 0, 0}, rr1 = rr0, rr2 = rr0, rr3 = rr0, rr4 = rr0;
+        if (res16) {
+            auto ld = [&](int u, bf16x8_t& r) {
+                const int cell = cell0 + 64 * u;
+                const int row = cell / NC8, c8 = (cell - row * NC8) * 8;
+                const int n = ocol0 + c8, m = mrow0 + row;
+                if (u < U && cell < ncell && n < nout && m < (int)p.M) r = *reinterpret_cast<const bf16x8_t*>(p.residual + (long long)m * p.ldr + n);
+            };
+            ld(0, rr0);
+            ld(1, rr1);
+            ld(2, rr2);
+            ld(3, rr3);
+            ld(4, rr4);
+        }
+#pragma nounroll
+        for (int u = 0; u < U; ++u) {
+        const int cell = cell0 + 64 * u;
+        if (cell >= ncell) continue;
         const int row = cell / NC8, c8 = (cell - row * NC8) * 8;
         const int n = ocol0 + c8;                               // output column of element 0
         if (n >= nout) continue;
@@ -215,19 +244,25 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
             else if (p.tap2)
                 *reinterpret_cast<f16x8*>(p.tap2 + tr + (n - p.tap_cols)) = t;
         }
-        if (p.residual) {
-            if (p.res_f32) {
-                const float* rp = reinterpret_cast<const float*>(p.residual) + (long long)m * p.ldr + n;
-                const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+        if (res16) {
+            bf16x8_t rr = rr0;                                  // u is uniform: scalar selects
+            if (u == 1) rr = rr1;
+            if (u == 2) rr = rr2;
+            if (u == 3) rr = rr3;
+            if (u == 4) rr = rr4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] += r0[e];
-                    v[4 + e] += r1[e];
-                }
-            } else {
-                const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + (long long)m * p.ldr + n);
+            for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
+        } else if (p.residual && !p.res_f32) {
+            const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + (long long)m * p.ldr + n);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
+            for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
+        } else if (p.residual) {
+            const float* rp = reinterpret_cast<const float*>(p.residual) + (long long)m * p.ldr + n;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] += r0[e];
+                v[4 + e] += r1[e];
             }
         }
         const long long oo = (long long)m * p.ldo + n;
@@ -245,6 +280,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
             *reinterpret_cast<f32x4*>(p.out_f32 + oo) = f32x4{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(p.out_f32 + oo + 4) = f32x4{v[4], v[5], v[6], v[7]};
         }
+        }
     }
 }
 
@@ -252,10 +288,11 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
 // which needs value and gate of the same lane) is selected by a uniform switch, phase 2 exists once.  Unrolled, the epilogue was
 // ~40 k instructions per kernel and instruction-fetch bound (10 us per 256 x 320 tile); bias, per-sample vector and SiLU moved to
 // phase 2 (same order of fp32 operations as before: + bias, + vector, SiLU, + rowadd, + residual).
-template <int NJ, int MI = 2>
+template <int NJ, int MI = 2, bool PRELOAD_ = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[MI][NJ], char* smem, long long mrow_base, int wcol_base,
                                               int lane, int wave, int split) {
     const int l31 = lane & 31, hi = lane >> 5;
+    constexpr bool PRELOAD = PRELOAD_ && (VS_EPI_PRELOAD != 0);
     constexpr int EP_LD = 68;                                  // fp32 row stride of the staging tile (64 + 4 pad)
     constexpr int NG = (NJ + 1) / 2;
     float* stage = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
@@ -305,9 +342,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         __builtin_amdgcn_wave_barrier();
         // ---- phase 2: 8 columns per lane, coalesced 16-byte global accesses
         if (geglu || !two)
-            epilogue_rows<4, EP_LD>(p, stage, mrow0, 32, geglu ? wcol0 / 2 : wcol0, nout, lane, split, fin, !geglu);
+            epilogue_rows<4, EP_LD, 2, PRELOAD>(p, stage, mrow0, 32, geglu ? wcol0 / 2 : wcol0, nout, lane, split, fin, !geglu);
         else
-            epilogue_rows<8, EP_LD>(p, stage, mrow0, 32, wcol0, nout, lane, split, fin, true);
+            epilogue_rows<8, EP_LD, 4, PRELOAD>(p, stage, mrow0, 32, wcol0, nout, lane, split, fin, true);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
@@ -686,7 +723,7 @@ __global__ void __launch_bounds__(256, NST == 2 ? 4 : 3) k_gemm_dma(GemmParams p
             ib = ib == 2 ? 0 : ib + 1;
         }
     }
-    gemm_epilogue<2>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, lane, wave, split);
+    gemm_epilogue<2, 2, NST != 2>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, lane, wave, split);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -867,7 +904,7 @@ __global__ void __launch_bounds__(WM * 128, MI == 1 ? 4 : (WM == 4 ? 1 : 2)) k_g
         __syncthreads();
     }
     compute((nk - 1) & 1);
-    gemm_epilogue<NJ, MI>(p, acc, smem, m0 + wm * (MI * 32), n0 + wn * (NJ * 32), lane, wave, split);
+    gemm_epilogue<NJ, MI, MI != 1>(p, acc, smem, m0 + wm * (MI * 32), n0 + wn * (NJ * 32), lane, wave, split);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1984,7 +2021,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                epilogue_rows<NJ * 2, EP_LD>(p, stage, t * 32 + 16 * i + 8 * h, 8, pbase, p.N, lane, 0, true, true);
+                epilogue_rows<NJ * 2, EP_LD, (8 * NJ * 2 + 63) / 64>(p, stage, t * 32 + 16 * i + 8 * h, 8, pbase, p.N, lane, 0, true, true);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
