@@ -637,7 +637,16 @@ def main():
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 mm = timed_masks_vs_reference(list(run_steps.record), refine, k_masks)
+                two = None
+                if not args.no_overlap and args.lanes == 1:              # the same windows with two feature passes in flight
+                    run_steps(2, nl=2)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    run_steps(n, nl=2)
+                    torch.cuda.synchronize()
+                    two = round(F_WIN * n / (time.perf_counter() - t1), 3)
                 out["exact_mode"] = {"value": round(F_WIN * n / dt, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n, 3), "steps": n,
+                                     "two_lanes_value": two,
                                      "mask_iou_vs_reference": {k: mm[k] for k in ("mean_iou", "min_iou", "windows_at_0.99", "n_windows",
                                                                                   "mean_identical_fraction")} if mm else None,
                                      "note": "UNetModel.set_precision('exact'): every activation in fp32, every conv / linear ONE call of the same "

@@ -393,8 +393,8 @@ def test_temporal_attention_T14(dev, Bv, T, S, H):
     `(b t) s c -> (b s) t c` (video_attention.py:171-196) -- on rows kept in the spatial order (b t) s."""
     from vidseg_diffusion_amd import ops
     C = H * 64
-    q, k, v = rnd((Bv * T, S, C), 31), rnd((Bv * T, S, C), 32), rnd((Bv * T, S, C), 33)
     ad = ops.act_dtype()
+    q, k, v = (rnd((Bv * T, S, C), sd).to(ad).float() for sd in (31, 32, 33))       # the bar is against fp32 of the SAME 16-bit inputs
     out = ops.temporal_attention(q.to(ad).to(dev), k.to(ad).to(dev), v.to(ad).to(dev), H, Bv, T, S)
     assert tuple(out.shape) == (Bv * T, S, C)
     tl = lambda t: t.view(Bv, T, S, H, 64).permute(0, 2, 3, 1, 4).reshape(Bv * S, H, T, 64)          # noqa: E731  -> (b s) h t d

@@ -90,6 +90,53 @@ def test_two_ranks_equal_sequential_windows():
         assert np.array_equal(res[r], seq), f"rank {r}: sharded labels differ from the sequential window loop"
 
 
+def _rccl_worker(port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)           # "nccl" IS RCCL on ROCm
+    from vidseg_diffusion_amd import parallel
+    from vidseg_diffusion_amd.pipeline import segment_window
+    eng = _setup(dev)
+    lat, c, uc, noise = _inputs(0, dev)
+    ref, _ = segment_window(eng, lat, c, uc, num_masks=K, is_refine_mask=True, seed=17, noise=noise, feature_folder="/nonexistent/rc",
+                            exp_name="ref")
+    # the sharded path proper with a group of one: every collective of resolve_windows goes through RCCL on device buffers
+    h = parallel.sharded_feature_pass(eng, lat, c, uc, noise=noise, seed=17, rank=0, feature_folder="/nonexistent/rc", exp_name="r0")
+    got = parallel.sharded_resolve(eng, h, num_masks=K, is_refine_mask=True, rank=0, world=1)
+    assert got.shape[0] == 1 and np.array_equal(got[0], ref), "sharded path over RCCL (world 1) differs from segment_window"
+    os.environ["VIDSEG_CHECK_RANKS"] = "1"                                          # + the int64 checksum all-gather
+    pipe = parallel.ShardedPipeline(eng, 0, 1, num_masks=K, is_refine_mask=True)    # collectives on the side stream
+    assert pipe.push(lat, c, uc, noise=noise, seed=17, feature_folder="/nonexistent/rc", exp_name="p0a") is None
+    first = pipe.push(lat, c, uc, noise=noise, seed=17, feature_folder="/nonexistent/rc", exp_name="p0b")
+    second = pipe.flush()
+    assert np.array_equal(first[0], ref) and np.array_equal(second[0], ref)
+    t = torch.tensor([1.5], device=dev, dtype=torch.float64)                        # bench.py's max-over-ranks of the step time
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    torch.cuda.synchronize()
+    q.put(float(t.item()))
+    dist.destroy_process_group()
+
+
+def test_sharded_path_over_rccl_with_one_rank():
+    """One box has one GPU, so RCCL cannot run two ranks here -- but a group of ONE over backend "nccl" still sends every collective of
+    the sharded path (fp16 feature all-gather, int32 index / track all-gathers, the int64 checksum, barrier, float64 max all-reduce)
+    through RCCL on device buffers and on the side stream: API, dtype and stream-semantics errors of the N > 1 path show up here."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    assert q.get(timeout=600) == 1.5
+    p.join(timeout=120)
+    assert p.exitcode == 0
+
+
 def test_bench_gpus_flag_starts_the_ranks():
     """`python bench.py --gpus 2` called directly (the driver's call) on a one-GPU box: both ranks on cuda:0, gloo collectives.
     The line must say n_gpus = 2 = the size of the group that was formed, and count two windows per step."""

@@ -4,6 +4,8 @@ T=${1:-r03_c}
 mkdir -p gpurun_out/$T
 ( time timeout 2400 python -m pytest tests -m gpu -q -s > gpurun_out/$T/pytest_gpu.log 2>&1 ) 2> gpurun_out/$T/pytest_time.txt
 tail -5 gpurun_out/$T/pytest_gpu.log; cat gpurun_out/$T/pytest_time.txt | tail -3
+( time VIDSEG_ACT=bf16 timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/$T/pytest_gpu_bf16.log 2>&1 ) 2>> gpurun_out/$T/pytest_time.txt
+tail -2 gpurun_out/$T/pytest_gpu_bf16.log
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/$T/bench.json 2> gpurun_out/$T/bench.err
 tail -c 800 gpurun_out/$T/bench.json
 cd /tmp && export TMPDIR=/tmp
