@@ -28,7 +28,7 @@ for d, n, c, v, s, e in rows:
     durs[d] = float(e - s)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for d, cs in per.items():
-    if not any(k in names[d] for k in ("k_gemm", "k_attention")):
+    if not any(k in names[d] for k in ("k_gemm", "attention")):
         continue
     a = agg[names[d]]
     a["launches"] += 1
