@@ -135,9 +135,12 @@ def split_planes(x):
     """fp32 [.., cols] (a column slice of a row-major buffer) -> fp16 planes hi = fp16(x), lo = fp16(x - hi), contiguous [.., cols]."""
     cols = x.shape[-1]
     rows = x.numel() // cols
+    ld = x.stride(-2) if x.dim() > 1 else cols
+    if x.dtype != F32 or x.stride(-1) != 1 or any(x.stride(i) != x.stride(i + 1) * x.shape[i + 1] for i in range(x.dim() - 2)):
+        raise VidsegError("split_planes: needs an fp32 column slice of a row-major buffer (rows at one constant stride)")
     hi = torch.empty(x.shape, dtype=F16, device=x.device)
     lo = torch.empty(x.shape, dtype=F16, device=x.device)
-    call("vidseg_x_split_planes", x.data_ptr(), x.stride(-2), rows, cols, ptr(hi), ptr(lo), stream())
+    call("vidseg_x_split_planes", x.data_ptr(), ld, rows, cols, ptr(hi), ptr(lo), stream())
     return hi, lo
 
 
