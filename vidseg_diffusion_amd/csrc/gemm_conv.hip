@@ -10,6 +10,7 @@
 // block tile 128x128 (2x2 waves) or 256x64 (4x1 waves), BK = 64, LDS double buffer with a 16-byte-slot XOR
 // swizzle, global->register prefetch of the next K chunk issued before the MFMAs of the current one.
 #include "common.h"
+#include <hip/hip_ext.h>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -2168,11 +2169,27 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     if (force < 0) { const char* e = getenv("VIDSEG_GEMM_TILE"); force = e ? atoi(e) : 0; }
     bool narrow = p.N <= 64 && p.act != 2 && p.M >= 256;
     if (force == 128) narrow = false;
+    // Timing (bench.py roofline): by default the two events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL: start /
+    // stop timestamps of the kernel, what rocprofv3 reports; with a split-K finish the stop event rides on the finish kernel).
+    // VIDSEG_PROF_EXT=0: two hipEventRecord calls around the launch instead -- two extra barrier packets per launch, which cost the
+    // window 1.7 ms and read ~9 us per launch more than the kernel trace.
+    static int prof_ext = -1;
+    if (prof_ext < 0) { const char* e = getenv("VIDSEG_PROF_EXT"); prof_ext = e ? atoi(e) : 1; }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (g_prof.on) {
-        (void)hipEventRecord(prof_event(), st);
+        ev0 = prof_event();
+        ev1 = prof_event();
+        if (!prof_ext) (void)hipEventRecord(ev0, st);
         g_prof.flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
         g_prof.launches++;
     }
+    const bool ext = g_prof.on && prof_ext;
+    auto launch = [&](auto kern, dim3 grid, unsigned block, size_t lds, auto... args) {
+        if (ext)
+            hipExtLaunchKernelGGL(kern, grid, dim3(block), (unsigned)lds, st, ev0, p.ksplit > 1 ? nullptr : ev1, 0, args...);
+        else
+            hipLaunchKernelGGL(kern, grid, dim3(block), (unsigned)lds, st, args...);
+    };
     p.ksplit = 1;
     p.ws = nullptr;
     int kind = 0;                                              // 0: 128x128, 1: big, 2: mid, 3: narrow (profile log only)
@@ -2213,18 +2230,18 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         const int epi = !plain ? 0 : (p.residual ? 2 : 1);
         const size_t l320 = 10 * 10 * 1024 + 8 * 8 * 164 * 4 + 640, l640 = 5 * 20 * 1024 + 8 * 8 * 84 * 4 + 320;
         if (p.K == 320) {
-            if (epi == 0) k_gemm_ws<10, 10, 0><<<dim3(256), 512, l320, st>>>(p, ws_np, cpx);
-            else if (epi == 1) k_gemm_ws<10, 10, 1><<<dim3(256), 512, l320, st>>>(p, ws_np, cpx);
-            else k_gemm_ws<10, 10, 2><<<dim3(256), 512, l320, st>>>(p, ws_np, cpx);
+            if (epi == 0) launch(k_gemm_ws<10, 10, 0>, dim3(256), 512, l320, p, ws_np, cpx);
+            else if (epi == 1) launch(k_gemm_ws<10, 10, 1>, dim3(256), 512, l320, p, ws_np, cpx);
+            else launch(k_gemm_ws<10, 10, 2>, dim3(256), 512, l320, p, ws_np, cpx);
         } else {
-            if (epi == 0) k_gemm_ws<5, 20, 0><<<dim3(256), 512, l640, st>>>(p, ws_np, cpx);
-            else if (epi == 1) k_gemm_ws<5, 20, 1><<<dim3(256), 512, l640, st>>>(p, ws_np, cpx);
-            else k_gemm_ws<5, 20, 2><<<dim3(256), 512, l640, st>>>(p, ws_np, cpx);
+            if (epi == 0) launch(k_gemm_ws<5, 20, 0>, dim3(256), 512, l640, p, ws_np, cpx);
+            else if (epi == 1) launch(k_gemm_ws<5, 20, 1>, dim3(256), 512, l640, p, ws_np, cpx);
+            else launch(k_gemm_ws<5, 20, 2>, dim3(256), 512, l640, p, ws_np, cpx);
         }
     } else if (narrow) {
         kind = 3;
         const long long tiles = ((p.M + 255) / 256) * ((p.N + 63) / 64);
-        k_gemm_conv<256, 64><<<dim3((unsigned)tiles), 256, 2 * (256 + 64) * BK * 2, st>>>(p);
+        launch(k_gemm_conv<256, 64>, dim3((unsigned)tiles), 256, 2 * (256 + 64) * BK * 2, p);
     } else {
         const int nk = p.K / BK;
         static int nosplit = -1, use_dma = -1, big_mode = -1, mid_mode = -1, ph_mode = 0, p7_mode = 1, p7_phases = 5;
@@ -2338,31 +2355,31 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             p.gn = pick_gn(224, 320, 32, S);
             const long long tiles_7 = ((p.M + 223) / 224) * ((p.N + 319) / 320);
             if (p7_phases == 3)
-                k_gemm_p7<3><<<dim3((unsigned)(tiles_7 * S)), 512, 2 * (256 + 320) * 128, st>>>(p);
+                launch(k_gemm_p7<3>, dim3((unsigned)(tiles_7 * S)), 512, 2 * (256 + 320) * 128, p);
             else
-                k_gemm_p7<5><<<dim3((unsigned)(tiles_7 * S)), 512, 2 * (256 + 320) * 128, st>>>(p);
+                launch(k_gemm_p7<5>, dim3((unsigned)(tiles_7 * S)), 512, 2 * (256 + 320) * 128, p);
             kind = 4;
         } else if (big) {
             p.ksplit = S;
             p.ws = S > 1 ? g_ws : nullptr;
             p.gn = pick_gn(256, NJ * 64, 32, S);
             if (ph_mode && NJ == 5)
-                k_gemm_ph<5><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 320) * 128, st>>>(p);
+                launch(k_gemm_ph<5>, dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 320) * 128, p);
             else if (ph_mode)
-                k_gemm_ph<4><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 256) * 128, st>>>(p);
+                launch(k_gemm_ph<4>, dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 256) * 128, p);
             else if (NJ == 5)
-                k_gemm_tile<5, 4, 64><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 320) * 128, st>>>(p);
+                launch(k_gemm_tile<5, 4, 64>, dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 320) * 128, p);
             else
-                k_gemm_tile<4, 4, 64><<<dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 256) * 128, st>>>(p);
+                launch(k_gemm_tile<4, 4, 64>, dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 256) * 128, p);
             kind = 1;
         } else if (mid_mode && p.M >= 128 && (mid_mode == 2 || mid_ok)) {
             p.ksplit = 1;
             p.ws = nullptr;
             p.gn = pick_gn(128, NJ * 64, 64, 1);
             if (NJ == 5)
-                k_gemm_tile<5, 4, 32, 1><<<dim3((unsigned)tiles_mid), 512, MID_LDS, st>>>(p);
+                launch(k_gemm_tile<5, 4, 32, 1>, dim3((unsigned)tiles_mid), 512, MID_LDS, p);
             else
-                k_gemm_tile<4, 4, 32, 1><<<dim3((unsigned)tiles_mid), 512, MID_LDS, st>>>(p);
+                launch(k_gemm_tile<4, 4, 32, 1>, dim3((unsigned)tiles_mid), 512, MID_LDS, p);
             kind = 2;
         } else {
             S = pick_split(tiles, 512);
@@ -2372,19 +2389,22 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             // grids that do not fill the 4 x 256 block slots gain from two K-steps in flight per block (measured -10..-20 %);
             // full grids prefer the fourth resident block (VIDSEG_GEMM_DMA=3 forces the 3-stage variant everywhere)
             if (use_dma == 3 || (use_dma == 1 && tiles * S <= 512 && p.act != 2))
-                k_gemm_dma<3><<<dim3((unsigned)(tiles * S)), 256, 49152, st>>>(p);
+                launch(k_gemm_dma<3>, dim3((unsigned)(tiles * S)), 256, 49152, p);
             else if (use_dma)
-                k_gemm_dma<2><<<dim3((unsigned)(tiles * S)), 256, 36864, st>>>(p);
+                launch(k_gemm_dma<2>, dim3((unsigned)(tiles * S)), 256, 36864, p);
             else
-                k_gemm_conv<128, 128><<<dim3((unsigned)(tiles * S)), 256, 2 * (128 + 128) * BK * 2, st>>>(p);
+                launch(k_gemm_conv<128, 128>, dim3((unsigned)(tiles * S)), 256, 2 * (128 + 128) * BK * 2, p);
         }
         if (p.ksplit > 1) {
             const long long n8 = p.M * (p.N / 8);
-            k_splitk_finish<<<dim3((unsigned)((n8 + 255) / 256)), 256, 0, st>>>(p);
+            if (ext)
+                hipExtLaunchKernelGGL(k_splitk_finish, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, nullptr, ev1, 0, p);
+            else
+                k_splitk_finish<<<dim3((unsigned)((n8 + 255) / 256)), 256, 0, st>>>(p);
         }
     }
     if (g_prof.on) {
-        (void)hipEventRecord(prof_event(), st);
+        if (!prof_ext) (void)hipEventRecord(ev1, st);
         const double n_out = p.act == 2 ? p.N / 2 : p.N;
         double ab = (double)p.x0_bytes + (double)p.x1_bytes + 2.0 * (double)p.N * (double)p.K;
         if (p.residual) ab += (p.res_f32 ? 4.0 : 2.0) * (double)p.M * n_out;
