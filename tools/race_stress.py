@@ -1,0 +1,94 @@
+"""Bitwise stability of the GEMM / attention / norm kernels while another stream keeps the memory system and some CUs busy (GPU box).
+Hand-counted vmcnt schedules read an LDS buffer as soon as their count says the DMA has landed: a count that is one short passes every
+quiet run and fails when a load arrives late.  Every op is run `--iters` times beside a stream of large copies and small f64 kernels;
+each result is compared bit for bit with the first.        python tools/race_stress.py [--iters 200]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from vidseg_diffusion_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=200)
+ap.add_argument("--quiet", action="store_true", help="no background stream")
+args = ap.parse_args()
+ad = ops.act_dtype()
+B = 28
+g = torch.Generator(device="cpu").manual_seed(3)
+
+
+def rn(*shape, s=1.0):
+    return (torch.randn(*shape, generator=g) * s).to(dev)
+
+
+cases = []
+
+
+def conv(H, Cin, Cout, C1=0, up=1, res=False):
+    x0 = rn(B, H, H, Cin).to(ad)
+    x1 = rn(B, H, H, C1).to(ad) if C1 else None
+    w = ops.pack_conv3x3(rn(Cout, Cin + C1, 3, 3, s=0.02).cpu(), dev)
+    b = rn(Cout)
+    r = rn(B, H * up, H * up, Cout).to(ad) if res else None
+    cases.append((f"conv H{H} {Cin}+{C1}->{Cout} up{up} res{int(res)}", lambda: ops.conv3x3(x0, w, b, x1=x1, up=up, residual=r)))
+
+
+def lin(M, K, N, act=0, res=False):
+    a = rn(M, K).to(ad)
+    w = (ops.pack_geglu(rn(N, K, s=0.02).cpu(), torch.zeros(N), dev)[0] if act == 2 else ops.pack_linear(rn(N, K, s=0.02).cpu(), dev))
+    b = rn(N)
+    r = rn(M, N).to(ad) if res else None
+    cases.append((f"linear M{M} K{K} N{N} act{act} res{int(res)}", lambda: ops.linear(a, w, b, act=act, residual=r)))
+
+
+def attn(N, H):
+    q, k, v = (rn(B, N, H * 64).to(ad) for _ in range(3))
+    cases.append((f"attention N{N} H{H}", lambda: ops.attention(q, k, v, H)))
+
+
+conv(64, 320, 320, res=True); conv(64, 640, 320, 320); conv(32, 640, 640, res=True); conv(32, 1280, 640, 640); conv(16, 1280, 1280, res=True)
+conv(16, 1280, 1280, 1280); conv(8, 1280, 1280, res=True); conv(32, 640, 640, up=2); conv(16, 1280, 1280, up=2)
+lin(114688, 320, 320); lin(114688, 320, 320, res=True); lin(114688, 320, 960); lin(114688, 320, 2560, act=2); lin(114688, 1280, 320, res=True)
+lin(28672, 640, 640, res=True); lin(28672, 640, 1920); lin(28672, 640, 5120, act=2); lin(28672, 2560, 640, res=True)
+lin(7168, 1280, 1280, res=True); lin(7168, 1280, 3840); lin(7168, 1280, 10240, act=2); lin(7168, 5120, 1280, res=True)
+lin(1792, 1280, 1280, res=True); lin(1792, 1280, 10240, act=2); lin(1792, 5120, 1280, res=True)
+attn(4096, 5); attn(1024, 10); attn(256, 20)
+
+side = torch.cuda.Stream()
+big_a = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+big_b = torch.empty_like(big_a)
+small = torch.randn(4096, 64, device=dev, dtype=torch.float64)
+stop = [False]
+
+
+def background(n):
+    with torch.cuda.stream(side):
+        for _ in range(n):
+            big_b.copy_(big_a)                                # 512 MB of HBM traffic
+            for _ in range(4):
+                (small @ small.t()).sum()                     # small f64 kernels: a few CUs at a time
+
+
+bad_total = 0
+for name, fn in cases:
+    ref = fn().clone()
+    torch.cuda.synchronize()
+    bad = 0
+    for it in range(args.iters):
+        if not args.quiet and it % 4 == 0:
+            background(2)
+        out = fn()
+        if not torch.equal(out, ref):
+            bad += 1
+            if bad <= 2:
+                d = (out.float() - ref.float()).abs()
+                print(f"   iter {it}: {int((d > 0).sum())} elements differ, max {float(d.max()):.4g}", flush=True)
+    torch.cuda.synchronize()
+    bad_total += bad
+    print(f"{name:48s} {'OK' if bad == 0 else f'{bad} of {args.iters} runs DIFFER'}", flush=True)
+print("unstable results:", bad_total)

@@ -309,6 +309,13 @@ class WindowPipeline:
             labels, state = analyse_window(self.engine, h, state=self.state if self.chain else WindowState(), **self.analysis_kw)
         if self.chain:
             self.state = state
+        if os.environ.get("VIDSEG_DEBUG_HASH"):                                      # run-to-run determinism hunts (tools/rep_bench.sh)
+            import hashlib
+            import sys
+            fm = state.ref_feature_map
+            fh_ = hashlib.sha256(fm.detach().cpu().numpy().tobytes()).hexdigest()[:12] if torch.is_tensor(fm) else "-"
+            print(f"HASH {h['exp_name']} features {fh_} masks {hashlib.sha256(np.ascontiguousarray(labels).tobytes()).hexdigest()[:12]}",
+                  file=sys.stderr, flush=True)
         FE.FeatureStore.clear(h["feature_folder"], h["exp_name"])                   # the window's dumps are no longer needed
         return labels
 
