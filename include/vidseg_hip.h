@@ -276,6 +276,10 @@ int vidseg_x_attention_f32(const float* q, int ldq, const float* k, int ldk, con
 int vidseg_linear_a16_rf32(const void* a, int K, long long M, const void* w, int N, const float* bias, const float* rowvec, int rv_stride,
                            int rows_per_sample, const float* residual_f32, int ldr, float* out_f32, int ldo, void* tap_f16, void* tap2_f16,
                            int tap_cols, int tap_ld, int act, vidseg_stream_t stream);
+/* GEGLU projection of the exact mode with the product value * gelu_erf(gate) formed in fp32 inside the epilogue and written as the FF
+ * output projection's split operand image (ATT:89-96); w / bias interleaved like the 16-bit GEGLU weights */
+int vidseg_linear_a16_geglu_x3(const void* a, int K, long long M, const void* w, int N, const float* bias,
+                               void* out_split3_f16 /* [M][3 * (N / 2)] */, vidseg_stream_t stream);
 int vidseg_conv3x3_a16_rf32(const void* x, int C, int B, int Hin, int Win, int stride, int up, const void* w, int Cout, const float* bias,
                             const float* rowvec, int rv_stride, const float* residual_f32, float* out_f32, vidseg_stream_t stream);
 /* the same attention on the matrix pipe: three fp16 MFMA products of split operands per contraction (fp32 accuracy).  q fp32; k / v as

@@ -41,6 +41,8 @@ struct GemmParams {
     bf16_t* out;             // [M][ldo] or nullptr
     int ldo;
     float* out_f32;          // [M][ldo] or nullptr
+    f16* out_split3;         // exact mode, GEGLU only (k_gemm_ph<4, true>): the result as the consumer's split operand image
+                             // [M][3 * ldo] = [hi | lo | hi], hi = fp16(x), lo = fp16(x - hi); or nullptr
     f16* tap;                // fp16 copy of columns [0, tap_cols) with leading dim tap_ld, or nullptr
     f16* tap2;               // fp16 copy of columns [tap_cols, 2*tap_cols) (same leading dim), or nullptr
     int tap_cols, tap_ld;
@@ -154,7 +156,7 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 #ifndef VS_EPI_PRELOAD
 #define VS_EPI_PRELOAD 1                                       // 0: A/B builds without the residual preload (tools/build_exp.py)
 #endif
-template <int NC8, int EP_LD, int U_ = (32 * NC8 + 63) / 64, bool PRELOAD = (VS_EPI_PRELOAD != 0)>
+template <int NC8, int EP_LD, int U_ = (32 * NC8 + 63) / 64, bool PRELOAD = (VS_EPI_PRELOAD != 0), bool X3 = false>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* stage, int mrow0, int nrows, int ocol0, int nout, int lane,
                                               int split, bool fin, bool pre) {
     constexpr int U = PRELOAD ? U_ : 1;                        // without the preload: the plain one-cell-at-a-time loop
@@ -281,6 +283,23 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
             *reinterpret_cast<f32x4*>(p.out_f32 + oo) = f32x4{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(p.out_f32 + oo + 4) = f32x4{v[4], v[5], v[6], v[7]};
         }
+        if constexpr (X3) {
+            if (p.out_split3) {
+                f16x8 h8, l8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = v[e];
+                    asm volatile("" : "+v"(x));                 // one fp32 value for both lines (see exact_ops.hip: split_hl)
+                    const f16 hh = (f16)x;
+                    h8[e] = hh;
+                    l8[e] = (f16)(x - (float)hh);
+                }
+                f16* o3 = p.out_split3 + (long long)m * 3 * p.ldo + n;
+                *reinterpret_cast<f16x8*>(o3) = h8;
+                *reinterpret_cast<f16x8*>(o3 + p.ldo) = l8;
+                *reinterpret_cast<f16x8*>(o3 + 2 * p.ldo) = h8;
+            }
+        }
         }
     }
 }
@@ -289,7 +308,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
 // which needs value and gate of the same lane) is selected by a uniform switch, phase 2 exists once.  Unrolled, the epilogue was
 // ~40 k instructions per kernel and instruction-fetch bound (10 us per 256 x 320 tile); bias, per-sample vector and SiLU moved to
 // phase 2 (same order of fp32 operations as before: + bias, + vector, SiLU, + rowadd, + residual).
-template <int NJ, int MI = 2, bool PRELOAD_ = true>
+template <int NJ, int MI = 2, bool PRELOAD_ = true, bool X3 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[MI][NJ], char* smem, long long mrow_base, int wcol_base,
                                               int lane, int wave, int split) {
     const int l31 = lane & 31, hi = lane >> 5;
@@ -324,7 +343,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        stage[row * EP_LD + l31] = (acc[ki][2 * kg][r] + bx) * gelu_erf(acc[ki][2 * kg + 1][r] + bg);
+                        if constexpr (X3) {                 // the exact mode's GELU: libm erf, the operation order of k_x_geglu_split3
+                            const float gt = acc[ki][2 * kg + 1][r] + bg;
+                            stage[row * EP_LD + l31] = (acc[ki][2 * kg][r] + bx) * (0.5f * gt * (1.0f + erff(gt * 0.70710678118654752440f)));
+                        } else {
+                            stage[row * EP_LD + l31] = (acc[ki][2 * kg][r] + bx) * gelu_erf(acc[ki][2 * kg + 1][r] + bg);
+                        }
                     }
                 }
             } else {
@@ -343,7 +367,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         __builtin_amdgcn_wave_barrier();
         // ---- phase 2: 8 columns per lane, coalesced 16-byte global accesses
         if (geglu || !two)
-            epilogue_rows<4, EP_LD, 2, PRELOAD>(p, stage, mrow0, 32, geglu ? wcol0 / 2 : wcol0, nout, lane, split, fin, !geglu);
+            epilogue_rows<4, EP_LD, 2, PRELOAD, X3>(p, stage, mrow0, 32, geglu ? wcol0 / 2 : wcol0, nout, lane, split, fin, !geglu);
         else
             epilogue_rows<8, EP_LD, 4, PRELOAD>(p, stage, mrow0, 32, wcol0, nout, lane, split, fin, true);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -925,7 +949,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int NJ>
+template <int NJ, bool X3 = false>
 __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 256, BN = NJ * 64, RB = 128;
@@ -1135,7 +1159,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
 #if PH_EXP & 64                                                // experiment: no epilogue (one store keeps the accumulators alive)
     if (acc[0][0][0] == 123.456f) p.out[0] = 1;
 #else
-    gemm_epilogue<NJ, 2>(p, acc, smem, m0 + wm * 64, n0 + wn * (NJ * 32), lane, wave, split);
+    gemm_epilogue<NJ, 2, true, X3>(p, acc, smem, m0 + wm * 64, n0 + wn * (NJ * 32), lane, wave, split);
 #endif
 }
 
@@ -2217,6 +2241,24 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(i < 3 ? l320 : l640)) != hipSuccess) ws_fits = 0;
         (void)hipGetLastError();                                 // a refused attribute must not surface as this launch's error
     }
+    if (p.out_split3) {                                        // exact mode's GEGLU projection: always the 256 x 256 phased tile
+        VS_REQUIRE(p.act == 2 && p.ksize == 1 && !p.out && !p.out_f32 && !p.residual && !p.tap && p.N % 64 == 0 && (p.ldo % 8) == 0,
+                   "gemm: the split3 output exists for the plain GEGLU linear only");
+        static bool attr3 = false;
+        if (!attr3) {
+            (void)hipFuncSetAttribute((const void*)k_gemm_ph<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
+            attr3 = true;
+        }
+        const long long tiles3 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+        p.gn = (p.N + 255) / 256 < 8 ? (p.N + 255) / 256 : 8;
+        launch(k_gemm_ph<4, true>, dim3((unsigned)tiles3), 512, 2 * (256 + 256) * 128, p);
+        if (g_prof.on) {
+            if (!prof_ext) (void)hipEventRecord(ev1, st);
+            g_prof.shapes.push_back({p.M, p.N, p.K, p.ksize, p.up, p.stride, p.act, 1, 1, (double)p.x0_bytes + 2.0 * p.N * p.K + 6.0 * p.M * (p.N / 2)});
+        }
+        VS_CHECK_LAUNCH("gemm_geglu_split3");
+        return VS_OK;
+    }
     const int ws_bn = p.K == 320 ? 160 : 80;
     const int ws_np = p.N / ws_bn;
     const bool ws_ok = ws_mode && ws_fits && p.ksize == 1 && !p.x1 && p.C1 == 0 && p.C0 == p.K && (p.K == 320 || p.K == 640) && p.act != 2 &&
@@ -2488,6 +2530,31 @@ int vidseg_linear_a16_rf32(const void* a, int K, long long M, const void* w, int
     p.tap_cols = tap_cols;
     p.tap_ld = tap_ld;
     p.act = act;
+    return launch_gemm(p, st);
+}
+
+// The exact mode's GEGLU projection (attention.py:89-96) with the product formed in the epilogue and written as the FF output
+// projection's split operand image: a split image [M][K] (K = 3 x the layer's width), w / bias GEGLU-interleaved like ops.pack_geglu,
+// out_split3 fp16 [M][3 * (N / 2)] = [hi | lo | hi] of value * gelu_erf(gate) evaluated in fp32.
+int vidseg_linear_a16_geglu_x3(const void* a, int K, long long M, const void* w, int N, const float* bias, void* out_split3, hipStream_t st) {
+    VS_REQUIRE(out_split3 != nullptr && N % 64 == 0 && M >= 1, "linear_geglu_x3: N=%d M=%lld", N, M);
+    GemmParams p{};
+    p.x0 = (const bf16_t*)a;
+    p.C0 = K;
+    p.ksize = 1;
+    p.stride = 1;
+    p.up = 1;
+    p.Hin = p.Win = p.Hout = p.Wout = 1;
+    p.w = (const bf16_t*)w;
+    p.N = N;
+    p.K = K;
+    p.M = M;
+    p.x0_bytes = M * K * 2;
+    p.bias = bias;
+    p.rows_per_sample = 1;
+    p.out_split3 = (f16*)out_split3;
+    p.ldo = N / 2;
+    p.act = 2;
     return launch_gemm(p, st);
 }
 

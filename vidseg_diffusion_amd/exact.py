@@ -38,6 +38,7 @@ _lib.register({
     "vidseg_x_groupnorm_split3": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _L, _P, _P],
     "vidseg_x_groupnorm_rows_per_chunk": [_I],
     "vidseg_linear_a16_rf32": [_P, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
+    "vidseg_linear_a16_geglu_x3": [_P, _I, _L, _P, _I, _P, _P, _P],
     "vidseg_conv3x3_a16_rf32": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
     "vidseg_x_layernorm_split3": [_P, _L, _I, _P, _P, _F, _P, _P],
     "vidseg_x_attention_f32": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
@@ -61,6 +62,33 @@ def _hl(w):
 def pack_linear_x(weight, device):
     hi, lo = _hl(weight)
     return torch.cat([hi, hi, lo], dim=1).to(device).contiguous()
+
+
+def pack_geglu_x(weight, bias, device):
+    """GEGLU proj [2*inner, K] -> rows interleaved in 32-row value | gate groups (ops.pack_geglu), then [hi | hi | lo] along K; the
+    bias interleaved alike (fp32)."""
+    two_inner, K = weight.shape
+    inner = two_inner // 2
+    if inner % 32:
+        raise VidsegError("pack_geglu_x: inner width must be a multiple of 32")
+    w = weight.detach().to(F32).view(2, inner // 32, 32, K).permute(1, 0, 2, 3).reshape(two_inner, K)
+    b = bias.detach().to(F32).view(2, inner // 32, 32).permute(1, 0, 2).reshape(two_inner)
+    return pack_linear_x(w, device), b.to(device).contiguous()
+
+
+def geglu_linear_x(a3, w3g, b_g):
+    """split3(value * gelu_erf(gate)) of the GEGLU projection in ONE launch: the product is formed in fp32 inside the GEMM epilogue
+    and written as the FF output projection's operand image (a3: [.., 3K] fp16; w3g / b_g from pack_geglu_x).  -> [.., 3 * inner]."""
+    ops.workspace(a3.device)
+    K3 = a3.shape[-1]
+    M = a3.numel() // K3
+    N = w3g.shape[0]
+    out = torch.empty(a3.shape[:-1] + (3 * (N // 2),), dtype=F16, device=a3.device)
+    call("vidseg_linear_a16_geglu_x3", ptr(a3), K3, M, ptr(w3g), N, ptr(b_g), ptr(out), stream())
+    return out
+
+
+_GEGLU_FUSED = os.environ.get("VIDSEG_X_GEGLU_FUSED", "1") != "0"    # 0: GEGLU projection to fp32, then k_x_geglu_split3
 
 
 def pack_conv3x3_x(weight, device):
@@ -278,6 +306,7 @@ class ExactRunner:
                         w_q=pack_linear_x(a2.to_q.weight, d), w_kv=pack_linear_x(torch.cat([a2.to_k.weight, a2.to_v.weight], 0), d),
                         w_o2=pack_linear_x(a2.to_out[0].weight, d), b_o2=f(a2.to_out[0].bias),
                         w_ff1=pack_linear_x(ff.net[0].proj.weight, d), b_ff1=f(ff.net[0].proj.bias),
+                        ff1g=pack_geglu_x(ff.net[0].proj.weight, ff.net[0].proj.bias, d),
                         w_ff2=pack_linear_x(ff.net[2].weight, d), b_ff2=f(ff.net[2].bias)))
                 if self.video and isinstance(m, self.V.SpatialVideoTransformer):     # video_attention.py:291-489
                     e["time"] = []
@@ -286,6 +315,8 @@ class ExactRunner:
                         e["time"].append(dict(
                             ln={n: (f(getattr(tb, n).weight), f(getattr(tb, n).bias)) for n in ("norm_in", "norm1", "norm2", "norm3")},
                             w_fi1=pack_linear_x(tb.ff_in.net[0].proj.weight, d), b_fi1=f(tb.ff_in.net[0].proj.bias),
+                            fi1g=pack_geglu_x(tb.ff_in.net[0].proj.weight, tb.ff_in.net[0].proj.bias, d),
+                            ff1g=pack_geglu_x(tb.ff.net[0].proj.weight, tb.ff.net[0].proj.bias, d),
                             w_fi2=pack_linear_x(tb.ff_in.net[2].weight, d), b_fi2=f(tb.ff_in.net[2].bias),
                             w_qkv=pack_linear_x(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0), d),
                             w_o1=pack_linear_x(a1.to_out[0].weight, d), b_o1=f(a1.to_out[0].bias),
@@ -353,6 +384,13 @@ class ExactRunner:
         h = add(conv_temporal3_x(h, ts["w2"], ts["cb2"], T), x)
         return blend(x, h, e["alpha"])
 
+    @staticmethod
+    def geglu(a3, bw, w, b, g):
+        """GEGLU projection -> the FF output projection's operand image: one fused launch, or projection + k_x_geglu_split3."""
+        if _GEGLU_FUSED and a3.numel() // a3.shape[-1] >= 256:
+            return geglu_linear_x(a3, *bw[g])
+        return geglu_split3(linear_x(a3, bw[w], bw[b]))
+
     def frame_emb(self, m, e, T):
         """time_pos_embed(timestep_embedding(arange(T))) (video_attention.py:417-427), fp32."""
         key = (id(m), T)
@@ -372,8 +410,8 @@ class ExactRunner:
         BT, S, C = x.shape
         b = BT // T
         heads = tb.attn1.heads
-        y = linear_x(layernorm_split3(x, *bw["ln"]["norm_in"]), bw["w_fi1"], bw["b_fi1"])            # VA:155-159
-        x = linear_x(geglu_split3(y), bw["w_fi2"], bw["b_fi2"], residual=x)
+        g3 = self.geglu(layernorm_split3(x, *bw["ln"]["norm_in"]), bw, "w_fi1", "b_fi1", "fi1g")     # VA:155-159
+        x = linear_x(g3, bw["w_fi2"], bw["b_fi2"], residual=x)
         qkv = linear_x(layernorm_split3(x, *bw["ln"]["norm1"]), bw["w_qkv"])                          # [(b t), S, 3C]
         tqkv = qkv.view(b, T, S, 3 * C).permute(0, 2, 1, 3).reshape(b * S, T, 3 * C)                 # (b t) s c -> (b s) t c (VA:171)
         a = attention_x(tqkv[..., :C], tqkv[..., C:], heads, b * S, T, T)
@@ -390,8 +428,8 @@ class ExactRunner:
         if dump:
             tb.attn2.q = q2.view(b, T, S, C).permute(0, 2, 1, 3).reshape(b * S, T, C).half()
             tb.attn2.k = tk[:, None].expand(b, S, L, C).reshape(b * S, L, C)
-        y = linear_x(layernorm_split3(x, *bw["ln"]["norm3"]), bw["w_ff1"], bw["b_ff1"])               # VA:252-281
-        return linear_x(geglu_split3(y), bw["w_ff2"], bw["b_ff2"], residual=x)
+        g3 = self.geglu(layernorm_split3(x, *bw["ln"]["norm3"]), bw, "w_ff1", "b_ff1", "ff1g")        # VA:252-281
+        return linear_x(g3, bw["w_ff2"], bw["b_ff2"], residual=x)
 
     def transformer(self, m, x, ctx3, tap):
         e = self.w[self.names[id(m)]]
@@ -421,8 +459,8 @@ class ExactRunner:
             if dump:
                 blk.attn2.q, blk.attn2.k = tq, tk
             # GEGLU feed-forward (ATT:728-757, :89-115)
-            y = linear_x(layernorm_split3(t, *bw["ln"][2]), bw["w_ff1"], bw["b_ff1"])
-            t = linear_x(geglu_split3(y), bw["w_ff2"], bw["b_ff2"], residual=t)
+            g3 = self.geglu(layernorm_split3(t, *bw["ln"][2]), bw, "w_ff1", "b_ff1", "ff1g")
+            t = linear_x(g3, bw["w_ff2"], bw["b_ff2"], residual=t)
             if "time" in e:                                                                            # VA:429-476
                 T = self.T
                 tm = self.time_block(m.time_stack[i], e["time"][i], add_rowvec(t, self.frame_emb(m, e, T), N), self.tctx3, T, dump)
