@@ -57,7 +57,10 @@ int vidseg_row_sqnorm_f64(const void* x16, int64_t n, int C, double* xsq, vidseg
 /* One k-means++ round (cluster/_kmeans.py:174-274) for all R restarts at once; the uniforms are drawn on the
  * host from numpy's RandomState in sklearn's order (FE:562 relies on np.random.seed, sd_pipeline_vspw.py:619-623).
  * c = 0 evaluates the first centres (cand[r] preset, closest = +inf); c = 1..K-1 finalises centre c-1 (first
- * minimum potential over the trials) and draws/evaluates Tnext candidates; c = K only finalises. */
+ * minimum potential over the trials) and draws/evaluates Tnext candidates; c = K only finalises.
+ * cand: int32 [2][R * Tmax] -- round c reads the candidates of round c - 1 in half (c - 1) & 1 (round 0: the caller's first picks
+ * cand[r] in half 0) and writes its own into half c & 1 (one buffer would let a restart's block overwrite candidates another
+ * restart's block has yet to read). */
 int vidseg_kpp_round(const void* x16, const double* mean, const double* xsq, int64_t n, int C, int R, int K, int c, int Tprev,
                      int Tnext, int Tmax, const double* u, int ustride, double* closest, double* dcand, double* part,
                      double* pot, int32_t* cand, int32_t* center_ids, vidseg_stream_t stream);

@@ -215,3 +215,33 @@ def test_edge_cases_vs_oracle(dev):
     out = A.trajectory_vote(tr, _to(dev, labs), 7).cpu().numpy()
     corr, _ = O.correct_low_res_mask(labs.reshape(1, 5, 7).astype(np.int64), th, tw)
     assert np.array_equal(out.reshape(-1), corr)
+
+
+def test_kmeans_is_bit_stable_beside_a_busy_stream(dev):
+    """K-means on a side stream while the main stream keeps every CU busy (how the window pipeline runs it): every restart's seeds,
+    iteration count, inertia and labels must be the same run after run.  k-means++ once kept the candidates of round c and of round
+    c - 1 in one buffer; in round 1 (one candidate per restart in, T out) restart 0's block overwrote entries that later-starting
+    blocks had yet to read -- invisible on an idle chip where all R blocks start together, 1 run in ~250 wrong beside a busy stream."""
+    from vidseg_diffusion_amd import analysis as A, ops
+    F, h, w, C, K = 14, 32, 32, 640, 20
+    blocks, _ = synthetic.attention_q_dumps(F, h, w, C, num_blocks=3, seed=7)
+    _, feat = A.mean_normalize([torch.from_numpy(b).to(dev) for b in blocks], F * h * w, F * h * w)
+    ad = ops.act_dtype()
+    x0 = torch.randn(28, 64, 64, 320, device=dev).to(ad)
+    wc = ops.pack_conv3x3(torch.randn(320, 320, 3, 3) * 0.02, dev)
+    bc = torch.zeros(320, device=dev)
+    side = torch.cuda.Stream()
+    first = None
+    for it in range(300):
+        for _ in range(60):
+            ops.conv3x3(x0, wc, bc)                                  # full-chip launches queued on the main stream
+        with torch.cuda.stream(side):
+            np.random.seed(17)
+            km = A.kmeans_fit(feat, K)
+            sig = (tuple(km.all_n_iter), tuple(float(v) for v in km.all_inertia), A.LAST_CENTER_IDS.cpu().numpy().tobytes(),
+                   km.all_labels.cpu().numpy().tobytes())
+        torch.cuda.synchronize()
+        if first is None:
+            first = sig
+        assert sig[0] == first[0] and sig[1] == first[1] and sig[2] == first[2] and sig[3] == first[3], \
+            f"run {it}: K-means differs from run 0 (n_iter {sig[0]} vs {first[0]})"

@@ -56,6 +56,7 @@ class KMeansResult:
     __slots__ = ("centers", "labels", "inertia", "n_iter", "best_restart", "total_lloyd_iters", "all_labels", "all_inertia", "all_n_iter")
 
 
+LAST_CENTER_IDS = None
 LAST_KMEANS = None          # the most recent KMeansResult of this process (diagnostics / parity tests; never read by the product path)
 
 
@@ -85,7 +86,7 @@ def _kmeanspp_init(x16, mean, xsq, n, C, K, R, rs, dev, st):
     dcand = torch.empty((R * Tmax, n), dtype=F64, device=dev)
     part = torch.empty((R * Tmax, ntiles), dtype=F64, device=dev)
     pot = torch.empty(R, dtype=F64, device=dev)
-    cand = torch.zeros(R * Tmax, dtype=I32, device=dev)
+    cand = torch.zeros(2 * R * Tmax, dtype=I32, device=dev)             # two halves: round c reads half (c - 1) & 1, writes half c & 1
     cand[:R] = torch.from_numpy(first).to(dev)
     center_ids = torch.empty(R * K, dtype=I32, device=dev)
     U_dev = torch.from_numpy(U).to(dev)
@@ -98,6 +99,8 @@ def _kmeanspp_init(x16, mean, xsq, n, C, K, R, rs, dev, st):
              ptr(closest), ptr(dcand), ptr(part), ptr(pot), ptr(cand), ptr(center_ids), st)
     centers = torch.empty((R, K, C), dtype=F64, device=dev)
     call("vidseg_gather_rows_f64", ptr(x16), ptr(mean), C, ptr(center_ids), R * K, ptr(centers), st)
+    global LAST_CENTER_IDS
+    LAST_CENTER_IDS = center_ids                                      # diagnostics only (tools/kmeans_race.py): the seeds picked, [R * K]
     return centers
 
 

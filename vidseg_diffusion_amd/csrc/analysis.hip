@@ -364,9 +364,14 @@ __global__ void __launch_bounds__(256) k_kpp_dist(RowsF16 X, const double* __res
 __global__ void __launch_bounds__(1024) k_kpp_pick(int64_t n, int R, int K, int c, int Tprev, int Tnext, const double* __restrict__ u,
                                                    int ustride, double* __restrict__ closest, const double* __restrict__ dcand,
                                                    const double* __restrict__ part, int ntiles, double* __restrict__ pot,
-                                                   int32_t* __restrict__ cand, int32_t* __restrict__ center_ids, int Tmax, int staged) {
+                                                   const int32_t* __restrict__ cand_prev, int32_t* __restrict__ cand,
+                                                   int32_t* __restrict__ center_ids, int Tmax, int staged) {
     // one block per restart r.  Finalises centre c-1 from the Tprev trial results, then (if c < K)
-    // draws Tnext candidates for centre c.  staged: the winning trial's n distances go through LDS (one coalesced read) and the
+    // draws Tnext candidates for centre c.  The candidates of the previous round are READ from cand_prev [r * Tprev + k] and the new
+    // ones WRITTEN to another buffer, cand [r * Tnext + k]: with one buffer, round 1 (Tprev = 1, Tnext = T) had block 0 write
+    // cand[0 .. T) while blocks 1 .. T-1 had yet to read cand[1], cand[2], .. -- harmless while all R blocks start together on an idle
+    // chip, a wrong first seed for a restart whose block starts late (another stream's kernels holding the CUs / the 112 KB of LDS):
+    // found as run-to-run differences of whole restarts when the analysis overlaps the next window's UNet (tools/kmeans_race.py).  staged: the winning trial's n distances go through LDS (one coalesced read) and the
     // two per-thread segment walks read them there -- the same per-thread arithmetic as the direct walk (whose 112-byte-strided
     // global reads were the rest of this kernel's time).
     extern __shared__ double s_src[];
@@ -391,7 +396,7 @@ __global__ void __launch_bounds__(1024) k_kpp_pick(int64_t n, int R, int K, int 
             if (s_pots[k] < s_pots[best]) best = k;
         s_best = best;
         pot[r] = s_pots[best];
-        center_ids[r * K + (c - 1)] = cand[r * Tprev + best];
+        center_ids[r * K + (c - 1)] = cand_prev[r * Tprev + best];
     }
     if (t < 16) s_cnt[t] = 0;
     __syncthreads();
@@ -1447,10 +1452,12 @@ int vidseg_kpp_round(const void* x16, const double* mean, const double* xsq, int
             (void)hipGetLastError();
         }
         const int staged = lds_ok && n * 8 <= 120 * 1024;              // 14336 tokens: 112 KB
-        k_kpp_pick<<<dim3(R), 1024, staged ? (size_t)n * 8 : 0, st>>>(n, R, K, c, Tprev, Tnext, u, ustride, closest, dcand, part, ntiles, pot, cand,
+        k_kpp_pick<<<dim3(R), 1024, staged ? (size_t)n * 8 : 0, st>>>(n, R, K, c, Tprev, Tnext, u, ustride, closest, dcand, part, ntiles, pot,
+                                                                   cand + (size_t)((c - 1) & 1) * R * Tmax, cand + (size_t)(c & 1) * R * Tmax,
                                                                    center_ids, Tmax, staged);
         VS_CHECK_LAUNCH("kpp_pick");
     }
+    cand += (size_t)(c & 1) * R * Tmax;                                // this round's candidates (round 0: the host's first picks in half 0)
     if (c < K) {
         // candidates of restart r live compactly at cand[r*Tnext + t]
         VS_REQUIRE(Tnext >= 1 && Tnext <= Tmax, "kpp_round: Tnext=%d out of [1,%d]", Tnext, Tmax);

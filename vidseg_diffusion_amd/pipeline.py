@@ -314,7 +314,13 @@ class WindowPipeline:
             import sys
             fm = state.ref_feature_map
             fh_ = hashlib.sha256(fm.detach().cpu().numpy().tobytes()).hexdigest()[:12] if torch.is_tensor(fm) else "-"
-            print(f"HASH {h['exp_name']} features {fh_} masks {hashlib.sha256(np.ascontiguousarray(labels).tobytes()).hexdigest()[:12]}",
+            from . import analysis as A_
+            km = A_.LAST_KMEANS
+            extra = ""
+            if km is not None:
+                extra = (f" best {km.best_restart} n_iter {list(km.all_n_iter)} inertia {[f'{v:.17g}' for v in km.all_inertia]} "
+                         f"labels {[hashlib.sha256(r.tobytes()).hexdigest()[:6] for r in km.all_labels.cpu().numpy()]}")
+            print(f"HASH {h['exp_name']} features {fh_} masks {hashlib.sha256(np.ascontiguousarray(labels).tobytes()).hexdigest()[:12]}{extra}",
                   file=sys.stderr, flush=True)
         FE.FeatureStore.clear(h["feature_folder"], h["exp_name"])                   # the window's dumps are no longer needed
         return labels
