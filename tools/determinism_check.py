@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="through WindowPipeline (analysis on the second stream), as bench.py runs it")
     ap.add_argument("--prof", action="store_true", help="with the GEMM timing events on, as in bench.py's timed region (VIDSEG_PROF_EXT=0/1 picks the mechanism)")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--refine", action="store_true", help="with Step 3b (dense tracking + trajectory vote)")
+    ap.add_argument("--chain", action="store_true", help="windows chained as one clip (4-NN label propagation instead of K-means after window 0)")
     args = ap.parse_args()
     a, _, b = args.windows.partition("-")
     wids = list(range(int(a), int(b or a) + 1))
@@ -50,7 +52,7 @@ def main():
         if args.prof:
             ops.gemm_profile_begin()
         if args.overlap:
-            pipe = WindowPipeline(eng, chain=False, num_masks=K, is_aggre_attn=True, is_refine_mask=False)
+            pipe = WindowPipeline(eng, chain=args.chain, num_masks=K, is_aggre_attn=True, is_refine_mask=args.refine)
             outs = []
             for w in wids:
                 lat = torch.from_numpy(synthetic.headline_latent(F, LAT, LAT, window_id=w)).to(dev)
