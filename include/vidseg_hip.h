@@ -60,10 +60,11 @@ int vidseg_row_sqnorm_f64(const void* x16, int64_t n, int C, double* xsq, vidseg
  * minimum potential over the trials) and draws/evaluates Tnext candidates; c = K only finalises.
  * cand: int32 [2][R * Tmax] -- round c reads the candidates of round c - 1 in half (c - 1) & 1 (round 0: the caller's first picks
  * cand[r] in half 0) and writes its own into half c & 1 (one buffer would let a restart's block overwrite candidates another
- * restart's block has yet to read). */
-int vidseg_kpp_round(const void* x16, const double* mean, const double* xsq, int64_t n, int C, int R, int K, int c, int Tprev,
-                     int Tnext, int Tmax, const double* u, int ustride, double* closest, double* dcand, double* part,
-                     double* pot, int32_t* cand, int32_t* center_ids, vidseg_stream_t stream);
+ * restart's block has yet to read).  cand_len = the int32 count the caller allocated, checked against 2 * R * Tmax: the
+ * _v2 name + this argument replace vidseg_kpp_round, whose callers allocated one half only. */
+int vidseg_kpp_round_v2(const void* x16, const double* mean, const double* xsq, int64_t n, int C, int R, int K, int c, int Tprev,
+                        int Tnext, int Tmax, const double* u, int ustride, double* closest, double* dcand, double* part,
+                        double* pot, int32_t* cand, int64_t cand_len, int32_t* center_ids, vidseg_stream_t stream);
 int vidseg_gather_rows_f64(const void* x16, const double* mean, int C, const int32_t* ids, int J, double* out,
                            vidseg_stream_t stream);
 

@@ -8,6 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("VIDSEG_KEEP_LAST", "1")      # analysis.LAST_KMEANS / LAST_CENTER_IDS (restart-level parity tests); off in the product
 
 
 def pytest_configure(config):

@@ -232,7 +232,7 @@ def test_kmeans_is_bit_stable_beside_a_busy_stream(dev):
     bc = torch.zeros(320, device=dev)
     side = torch.cuda.Stream()
     first = None
-    for it in range(300):
+    for it in range(300 if os.environ.get("VIDSEG_SLOW_TESTS") else 40):   # ~1 wrong run in 250 before the fix: the long form is the hunt
         for _ in range(60):
             ops.conv3x3(x0, wc, bc)                                  # full-chip launches queued on the main stream
         with torch.cuda.stream(side):

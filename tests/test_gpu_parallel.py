@@ -154,3 +154,68 @@ def test_bench_gpus_flag_starts_the_ranks():
     out = lines[0]
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["scaling"] == "weak"
     assert abs(out["value"] - 2 * 14 * 2 / (out["ms_per_step"] * 2 / 1e3)) / out["value"] < 1e-2      # frames of BOTH ranks / max-rank time
+
+
+def _frames_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    from vidseg_diffusion_amd import parallel
+    eng = _setup(dev)
+    lat, c, uc, noise = _inputs(0, dev)                                  # every rank holds the WINDOW's inputs, runs its frame slice
+    kw = dict(noise=noise, seed=17, feature_folder="/nonexistent/fr")
+    h = parallel.frame_sharded_feature_pass(eng, lat, c, uc, rank=rank, world=world, exp_name=f"t{rank}", **kw)
+    taps = parallel.frame_sharded_resolve(eng, h, num_masks=K, is_refine_mask=True, rank=rank, world=world,
+                                          analysis=lambda t, F_, fh, fw, seed: {b: v.cpu().numpy() for b, v in t.items()})
+    labels = parallel.segment_window_frame_sharded(eng, lat, c, uc, rank=rank, world=world, num_masks=K, is_refine_mask=True,
+                                                   exp_name=f"f{rank}", **kw)
+    q.put((rank, labels, taps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sd_window_sharded_by_frames():
+    """SURVEY 8(e), SD: the frames of ONE window over two ranks (2 + 1 frames, both on cuda:0, gloo): every rank ends with the same
+    gathered tap stacks and the same labels; the labels are the oracle's analysis of those taps bit for bit; the taps are the
+    one-rank pass's up to the fp32 summation order of another batch size (GEMM tiling / split-K follow M)."""
+    from oracle import analysis as OA
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_frames_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (lab, taps) for r, lab, taps in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][0], res[1][0])
+    for b in (6, 7, 8):
+        assert np.array_equal(res[0][1][b], res[1][1][b])
+    taps = res[0][1]
+    fh = fw = 8
+    pad = [np.concatenate([np.zeros_like(taps[b]), taps[b]], 0) for b in (8, 7, 6)]
+    np.random.seed(17)
+    _, lab, _ = OA.match_gt_mask(OA.aggregate_blocks(pad), K, np.random.mtrand._rand)
+    th, tw = OA.dense_tracking(pad[1], F, fh, fw)
+    corr, _ = OA.correct_low_res_mask(lab.reshape(F, fh, fw), th, tw)
+    assert np.array_equal(res[0][0].reshape(-1), corr.reshape(-1)), "frame-sharded labels differ from the oracle's analysis of the gathered taps"
+    # the one-rank pass of the same window
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import segment_window
+    dev = torch.device("cuda:0")
+    eng = _setup(dev)
+    FE.FeatureStore.clear()
+    lat, c, uc, noise = _inputs(0, dev)
+    segment_window(eng, lat, c, uc, num_masks=K, is_refine_mask=True, seed=17, noise=noise, feature_folder="/nonexistent/one", exp_name="w")
+    st = FE.FeatureStore.folder("/nonexistent/one", "w")
+    for b in (6, 7, 8):
+        one = st[f"output_block_{b}_spatial_self_attn_q_time_24"][F:].float().cpu().numpy()
+        e = float(np.linalg.norm(taps[b].astype(np.float32) - one) / np.linalg.norm(one))
+        print(f"block {b}: frame-sharded taps vs the one-rank pass: nrms {e:.2e}")
+        assert e <= 2e-3, (b, e)
+    FE.FeatureStore.clear()

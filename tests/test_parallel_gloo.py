@@ -119,3 +119,80 @@ def test_bench_self_launch():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-dry-run"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode != 0 and "disagree" in (r.stderr + r.stdout)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# SD frame-level sharding (parallel.frame_slices / gather_frames / frame_sharded_resolve): the frames of ONE window over the ranks
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_frame_slices_cover_the_window():
+    from vidseg_diffusion_amd.parallel import frame_slices
+    assert frame_slices(14, 1) == [(0, 14)]
+    assert frame_slices(14, 2) == [(0, 7), (7, 14)]
+    assert frame_slices(14, 4) == [(0, 4), (4, 8), (8, 11), (11, 14)]
+    assert frame_slices(14, 8) == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 10), (10, 12), (12, 13), (13, 14)]
+    for F_ in (1, 5, 14, 25):
+        for w in (1, 2, 3, 8):
+            sl = frame_slices(F_, w)
+            assert len(sl) == w and sl[0][0] == 0 and sl[-1][1] == F_ and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+            assert max(hi - lo for lo, hi in sl) - min(hi - lo for lo, hi in sl) <= 1
+
+
+FF = 9                                                               # frames of the frame-sharded window: 8 ranks -> slices of 2,1,1,...
+
+
+def _frames_window():
+    blocks, _ = synthetic.attention_q_dumps(FF, H, W, C, num_blocks=3, seed=77)
+    return blocks                                                    # three [2F, N, C] fp16 dumps (blocks 8, 7, 6 in Step 3's order)
+
+
+def _frames_reference(refine):
+    blocks = _frames_window()
+    np.random.seed(17)
+    _, labels, _ = OA.match_gt_mask(OA.aggregate_blocks(blocks), K, np.random.mtrand._rand)
+    if refine:
+        th, tw = OA.dense_tracking(blocks[1], FF, H, W)
+        labels, _ = OA.correct_low_res_mask(labels.reshape(FF, H, W), th, tw)
+    return labels.reshape(FF, N)
+
+
+def _frames_worker(rank, world, port, refine, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vidseg_diffusion_amd.parallel import frame_slices, gather_frames
+    blocks = _frames_window()
+    sl = frame_slices(FF, world)
+    lo, hi = sl[rank]
+    # this rank's taps: the conditional half of ITS frames only (what its feature pass would leave), block order 8, 7, 6
+    mine = {b: torch.from_numpy(np.ascontiguousarray(blk[FF + lo:FF + hi])) for b, blk in zip((8, 7, 6), blocks)}
+    full = {b: gather_frames(mine[b], sl, world).numpy() for b in (8, 7, 6)}
+    for b, blk in zip((8, 7, 6), blocks):
+        assert np.array_equal(full[b], blk[FF:]), f"rank {rank}: gathered block {b} differs from the window's stack"
+    pad = [np.concatenate([np.zeros_like(full[b]), full[b]], 0) for b in (8, 7, 6)]      # the oracle reads [2F, N, C] dumps
+    np.random.seed(17)
+    _, labels, _ = OA.match_gt_mask(OA.aggregate_blocks(pad), K, np.random.mtrand._rand)
+    if refine:
+        th, tw = OA.dense_tracking(pad[1], FF, H, W)
+        labels, _ = OA.correct_low_res_mask(labels.reshape(FF, H, W), th, tw)
+    q.put((rank, labels.reshape(FF, N)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,refine", [(2, True), (8, True)])
+def test_frame_sharded_window_equals_one_rank(world, refine):
+    """The exchange of the frame-sharded SD window (padded fp16 all-gather of uneven frame slices, parallel.gather_frames) rebuilds
+    the window's tap stacks bit for bit on every rank, so Steps 3-3b give the one-rank masks (world 2: 5 + 4 frames; world 8: 2,1,...)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_frames_worker, args=(r, world, port, refine, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _frames_reference(refine)
+    for r in range(world):
+        assert np.array_equal(res[r], ref), f"rank {r}: frame-sharded labels differ from the one-rank window"

@@ -19,8 +19,14 @@ blocks are built with spatial_transformer_attn_type="softmax" (SURVEY a11).
 The fixture stores subsamples (conditional video, every 16th location, every 4th channel, fp16) of the six taps + full-tensor
 norms, the Euler-step result, the reference's labels / corrected labels / ten restarts, and sha256 of every input.
 
-    python tools/gen_golden_c3_window.py
+    python tools/gen_golden_c3_window.py                                   # the one-step fixture c3_window.npz (t_start = 24, window 0)
+    python tools/gen_golden_c3_window.py --t-start 17 --windows 0 1 2      # the REFERENCE's schedule (svd_pipeline_vspw.py:236-237, 598:
+                                                                           # modulate_timestep 17 -> 8 Euler steps, 8 CFG evaluations,
+                                                                           # ~75 min and ~30 GB per window here) -> c3_t17_w{0,1,2}.npz
+The t_start = 17 fixtures hold coarser subsamples (every 32nd location, every 8th channel; x_final every 2nd latent row / column + its
+norm and the per-step norms of x) so that three windows stay ~2 MB each.
 """
+import argparse
 import os
 import shutil
 import sys
@@ -56,6 +62,15 @@ def svd_inputs(window_id=0):
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--t-start", type=int, default=24)
+    ap.add_argument("--windows", type=int, nargs="*", default=[0])
+    ap.add_argument("--threads", type=int, default=0)
+    args = ap.parse_args()
+    if args.threads:
+        torch.set_num_threads(args.threads)
+    global T_START
+    T_START = args.t_start
     fe = import_reference()
     from sgm.modules.diffusionmodules.denoiser import Denoiser
     from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
@@ -68,9 +83,19 @@ def main():
     sd = synthetic.fill_state_dict(shapes, seed=1234)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     del sd
+    for wid in args.windows:
+        one_window(fe, net, shapes, wid, t_all)
+
+
+def one_window(fe, net, shapes, wid, t_all):
+    from sgm.modules.diffusionmodules.denoiser import Denoiser
+    from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    from sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+    full = T_START == 24 and wid == 0                                  # the original one-step fixture keeps its finer subsamples
+    LS, CS = (16, 4) if full else (32, 8)
     rec = dict(state_dict_signature=synthetic.state_dict_signature(shapes), weight_seed=1234, F=F, lat_h=LH, lat_w=LW, K=K,
-               t_start=T_START, num_steps=NUM_STEPS, seed=17, window_id=0)
-    lat, c, uc, noise = svd_inputs(0)
+               t_start=T_START, num_steps=NUM_STEPS, seed=17, window_id=wid, loc_stride=LS, ch_stride=CS)
+    lat, c, uc, noise = svd_inputs(wid)
     rec.update(latent_sha256=synthetic.sha256_of(lat.numpy()), noise_sha256=synthetic.sha256_of(noise.numpy()),
                ctx_sha256=synthetic.sha256_of(c["crossattn"].numpy()), vector_sha256=synthetic.sha256_of(c["vector"].numpy()))
 
@@ -80,6 +105,7 @@ def main():
         assert "SpatialVideoTransformer" in str(type(st))
         mods[f"s{b}"] = st.transformer_blocks[0].attn1               # spatial self-attention: q/k [(b t), s, c]
         mods[f"t{b}"] = st.time_stack[0].attn1                       # temporal self-attention: q/k [(b s), t, c]
+    net.__dict__.pop("forward", None)                                  # a previous window's wrapper is dropped first
     orig_forward = net.forward
     got = {}
 
@@ -111,29 +137,38 @@ def main():
         return den_m(model, inp, sigma, cc, is_modulate_step=is_modulate_step, is_injected_step=is_injected_step,
                      modulate_params=modulate_params, **extra)
 
-    torch.manual_seed(100)                                    # add_noise draws torch.randn_like(x): the generator-seeded draw above
+    torch.manual_seed(100 + wid)                              # add_noise draws torch.randn_like(x): the generator-seeded draw above
     noised = sampler.add_noise(lat.clone(), cond=c, uc=uc, num_steps=NUM_STEPS, noise_level=T_START)
     sig = sampler.discretization(NUM_STEPS, device="cpu")
     chk = (lat + noise * sig[T_START]) / torch.sqrt(1.0 + sig[0] ** 2.0)
     assert torch.equal(noised, chk), "torch.randn_like under manual_seed != Generator draw"
 
+    step_norms = []
+
     def cb(xt, i):
-        assert i == NUM_STEPS - 1
-        for k, a in mods.items():
-            got[k + "q"], got[k + "k"] = a.q.half(), a.k.half()
+        step_norms.append(float(torch.linalg.norm(xt.double())))
+        if i == NUM_STEPS - 1:
+            for k, a in mods.items():
+                got[k + "q"], got[k + "k"] = a.q.half(), a.k.half()
 
     final = sampler(denoiser, noised.clone(), cond=c, uc=uc, img_callback=cb, t_start=T_START)
-    rec.update(x_final=final.numpy().astype(np.float32), x_noised_sub=noised.numpy()[:, :, ::4, ::4].astype(np.float32))
+    assert len(step_norms) == NUM_STEPS - T_START
+    rec.update(x_noised_sub=noised.numpy()[:, :, ::4, ::4].astype(np.float32), x_step_norms=np.array(step_norms, dtype=np.float64))
+    if full:
+        rec["x_final"] = final.numpy().astype(np.float32)
+    else:
+        rec["x_final_sub"] = final.numpy()[:, :, ::2, ::2].astype(np.float32)
+        rec["x_final_norm"] = np.float64(torch.linalg.norm(final.double()))
     S = (LH // 2) * (LW // 2)
     for b in (6, 7, 8):
         q = got[f"s{b}q"].numpy()                             # [2F, S, 640] fp16, unconditional video first
         assert q.shape == (2 * F, S, 640)
-        rec[f"sq{b}_sub"] = q[F:, ::16, ::4]
+        rec[f"sq{b}_sub"] = q[F:, ::LS, ::CS]
         rec[f"sq{b}_norm"] = np.float64(np.linalg.norm(q[F:].astype(np.float64)))
         for w in ("q", "k"):
             t = got[f"t{b}{w}"].numpy()                       # [(b s), t, 640]: b-major, the conditional video is the second S rows
             assert t.shape == (2 * S, F, 640)
-            rec[f"t{w}{b}_sub"] = t[S::16, :, ::4]
+            rec[f"t{w}{b}_sub"] = t[S::LS, :, ::CS]
             rec[f"t{w}{b}_norm"] = np.float64(np.linalg.norm(t[S:].astype(np.float64)))
 
     base = tempfile.mkdtemp(prefix="vidseg_c3_")
@@ -171,8 +206,8 @@ def main():
     rec["versions"] = np.array([f"torch {torch.__version__}", f"sklearn {sklearn.__version__}", f"numpy {np.__version__}"])
     if os.environ.get("C3_TAP_CACHE"):
         os.makedirs(os.environ["C3_TAP_CACHE"], exist_ok=True)
-        np.savez(os.path.join(os.environ["C3_TAP_CACHE"], "c3_taps.npz"), **{k: v.numpy() for k, v in got.items()})
-    out_path = os.path.join(ROOT, "tests", "golden", "c3_window.npz")
+        np.savez(os.path.join(os.environ["C3_TAP_CACHE"], f"c3_taps_t{T_START}_w{wid}.npz"), **{k: v.numpy() for k, v in got.items()})
+    out_path = os.path.join(ROOT, "tests", "golden", "c3_window.npz" if full else f"c3_t{T_START}_w{wid}.npz")
     np.savez_compressed(out_path, **rec)
     print("wrote", out_path, os.path.getsize(out_path) // 1024, "KiB in", f"{time.time() - t_all:.0f} s; labels", len(np.unique(rec["match_labels"])))
 

@@ -10,6 +10,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from vidseg_diffusion_amd import analysis as A, ops, synthetic  # noqa: E402
+A.KEEP_LAST = True
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=12)

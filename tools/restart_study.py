@@ -28,6 +28,7 @@ def main():
     a, _, b = args.windows.partition("-")
     wids = list(range(int(a), int(b or a) + 1))
     from vidseg_diffusion_amd import analysis as A
+    A.KEEP_LAST = True
     from vidseg_diffusion_amd import feature_extraction as FE
     from vidseg_diffusion_amd.pipeline import build_sd_engine, segment_window
     from vidseg_diffusion_amd.unet import UNetModel

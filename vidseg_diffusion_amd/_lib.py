@@ -29,7 +29,7 @@ _SIGS = {
     "vidseg_mean_normalize_f16": [ctypes.POINTER(_P), _I, _L, _L, _I, _P, _P, _P],
     "vidseg_kmeans_prepare": [_P, _L, _I, _P, _P, _P, _P, _P],
     "vidseg_row_sqnorm_f64": [_P, _L, _I, _P, _P],
-    "vidseg_kpp_round": [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "vidseg_kpp_round_v2": [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _L, _P, _P],
     "vidseg_gather_rows_f64": [_P, _P, _I, _P, _I, _P, _P],
     "vidseg_lloyd_iter": [_P, _P, _L, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "vidseg_lloyd_status": [_I, _I, _I, _D, _P, _P, _P, _P, _P],

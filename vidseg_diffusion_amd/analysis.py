@@ -56,6 +56,7 @@ class KMeansResult:
     __slots__ = ("centers", "labels", "inertia", "n_iter", "best_restart", "total_lloyd_iters", "all_labels", "all_inertia", "all_n_iter")
 
 
+KEEP_LAST = any(os.environ.get(k) for k in ("VIDSEG_KEEP_LAST", "VIDSEG_DEBUG_HASH"))   # tests / study tools set this: the two globals pin device tensors
 LAST_CENTER_IDS = None
 LAST_KMEANS = None          # the most recent KMeansResult of this process (diagnostics / parity tests; never read by the product path)
 
@@ -95,12 +96,13 @@ def _kmeanspp_init(x16, mean, xsq, n, C, K, R, rs, dev, st):
         tprev = 0 if c == 0 else (1 if c == 1 else T)
         tnext = 1 if c == 0 else (T if c < K else 0)
         u_ptr = U_dev.data_ptr() + 8 * (c - 1) * T if 1 <= c < K else None
-        call("vidseg_kpp_round", ptr(x16), ptr(mean), ptr(xsq), n, C, R, K, c, tprev, tnext, Tmax, u_ptr, ustride,
-             ptr(closest), ptr(dcand), ptr(part), ptr(pot), ptr(cand), ptr(center_ids), st)
+        call("vidseg_kpp_round_v2", ptr(x16), ptr(mean), ptr(xsq), n, C, R, K, c, tprev, tnext, Tmax, u_ptr, ustride,
+             ptr(closest), ptr(dcand), ptr(part), ptr(pot), ptr(cand), cand.numel(), ptr(center_ids), st)
     centers = torch.empty((R, K, C), dtype=F64, device=dev)
     call("vidseg_gather_rows_f64", ptr(x16), ptr(mean), C, ptr(center_ids), R * K, ptr(centers), st)
-    global LAST_CENTER_IDS
-    LAST_CENTER_IDS = center_ids                                      # diagnostics only (tools/kmeans_race.py): the seeds picked, [R * K]
+    if KEEP_LAST:
+        global LAST_CENTER_IDS
+        LAST_CENTER_IDS = center_ids                                  # diagnostics only (tools/kmeans_race.py): the seeds picked, [R * K]
     return centers
 
 
@@ -212,8 +214,9 @@ def kmeans_fit(x16: torch.Tensor, n_clusters: int, n_init: int = 10, max_iter: i
     res.best_restart = best
     res.total_lloyd_iters = total
     res.all_labels, res.all_inertia, res.all_n_iter = labels, h_inertia, n_iter
-    global LAST_KMEANS
-    LAST_KMEANS = res
+    if KEEP_LAST:
+        global LAST_KMEANS
+        LAST_KMEANS = res
     return res
 
 

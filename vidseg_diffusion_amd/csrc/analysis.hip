@@ -1438,11 +1438,12 @@ int vidseg_row_sqnorm_f64(const void* x16, int64_t n, int C, double* xsq, hipStr
 // One k-means++ round for all R restarts: finalise centre c-1 (Tprev trials), draw Tnext candidates for
 // centre c (if c < K) and evaluate them.  Call with c = 0 after writing cand[r] = first centre ids
 // and closest = +inf (Tprev = 0, Tnext = 1 evaluates the first centre), then c = 1..K.
-int vidseg_kpp_round(const void* x16, const double* mean, const double* xsq, int64_t n, int C, int R, int K, int c, int Tprev,
-                     int Tnext, int Tmax, const double* u /*[R][ustride], this round's uniforms*/, int ustride, double* closest,
-                     double* dcand /*[R*Tmax][n]*/, double* part /*[R*Tmax][ntiles]*/, double* pot, int32_t* cand,
-                     int32_t* center_ids, hipStream_t st) {
+int vidseg_kpp_round_v2(const void* x16, const double* mean, const double* xsq, int64_t n, int C, int R, int K, int c, int Tprev,
+                        int Tnext, int Tmax, const double* u /*[R][ustride], this round's uniforms*/, int ustride, double* closest,
+                        double* dcand /*[R*Tmax][n]*/, double* part /*[R*Tmax][ntiles]*/, double* pot, int32_t* cand, int64_t cand_len,
+                        int32_t* center_ids, hipStream_t st) {
     VS_REQUIRE(R >= 1 && R <= 32 && Tmax <= 8 && K >= 1, "kpp_round: R=%d Tmax=%d K=%d", R, Tmax, K);
+    VS_REQUIRE(cand_len >= 2ll * R * Tmax, "kpp_round: cand holds %lld int32, needs 2 * R * Tmax = %d (two halves)", (long long)cand_len, 2 * R * Tmax);
     const int ntiles = (int)cdiv64(n, TS);
     RowsF16 X{(const f16*)x16, nullptr, mean, n, C};
     if (c > 0) {

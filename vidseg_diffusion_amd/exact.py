@@ -339,6 +339,7 @@ class ExactRunner:
             le = net.label_emb[0]
             self.le = (pack_linear_x(le[0].weight, d), f(le[0].bias), pack_linear_x(le[2].weight, d), f(le[2].bias))
         self._temb = {}
+        self._temb_dev = {}
         rbs = net._resblocks()
         off = 0
         self.emb_off = {}
@@ -468,9 +469,11 @@ class ExactRunner:
         out = linear_x(split3(t), e["w_out"], e["b_out"], residual=x.view(B, N, C))                    # ATT:921-927
         return out.view(B, H, W, C)
 
-    def block(self, blk, x, x_skip, emb_all, ctx3):
+    def block(self, blk, x, x_skip, emb_all, ctx3, skip_resample=False):
         U = self.U
         for layer in blk:
+            if skip_resample and isinstance(layer, (U.Upsample, U.Downsample)):   # taps-only evaluation: nothing downstream reads this
+                continue
             if isinstance(layer, U.ResBlock):
                 x = self.resblock(layer, x, x_skip, emb_all)
                 x_skip = None
@@ -486,17 +489,32 @@ class ExactRunner:
                 raise VidsegError(f"unexpected layer {type(layer)}")
         return x
 
-    def forward(self, x_nchw, timesteps, context, y=None, num_video_frames=None):
+    def timestep_embedding(self, timesteps, dim):
+        """timestep_embedding (DU:209-233) with torch's own fp32 exp / cos / sin on the host -- the arguments reach ~1e3 rad, so one ulp
+        of a frequency is 6e-5 of a cosine: the device's expf would not do.  The denoiser hands the host copy of the timesteps along
+        (`_vidseg_host`, sampling.Denoiser.forward), so no device-to-host copy stalls the lane; one upload per distinct vector."""
+        ts = getattr(timesteps, "_vidseg_host", None)
+        if ts is None:
+            ts = timesteps.detach().float().cpu()                                                     # blocking: direct callers only
+        key = (dim, tuple(ts.tolist()))
+        if key not in self._temb_dev:
+            if len(self._temb_dev) > 64:
+                self._temb_dev.clear()
+            half = dim // 2
+            freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=F32) / half)
+            args = ts.float()[:, None] * freqs[None]
+            self._temb_dev[key] = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(self.dev)
+        return self._temb_dev[key]
+
+    def forward(self, x_nchw, timesteps, context, y=None, num_video_frames=None, stop_after_block=None):
+        """stop_after_block=b: taps-only evaluation (pipeline.feature_pass(masks_only=True)) -- output blocks 0..b run (b without its
+        Upsample), their Q/K taps are left on the attention modules and None is returned."""
         net, dev = self.net, self.dev
         self.T = int(num_video_frames) if num_video_frames is not None else None
         if self.video and (y is None or self.T is None):
             raise VidsegError("exact VideoUNet needs y and num_video_frames")
         mc = net.model_channels
-        half = mc // 2                                                                                # timestep_embedding, DU:209-233 (host fp32)
-        ts = timesteps.detach().float().cpu()
-        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=F32) / half)
-        args = ts[:, None] * freqs[None]
-        t_emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(dev)
+        t_emb = self.timestep_embedding(timesteps, mc)
         w1, b1, w2, b2 = self.te
         emb = linear_x(split3(linear_x(split3(t_emb), w1, b1, act=ops.ACT_SILU)), w2, b2)
         if self.video:                                                                                # label_emb(y), OAI:851-853
@@ -515,7 +533,10 @@ class ExactRunner:
             h = self.block(blk, h, None, emb_all, ctx3)
             hs.append(h)
         h = self.block(net.middle_block, h, None, emb_all, ctx3)
-        for blk in net.output_blocks:
+        for i, blk in enumerate(net.output_blocks):
+            if stop_after_block is not None and i == stop_after_block:
+                self.block(blk, h, hs.pop(), emb_all, ctx3, skip_resample=True)
+                return None
             h = self.block(blk, h, hs.pop(), emb_all, ctx3)                                            # OAI:911-948
         h3 = groupnorm_split3(h, self.out_g, self.out_beta, eps=1e-5, silu=True)
         return ops.conv_out4(h3, self.out_w, self.out_b)

@@ -53,25 +53,36 @@ def _all_gather(t: torch.Tensor, world: int):
     return out.view((world,) + tuple(t.shape))
 
 
-def resolve_windows(feat: torch.Tensor, tracks: Optional[torch.Tensor], ops: ChainOps, rank: int, world: int, num_frames: int,
-                    seed: int = 17, check: Optional[bool] = None):
-    """feat: this rank's normalised tokens fp16 [F*N, C]; tracks: this rank's dense tracks int32 [F, N] or None; seed: this rank's
-    window seed (sd_pipeline_vspw.py:255).  Returns final labels of ALL windows, int32 [world, F*N], identical on every rank.
-
-    Window 0's K-means runs redundantly on every rank and must be seeded with WINDOW 0's seed, i.e. rank 0's: each rank's seed
-    travels as one extra row of the int32 all-gather and every rank reads row 0's.  check (default: VIDSEG_CHECK_RANKS=1): one more
-    tiny all-gather of a checksum of labels0, so a kernel that is not bit-deterministic across devices is detected, not assumed."""
-    import os
+def exchange_seed(seed: int, world: int, device) -> int:
+    """Rank 0's window seed on every rank.  Window 0's K-means runs redundantly on every rank and must draw WINDOW 0's numbers
+    (sd_pipeline_vspw.py:255), i.e. rank 0's seed: one int64 all-gather of a single element (any seed numpy accepts survives),
+    read back on the host.  Callers issue it BEFORE the step's feature pass is queued on a stream that is idle, so the read-back
+    waits for nothing and the collectives of `resolve_windows` stay asynchronous."""
+    if world == 1:
+        return int(seed)
     import torch.distributed as dist
+    t = torch.tensor([int(seed)], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else device)
+    return int(_all_gather(t, world).reshape(-1)[0].item())
+
+
+def resolve_windows(feat: torch.Tensor, tracks: Optional[torch.Tensor], ops: ChainOps, rank: int, world: int, num_frames: int,
+                    seed: int = 17, check: Optional[bool] = None, seed0: Optional[int] = None):
+    """feat: this rank's normalised tokens fp16 [F*N, C]; tracks: this rank's dense tracks int32 [F, N] or None; seed: this rank's
+    window seed (sd_pipeline_vspw.py:255); seed0: rank 0's seed if the caller already exchanged it (`exchange_seed`, done by
+    ShardedPipeline.push / segment_windows_sharded before the feature pass is queued), else it is exchanged here, first.
+    Returns final labels of ALL windows, int32 [world, F*N], identical on every rank.
+
+    check (default: VIDSEG_CHECK_RANKS=1): one more tiny all-gather of a checksum of labels0, so a kernel that is not
+    bit-deterministic across devices is detected, not assumed."""
+    import os
     FN = feat.shape[0]
+    if seed0 is None:
+        seed0 = exchange_seed(seed, world, feat.device)
     all_feat = _all_gather(feat, world)                               # [W, F*N, C]   <- the RCCL all-gather over xGMI
-    nn_idx = torch.full((FN + 1, 4), -1, dtype=torch.int32, device=feat.device)
+    nn_idx = torch.full((FN, 4), -1, dtype=torch.int32, device=feat.device)
     if rank != 0:
-        nn_idx[:FN] = ops.knn_top4(all_feat[rank - 1], feat).to(torch.int32)
-    nn_idx[FN, 0] = int(seed)
-    all_idx = _all_gather(nn_idx, world)                              # [W, F*N + 1, 4] (issued before the K-means so it overlaps it)
-    seed0 = int(all_idx[0, FN, 0].item())
-    all_idx = all_idx[:, :FN]
+        nn_idx[:] = ops.knn_top4(all_feat[rank - 1], feat).to(torch.int32)
+    all_idx = _all_gather(nn_idx, world)                              # [W, F*N, 4]: queued before the K-means, no host read in between
     labels0 = ops.first_window_labels(all_feat[0], seed0).to(torch.int32)    # every rank, same bits (see module docstring)
     if os.environ.get("VIDSEG_CHECK_RANKS") == "1" if check is None else check:
         w = torch.arange(1, FN + 1, dtype=torch.int64, device=labels0.device)
@@ -162,7 +173,7 @@ def sharded_resolve(engine, h, *, num_masks=20, is_aggre_attn=True, is_refine_ma
 
     ops = ChainOps(first_window_labels=first_window, knn_top4=A.knn_top4, vote4=A.vote4,
                    refine=(lambda t, l: A.trajectory_vote(t.contiguous(), l.contiguous(), fw)) if is_refine_mask else None)
-    labels = resolve_windows(feat, tracks, ops, rank, world, F, seed=seed)
+    labels = resolve_windows(feat, tracks, ops, rank, world, F, seed=seed, seed0=h.get("seed0"))
     out = labels.view(world, F, N).cpu().numpy().astype(np.int64)
     FE.FeatureStore.clear(h["feature_folder"], h["exp_name"])
     return out
@@ -187,6 +198,7 @@ class ShardedPipeline:
     def push(self, latent, c, uc, **feature_kw):
         lane = self.lanes[self.count % len(self.lanes)]
         self.count += 1
+        seed0 = exchange_seed(feature_kw.get("seed", 17), self.world, latent.device)   # on the caller's (idle) stream, before anything is queued
         if lane is None:
             h = sharded_feature_pass(self.engine, latent, c, uc, rank=self.rank, **feature_kw)
         else:
@@ -195,6 +207,7 @@ class ShardedPipeline:
             hand_to_stream(lane, latent, c, uc, feature_kw.get("noise"))
             with torch.cuda.stream(lane):
                 h = sharded_feature_pass(self.engine, latent, c, uc, rank=self.rank, **feature_kw)
+        h["seed0"] = seed0
         self.pending.append(h)
         return self._resolve(self.pending.pop(0)) if len(self.pending) > len(self.lanes) else None
 
@@ -223,8 +236,113 @@ def segment_windows_sharded(engine, latent, c, uc, *, noise=None, num_masks=20, 
                                    feature_timestep=str(num_steps - 1 if feature_timestep is None else int(feature_timestep)),
                                    inversion_type=inversion_type)
         return labels
+    seed0 = exchange_seed(seed, world, latent.device)
     h = sharded_feature_pass(engine, latent, c, uc, noise=noise, num_steps=num_steps, t_start=t_start, seed=seed, rank=rank,
                              feature_folder=feature_folder, exp_name=exp_name, masks_only=masks_only, feature_timestep=feature_timestep,
                              inversion_type=inversion_type)
+    h["seed0"] = seed0
     return sharded_resolve(engine, h, num_masks=num_masks, is_aggre_attn=is_aggre_attn, is_refine_mask=is_refine_mask, rank=rank,
                            world=world)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# SD frame-level sharding ("SD (C2-like)"): UNetModel has no cross-frame operator (openaimodel.py:831-954 -- GroupNorm
+# statistics, attention and convolutions are all per sample), so the F frames of ONE window shard over the ranks: rank r runs the
+# feature pass on its contiguous frame slice (each frame's CFG pair stays together: batch 2 * F_r), the conditional half's Q taps
+# of decoder blocks 6-8 are all-gathered (one fp16 exchange per block, padded to the largest slice), and Steps 3-3b run on the
+# gathered stack on every rank (deterministic kernels: same bits everywhere; rank 0's are the result).  The SVD VideoUNet mixes
+# the frames of a window (temporal attention / conv), so for it the atomic unit stays the window (the functions above).
+# ----------------------------------------------------------------------------------------------------------------------------------
+def frame_slices(num_frames: int, world: int):
+    """Contiguous frame ranges [(lo, hi)] per rank, sizes differing by at most one (the first num_frames % world ranks hold one more);
+    ranks beyond the frame count hold an empty slice."""
+    base, extra = divmod(num_frames, world)
+    out, lo = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((lo, lo + n))
+        lo += n
+    return out
+
+
+def gather_frames(local: torch.Tensor, slices, world: int) -> torch.Tensor:
+    """All-gather of per-rank frame slices [F_r, ...] into the window's [F, ...] (slices padded to the largest one: a rank with
+    fewer frames sends zero rows that are dropped on arrival)."""
+    fmax = max(hi - lo for lo, hi in slices)
+    pad = torch.zeros((fmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    allp = _all_gather(pad, world)                                    # [W, fmax, ...]
+    return torch.cat([allp[r, :hi - lo] for r, (lo, hi) in enumerate(slices)], 0)
+
+
+def frame_sharded_feature_pass(engine, latent, c, uc, *, noise=None, num_steps=25, t_start=22, seed=17, rank=0, world=1,
+                               feature_folder="features_outputs_VSPW", exp_name=None, masks_only=False):
+    """Steps 1-2 of ONE SD window on this rank's frame slice (`latent`, `c`, `uc`, `noise` are the WINDOW's full tensors, identical on
+    every rank; a missing `noise` is drawn for the whole window under the window's seed, then sliced, so every frame sees the noise
+    the one-rank pass gives it).  Returns the handle for `frame_sharded_resolve`."""
+    from .pipeline import seed_everything
+    if engine.video:
+        raise ValueError("frame-level sharding is for the per-sample SD UNet; the SVD VideoUNet shards by window (segment_windows_sharded)")
+    F = latent.shape[0]
+    sl = frame_slices(F, world)
+    lo, hi = sl[rank]
+    if noise is None:
+        seed_everything(seed)                                             # SDP:255, then add_noise's randn_like over the whole window (SAM:138)
+        noise = torch.randn(latent.shape, dtype=latent.dtype, device=latent.device)
+    exp_name = exp_name or f"frames{rank}"
+    cut = lambda d: {k: v[lo:hi] for k, v in d.items()}                   # noqa: E731
+    h = None
+    if hi > lo:
+        h = sharded_feature_pass(engine, latent[lo:hi].contiguous(), cut(c), cut(uc), noise=noise[lo:hi].contiguous(), num_steps=num_steps,
+                                 t_start=t_start, seed=seed, rank=rank, feature_folder=feature_folder, exp_name=exp_name, masks_only=masks_only)
+    return dict(h=h, F=F, fh=latent.shape[2] // 2, fw=latent.shape[3] // 2, slices=sl, seed=seed, feature_folder=feature_folder,
+                exp_name=exp_name, feature_timestep=num_steps - 1, device=latent.device)
+
+
+def frame_sharded_resolve(engine, fh_, *, num_masks=20, is_aggre_attn=True, is_refine_mask=False, rank=0, world=1, analysis=None):
+    """Exchange + Steps 3-3b of a frame-sharded window: the conditional half's block-6/7/8 Q taps of every rank's frames are
+    all-gathered into the window's [F, N, 640] stacks, then the one-window analysis (3-block mean, max-abs normalise, K-means++ /
+    Lloyd best-of-10, 4-NN, optional dense tracking + vote) runs on every rank.  Returns int64 [F, N], identical on every rank.
+    analysis: test hook -- a callable (blocks {6,7,8: fp16 [F, N, C]}, F, fh, fw, seed) -> labels replacing the device analysis."""
+    from . import analysis as A
+    from . import feature_extraction as FE
+    F, fh, fw, sl = fh_["F"], fh_["fh"], fh_["fw"], fh_["slices"]
+    N = fh * fw
+    h = fh_["h"]
+    lo, hi = sl[rank]
+    ts = fh_["feature_timestep"]
+    names = (8, 7, 6) if is_aggre_attn else (7,)
+    need = sorted(set(names) | ({7} if is_refine_mask else set()))
+    taps = {}
+    if h is not None:
+        torch.cuda.current_stream().wait_event(h["done"])
+        store = FE.FeatureStore.folder(h["feature_folder"], h["exp_name"])
+        Fr = hi - lo
+        for b in need:
+            taps[b] = store[f"output_block_{b}_spatial_self_attn_q_time_{ts}"][Fr:2 * Fr]       # conditional half (FE:550-551)
+    shape_c = next(iter(taps.values())).shape[1:] if taps else None
+    if world > 1:
+        if shape_c is None:                                               # a rank without frames still joins the collectives
+            raise ValueError("frame_sharded_resolve: more ranks than frames is not supported (every rank must hold >= 1 frame)")
+        taps = {b: gather_frames(taps[b].contiguous(), sl, world) for b in need}
+    if analysis is not None:
+        return analysis(taps, F, fh, fw, fh_["seed"])
+    _, feat = A.mean_normalize([taps[b].contiguous() for b in names], 0, F * N)          # the gathered stacks hold the conditional half only
+    np.random.seed(fh_["seed"])
+    km = A.kmeans_fit(feat, num_masks, n_init=10)
+    fake = A.kmeans_predict(feat[:N], km.centers)
+    labels = A.knn_predict(feat[:N].contiguous(), fake, feat)
+    if is_refine_mask:
+        tracks, _ = A.dense_tracking(taps[7].contiguous(), F, fh, fw)
+        labels = A.trajectory_vote(tracks.contiguous(), labels.view(F, N).contiguous(), fw).reshape(-1)
+    if h is not None:
+        FE.FeatureStore.clear(h["feature_folder"], h["exp_name"])
+    return labels.view(F, N).cpu().numpy().astype(np.int64)
+
+
+def segment_window_frame_sharded(engine, latent, c, uc, *, rank=0, world=1, num_masks=20, is_aggre_attn=True, is_refine_mask=False,
+                                 **feature_kw):
+    """One SD window over `world` ranks by frames; every rank passes the window's full inputs and receives the window's labels."""
+    h = frame_sharded_feature_pass(engine, latent, c, uc, rank=rank, world=world, **feature_kw)
+    return frame_sharded_resolve(engine, h, num_masks=num_masks, is_aggre_attn=is_aggre_attn, is_refine_mask=is_refine_mask, rank=rank,
+                                 world=world)

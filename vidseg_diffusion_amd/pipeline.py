@@ -218,7 +218,10 @@ def _taps_only_eval(engine: Engine, sampler, x, c, F, num_steps, step):
     _, _, c_in, c_noise = den.scaling(sigma)
     c_noise = den.possibly_quantize_c_noise(c_noise.reshape(sigma.shape))
     extra = {"image_only_indicator": torch.zeros(1, F), "num_video_frames": F} if engine.video else {}
-    engine.model(ops.rows_axpby(x, c_in), c_noise.float().to(x.device), c, stop_after_block=8, **extra)
+    t_host = c_noise.float()
+    t_dev = t_host.to(x.device)
+    t_dev._vidseg_host = t_host
+    engine.model(ops.rows_axpby(x, c_in), t_dev, c, stop_after_block=8, **extra)
 
 
 def analyse_window(engine: Engine, h: dict, *, num_masks=20, is_aggre_attn=True, is_refine_mask=False, state: WindowState = None,

@@ -115,7 +115,10 @@ class Denoiser(nn.Module):
         sigma = self.possibly_quantize_sigma(sigma.detach().float().cpu())
         c_skip, c_out, c_in, c_noise = self.scaling(sigma)
         c_noise = self.possibly_quantize_c_noise(c_noise.reshape(sigma.shape))
-        net = network(ops.rows_axpby(input, c_in), c_noise.float().to(input.device), cond, is_modulate_step=is_modulate_step,
+        t_host = c_noise.float()
+        t_dev = t_host.to(input.device)
+        t_dev._vidseg_host = t_host                                           # exact.ExactRunner embeds the timesteps on the host: no read-back
+        net = network(ops.rows_axpby(input, c_in), t_dev, cond, is_modulate_step=is_modulate_step,
                       is_injected_step=is_injected_step, modulate_params=modulate_params, **additional_model_inputs)
         return ops.rows_axpby(net, c_out, input, c_skip)                     # net * c_out + input * c_skip
 

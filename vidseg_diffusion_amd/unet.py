@@ -459,9 +459,11 @@ class UNetModel(nn.Module):
         work; feature-dump path of the SD UNet only)."""
         if mode not in ("fp16", "exact"):
             raise ValueError(f"unknown precision {mode!r}")
-        self.precision = mode
-        if mode == "fp16":
-            self._exact = None
+        self.precision = mode                                       # the exact runner (its split weight images) stays cached: release_exact()
+
+    def release_exact(self):
+        """Drop the exact mode's weight images (3x the 16-bit ones)."""
+        self._exact = None
 
     def stash_resblock_features(self, on=True):
         """Make every ResBlock leave `in_layers_features` / `out_layers_features` (openaimodel.py:349-350, 367-368) after a forward.
@@ -570,8 +572,11 @@ class UNetModel(nn.Module):
         if not x.is_cuda:
             raise VidsegError("UNetModel runs on a HIP device only (no CPU fallback)")
         if self.precision == "exact":
-            if is_modulate_step or is_injected_step or stop_after_block is not None:
-                raise NotImplementedError("exact precision covers the feature-dump pass (no modulation / injection / early stop)")
+            if is_modulate_step or is_injected_step:
+                raise NotImplementedError("exact precision covers the feature-dump pass (no modulation / injection)")
+            if any(rb.stash_features for rb in self._resblocks()):
+                raise NotImplementedError("exact precision does not produce ResBlock.in_layers_features / out_layers_features: "
+                                          "stash_resblock_features(False) or set_precision('fp16')")
             if self._exact is None:
                 from .exact import ExactRunner
                 for p in self.parameters():
@@ -579,7 +584,7 @@ class UNetModel(nn.Module):
                         raise VidsegError("UNetModel has no weights: call load_state_dict() first")
                 self._set_taps()
                 self._exact = ExactRunner(self, x.device)
-            return self._exact.forward(x, timesteps, context)
+            return self._exact.forward(x, timesteps, context, stop_after_block=stop_after_block)
         xn = x.float().permute(0, 2, 3, 1).contiguous()
         ctx = context if context.dtype == ops.act_dtype() else \
             ops.window_cached(self, "_ctx16", (context,), lambda: ops.to_bf16(context.float().contiguous()))

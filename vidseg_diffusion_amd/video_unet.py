@@ -377,13 +377,16 @@ class VideoUNet(UNetModel):
         if not x.is_cuda:
             raise VidsegError("VideoUNet runs on a HIP device only (no CPU fallback)")
         if self.precision == "exact":                                 # UNetModel.set_precision: exact.ExactRunner (fp32-accurate, 3x MFMA work)
-            if is_modulate_step or is_injected_step or stop_after_block is not None:
-                raise NotImplementedError("exact precision covers the feature-dump pass (no modulation / injection / early stop)")
+            if is_modulate_step or is_injected_step:
+                raise NotImplementedError("exact precision covers the feature-dump pass (no modulation / injection)")
             if self._exact is None:
                 from .exact import ExactRunner
+                for p in self.parameters():
+                    if p.is_meta:
+                        raise VidsegError("VideoUNet has no weights: call load_state_dict() first")
                 self._set_taps()
                 self._exact = ExactRunner(self, x.device)
-            return self._exact.forward(x, timesteps, context, y=y, num_video_frames=num_video_frames)
+            return self._exact.forward(x, timesteps, context, y=y, num_video_frames=num_video_frames, stop_after_block=stop_after_block)
         xn = x.float().permute(0, 2, 3, 1).contiguous()
         ctx = context if context.dtype == ops.act_dtype() else ops.to_bf16(context.float().contiguous())
         return self.forward_nhwc(xn, timesteps, ctx, y, num_video_frames, is_modulate_step, is_injected_step, modulate_params,
