@@ -462,6 +462,7 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False):
         # latent blending on, no feature injection), after an untimed window that keeps the x_t of every step in HBM for it.
         net4 = eng.model.diffusion_model
         prec4 = net4.precision
+        stage("step 4 (modulated passes, 16-bit mode)")
         try:
             from vidseg_diffusion_amd.pipeline import modulation_sweep, segment_window
             net4.set_precision("fp16")                               # the modulated / injected passes exist in the 16-bit mode only
@@ -514,6 +515,11 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False):
                                       "(24 evaluations) then the feature pass from t_start = 0 (25 evaluations, Q/K dumps kept for the step that "
                                       "is read)")
     return out, sd_cpu, cfg, eng, labels, run_steps, timed
+
+
+def stage(msg):
+    """Progress on stderr (stdout carries the one JSON line): which leg of the run a failure belongs to."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -600,7 +606,9 @@ def main():
         raise SystemExit("bench.py: --precision parity / exact needs the fp16 build of libvidseg_hip.so; use --precision fp16 with the bf16 build")
     if args.exact and (args.fp8_attn or args.inversion):
         raise SystemExit("bench.py: --fp8-attn / --inversion are variants of the 16-bit mode: add --precision fp16")
+    stage(f"headline: config {args.config}, precision {args.precision}, masks_only {args.masks_only}, {args.warmup} + {args.steps} steps")
     out, sd_cpu, cfg, eng, labels, run_steps, timed = run_config(args, svd, rank, world, dev, args.steps, args.warmup)
+    stage("headline done")
 
     if out is not None:
         out["rccl_ranks"] = rccl_ranks
@@ -635,6 +643,7 @@ def main():
             out[key] = {"iou": round(float(iou), 4), "identical_fraction": round(float(exact), 4)}
         plain = world == 1 and not args.no_secondary and not args.narrow and (not args.masks_only or args.parity) and not args.fp8_attn
         if plain and not args.no_overlap:                            # windows chained like one long clip (outside the headline timing)
+            stage("chained windows")
             n = max(3, min(args.steps, 8))
             run_steps(2, chain=True)
             torch.cuda.synchronize()
@@ -647,6 +656,7 @@ def main():
                                              "K-means, every later one the 14336 x 14336 x 640 float64 4-NN against its predecessor "
                                              "(feature_extraction.py:603-613)"}
         if plain and not args.no_overlap and args.lanes == 1:        # two feature passes in flight (outside the headline timing)
+            stage("two lanes")
             n = max(4, min(args.steps, 10))
             run_steps(3, nl=2)
             torch.cuda.synchronize()
@@ -665,6 +675,7 @@ def main():
             prec0, mo0 = net.precision, run_steps.fkw["masks_only"]
 
             def time_mode(prec, mo, note):
+                stage(f"mode precision={prec} masks_only={mo}")
                 try:
                     net.set_precision(prec)
                     run_steps.fkw["masks_only"] = mo
@@ -704,6 +715,7 @@ def main():
         if args.vae:                                                 # outside the timed region, never part of `value`
             out["first_stage"] = first_stage_timing(dev, svd)
         if plain and not svd:
+            stage("PMC traffic passes (two rocprofv3 children)")
             tr = pmc_traffic((["--refine"] if args.refine else []) + ["--precision", args.precision]) \
                 if os.environ.get("VIDSEG_BENCH_PMC", "1") != "0" else None
             dom = out["roofline"]["kernel"]
@@ -725,11 +737,13 @@ def main():
                         out["roofline"]["traffic_static"] = {"bytes_per_launch": rec["traffic_bytes_per_launch"],
                                                              "source": os.path.relpath(static[-1], ROOT) + " (an earlier PMC pass, not this run)"}
         if not args.no_cpu_baseline and not args.narrow and not svd and world == 1:     # host-side leg: rank 0 at N = 1 only
+            stage("cpu baseline (oracle on the host)")
             out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, k_masks)
             out["cpu_baseline"]["reference_style_dump_io"] = dump_io_cost()
         if plain and not svd:                                        # BASELINE configs[2] as a secondary record
             del eng, sd_cpu, run_steps
             torch.cuda.empty_cache()
+            stage("secondary: SVD configs[2]")
             try:
                 args.inversion = False
                 sec, _sd2, _cfg2, eng2, _lab2, rs2, _t2 = run_config(args, True, rank, world, dev, steps=3, warmup=1, secondary=True)
@@ -737,6 +751,7 @@ def main():
                                                        "step4_latent_blending") if k in sec}
                 out["secondary"]["roofline"] = {k: sec["roofline"][k] for k in ("achieved", "frac", "kernel", "family")}
                 if args.exact:                                       # the 16-bit mode of the same config beside it
+                    stage("secondary: 16-bit mode")
                     net2 = eng2.model.diffusion_model
                     net2.set_precision("fp16")
                     rs2.fkw["masks_only"] = False

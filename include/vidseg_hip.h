@@ -276,7 +276,12 @@ int vidseg_x_layernorm_split3(const float* x, long long M, int C, const float* g
 int vidseg_x_attention_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int B, int H,
                            int Nq, int Nk, float scale, vidseg_stream_t stream);
 /* linear / 3x3 conv of the exact mode with the fp32 residual added in the epilogue (ATT:636-757, 921-927; OAI:369): split operand
- * image in, fp32 out, `residual_f32` [M][ldr] / NHWC [B][Ho][Wo][Cout] or NULL */
+ * images in, fp32 out, `residual_f32` [M][ldr] / NHWC [B][Ho][Wo][Cout] or NULL.  These entry points (and
+ * vidseg_conv_temporal3_a16_f32) REQUIRE split images -- activation rows [a_hi | a_lo | a_hi] (K = 3 x the layer's width), weight rows
+ * [w_hi | w_hi | w_lo] in the usual K order over those 3 x Cin channels: where the 224 x 320 tile is chosen the kernel stages each
+ * plane once per 64 original channels and forms a_lo w_hi + a_hi w_hi + a_hi w_lo from them (k_gemm_p7x), i.e. it reads the FIRST
+ * TWO planes of the activation image and the FIRST and THIRD of the weight image.  Plain 16-bit operands belong to vidseg_linear_a16
+ * / vidseg_conv3x3_a16. */
 int vidseg_linear_a16_rf32(const void* a, int K, long long M, const void* w, int N, const float* bias, const float* rowvec, int rv_stride,
                            int rows_per_sample, const float* residual_f32, int ldr, float* out_f32, int ldo, void* tap_f16, void* tap2_f16,
                            int tap_cols, int tap_ld, int act, vidseg_stream_t stream);

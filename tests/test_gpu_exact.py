@@ -79,6 +79,68 @@ def test_split_gemm_is_fp32_accurate(X):
         assert e <= 5e-6, (kw, e)
 
 
+def test_split_tile_stages_each_plane_once(X):
+    """k_gemm_p7x (csrc/gemm_conv.hip): where the 224 x 320 tile is chosen, the split-operand entry points stage a_hi, a_lo, w_hi, w_lo
+    once per 64 original channels and form a_lo w_hi + a_hi w_hi + a_hi w_lo from them, reading planes 0 / 1 of the [hi | lo | hi]
+    activation image and planes 0 / 2 of the [hi | hi | lo] weight image in place.  Shapes chosen so that the tile IS selected (a full
+    round of 256 CUs) while the float64 reference stays cheap: 3x3 conv (nine taps per 64-channel chunk), stride 2, nearest-2x
+    upsample, per-sample vector + fp32 residual, taps, a split-K linear, the [3,1,1] temporal conv.  Same bar as the 3K walk."""
+    from vidseg_diffusion_amd import ops
+    dev = torch.device("cuda:0")
+    ops.gemm_profile_begin()
+    # 3x3 conv, stride 1, + bias + per-sample vector + fp32 residual: B = 10 at 64 x 64 -> M = 40960 (183 tiles of 224 rows)
+    x, w, b = rnd((10, 64, 64, 64), 61), rnd((320, 64, 3, 3), 62, 0.05), rnd((320,), 63)
+    rv, r = rnd((10, 320), 64), rnd((10, 64, 64, 320), 65, 2.0)
+    out = X.conv3x3_x(X.split3(x.to(dev)), X.pack_conv3x3_x(w, dev), ops.f32(b, dev), rowvec=rv.to(dev), residual=r.to(dev)).cpu()
+    ref = TF.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1).permute(0, 2, 3, 1) + rv.double()[:, None, None, :] + r.double()
+    e = rel(out, ref)
+    print(f"split tile conv3x3 10x64x64 64->320 + vector + residual: max err {e:.2e}")
+    assert e <= 5e-6, e
+    # stride 2 (B = 40: M = 40960) and nearest-2x upsample (B = 10 at 32 x 32 -> 64 x 64), two 64-channel chunks
+    x, w, b = rnd((40, 64, 64, 128), 66), rnd((320, 128, 3, 3), 67, 0.05), rnd((320,), 68)
+    out = X.conv3x3_x(X.split3(x.to(dev)), X.pack_conv3x3_x(w, dev), ops.f32(b, dev), stride=2).cpu()
+    ref = TF.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1, stride=2).permute(0, 2, 3, 1)
+    e = rel(out, ref)
+    print(f"split tile conv3x3 stride 2: max err {e:.2e}")
+    assert e <= 5e-6, e
+    x = rnd((10, 32, 32, 128), 69)
+    out = X.conv3x3_x(X.split3(x.to(dev)), X.pack_conv3x3_x(w, dev), ops.f32(b, dev), up=2).cpu()
+    ref = TF.conv2d(TF.interpolate(x.double().permute(0, 3, 1, 2), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    e = rel(out, ref)
+    print(f"split tile conv3x3 up 2: max err {e:.2e}")
+    assert e <= 5e-6, e
+    # linears: K = 320 with residual + fp16 taps of the first columns; split-K shape
+    M, K, N = 40960, 320, 960
+    a, w, b = rnd((M, K), 70), rnd((N, K), 71, 0.05), rnd((N,), 72)
+    t1, t2 = torch.empty((M, 320), dtype=torch.float16, device=dev), torch.empty((M, 320), dtype=torch.float16, device=dev)
+    out = X.linear_x(X.split3(a.to(dev)), X.pack_linear_x(w, dev), ops.f32(b, dev), tap=t1, tap2=t2, tap_cols=320).cpu()
+    ref = a.double() @ w.double().t() + b.double()
+    e = rel(out, ref)
+    print(f"split tile linear {M}x{N}x{K} + taps: max err {e:.2e}")
+    assert e <= 5e-6, e
+    assert torch.equal(t1.cpu(), out[:, :320].half()) and torch.equal(t2.cpu(), out[:, 320:640].half())
+    for (M, K, N) in ((7168, 5120, 1280), (28672, 640, 640)):
+        a, w, b, r = rnd((M, K), 73), rnd((N, K), 74, 0.02), rnd((N,), 75), rnd((M, N), 76, 2.0)
+        out = X.linear_x(X.split3(a.to(dev)), X.pack_linear_x(w, dev), ops.f32(b, dev), residual=r.to(dev)).cpu()
+        e = rel(out, a.double() @ w.double().t() + b.double() + r.double())
+        print(f"split tile linear {M}x{N}x{K} + fp32 residual: max err {e:.2e}")
+        assert e <= 5e-6, (M, K, N, e)
+    # [3,1,1] temporal conv over T = 14 frames of two videos, 64 x 64 locations, 128 -> 320 channels
+    T, BT, H, W, C, Co = 14, 28, 64, 64, 128, 320
+    x, w, b = rnd((BT, H, W, C), 77), rnd((Co, C, 3, 1, 1), 78, 0.05), rnd((Co,), 79)
+    rv = rnd((BT, Co), 80)
+    out = X.conv_temporal3_x(X.split3(x.to(dev)), X.pack_conv_temporal3_x(w, dev), ops.f32(b, dev), T, rowvec=rv.to(dev)).cpu()
+    x5 = x.double().view(2, T, H, W, C).permute(0, 4, 1, 2, 3)                               # (b t) h w c -> b c t h w
+    ref = TF.conv3d(x5, w.double(), b.double(), padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(BT, H, W, Co) + rv.double()[:, None, None, :]
+    e = rel(out, ref)
+    print(f"split tile temporal conv T=14 128->320: max err {e:.2e}")
+    assert e <= 5e-6, e
+    ops.gemm_profile_end()
+    kinds = {n.split(" ")[0]: ln for (n, ms, fl, ln, ab) in ops.gemm_profile_kinds()}
+    print("launches by kernel:", kinds)
+    assert kinds.get("k_gemm_p7x", 0) >= 6, kinds                                           # the shapes above must exercise the new tile
+
+
 def test_fp32_glue_operators(X):
     from vidseg_diffusion_amd import ops
     dev = torch.device("cuda:0")

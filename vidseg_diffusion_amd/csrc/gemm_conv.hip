@@ -11,6 +11,7 @@
 // swizzle, global->register prefetch of the next K chunk issued before the MFMAs of the current one.
 #include "common.h"
 #include <hip/hip_ext.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -56,6 +57,8 @@ struct GemmParams {
     int tap_T, tap_S;        // >0: taps are written in the reference's temporal layout [(b s), t, c] (row permutation)
     const float* rowadd;     // per-row scalar added to every column before the residual (attention-output modulation
                              // lambda*mask[:,None], attention.py:646-663, 697-719) or nullptr
+    int split2;              // exact mode: the operands are split images -- A rows [a_hi | a_lo | a_hi], W rows [w_hi | w_hi | w_lo] in the
+                             // usual K order over the 3 * Cin channels (exact.py); k_gemm_p7x then stages each plane once
     int gn;                  // tile columns per panel of the launch order (map_tile)
     int taps, kchunk;        // K order of a conv weight row: k = (c / kchunk) * taps * kchunk + tap * kchunk + c % kchunk.
                              // kchunk = 64 (channel-chunk major: the taps of one 64-channel chunk are consecutive K-tiles, so the
@@ -1291,6 +1294,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7(GemmParams p) {
         const bool ok = live && (unsigned)ih < (unsigned)hb && (unsigned)iw < (unsigned)wb;
         const int pix = a_base[s4] + (ih >> upsh) * wmul + (iw >> upsh);
         const unsigned off = ok ? (unsigned)(pix * t_Cs + t_cc) * 2u + swz16 : OOB;
+#if PH_EXP & 512                                                // experiment: every third K-tile stages nothing (wrong results): the issue count of a native (hi, lo) tile
+        if (u % 3 == 2) return;
+#endif
         if (a_second)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
         else
@@ -1300,6 +1306,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7(GemmParams p) {
         const bool live = u < nk;
         char* dst = smem + 2 * A_BYTES + buf * B_BYTES + (b_r0 + g * 16) * RB;
         const unsigned off = (live && b_n + g * 16 < p.N) ? b_off0 + (unsigned)g * b_gstep + (unsigned)(ks_begin + u) * 128u : OOB;
+#if PH_EXP & 512
+        if (u % 3 == 2) return;
+#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
     };
 
@@ -1466,6 +1475,213 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7(GemmParams p) {
         tile(t, 0);
         if (t + 1 < nk) tile(t + 1, 1);
     }
+    }
+    wait_vmcnt<0>();
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    gemm_epilogue16<MI, NJ>(p, acc, smem, (int)m0 + wm * 112, n0 + wn * 80, lane, wave, split);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gemm_p7x: k_gemm_p7 for the exact mode's split operands (GemmParams::split2).  The operand images are those of exact.py --
+// A rows [a_hi | a_lo | a_hi] (3 * Cin channels per pixel), W rows [w_hi | w_hi | w_lo] in the usual K order over the 3 * Cin
+// channels -- and the product is the same a_hi w_hi + a_lo w_hi + a_hi w_lo with fp32 accumulation.  k_gemm_p7 walks the 3K axis
+// and stages every 64-wide K-tile of both images: per 64 channels of the ORIGINAL K three A tiles and three B tiles, of which one A
+// tile (a_hi) and one B tile (w_hi) are staged twice.  Its K loop is bound by the staging (9 LDS-DMA instructions per wave and
+// K-tile at 100-185 cycles each inside a read section against 1120 cycles of MFMA, MI355X_MICROARCH.md), so this kernel stages the
+// FOUR distinct tiles of a 64-channel macro-tile once -- LDS map A[0] = a_hi, A[1] = a_lo, B[0] = w_hi, B[1] = w_lo, the planes
+// read in place out of the 3-plane images -- and runs three K-steps on them:
+//     s0: a_lo . w_hi  (A[1], B[0])      s1: a_hi . w_hi  (A[0], B[0])      s2: a_hi . w_lo  (A[0] fragments kept from s1, B[1])
+// 18 DMA instructions per wave and macro-tile instead of 27, 58 fragment reads instead of 72, same 210 MFMAs.  A step keeps
+// k_gemm_p7's five phases (B fragment column j per phase, A fragments read in phase 0, two barriers per phase, wave groups half a
+// phase apart).  Staging schedule of macro-tile kc (piece = one A set / one B block, in per-wave issue order):
+//     s0(kc): p0 A0(kc).1 | p1 A0(kc).2 | p2 A0(kc).3, A1(kc+1).0 | p3 A1(kc+1).1 | p4 A1(kc+1).2
+//     s1(kc): pj B1(kc).j (j = 0..4), p4 also A1(kc+1).3
+//     s2(kc): pj B0(kc+1).j (j = 0..4), p4 also A0(kc+1).0
+// Every piece overwrites a region whose last read lies at least one full phase back (A rows are read in phase 0 only, B block j in
+// phase j only; s2 reads no A rows), and lands at least two phases before it is read.  Counted waits (loads younger than the last
+// one the next phase needs): s0 5,5,6,6,3; s1 -,-,-,-,5; s2 5,5,5,5,5.  One source only (exact.py materialises channel concats).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 2) k_gemm_p7x(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NJ = 5, MI = 7;
+    constexpr int BM = 224, BN = 320, RB = 128;
+    constexpr int A_BYTES = 256 * RB, B_BYTES = BN * RB;                 // LDS map: A[0] A[1] B[0] B[1] (hi, lo, hi, lo)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
+    int split, tn;
+    long long tm;
+    map_tile(p, BM, BN, split, tm, tn);
+    const long long m0 = tm * BM;
+    const int n0 = tn * BN;
+
+    constexpr unsigned OOB = 0xF0000000u;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w), 0, (int)((long long)p.N * p.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x0), 0, (int)p.x0_bytes, 0x00020000);
+
+    const int Cin = p.C0 / 3;                                            // channels of the ORIGINAL operand; a pixel holds [hi | lo | hi] = 3 * Cin
+    const int HWo = p.Hout * p.Wout;
+    const int upsh = p.up - 1;
+    const int Hup = p.Hin << upsh, Wup = p.Win << upsh;
+    const int lrow = lane >> 3, lch = lane & 7;
+    const unsigned swz16 = (unsigned)((lch ^ (((wave & 1) << 2) | (lrow >> 1))) << 4);
+    const int hb = p.ksize == 1 ? 1 : (p.tmode ? p.T : Hup), wb = (p.ksize == 1 || p.tmode) ? 1 : Wup;
+    const int wmul = p.tmode ? HWo : p.Win;
+    int a_base[4], a_hw[4];                                            // a_hw = (ih0 + 0x4000) << 16 | (iw0 + 0x4000)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int r = (s4 >> 1) * 128 + (wave + 8 * (s4 & 1)) * 8 + lrow;
+        const long long m = m0 + r;
+        const bool ok = r < BM && m < p.M;
+        const int mm = ok ? (int)m : 0;
+        int ih0 = 0, iw0 = 0;
+        if (p.ksize == 1) {
+            a_base[s4] = mm;
+        } else if (p.tmode) {
+            const int t = (mm / HWo) % p.T;
+            a_base[s4] = mm - t * HWo;
+            ih0 = t - 1;
+        } else {
+            const int b = mm / HWo, rem = mm - b * HWo;
+            const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
+            a_base[s4] = b * p.Hin * p.Win;
+            ih0 = oh * p.stride - p.pad;
+            iw0 = ow * p.stride - p.pad;
+        }
+        if (!ok) ih0 = -0x4000;
+        a_hw[s4] = ((ih0 + 0x4000) << 16) | (iw0 + 0x4000);
+    }
+    const int b_r0 = (wave >> 1) * 80 + (wave & 1) * 8;
+    const int b_n = n0 + b_r0 + lrow;
+    const unsigned b_off0 = (unsigned)((long long)b_n * p.K * 2) + swz16;
+    const unsigned b_gstep = (unsigned)p.K * 32u;                            // 16 weight rows
+    const unsigned b_lo = (unsigned)(p.K / 3) * 4u;                          // w_lo = third plane of the row: 2 * (K / 3) elements further
+    const int kchunk = p.ksize == 1 ? Cin : 64;                              // K order of the ORIGINAL axis (chunk-major for convolutions)
+    const int nk_all = p.K / 192;                                            // macro-tiles: 64 channels of the original K
+    const int ks_begin = p.ksplit > 1 ? (int)((long long)nk_all * split / p.ksplit) : 0;
+    const int ks_end = p.ksplit > 1 ? (int)((long long)nk_all * (split + 1) / p.ksplit) : nk_all;
+    const int nk = ks_end - ks_begin;
+    // one K cursor per A plane: the hi plane runs one macro-tile behind the lo plane (see the schedule)
+    KCursor cur0, cur1;
+    cur0.init(ks_begin * 64, p.taps, kchunk);
+    cur1 = cur0;
+    int u0 = 0, u1 = 0;                                                       // macro-tile each cursor points at
+    int k0h = 0, k0w = 0, k0c = 0, k1h = 0, k1w = 0, k1c = 0;
+    bool live0 = false, live1 = false;
+    auto stage_a = [&](auto PL, int s4) {                                     // PL: 0 = hi plane -> A[0], 1 = lo plane -> A[1]
+        constexpr int pl = decltype(PL)::value;
+        KCursor& cur = pl ? cur1 : cur0;
+        int& kh = pl ? k1h : k0h;
+        int& kw = pl ? k1w : k0w;
+        int& cc = pl ? k1c : k0c;
+        bool& live = pl ? live1 : live0;
+        int& u = pl ? u1 : u0;
+        if (s4 == 0) {
+            live = u < nk;
+            ++u;
+            cc = cur.c0();
+            const int t3 = cur.tap / 3;
+            kh = p.tmode ? cur.tap : t3;
+            kw = p.tmode ? 0 : cur.tap - t3 * 3;
+            cur.advance(64, p.taps, kchunk);
+        }
+        char* dst = smem + pl * A_BYTES + ((s4 >> 1) * 128 + (wave + 8 * (s4 & 1)) * 8) * RB;
+        const int ih = (a_hw[s4] >> 16) - 0x4000 + kh, iw = (a_hw[s4] & 0xFFFF) - 0x4000 + kw;
+        const bool ok = live && (unsigned)ih < (unsigned)hb && (unsigned)iw < (unsigned)wb;
+        const int pix = a_base[s4] + (ih >> upsh) * wmul + (iw >> upsh);
+        const unsigned off = ok ? (unsigned)(pix * p.C0 + pl * Cin + cc) * 2u + swz16 : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+    };
+    auto stage_b = [&](auto PL, int g, int u) {                               // PL: 0 = w_hi -> B[0], 1 = w_lo -> B[1]; u = macro-tile
+        constexpr int pl = decltype(PL)::value;
+        const bool live = u < nk;
+        char* dst = smem + 2 * A_BYTES + pl * B_BYTES + (b_r0 + g * 16) * RB;
+        const unsigned off = (live && b_n + g * 16 < p.N) ? b_off0 + (unsigned)g * b_gstep + (pl ? b_lo : 0u) + (unsigned)(ks_begin + u) * 128u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int sw = (l15 >> 1) & 7;
+    const int arow = (wm * 112 + l15) * RB, brow = 2 * A_BYTES + (wn * 80 + l15) * RB;
+
+    // prologue: what the steady state would have issued before s0(0), in its issue order
+#pragma unroll
+    for (int g = 0; g < 4; ++g) stage_a(P1{}, g);                             // A1(0)
+#pragma unroll
+    for (int g = 0; g < NJ; ++g) stage_b(P0{}, g, 0);                         // B0(0)
+    stage_a(P0{}, 0);                                                         // A0(0).0
+    wait_vmcnt<5>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+
+    bf16x8_t fa[MI][2];
+    auto step = [&](auto SK, int kc) {                                        // SK: 0 a_lo.w_hi, 1 a_hi.w_hi, 2 a_hi.w_lo of macro-tile kc
+        constexpr int sk = decltype(SK)::value;
+        const char* A = smem + (sk == 0 ? A_BYTES : 0) + arow;
+        const char* B = smem + (sk == 2 ? B_BYTES : 0) + brow;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            // ---- read section
+            bf16x8_t fb[2];
+            if (j == 0 && sk != 2) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i][0] = *reinterpret_cast<const bf16x8_t*>(A + i * 16 * RB + ((l4 ^ sw) << 4));
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fb[kk] = *reinterpret_cast<const bf16x8_t*>(B + j * 16 * RB + (((kk * 4 + l4) ^ sw) << 4));
+            if (sk == 0) {
+                if (j <= 2) stage_a(P0{}, j + 1);                             // A0(kc).1..3
+                if (j >= 2) stage_a(P1{}, j - 2);                             // A1(kc+1).0..2
+                if (j <= 1) wait_vmcnt<5>();
+                else if (j <= 3) wait_vmcnt<6>();
+                else wait_vmcnt<3>();
+            } else if (sk == 1) {
+                stage_b(P1{}, j, kc);                                         // B1(kc).j
+                if (j == 4) {
+                    stage_a(P1{}, 3);                                         // A1(kc+1).3
+                    wait_vmcnt<5>();
+                }
+            } else {
+                stage_b(P0{}, j, kc + 1);                                     // B0(kc+1).j
+                if (j == 4) stage_a(P0{}, 0);                                 // A0(kc+1).0
+                wait_vmcnt<5>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- matrix section
+            if (j == 0 && sk != 2) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i][1] = *reinterpret_cast<const bf16x8_t*>(A + i * 16 * RB + (((4 + l4) ^ sw) << 4));
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = mfma_16x16x32(fa[i][kk], fb[kk], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    for (int kc = 0; kc < nk; ++kc) {
+        step(S0{}, kc);
+        step(S1{}, kc);
+        step(S2{}, kc);
     }
     wait_vmcnt<0>();
     if (grp == 0) __builtin_amdgcn_s_barrier();
@@ -1755,8 +1971,8 @@ struct GemmProf {
     std::vector<Shape> shapes;      // one per event pair
 };
 static GemmProf g_prof;
-static double g_kind_stats[18];
-static double g_kind_bytes[6];
+static double g_kind_stats[21];
+static double g_kind_bytes[7];
 
 static inline hipEvent_t prof_event() {
     if (g_prof.used == g_prof.ev.size()) {
@@ -2075,8 +2291,8 @@ int vidseg_gemm_profile_begin(void) {
 int vidseg_gemm_profile_end(double* out) {
     g_prof.on = false;
     double ms = 0.0;
-    for (int i = 0; i < 18; ++i) g_kind_stats[i] = 0.0;
-    for (int i = 0; i < 6; ++i) g_kind_bytes[i] = 0.0;
+    for (int i = 0; i < 21; ++i) g_kind_stats[i] = 0.0;
+    for (int i = 0; i < 7; ++i) g_kind_bytes[i] = 0.0;
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
         float t = 0.f;
         hipError_t e = hipEventSynchronize(g_prof.ev[i + 1]);
@@ -2085,7 +2301,7 @@ int vidseg_gemm_profile_end(double* out) {
         ms += t;
         if (i / 2 < g_prof.shapes.size()) {
             const GemmProf::Shape& h = g_prof.shapes[i / 2];
-            const int kd = h.kind >= 0 && h.kind < 6 ? h.kind : 0;
+            const int kd = h.kind >= 0 && h.kind < 7 ? h.kind : 0;
             g_kind_stats[kd * 3] += t;
             g_kind_stats[kd * 3 + 1] += 2.0 * (double)h.M * (double)h.N * (double)h.K;
             g_kind_stats[kd * 3 + 2] += 1.0;
@@ -2105,9 +2321,9 @@ int vidseg_gemm_profile_end(double* out) {
 
 // Per-kernel split of the last profiled region: out[k*3 + {0,1,2}] = {milliseconds, algorithmic FLOPs, launches} for
 // k = 0: k_gemm_dma (128x128), 1: k_gemm_ph big (256x320 / 256x256), 2: k_gemm_tile mid (128x320), 3: k_gemm_conv<256,64>,
-// 4: k_gemm_p7 (224x320), 5: k_gemm_ws (weight-stationary streaming, short K).
+// 4: k_gemm_p7 (224x320), 5: k_gemm_ws (weight-stationary streaming, short K), 6: k_gemm_p7x (224x320 on split operands).
 int vidseg_gemm_profile_kinds(double* out) {
-    for (int i = 0; i < 18; ++i) out[i] = g_kind_stats[i];
+    for (int i = 0; i < 21; ++i) out[i] = g_kind_stats[i];
     return VS_OK;
 }
 
@@ -2115,7 +2331,7 @@ int vidseg_gemm_profile_kinds(double* out) {
 // reads (the whole input image for a conv: the 9 taps re-read it through L1/L2, not through memory), the weight matrix, the
 // residual, and every output it writes (16-bit result, fp32 result, fp16 taps); split-K partials are NOT algorithmic.
 int vidseg_gemm_profile_bytes(double* out) {
-    for (int i = 0; i < 6; ++i) out[i] = g_kind_bytes[i];
+    for (int i = 0; i < 7; ++i) out[i] = g_kind_bytes[i];
     return VS_OK;
 }
 
@@ -2396,11 +2612,24 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             p.ws = S > 1 ? g_ws : nullptr;
             p.gn = pick_gn(224, 320, 32, S);
             const long long tiles_7 = ((p.M + 223) / 224) * ((p.N + 319) / 320);
-            if (p7_phases == 3)
-                launch(k_gemm_p7<3>, dim3((unsigned)(tiles_7 * S)), 512, 2 * (256 + 320) * 128, p);
-            else
-                launch(k_gemm_p7<5>, dim3((unsigned)(tiles_7 * S)), 512, 2 * (256 + 320) * 128, p);
-            kind = 4;
+            // split operand images (exact mode): every plane staged once per 64 original channels (k_gemm_p7x); VIDSEG_GEMM_P7X=0 keeps
+            // the plain walk over the 3K axis
+            static int p7x_mode = -1;
+            if (p7x_mode < 0) {
+                const char* e = getenv("VIDSEG_GEMM_P7X");
+                p7x_mode = e ? atoi(e) : 1;
+                (void)hipFuncSetAttribute((const void*)k_gemm_p7x, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
+            }
+            if (p7x_mode && p.split2 && !p.x1 && p.C1 == 0 && p.K % 192 == 0 && p.C0 % 192 == 0 && (p.K / 192) / S >= 1) {
+                launch(k_gemm_p7x, dim3((unsigned)(tiles_7 * S)), 512, 2 * (256 + 320) * 128, p);
+                kind = 6;
+            } else {
+                if (p7_phases == 3)
+                    launch(k_gemm_p7<3>, dim3((unsigned)(tiles_7 * S)), 512, 2 * (256 + 320) * 128, p);
+                else
+                    launch(k_gemm_p7<5>, dim3((unsigned)(tiles_7 * S)), 512, 2 * (256 + 320) * 128, p);
+                kind = 4;
+            }
         } else if (big) {
             p.ksplit = S;
             p.ws = S > 1 ? g_ws : nullptr;
@@ -2530,6 +2759,7 @@ int vidseg_linear_a16_rf32(const void* a, int K, long long M, const void* w, int
     p.tap_cols = tap_cols;
     p.tap_ld = tap_ld;
     p.act = act;
+    p.split2 = 1;                                              // the operands of this entry point ARE split images (header)
     return launch_gemm(p, st);
 }
 
@@ -2588,7 +2818,8 @@ int vidseg_linear_a16_ttap(const void* a0, long long M, int C0, const void* w, i
 // Conv3d with kernel [3,1,1], padding [1,0,0] over frames (video_model.py:45-58): x NHWC bf16 [(b t)][HW][C],
 // w packed [Cout][c/64][dt][c%64] (chunk-major K order, see GemmParams), + bias + per-sample emb vector + residual.
 static int conv_temporal3_impl(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
-                               const float* rowvec, int rv_stride, const void* residual, void* out, float* out_f32, hipStream_t st) {
+                               const float* rowvec, int rv_stride, const void* residual, void* out, float* out_f32, hipStream_t st,
+                               int split2 = 0) {
     VS_REQUIRE(T >= 1 && BT % T == 0, "conv_temporal3: BT=%d T=%d", BT, T);
     GemmParams p{};
     p.x0 = (const bf16_t*)x;
@@ -2614,6 +2845,7 @@ static int conv_temporal3_impl(const void* x, int C, int BT, int HW, int T, cons
     p.out = (bf16_t*)out;
     p.out_f32 = out_f32;
     p.ldo = Cout;
+    p.split2 = split2;
     return launch_gemm(p, st);
 }
 
@@ -2625,13 +2857,13 @@ int vidseg_conv_temporal3_a16(const void* x, int C, int BT, int HW, int T, const
 int vidseg_conv_temporal3_a16_f32(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
                                    const float* rowvec, int rv_stride, float* out_f32, hipStream_t st) {
     VS_REQUIRE(out_f32 != nullptr, "conv_temporal3_f32: output is null");
-    return conv_temporal3_impl(x, C, BT, HW, T, w, Cout, bias, rowvec, rv_stride, nullptr, nullptr, out_f32, st);
+    return conv_temporal3_impl(x, C, BT, HW, T, w, Cout, bias, rowvec, rv_stride, nullptr, nullptr, out_f32, st, 1);   // split images (header)
 }
 
 // 3x3 convolution, padding 1, NHWC bf16 activations, weight packed [Cout][c/64][kh*3+kw][c%64] (chunk-major K order).
 static int conv3x3_impl(const void* x0, const void* x1, int C0, int C1, int B, int Hin, int Win, int stride, int up, const void* w,
                         int Cout, const float* bias, const float* rowvec, int rv_stride, const void* residual, void* out,
-                        int pad, float* out_f32, void* tap, int tap_early, hipStream_t st, int res_f32 = 0) {
+                        int pad, float* out_f32, void* tap, int tap_early, hipStream_t st, int res_f32 = 0, int split2 = 0) {
     VS_REQUIRE((stride == 1 || stride == 2) && (up == 1 || up == 2) && (pad == 0 || pad == 1), "conv3x3: stride=%d up=%d pad=%d", stride,
                up, pad);
     GemmParams p{};
@@ -2660,6 +2892,7 @@ static int conv3x3_impl(const void* x0, const void* x1, int C0, int C1, int B, i
     p.rows_per_sample = p.Hout * p.Wout;
     p.residual = (const bf16_t*)residual;
     p.res_f32 = res_f32;
+    p.split2 = split2;
     p.ldr = Cout;
     p.out = (bf16_t*)out;
     p.ldo = Cout;
@@ -2684,7 +2917,7 @@ int vidseg_conv3x3_a16_rf32(const void* x, int C, int B, int Hin, int Win, int s
                             const float* rowvec, int rv_stride, const float* residual_f32, float* out_f32, hipStream_t st) {
     VS_REQUIRE(out_f32 != nullptr, "conv3x3_rf32: needs an fp32 output");
     return conv3x3_impl(x, nullptr, C, 0, B, Hin, Win, stride, up, w, Cout, bias, rowvec, rv_stride, residual_f32, nullptr, 1, out_f32, nullptr, 0,
-                        st, 1);
+                        st, 1, 1);
 }
 
 // The same convolution with an fp16 copy of the result taken inside the epilogue: tap_early = 1 after the bias and before the

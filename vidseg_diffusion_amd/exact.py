@@ -204,16 +204,11 @@ def linear_x(a3, w3, bias=None, *, rowvec=None, rows_per_sample=0, act=ops.ACT_N
     M = a3.numel() // K3
     N = w3.shape[0]
     out = torch.empty(a3.shape[:-1] + (N,), dtype=F32, device=a3.device)
-    if residual is not None:
-        if residual.dtype != F32 or residual.numel() != M * N or not residual.is_contiguous():
-            raise VidsegError("linear_x: residual must be a contiguous fp32 [.., N] tensor")
-        call("vidseg_linear_a16_rf32", ptr(a3), K3, M, ptr(w3), N, ptr(bias), ptr(rowvec), rowvec.stride(0) if rowvec is not None else 0,
-             rows_per_sample, ptr(residual), N, ptr(out), N, ptr(tap), ptr(tap2), tap_cols, tap.shape[-1] if tap is not None else 0, act,
-             stream())
-        return out
-    call("vidseg_linear_a16", ptr(a3), None, K3, 0, M, ptr(w3), N, ptr(bias), ptr(rowvec), rowvec.stride(0) if rowvec is not None else 0,
-         rows_per_sample, None, 0, None, ptr(out), N, ptr(tap), ptr(tap2), tap_cols, tap.shape[-1] if tap is not None else 0, None, act,
-         stream())
+    if residual is not None and (residual.dtype != F32 or residual.numel() != M * N or not residual.is_contiguous()):
+        raise VidsegError("linear_x: residual must be a contiguous fp32 [.., N] tensor")
+    call("vidseg_linear_a16_rf32", ptr(a3), K3, M, ptr(w3), N, ptr(bias), ptr(rowvec), rowvec.stride(0) if rowvec is not None else 0,
+         rows_per_sample, ptr(residual), N, ptr(out), N, ptr(tap), ptr(tap2), tap_cols, tap.shape[-1] if tap is not None else 0, act,
+         stream())                                                          # the split-operand entry point (residual optional)
     return out
 
 
@@ -224,14 +219,10 @@ def conv3x3_x(x3, w3, bias, *, stride=1, up=1, rowvec=None, residual=None):
     Cout = w3.shape[0]
     Ho, Wo = (H * up + 2 - 3) // stride + 1, (W * up + 2 - 3) // stride + 1
     out = torch.empty((B, Ho, Wo, Cout), dtype=F32, device=x3.device)
-    if residual is not None:
-        if residual.dtype != F32 or tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous():
-            raise VidsegError("conv3x3_x: residual must be a contiguous fp32 tensor of the output's shape")
-        call("vidseg_conv3x3_a16_rf32", ptr(x3), C3, B, H, W, stride, up, ptr(w3), Cout, ptr(bias), ptr(rowvec),
-             rowvec.stride(0) if rowvec is not None else 0, ptr(residual), ptr(out), stream())
-        return out
-    call("vidseg_conv3x3_a16", ptr(x3), None, C3, 0, B, H, W, stride, up, ptr(w3), Cout, ptr(bias), ptr(rowvec),
-         rowvec.stride(0) if rowvec is not None else 0, None, None, 1, ptr(out), stream())
+    if residual is not None and (residual.dtype != F32 or tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous()):
+        raise VidsegError("conv3x3_x: residual must be a contiguous fp32 tensor of the output's shape")
+    call("vidseg_conv3x3_a16_rf32", ptr(x3), C3, B, H, W, stride, up, ptr(w3), Cout, ptr(bias), ptr(rowvec),
+         rowvec.stride(0) if rowvec is not None else 0, ptr(residual), ptr(out), stream())   # the split-operand entry point
     return out
 
 
@@ -504,6 +495,7 @@ class ExactRunner:
             freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=F32) / half)
             args = ts.float()[:, None] * freqs[None]
             self._temb_dev[key] = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(self.dev)
+            torch.cuda.current_stream().synchronize()                      # once per distinct vector: other lanes' streams read it too
         return self._temb_dev[key]
 
     def forward(self, x_nchw, timesteps, context, y=None, num_video_frames=None, stop_after_block=None):
