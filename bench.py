@@ -125,7 +125,7 @@ def cpu_baseline(sd_cpu, cfg, k_masks):
     return out
 
 
-def timed_masks_vs_reference(timed, refine, k_masks, world=1, last_step_index=None, win_ids=None):
+def timed_masks_vs_reference(timed, refine, k_masks, world=1, last_step_index=None, win_ids=None, svd=False):
     """The metric's second half on the work that was TIMED: every step's masks against the labels the REFERENCE produced for that
     window in fp32 (tests/golden/c2_window*.npz, tools/gen_golden_c2_window.py).  timed: [(window id, labels [F, N])] in step order.
     A window that was run more than once must have given identical masks (deterministic kernels) -- reported as `repeats_identical`."""
@@ -140,7 +140,7 @@ def timed_masks_vs_reference(timed, refine, k_masks, world=1, last_step_index=No
             same = same and np.array_equal(first[w], lab)
             continue
         first[w] = lab
-        path = os.path.join(ROOT, "tests", "golden", "c2_window.npz" if w == 0 else f"c2_window_w{w}.npz")
+        path = os.path.join(ROOT, "tests", "golden", f"c3_t17_w{w}.npz" if svd else ("c2_window.npz" if w == 0 else f"c2_window_w{w}.npz"))
         if not os.path.exists(path):
             continue
         g = np.load(path)
@@ -155,9 +155,12 @@ def timed_masks_vs_reference(timed, refine, k_masks, world=1, last_step_index=No
             "windows_at_0.99": int((ious >= 0.99).sum()), "n_windows": len(wins),
             "mean_identical_fraction": round(float(np.mean([x["identical_fraction"] for x in wins])), 4),
             "repeats_identical": bool(same),
-            "case": "the masks of the TIMED steps (BASELINE configs[1] at full size: 14x512x512, K=20, 3 CFG steps, full-width UNet; the steps "
-                    "cycle over the fixture windows of the synthetic clip) vs the reference's fp32 masks for the same windows "
-                    "(tests/golden/c2_window*.npz, generated from /root/reference by tools/gen_golden_c2_window.py)"
+            "case": ("the masks of the TIMED steps (BASELINE configs[2] at full size: SVD 14x576x1024, K=20, t_start 17 = 8 CFG steps, full-width "
+                     "VideoUNet) vs the reference's fp32 masks for the same windows (tests/golden/c3_t17_w*.npz, generated from /root/reference by "
+                     "tools/gen_golden_c3_window.py --t-start 17)" if svd else
+                     "the masks of the TIMED steps (BASELINE configs[1] at full size: 14x512x512, K=20, 3 CFG steps, full-width UNet; the steps "
+                     "cycle over the fixture windows of the synthetic clip) vs the reference's fp32 masks for the same windows "
+                     "(tests/golden/c2_window*.npz, generated from /root/reference by tools/gen_golden_c2_window.py)")
                     + ("; Step 3b (correct_low_res_mask) included" if refine else ""),
             "note": "best-of-10 K-means++ is chaotic in its input: a 1e-3 (fp16-level) change of the features re-rolls about half of the ten "
                     "restarts into other local optima (tools/mask_knee_study.py on the reference's own taps, tools/restart_study.py on the "
@@ -281,7 +284,36 @@ def build(svd, narrow, dev):
     return eng, cfg, sd_cpu, sum(int(np.prod(s)) for s in shapes.values())
 
 
-def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False):
+def fp8_attention_roofline(dev, B=28, H=5, N=9216, reps=10):
+    """The e4m3 attention kernel of configs[4] alone, at the SVD window's largest spatial self-attention (72x128 = 9216 tokens, 5 heads,
+    CFG batch 28), operands already quantised: HIP events on the launch stream, algorithmic FLOPs 4 * Nq * Nk * 64 per head against the
+    dense MX-fp8 MFMA peak (5 PFLOP/s, MI355X_MICROARCH.md)."""
+    from vidseg_diffusion_amd import ops
+    from vidseg_diffusion_amd._lib import call, ptr, stream
+    C = H * 64
+    g = torch.Generator().manual_seed(5)
+    q8, k8, v8 = (ops.quant_fp8(torch.randn((B, N, C), generator=g).to(dev).to(ops.act_dtype())) for _ in range(3))
+    out = torch.empty((B, N, C), dtype=ops.act_dtype(), device=dev)
+
+    def launch():
+        call("vidseg_attention_fp8", ptr(q8), C, ptr(k8), C, ptr(v8), C, ptr(out), C, B, H, N, N, 64, stream())
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / reps
+    fl = 4.0 * N * N * 64 * H * B
+    return {"bound": "mfma", "kernel": "k_attention_mx8 (e4m3 q, k, v, P; block-scaled 32x32x64 MFMA)", "achieved": round(fl / us / 1e6, 1), "peak": 5000.0,
+            "unit": "TFLOP/s", "frac": round(fl / us / 1e6 / 5000.0, 4), "avg_launch_us": round(us, 1), "shape": {"B": B, "heads": H, "Nq": N, "Nk": N},
+            "algorithmic_bytes": int(3 * B * N * C + 2 * B * N * C),
+            "note": "kernel alone, back-to-back launches outside the window (in the window the quantisation of q, k, v adds three small launches)"}
+
+
+def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, prebuilt=None):
     """Time `steps` steps of one config; returns (out dict for rank 0 | None, sd_cpu, cfg, eng, labels)."""
     from vidseg_diffusion_amd import feature_extraction as FE
     from vidseg_diffusion_amd import ops, parallel
@@ -289,9 +321,8 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False):
     k_masks = args.masks or 20
     t_start = 17 if svd else 22
     refine = True if svd else args.refine
-    eng, cfg, sd_cpu, n_params = build(svd, args.narrow, dev)
-    if args.exact:
-        eng.model.diffusion_model.set_precision("exact")
+    eng, cfg, sd_cpu, n_params = prebuilt or build(svd, args.narrow, dev)
+    eng.model.diffusion_model.set_precision("exact" if args.exact else "fp16")
     # The timed steps CYCLE over the windows of the synthetic clip (step i of rank r = window (i * world + r) mod n): K-means
     # iteration counts, restarts and tie replays are data dependent, so one repeated window would time -- and score -- a single
     # draw.  SD headline: the windows for which the reference's labels are committed (tests/golden/c2_window*.npz), so that
@@ -455,7 +486,7 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False):
         out["dtype"] += " + e4m3 attention (q, k, v, P; >= 1024 keys)"
         out["config"]["workload"] += "; BASELINE configs[4] attention path: OCP e4m3 MFMA on the spatial self-attentions"
     out["config"]["windows_cycled"] = win_ids
-    if svd and world == 1 and not args.narrow and (not args.masks_only or args.parity):
+    if svd and world == 1 and not args.narrow and (not args.masks_only or args.parity) and not args.fp8_attn:
         # BASELINE configs[2] names "is_refine_mask + latent blending": the blending lives in Step 4's modulated sampler passes
         # (sampling.py:229-250; svd_pipeline_vspw.py:396-487 -- 2*K of them per window).  One label's +lambda / -lambda pair is run and
         # timed here with the SVD driver's defaults (block 8, spatial + temporal self-attention rows, modulate_timestep 17 = t_start,
@@ -615,6 +646,10 @@ def main():
         out["dist_backend"] = (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from tools_metrics import matched_iou
+        if svd and not args.narrow and world == 1:
+            m = timed_masks_vs_reference(timed, refine, k_masks, svd=True)
+            if m is not None:
+                out["mask_iou_vs_reference"] = m
         if not svd and not args.narrow:
             if world == 1:
                 m = timed_masks_vs_reference(timed, refine, k_masks)
@@ -750,6 +785,10 @@ def main():
                 out["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "unique_labels",
                                                        "step4_latent_blending") if k in sec}
                 out["secondary"]["roofline"] = {k: sec["roofline"][k] for k in ("achieved", "frac", "kernel", "family")}
+                m2 = timed_masks_vs_reference(_t2, True, k_masks, svd=True)
+                if m2 is not None:
+                    out["secondary"]["mask_iou_vs_reference"] = {k: m2[k] for k in ("mean_iou", "min_iou", "windows_at_0.99", "n_windows",
+                                                                                    "mean_identical_fraction", "windows", "case")}
                 if args.exact:                                       # the 16-bit mode of the same config beside it
                     stage("secondary: 16-bit mode")
                     net2 = eng2.model.diffusion_model
@@ -757,16 +796,34 @@ def main():
                     rs2.fkw["masks_only"] = False
                     rs2(1)
                     torch.cuda.synchronize()
+                    del rs2.record[:]
                     t0 = time.perf_counter()
                     rs2(3)
                     torch.cuda.synchronize()
                     dt = time.perf_counter() - t0
+                    m3 = timed_masks_vs_reference(list(rs2.record), True, k_masks, svd=True)
                     out["secondary"]["fast_mode"] = {"value": round(F_WIN * 3 / dt, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dt / 3, 3),
                                                      "steps": 3, "precision": "fp16", "masks_only": False,
+                                                     "mask_iou_vs_reference": {k: m3[k] for k in ("mean_iou", "min_iou", "windows_at_0.99",
+                                                                                                  "n_windows")} if m3 else None,
                                                      "note": "16-bit activations, every step in full; NOT at mask parity "
                                                              "(tests/test_gpu_c3_window.py: exact mode 0.9994, 16-bit mode 0.72 on the fixture window)"}
+                # BASELINE configs[4]: the same SVD window with the e4m3 attention path and K = 50 masks (16-bit mode elsewhere), same engine
+                stage("secondary: configs[4] (SVD, fp8 attention, K = 50)")
+                a4 = argparse.Namespace(**vars(args))
+                a4.precision, a4.exact, a4.parity, a4.masks_only, a4.fp8_attn, a4.masks = "fp16", False, False, False, True, 50
+                prev8 = ops.set_attention_fp8(True)
+                try:
+                    n2 = sum(int(p_.numel()) for p_ in eng2.model.diffusion_model.parameters())
+                    sec8, *_r8 = run_config(a4, True, rank, world, dev, steps=3, warmup=1, secondary=True, prebuilt=(eng2, _cfg2, _sd2, n2))
+                    out["secondary_fp8"] = {k: sec8[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "unique_labels")
+                                            if k in sec8}
+                    out["secondary_fp8"]["roofline"] = fp8_attention_roofline(dev)
+                    out["secondary_fp8"]["gemm_family"] = {k: sec8["roofline"]["family"][k] for k in ("achieved", "frac", "gemm_ms_per_step")}
+                finally:
+                    ops.set_attention_fp8(prev8)
             except Exception as e:                                   # never lose the headline line to the secondary
-                out["secondary"] = {"error": repr(e)[:200]}
+                out.setdefault("secondary", {})["error"] = repr(e)[:300]
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

@@ -138,7 +138,7 @@ def test_split_tile_stages_each_plane_once(X):
     ops.gemm_profile_end()
     kinds = {n.split(" ")[0]: ln for (n, ms, fl, ln, ab) in ops.gemm_profile_kinds()}
     print("launches by kernel:", kinds)
-    assert kinds.get("k_gemm_p7x", 0) >= 6, kinds                                           # the shapes above must exercise the new tile
+    assert kinds.get("k_gemm_p7x", 0) >= 4, kinds                                           # the convolutions above must exercise the new tile (the N = 960 / split-K linears go to other tiles)
 
 
 def test_fp32_glue_operators(X):

@@ -62,16 +62,16 @@ def test_linear_concat_rowvec_tap(dev):
 _EPI_CASES = [  # (M, K, N, rows_per_sample, env): every GEMM kernel of the family, ragged rows / columns, samples shorter than a 32-row block
     (777, 320, 328, 37, {}),                                      # 128x128 LDS-DMA tile, ragged M and N, rows_per_sample > 32
     (300, 128, 192, 5, {}),                                       # rows_per_sample < 32: per-row sample lookup
-    (1031, 1280, 320, 1031, {"VIDSEG_GEMM_BIG": "2"}),            # phased 256x320 tile forced (one ragged round)
-    (520, 2560, 512, 130, {"VIDSEG_GEMM_BIG": "2"}),              # phased 256x256 tile with split-K partials + finish kernel
-    (700, 640, 640, 100, {"VIDSEG_GEMM_MID": "2", "VIDSEG_GEMM_BIG": "0"}),   # 128x320 tile
-    (1031, 1280, 320, 1031, {"VIDSEG_GEMM_BIG": "2", "VIDSEG_GEMM_P7": "2"}),  # 224x320 tile (16x16x32 fragments), ragged last tile row
-    (1500, 2560, 640, 130, {"VIDSEG_GEMM_BIG": "2", "VIDSEG_GEMM_P7": "2"}),   # 224x320 tile with split-K partials + finish kernel
-    (224 * 9, 320, 960, 224, {"VIDSEG_GEMM_BIG": "2", "VIDSEG_GEMM_P7": "2"}),  # 224x320 tile, short K (5 K-tiles), three tile columns
+    (1031, 1280, 320, 1031, {"VIDSEG_GEMM": "big=2"}),            # phased 256x320 tile forced (one ragged round)
+    (520, 2560, 512, 130, {"VIDSEG_GEMM": "big=2"}),              # phased 256x256 tile with split-K partials + finish kernel
+    (700, 640, 640, 100, {"VIDSEG_GEMM": "mid=2,big=0"}),   # 128x320 tile
+    (1031, 1280, 320, 1031, {"VIDSEG_GEMM": "big=2,p7=2"}),  # 224x320 tile (16x16x32 fragments), ragged last tile row
+    (1500, 2560, 640, 130, {"VIDSEG_GEMM": "big=2,p7=2"}),   # 224x320 tile with split-K partials + finish kernel
+    (224 * 9, 320, 960, 224, {"VIDSEG_GEMM": "big=2,p7=2"}),  # 224x320 tile, short K (5 K-tiles), three tile columns
     (515, 192, 56, 103, {}),                                      # narrow-N register-staged kernel
-    (1000, 320, 320, 37, {"VIDSEG_GEMM_WS": "2"}),                # weight-stationary streaming kernel, K = 320: two 160-column panels, ragged M
-    (4099, 320, 960, 224, {"VIDSEG_GEMM_WS": "2"}),               # ... six panels (two of an XCD's 32 blocks idle), ragged M
-    (2100, 640, 640, 130, {"VIDSEG_GEMM_WS": "2"}),               # ... K = 640: eight 80-column panels, ring refilled inside the tile
+    (1000, 320, 320, 37, {"VIDSEG_GEMM": "ws=2"}),                # weight-stationary streaming kernel, K = 320: two 160-column panels, ragged M
+    (4099, 320, 960, 224, {"VIDSEG_GEMM": "ws=2"}),               # ... six panels (two of an XCD's 32 blocks idle), ragged M
+    (2100, 640, 640, 130, {"VIDSEG_GEMM": "ws=2"}),               # ... K = 640: eight 80-column panels, ring refilled inside the tile
     (40000, 320, 320, 5000, {}),                                  # ... as selected by default (M >= 16384), several tiles per wave
 ]
 
@@ -96,7 +96,7 @@ for out, ref in ((ops.linear(ad, wd, b.to(dev)), a @ w.T + b), (ops.linear(ad, w
     assert (err <= 2.0 ** -7 * ref.abs() + 2e-3 * ref.abs().max()).all(), float(err.max())
 print("ok")
 """
-    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "VIDSEG_GEMM_WS": "2"}, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "VIDSEG_GEMM": "ws=2"}, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
@@ -145,9 +145,9 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("env", [{"VIDSEG_GEMM_BIG": "2"}, {"VIDSEG_GEMM_BIG": "2", "VIDSEG_GEMM_PH": "0"},
-                                 {"VIDSEG_GEMM_BIG": "2", "VIDSEG_GEMM_P7": "2"},
-                                 {"VIDSEG_GEMM_MID": "2", "VIDSEG_GEMM_BIG": "0"}, {"VIDSEG_GEMM_DMA": "3", "VIDSEG_GEMM_BIG": "0", "VIDSEG_GEMM_MID": "0"}])
+@pytest.mark.parametrize("env", [{"VIDSEG_GEMM": "big=2"}, {"VIDSEG_GEMM": "big=2,ph=0"},
+                                 {"VIDSEG_GEMM": "big=2,p7=2"},
+                                 {"VIDSEG_GEMM": "mid=2,big=0"}, {"VIDSEG_GEMM": "dma=3,big=0,mid=0"}])
 def test_conv3x3_on_every_tile(env):
     """3x3 convolutions (concat input, stride 2, fused 2x upsample, ragged edges, chunk-major K order with a source switch inside the
     K loop) forced onto each LDS-DMA kernel: phased big tile, unphased big tile, 224x320 tile (k_gemm_p7, for Cout = 320 / 640),

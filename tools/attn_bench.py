@@ -27,7 +27,7 @@ for B, H, N in ((28, 5, 4096), (28, 10, 1024), (28, 20, 256)):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     fl = 4.0 * B * H * N * N * 64
-    print(f"attention B={B} H={H} N={N}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  (TR={os.environ.get('VIDSEG_ATTN_TR', '1')})", flush=True)
+    print(f"attention B={B} H={H} N={N}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  (TR={os.environ.get('VIDSEG_ATTN', 'default')})", flush=True)
 
 # experiment builds with -DVS_ATTN_STAMPS (tools/build_exp.py): phase timeline of tiles 8..11 of one block, per wave
 import ctypes  # noqa: E402

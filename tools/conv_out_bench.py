@@ -1,4 +1,4 @@
-"""Time the UNet's output conv (Cout = 4) at the window's size (GPU box): python tools/conv_out_bench.py  (VIDSEG_CONV_OUT_WS=0/1)"""
+"""Time the UNet's output conv (Cout = 4) at the window's size (GPU box): python tools/conv_out_bench.py  (VIDSEG_GEMM=convout=0/1)"""
 import os
 import sys
 
@@ -23,4 +23,4 @@ for B, H, C in ((28, 64, 320), (14, 512, 128)):
     e.record()
     torch.cuda.synchronize()
     us = s.elapsed_time(e) * 1e3 / 20
-    print(f"conv_out4 B={B} {H}x{H} Cin={C}: {us:8.1f} us  ({x.numel() * 2 / us / 1e6:.2f} TB/s of input)  WS={os.environ.get('VIDSEG_CONV_OUT_WS', '1')}", flush=True)
+    print(f"conv_out4 B={B} {H}x{H} Cin={C}: {us:8.1f} us  ({x.numel() * 2 / us / 1e6:.2f} TB/s of input)  WS={os.environ.get('VIDSEG_GEMM', 'default')}", flush=True)

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--windows", default="0-3")
     ap.add_argument("--precision", default="fp16")
     ap.add_argument("--overlap", action="store_true", help="through WindowPipeline (analysis on the second stream), as bench.py runs it")
-    ap.add_argument("--prof", action="store_true", help="with the GEMM timing events on, as in bench.py's timed region (VIDSEG_PROF_EXT=0/1 picks the mechanism)")
+    ap.add_argument("--prof", action="store_true", help="with the GEMM timing events on, as in bench.py's timed region (VIDSEG_GEMM=ext=0/1 picks the mechanism)")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--refine", action="store_true", help="with Step 3b (dense tracking + trajectory vote)")
     ap.add_argument("--chain", action="store_true", help="windows chained as one clip (4-NN label propagation instead of K-means after window 0)")

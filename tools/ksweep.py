@@ -1,5 +1,5 @@
 """Fixed cost per round of the big GEMM tiles: time linears of growing K on a shape that is exactly one / two rounds of 256 tiles and
-fit t = a + b K (GPU box).  python tools/ksweep.py   (VIDSEG_GEMM_BIG=2 VIDSEG_GEMM_P7=2 force the 224x320 tile)"""
+fit t = a + b K (GPU box).  python tools/ksweep.py   (VIDSEG_GEMM=big=2,p7=2 forces the 224x320 tile)"""
 import os
 import sys
 

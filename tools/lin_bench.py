@@ -1,4 +1,4 @@
-"""Time the short-K linears of the window (GPU box): python tools/lin_bench.py   (VIDSEG_GEMM_WS=0/1 to compare)"""
+"""Time the short-K linears of the window (GPU box): python tools/lin_bench.py   (VIDSEG_GEMM=ws=0/1 to compare)"""
 import os
 import sys
 
@@ -31,7 +31,7 @@ for M, K, N, res in ((114688, 320, 320, False), (114688, 320, 320, True), (11468
     b = torch.zeros(N, device=dev)
     r = torch.randn(M, N, device=dev).to(ops.act_dtype()) if res else None
     bench(lambda: ops.linear(a, w, b, residual=r), 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N * (2 if res else 1)),
-          f"linear M{M} K{K} N{N}{' +res' if res else ''} (WS={os.environ.get('VIDSEG_GEMM_WS', '1')})")
+          f"linear M{M} K{K} N{N}{' +res' if res else ''} (WS={os.environ.get('VIDSEG_GEMM', 'default')})")
 
 # experiment builds with -DVS_WS_STAMPS: phase timeline of tiles 1..4 of block 40, per wave (the scalar counter path adds its own latency)
 import ctypes  # noqa: E402

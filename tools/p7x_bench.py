@@ -66,7 +66,7 @@ if __name__ == "__main__":
         run(sys.argv[1])
     else:
         import torch
-        for tag, env in (("p7", {"VIDSEG_GEMM_P7X": "0"}), ("p7x", {"VIDSEG_GEMM_P7X": "1"})):
+        for tag, env in (("p7", {"VIDSEG_GEMM": "p7x=0"}), ("p7x", {"VIDSEG_GEMM": "p7x=1"})):
             subprocess.run([sys.executable, __file__, tag], env={**os.environ, **env}, check=True, timeout=900)
         a, b = torch.load("/tmp/p7x_p7.pt"), torch.load("/tmp/p7x_p7x.pt")
         worst = 0.0

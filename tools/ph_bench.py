@@ -1,4 +1,4 @@
-"""A/B of the phased big tile (VIDSEG_GEMM_PH=1) against k_gemm_tile: bit-equality of outputs (same MFMA order), run-to-run
+"""A/B of the phased big tile (VIDSEG_GEMM=ph=1) against k_gemm_tile: bit-equality of outputs (same MFMA order), run-to-run
 stability (race screen) and time per launch.  usage: python tools/ph_bench.py            (spawns both modes)"""
 import os
 import subprocess
@@ -45,8 +45,8 @@ if __name__ == "__main__":
         run(sys.argv[1])
     else:
         import torch
-        for tag, env in (("base", {"VIDSEG_GEMM_PH": "0"}), ("ph", {"VIDSEG_GEMM_PH": "1"})):
-            subprocess.run([sys.executable, __file__, tag], env={**os.environ, "VIDSEG_GEMM_BIG": os.environ.get("VIDSEG_GEMM_BIG", "2"), **env}, check=True, timeout=600)
+        for tag, env in (("base", {"VIDSEG_GEMM": "big=2,ph=0"}), ("ph", {"VIDSEG_GEMM": "big=2,ph=1"})):
+            subprocess.run([sys.executable, __file__, tag], env={**os.environ, **env}, check=True, timeout=600)
         a, b = torch.load("/tmp/ph_base.pt"), torch.load("/tmp/ph_ph.pt")
         for sh, x, y in zip(SHAPES, a, b):
             print(sh, "bit-equal" if torch.equal(x, y) else f"DIFF max {(x.float()-y.float()).abs().max().item():.4g} frac {(x != y).float().mean().item():.4g}")

@@ -3,7 +3,7 @@ T=${1:-r04_b}
 mkdir -p gpurun_out/$T
 timeout 900 python tools/p7x_bench.py > gpurun_out/$T/p7x_bench.txt 2>&1
 tail -70 gpurun_out/$T/p7x_bench.txt
-VIDSEG_GEMM_P7X=0 VIDSEG_BENCH_PMC=0 timeout 1200 python bench.py --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/$T/bench_p7.json 2> gpurun_out/$T/bench_p7.err
+VIDSEG_GEMM=p7x=0 VIDSEG_BENCH_PMC=0 timeout 1200 python bench.py --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/$T/bench_p7.json 2> gpurun_out/$T/bench_p7.err
 tail -12 gpurun_out/$T/bench_p7.err
 VIDSEG_BENCH_PMC=0 timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/$T/bench_p7x.json 2> gpurun_out/$T/bench_p7x.err
 tail -5 gpurun_out/$T/bench_p7x.err

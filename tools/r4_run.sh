@@ -27,7 +27,7 @@ try:
 except Exception as e:
     print("bench parse failed", e)
 PY
-VIDSEG_GEMM_SHAPES=1 timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --one-window > /dev/null 2> gpurun_out/$T/shapes.log
+VIDSEG_GEMM=shapes=1 timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --one-window > /dev/null 2> gpurun_out/$T/shapes.log
 python tools/shape_summary.py gpurun_out/$T/shapes.log > gpurun_out/$T/shape_summary_parity.txt; head -45 gpurun_out/$T/shape_summary_parity.txt
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_d -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $GRAFT_REPO_ROOT/gpurun_out/$T/bench_under_rocprof.json 2>/tmp/prof_d.err

@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/rep
 for i in $(seq 1 ${REPS:-6}); do
-VIDSEG_DEBUG_HASH=1 VIDSEG_PROF_EXT=${PROF_EXT:-1} VIDSEG_BENCH_EXACT=0 VIDSEG_BENCH_PMC=0 python bench.py --steps 16 --warmup 4 --no-secondary --no-cpu-baseline 2> gpurun_out/rep/err_$i.txt | python -c "
+VIDSEG_DEBUG_HASH=1 VIDSEG_GEMM=ext=${PROF_EXT:-1} VIDSEG_BENCH_EXACT=0 VIDSEG_BENCH_PMC=0 python bench.py --steps 16 --warmup 4 --no-secondary --no-cpu-baseline 2> gpurun_out/rep/err_$i.txt | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); m=d['mask_iou_vs_reference']
 print(d['value'], m['mean_iou'])"

@@ -1,4 +1,4 @@
-"""Aggregate `GEMMSHAPE` lines (VIDSEG_GEMM_SHAPES=1 python bench.py ... 2> log) per problem shape."""
+"""Aggregate `GEMMSHAPE` lines (VIDSEG_GEMM=shapes=1 python bench.py ... 2> log) per problem shape."""
 import collections, re, sys
 agg = collections.OrderedDict()
 for line in open(sys.argv[1]):

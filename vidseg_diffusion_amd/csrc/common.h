@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #define VS_OK 0
 #define VS_ERR_ARG (-1)
@@ -115,4 +116,21 @@ __device__ __forceinline__ void attn_block(int& bh, int& qb) {
     const long long id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     bh = (int)(id / gx);
     qb = (int)(id % gx);
+}
+
+// Host-side override of a kernel-selection default, for tests and same-box A/B runs only: VAR="key=value,key=value".  The product
+// path sets none of them; every kernel choice is a fixed function of the problem.  (VIDSEG_GEMM: csrc/gemm_conv.hip, VIDSEG_ATTN: the
+// attention kernels of csrc/unet_ops.hip and csrc/exact_ops.hip.)
+static inline int vs_knob(const char* var, const char* key, int dflt) {
+    const char* e = getenv(var);
+    const size_t kl = strlen(key);
+    while (e && *e) {
+        const char* eq = strchr(e, '=');
+        if (!eq) break;
+        if ((size_t)(eq - e) == kl && !strncmp(e, key, kl)) return atoi(eq + 1);
+        const char* c = strchr(eq, ',');
+        if (!c) break;
+        e = c + 1;
+    }
+    return dflt;
 }

@@ -753,8 +753,7 @@ int vidseg_x_attention_mfma(const float* q, int ldq, const void* k_hi, const voi
     if (B * H * Nq == 0) return VS_OK;
     const float scale_log2e = scale * 1.44269504088896340736f;
     const dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)(B * H));
-    static int flush = -1;                                   // VIDSEG_X_ATTN_FLUSH=0: the PV products accumulate across tiles inside the MFMA
-    if (flush < 0) { const char* e = getenv("VIDSEG_X_ATTN_FLUSH"); flush = e ? atoi(e) : 1; }
+    static const int flush = vs_knob("VIDSEG_ATTN", "flush", 1);   // VIDSEG_ATTN="flush=0": the PV products accumulate across tiles inside the MFMA
 #define XA_LAUNCH(R, F) k_x_attention_mfma<R, F><<<grid, 256, 0, st>>>(q, ldq, (const f16*)k_hi, (const f16*)k_lo, (const f16*)v_hi, \
                                                                         (const f16*)v_lo, ldkv, out, ldo, (f16*)out_split3, Nq, Nk, H, scale_log2e)
     if (Nk % 64 == 0) { if (flush) XA_LAUNCH(false, true); else XA_LAUNCH(false, false); }

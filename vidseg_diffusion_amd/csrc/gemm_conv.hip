@@ -117,9 +117,6 @@ struct KCursor {
 };
 
 #define BK 64
-#ifndef PH_EXP
-#define PH_EXP 0                                               // kernel experiments (tools/dbg/build_exp.sh); 0 in the product build
-#endif
 
 __device__ __forceinline__ long long tap_row(const GemmParams& p, long long m) {
     if (p.tap_T <= 0) return m;
@@ -156,10 +153,7 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 // next to the 140 live accumulators) and picks its cell's registers by the uniform loop counter.  One cell at a time, every cell
 // paid its own residual round trip (the load sits behind the tap stores, which the compiler must assume may alias it) -- with the 8
 // waves of a CU all in the epilogue nothing else covered those ~1000 cycles, 20 times per tile.
-#ifndef VS_EPI_PRELOAD
-#define VS_EPI_PRELOAD 1                                       // 0: A/B builds without the residual preload (tools/build_exp.py)
-#endif
-template <int NC8, int EP_LD, int U_ = (32 * NC8 + 63) / 64, bool PRELOAD = (VS_EPI_PRELOAD != 0), bool X3 = false>
+template <int NC8, int EP_LD, int U_ = (32 * NC8 + 63) / 64, bool PRELOAD = true, bool X3 = false>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* stage, int mrow0, int nrows, int ocol0, int nout, int lane,
                                               int split, bool fin, bool pre) {
     constexpr int U = PRELOAD ? U_ : 1;                        // without the preload: the plain one-cell-at-a-time loop
@@ -276,11 +270,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
             bf16x8_t o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(v[e]);
-#if PH_EXP & 256                                               // experiment: no output stores (one conditional store keeps the values alive)
-            if (o[0] == 12345) *reinterpret_cast<bf16x8_t*>(p.out + oo) = o;
-#else
             *reinterpret_cast<bf16x8_t*>(p.out + oo) = o;
-#endif
         }
         if (p.out_f32) {
             *reinterpret_cast<f32x4*>(p.out_f32 + oo) = f32x4{v[0], v[1], v[2], v[3]};
@@ -315,7 +305,7 @@ template <int NJ, int MI = 2, bool PRELOAD_ = true, bool X3 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[MI][NJ], char* smem, long long mrow_base, int wcol_base,
                                               int lane, int wave, int split) {
     const int l31 = lane & 31, hi = lane >> 5;
-    constexpr bool PRELOAD = PRELOAD_ && (VS_EPI_PRELOAD != 0);
+    constexpr bool PRELOAD = PRELOAD_;
     constexpr int EP_LD = 68;                                  // fp32 row stride of the staging tile (64 + 4 pad)
     constexpr int NG = (NJ + 1) / 2;
     float* stage = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
@@ -1026,11 +1016,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
     bool a_second = false;
     // stage group g of tile u into buffer buf (groups of one tile are staged in order g = 0, 1, ..; the cursor moves after G1)
     auto stage = [&](int g, int u, int buf) {
-#if PH_EXP & 16
-        const bool live = u < 2;
-#else
         const bool live = u < nk;
-#endif
         if (g == 0) {
             const int c0 = cur.c0();
             a_second = c0 >= p.C0;
@@ -1092,10 +1078,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
         for (int j = 0; j < NJ; ++j) {
             // ---- read section
             bf16x8_t fb[4];
-#if PH_EXP & 1                                                 // experiment: no LDS reads in the loop (wrong results)
-            if (t == 0) {
-#endif
-            if (j == 0 && (!(PH_EXP & 32) || t == 0)) {
+            if (j == 0) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -1103,27 +1086,13 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) fb[s] = *reinterpret_cast<const bf16x8_t*>(B + j * 32 * RB + (((s * 2 + hi) ^ sw) << 4));
-#if PH_EXP & 1
-            }
-#endif
-#if PH_EXP & 2                                                 // experiment: no DMA in the loop (wrong results)
-            if (t < 0) {
-#endif
             if (j >= 2)
                 stage(j - 2, t + 2, buf);
             else
                 stage(j - 2 + NJ, t + 1, buf ^ 1);
-#if PH_EXP & 2
-            }
-#endif
             // counted wait for what phase j+1 reads
             const int jn = (j + 1) % NJ;
-#if PH_EXP & 4
-            if (false) {
-            } else if (t < 0)
-#else
             if (jn == 0)
-#endif
                 wait_vmcnt<CNT_ALL - 8>();
             else if (cnt(jn) + cnt((jn + 1) % NJ) + cnt((jn + 2) % NJ) == 7)
                 wait_vmcnt<CNT_ALL - 7>();
@@ -1135,35 +1104,25 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             // ---- matrix section
-#if !(PH_EXP & 8)
             __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) acc[i][j] = mfma_32x32x16(fa[i][s], fb[s], acc[i][j]);
-#if !(PH_EXP & 8)
             __builtin_amdgcn_s_setprio(0);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-#if !(PH_EXP & 128)                                            // experiment: no main loop
     for (int t = 0; t < nk; t += 2) {
         tile(t, 0);
         if (t + 1 < nk) tile(t + 1, 1);
     }
-#endif
     wait_vmcnt<0>();
     if (grp == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
-#if PH_EXP & 64                                                // experiment: no epilogue (one store keeps the accumulators alive)
-    if (acc[0][0][0] == 123.456f) p.out[0] = 1;
-#else
     gemm_epilogue<NJ, 2, true, X3>(p, acc, smem, m0 + wm * 64, n0 + wn * (NJ * 32), lane, wave, split);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1294,9 +1253,6 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7(GemmParams p) {
         const bool ok = live && (unsigned)ih < (unsigned)hb && (unsigned)iw < (unsigned)wb;
         const int pix = a_base[s4] + (ih >> upsh) * wmul + (iw >> upsh);
         const unsigned off = ok ? (unsigned)(pix * t_Cs + t_cc) * 2u + swz16 : OOB;
-#if PH_EXP & 512                                                // experiment: every third K-tile stages nothing (wrong results): the issue count of a native (hi, lo) tile
-        if (u % 3 == 2) return;
-#endif
         if (a_second)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
         else
@@ -1306,9 +1262,6 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7(GemmParams p) {
         const bool live = u < nk;
         char* dst = smem + 2 * A_BYTES + buf * B_BYTES + (b_r0 + g * 16) * RB;
         const unsigned off = (live && b_n + g * 16 < p.N) ? b_off0 + (unsigned)g * b_gstep + (unsigned)(ks_begin + u) * 128u : OOB;
-#if PH_EXP & 512
-        if (u % 3 == 2) return;
-#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
     };
 
@@ -1961,6 +1914,45 @@ __global__ void __launch_bounds__(256) k_conv_out4_ws(const bf16_t* __restrict__
 // synchronises, sums the elapsed times and the algorithmic FLOPs (2*M*N*K per launch).
 #include <vector>
 #include <stdlib.h>
+// Kernel selection is a fixed function of the problem (the decision table in launch_gemm).  ONE override exists, for the per-kernel
+// tests and same-box A/B runs: VIDSEG_GEMM="key=value,key=value", read once per process.  Keys (default):
+//   big (1)   0 never / 1 where the table picks it / 2 whenever legal -- the 8-wave phased tiles (k_gemm_ph 256x320 / 256x256, k_gemm_p7 224x320)
+//   p7 (1)    0 / 1 / 2 likewise for the 224-row tile among the big ones;  p7x (1): 0 keeps k_gemm_p7 on split operands
+//   p7ph (5)  phases per K-tile of k_gemm_p7 (5 or 3);  ph (1): 0 = the unphased k_gemm_tile for the big shapes
+//   mid (1)   0 / 1 / 2 the 128x320 tile;  dma (1): 0 = k_gemm_conv<128,128>, 3 = the 3-stage 128x128 everywhere;  tile (0): 128 forbids the narrow 256x64 tile
+//   ws (1)    0 / 1 / 2 the weight-stationary streaming kernel;  convout (1): 0 = the plain 4-channel output conv
+//   split (1) 0 = no split-K;  panel (1): 0 = row-major tile order
+//   ext (1)   0 = hipEventRecord pairs instead of dispatch-packet timestamps (profiling);  fence (0): 1 = system-scope fence at the events
+//   shapes (0) 1 = one GEMMSHAPE line per profiled launch on stderr (tools/shape_summary.py)
+struct GemmKnobs {
+    int big = 1, p7 = 1, p7x = 1, p7ph = 5, ph = 1, mid = 1, dma = 1, tile = 0, ws = 1, convout = 1, split = 1, panel = 1, ext = 1, fence = 0, shapes = 0;
+};
+static const GemmKnobs& knobs() {
+    static const GemmKnobs k = [] {
+        GemmKnobs g;
+        const char* e = getenv("VIDSEG_GEMM");
+        if (!e) return g;
+        struct { const char* name; int* v; } tab[] = {{"big", &g.big}, {"p7", &g.p7}, {"p7x", &g.p7x}, {"p7ph", &g.p7ph}, {"ph", &g.ph}, {"mid", &g.mid},
+                                                      {"dma", &g.dma}, {"tile", &g.tile}, {"ws", &g.ws}, {"convout", &g.convout}, {"split", &g.split},
+                                                      {"panel", &g.panel}, {"ext", &g.ext}, {"fence", &g.fence}, {"shapes", &g.shapes}};
+        while (*e) {
+            const char* eq = strchr(e, '=');
+            if (!eq) break;
+            bool known = false;
+            for (auto& t : tab)
+                if ((size_t)(eq - e) == strlen(t.name) && !strncmp(e, t.name, eq - e)) {
+                    *t.v = atoi(eq + 1);
+                    known = true;
+                }
+            if (!known) fprintf(stderr, "vidseg: VIDSEG_GEMM: unknown key in '%s'\n", e);
+            const char* c = strchr(eq, ',');
+            if (!c) break;
+            e = c + 1;
+        }
+        return g;
+    }();
+    return k;
+}
 struct GemmProf {
     bool on = false;
     std::vector<hipEvent_t> ev;      // pairs
@@ -1979,7 +1971,7 @@ static inline hipEvent_t prof_event() {
         hipEvent_t e;
         // no system-scope release at the record: the default flag flushes the L2 to make the kernels' results host-visible at
         // every event (measured: the 1200 records of a window cost 4-5 % of the step); timing needs no such fence
-        static const unsigned flags = getenv("VIDSEG_PROF_SYSFENCE") ? hipEventDefault : hipEventDisableSystemFence;
+        static const unsigned flags = knobs().fence ? hipEventDefault : hipEventDisableSystemFence;
         (void)hipEventCreateWithFlags(&e, flags);
         g_prof.ev.push_back(e);
     }
@@ -2001,12 +1993,6 @@ static inline hipEvent_t prof_event() {
 // three 8-column cells of an 8-row pass sit at fixed columns, so their bias lives in registers, the residual of the NEXT pass is
 // requested before the stores of this one (vmcnt retires in order: a load queued behind stores waits for them), and the
 // compiler's counted waits do the rest.
-#ifdef VS_WS_STAMPS                                        /* experiment builds only (tools/build_exp.py): s_memtime at the phase boundaries */
-__device__ unsigned long long vs_ws_stamps[8 * 4 * 4];
-#define VS_WS_STAMP(i) do { if (blockIdx.x == 40 && lane == 0 && tile_no >= 1 && tile_no < 5) vs_ws_stamps[(wave * 4 + (tile_no - 1)) * 4 + (i)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define VS_WS_STAMP(i)
-#endif
 template <int NJ, int KT, int EPI>
 __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cpx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2092,10 +2078,8 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
     // one tile; FIRST: no epilogue lies between the prologue's loads and this tile's k-steps (separate instantiations, not a
     // runtime flag: two wait statements tied to the same ring registers in two branches make the compiler copy those registers
     // ahead of the wait)
-    int tile_no = 0;
     auto tile_body = [&](auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
-        VS_WS_STAMP(0);
         const int tn = t + 8 < t_end ? t + 8 : t;              // the tile whose first k-steps refill the ring at the end of this one
         f32x4 acc[2][NJ];
 #pragma unroll
@@ -2138,7 +2122,6 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
         }                                                      // below the last MFMA otherwise)
         // epilogue: four passes of 8 rows; lanes whose row lies in the pass write their 16 columns-of-four, then every lane
         // takes 8-column cells of the staged rows (bias, residual, taps ... exactly as the tiled kernels)
-        VS_WS_STAMP(1);
         if (EPI && STAGED) {
             // residual cells: like the A ring, loaded and waited for by hand (a compiler-tracked load next to the stores makes
             // every wait a vmcnt(0): PMC showed these waves parked 57 % of their cycles).  The next pass's cells are requested
@@ -2197,8 +2180,6 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
-            VS_WS_STAMP(2);
-            ++tile_no;
             return;
         }
         if (EPI) {
@@ -2248,8 +2229,6 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
                     if (m <= mlast) *reinterpret_cast<u32x2*>(orow + 16 * (NJ - 1) + 4 * q) = o;
                 }
             }
-            VS_WS_STAMP(2);
-            ++tile_no;
             return;
         }
 #pragma unroll
@@ -2271,11 +2250,6 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
     for (t += 8; t < t_end; t += 8) tile_body(std::false_type{});
 }
 
-#ifdef VS_WS_STAMPS
-extern "C" int vidseg_debug_ws_stamps(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vs_ws_stamps), sizeof(unsigned long long) * 8 * 4 * 4) == hipSuccess ? 0 : -1;
-}
-#endif
 extern "C" {
 
 int vidseg_gemm_profile_begin(void) {
@@ -2307,7 +2281,7 @@ int vidseg_gemm_profile_end(double* out) {
             g_kind_stats[kd * 3 + 2] += 1.0;
             g_kind_bytes[kd] += h.alg_bytes;
         }
-        if (getenv("VIDSEG_GEMM_SHAPES") && i / 2 < g_prof.shapes.size()) {
+        if (knobs().shapes && i / 2 < g_prof.shapes.size()) {
             const GemmProf::Shape& h = g_prof.shapes[i / 2];
             fprintf(stderr, "GEMMSHAPE M=%lld N=%d K=%d ks=%d up=%d st=%d act=%d split=%d us=%.1f kind=%d\n", h.M, h.N, h.K, h.ksize, h.up,
                     h.stride, h.act, h.ksplit, t * 1e3, h.kind);
@@ -2405,16 +2379,14 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)k_gemm_conv<256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
         attr = true;
     }
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("VIDSEG_GEMM_TILE"); force = e ? atoi(e) : 0; }
+    const int force = knobs().tile;
     bool narrow = p.N <= 64 && p.act != 2 && p.M >= 256;
     if (force == 128) narrow = false;
     // Timing (bench.py roofline): by default the two events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL: start /
     // stop timestamps of the kernel, what rocprofv3 reports; with a split-K finish the stop event rides on the finish kernel).
     // VIDSEG_PROF_EXT=0: two hipEventRecord calls around the launch instead -- two extra barrier packets per launch, which cost the
     // window 1.7 ms and read ~9 us per launch more than the kernel trace.
-    static int prof_ext = -1;
-    if (prof_ext < 0) { const char* e = getenv("VIDSEG_PROF_EXT"); prof_ext = e ? atoi(e) : 1; }
+    const int prof_ext = knobs().ext;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (g_prof.on) {
         ev0 = prof_event();
@@ -2436,11 +2408,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     // weight-stationary streaming kernel: plain linears with K = 320 (160-column panels) or K = 640 (80-column panels) and enough
     // rows to give every wave of the 256 persistent blocks a few 32-row tiles; the 32 blocks of an XCD split into np panels x
     // cpx row chunks, and the launch is taken only when at most 2 of them stay idle.  VIDSEG_GEMM_WS=0 disables.
-    static int ws_mode = -1;
-    if (ws_mode < 0) {
-        const char* e = getenv("VIDSEG_GEMM_WS");
-        ws_mode = e ? atoi(e) : 1;
-    }
+    const int ws_mode = knobs().ws;
     // k_gemm_ws is written for this chip: a fixed grid of 256 persistent blocks laid out over 8 XCDs and ~142 KB of dynamic LDS.  On
     // a device that does not offer that (fewer CUs, less LDS per block) or when the attribute call is refused, the launch goes to
     // the tiled kernels instead of failing (or idling half a larger chip).
@@ -2502,33 +2470,23 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         launch(k_gemm_conv<256, 64>, dim3((unsigned)tiles), 256, 2 * (256 + 64) * BK * 2, p);
     } else {
         const int nk = p.K / BK;
-        static int nosplit = -1, use_dma = -1, big_mode = -1, mid_mode = -1, ph_mode = 0, p7_mode = 1, p7_phases = 5;
+        const int nosplit = !knobs().split, use_dma = knobs().dma, big_mode = knobs().big, mid_mode = knobs().mid, ph_mode = knobs().ph,
+                  p7_mode = knobs().p7, p7_phases = knobs().p7ph;
         constexpr int MID_LDS = 8 * 32 * 68 * 4;               // epilogue staging of 8 waves (69.6 KiB) > 2 x (128+320) x 64 B
-        if (nosplit < 0) {
-            const char* e = getenv("VIDSEG_NO_SPLITK");
-            nosplit = e ? atoi(e) : 0;
-            e = getenv("VIDSEG_GEMM_DMA");
-            use_dma = e ? atoi(e) : 1;
-            e = getenv("VIDSEG_GEMM_BIG");                       // 0 never, 1 auto, 2 whenever legal
-            big_mode = e ? atoi(e) : 1;
+        static bool attr2 = false;
+        if (!attr2) {
+            attr2 = true;
             (void)hipFuncSetAttribute((const void*)k_gemm_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 36864);
             (void)hipFuncSetAttribute((const void*)k_gemm_dma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
-            e = getenv("VIDSEG_GEMM_MID");                       // 0 never, 1 auto, 2 whenever the big tile is not chosen
-            mid_mode = e ? atoi(e) : 1;
             (void)hipFuncSetAttribute((const void*)k_gemm_tile<4, 4, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS);
             (void)hipFuncSetAttribute((const void*)k_gemm_tile<5, 4, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS);
             (void)hipFuncSetAttribute((const void*)k_gemm_tile<4, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
             (void)hipFuncSetAttribute((const void*)k_gemm_tile<5, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
-            e = getenv("VIDSEG_GEMM_PH");                        // phased big tile (k_gemm_ph)
-            ph_mode = e ? atoi(e) : 1;
             (void)hipFuncSetAttribute((const void*)k_gemm_ph<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
             (void)hipFuncSetAttribute((const void*)k_gemm_ph<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
-            e = getenv("VIDSEG_GEMM_P7");                        // 224 x 320 tile (k_gemm_p7): 0 never, 1 where it fills the chip better, 2 whenever legal
-            p7_mode = e ? atoi(e) : 1;
             (void)hipFuncSetAttribute((const void*)k_gemm_p7<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
             (void)hipFuncSetAttribute((const void*)k_gemm_p7<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
-            e = getenv("VIDSEG_P7_PHASES");                      // 5: one B fragment column per phase; 3: columns {0,1} {2,3} {4}
-            p7_phases = e ? atoi(e) : 5;
+            (void)hipFuncSetAttribute((const void*)k_gemm_p7x, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
         }
         // Blocks run in rounds over the resident slots, so the last round's fill decides the efficiency.  Pick the K
         // split that maximises fill / (1 + cost of writing+reading the fp32 partials); deterministic finish kernel.
@@ -2589,8 +2547,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
                 big = true;
         }
         // panel width of the tile order: the `res` tiles resident on one XCD read (res/gn) A slabs and gn W slabs per pass
-        static int panel_mode = -1;
-        if (panel_mode < 0) { const char* e = getenv("VIDSEG_GEMM_PANEL"); panel_mode = e ? atoi(e) : 1; }
+        const int panel_mode = knobs().panel;
         auto pick_gn = [&](int bm, int bn, int res, int split) {
             const int tn_all = (p.N + bn - 1) / bn;
             if (!panel_mode) return tn_all;
@@ -2612,15 +2569,9 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             p.ws = S > 1 ? g_ws : nullptr;
             p.gn = pick_gn(224, 320, 32, S);
             const long long tiles_7 = ((p.M + 223) / 224) * ((p.N + 319) / 320);
-            // split operand images (exact mode): every plane staged once per 64 original channels (k_gemm_p7x); VIDSEG_GEMM_P7X=0 keeps
-            // the plain walk over the 3K axis
-            static int p7x_mode = -1;
-            if (p7x_mode < 0) {
-                const char* e = getenv("VIDSEG_GEMM_P7X");
-                p7x_mode = e ? atoi(e) : 1;
-                (void)hipFuncSetAttribute((const void*)k_gemm_p7x, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
-            }
-            if (p7x_mode && p.split2 && !p.x1 && p.C1 == 0 && p.K % 192 == 0 && p.C0 % 192 == 0 && (p.K / 192) / S >= 1) {
+            // split operand images (exact mode): every plane staged once per 64 original channels (k_gemm_p7x); p7x=0 keeps the plain
+            // walk over the 3K axis
+            if (knobs().p7x && p.split2 && !p.x1 && p.C1 == 0 && p.K % 192 == 0 && p.C0 % 192 == 0 && (p.K / 192) / S >= 1) {
                 launch(k_gemm_p7x, dim3((unsigned)(tiles_7 * S)), 512, 2 * (256 + 320) * 128, p);
                 kind = 6;
             } else {
@@ -2967,7 +2918,7 @@ int vidseg_conv_out4(const void* x, const void* w, const float* bias, int B, int
     const long long pix = (long long)B * H * W;
     if (pix == 0) return VS_OK;
     static int ws4 = -1;                                       // VIDSEG_CONV_OUT_WS=0: one wave per pixel, weights re-read per pixel
-    if (ws4 < 0) { const char* e = getenv("VIDSEG_CONV_OUT_WS"); ws4 = e ? atoi(e) : 1; }
+    if (ws4 < 0) ws4 = knobs().convout;
     const int npieces = 9 * (Cin / 8);
     const unsigned nblk = (unsigned)((pix + 3) / 4 < 2048 ? (pix + 3) / 4 : 2048);      // 8 blocks per CU walk the pixel list
     if (ws4 && pix >= 4096 && npieces <= 64 * 3)

@@ -1694,19 +1694,16 @@ int vidseg_attention_a16(const void* q, int ldq, const void* k, int ldk, const v
     VS_REQUIRE(Nq > 0 && Nk > 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attention: bad sizes/strides");
     const float scale_log2e = 0.125f * 1.44269504088896340736f;           // dim_head ** -0.5 * log2(e)
     // 64 queries per wave for sequences >= 1024 (k_attention3 vs k_attention: 4096 tokens 1034 -> 720 us, 1024 tokens 132 -> 110 us, 256
-    // tokens 27.7 -> 29.7 us so those stay on k_attention); VIDSEG_ATTN2=0 disables
-    static int attn2 = -1;
-    if (attn2 < 0) { const char* e = getenv("VIDSEG_ATTN2"); attn2 = e ? atoi(e) : 1; }
-    static int attn_tr = -1;                                               // VIDSEG_ATTN_TR=0: V transposed by the LDS store instead
-    if (attn_tr < 0) { const char* e = getenv("VIDSEG_ATTN_TR"); attn_tr = e ? atoi(e) : 1; }
-    static int attn3 = -1;                                                 // VIDSEG_ATTN3=0: k_attention2's per-tile running maximum
+    // tokens 27.7 -> 29.7 us so those stay on k_attention).  Overrides (tests / A/B only): VIDSEG_ATTN="a2=0" disables it,
+    // "tr=0": V transposed by the LDS store instead, "a3=0": k_attention2's per-tile running maximum, "minq=N": shortest sequence the
+    // 64-queries-per-wave kernels take, "a4=1|2": k_attention4 (software-pipelined; 2-4 % slower so far), "mx=0": plain fp8 MFMA
+    static const int attn2 = vs_knob("VIDSEG_ATTN", "a2", 1);
+    static const int attn_tr = vs_knob("VIDSEG_ATTN", "tr", 1);
     // (fp16 build only by default: the pre-scaled Q is one more 16-bit rounding of Q -- 2^-12 relative in fp16, 2^-9 in bf16, where it
     // shows: tests/test_gpu_ops.py::test_attention at 1024 tokens leaves its tolerance)
-    if (attn3 < 0) { const char* e = getenv("VIDSEG_ATTN3"); attn3 = e ? atoi(e) : VIDSEG_ACT_IS_F16; }
-    static int minq = -1;                                                  // VIDSEG_ATTN2_MINQ: shortest sequence the 64-queries-per-wave kernels take
-    if (minq < 0) { const char* e = getenv("VIDSEG_ATTN2_MINQ"); minq = e ? atoi(e) : 1024; }
-    static int attn4 = -1;                                                 // VIDSEG_ATTN4=1 / 2: k_attention4 (software-pipelined; 2-4 % slower so far)
-    if (attn4 < 0) { const char* e = getenv("VIDSEG_ATTN4"); attn4 = e ? atoi(e) : 0; }
+    static const int attn3 = vs_knob("VIDSEG_ATTN", "a3", VIDSEG_ACT_IS_F16);
+    static const int minq = vs_knob("VIDSEG_ATTN", "minq", 1024);
+    static const int attn4 = vs_knob("VIDSEG_ATTN", "a4", 0);
     if (attn2 && attn3 && attn4 && Nk % 64 == 0 && Nq >= minq)
         (attn4 == 2 ? k_attention4<1> : k_attention4<2>)<<<dim3((Nq + 255) / 256, B * H), 256, 0, st>>>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
                                                                      (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);
@@ -1742,8 +1739,7 @@ int vidseg_attention_fp8(const void* q, int ldq, const void* k, int ldk, const v
     VS_REQUIRE(head_dim == 64, "attention_fp8: head_dim=%d (only 64 is on the path)", head_dim);
     VS_REQUIRE(Nq > 0 && Nk > 0 && ldq % 16 == 0 && ldk % 16 == 0 && ldv % 16 == 0 && ldo % 4 == 0, "attention_fp8: bad sizes/strides");
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
-    static int mx = -1;                                   // block-scaled 32x32x64 instruction (default) or plain 32x32x16 fp8
-    if (mx < 0) { const char* e = getenv("VIDSEG_ATTN_MX"); mx = e ? atoi(e) : 1; }
+    static const int mx = vs_knob("VIDSEG_ATTN", "mx", 1);   // block-scaled 32x32x64 instruction (default) or plain 32x32x16 fp8
     if (mx && Nk % 64 == 0)
         k_attention_mx8<false><<<dim3((Nq + 127) / 128, B * H), 256, 0, st>>>((const unsigned char*)q, ldq, (const unsigned char*)k, ldk,
                                                                                (const unsigned char*)v, ldv, (bf16_t*)o, ldo, Nq, Nk, H, scale_log2e);

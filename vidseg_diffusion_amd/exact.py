@@ -153,6 +153,9 @@ def layernorm_split3(x, gamma, beta, eps=1e-5):
 
 def attention_f32(q, k, v, heads, B, Nq, Nk):
     """softmax(q k^T / 8) v per 64-wide head; q / k / v: fp32 column slices [B, N, >= heads*64] of row-major buffers."""
+    for t, n in ((q, Nq), (k, Nk), (v, Nk)):
+        if t.dim() != 3 or t.stride(2) != 1 or (t.shape[0] > 1 and t.stride(0) != n * t.stride(1)):
+            raise VidsegError("attention_f32: q / k / v must be column slices of row-major [B, N, ld] buffers (batches N * ld apart)")
     out = torch.empty((B, Nq, heads * 64), dtype=F32, device=q.device)
     call("vidseg_x_attention_f32", q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), v.data_ptr(), v.stride(1), ptr(out), heads * 64,
          B, heads, Nq, Nk, 0.125, stream())
@@ -405,9 +408,11 @@ class ExactRunner:
         g3 = self.geglu(layernorm_split3(x, *bw["ln"]["norm_in"]), bw, "w_fi1", "b_fi1", "fi1g")     # VA:155-159
         x = linear_x(g3, bw["w_fi2"], bw["b_fi2"], residual=x)
         qkv = linear_x(layernorm_split3(x, *bw["ln"]["norm1"]), bw["w_qkv"])                          # [(b t), S, 3C]
-        tqkv = qkv.view(b, T, S, 3 * C).permute(0, 2, 1, 3).reshape(b * S, T, 3 * C)                 # (b t) s c -> (b s) t c (VA:171)
+        # (b t) s c -> (b s) t c (VA:171); .contiguous(): with ONE video (the taps-only evaluation of the conditional half) the reshape
+        # alone is a strided view, and the kernels take batches at Nq * ld
+        tqkv = qkv.view(b, T, S, 3 * C).permute(0, 2, 1, 3).contiguous().view(b * S, T, 3 * C)
         a = attention_x(tqkv[..., :C], tqkv[..., C:], heads, b * S, T, T)
-        a = a.view(b, S, T, C).permute(0, 2, 1, 3).reshape(BT, S, C)
+        a = a.view(b, S, T, C).permute(0, 2, 1, 3).contiguous().view(BT, S, C)
         if dump:
             tb.attn1.q, tb.attn1.k = tqkv[..., :C].half(), tqkv[..., C:2 * C].half()                  # the reference's [(b s), t, c] layout
         x = linear_x(split3(a), bw["w_o1"], bw["b_o1"], residual=x)                                  # VA:197-218
@@ -418,7 +423,7 @@ class ExactRunner:
         a23 = attention_x(q2.view(b, T * S, C), kv, heads, b, T * S, L, split_out=True)       # VA:224-250
         x = linear_x(a23.view(BT, S, 3 * C), bw["w_o2"], bw["b_o2"], residual=x)
         if dump:
-            tb.attn2.q = q2.view(b, T, S, C).permute(0, 2, 1, 3).reshape(b * S, T, C).half()
+            tb.attn2.q = q2.view(b, T, S, C).permute(0, 2, 1, 3).contiguous().view(b * S, T, C).half()
             tb.attn2.k = tk[:, None].expand(b, S, L, C).reshape(b * S, L, C)
         g3 = self.geglu(layernorm_split3(x, *bw["ln"]["norm3"]), bw, "w_ff1", "b_ff1", "ff1g")        # VA:252-281
         return linear_x(g3, bw["w_ff2"], bw["b_ff2"], residual=x)
