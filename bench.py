@@ -579,8 +579,9 @@ def main():
     ap.add_argument("--masks", type=int, default=None, help="number of masks K (default 20; configs[4] uses 50)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the chained-window figure, the in-run PMC passes and the SVD secondary")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # one window under rocprofv3 --pmc (see pmc_traffic)
-    ap.add_argument("--precision", default="parity", choices=["parity", "exact", "fp16"],
-                    help="parity (default, the headline): the cheapest mode whose masks are the reference's on >= 14 of the 16 fixture windows "
+    ap.add_argument("--precision", default=None, choices=["parity", "exact", "fp16"],
+                    help="parity (default with the fp16 build of the library, the headline; the bf16 build has no exact mode and defaults to fp16): "
+                         "the cheapest mode whose masks are the reference's on >= 14 of the 16 fixture windows "
                          "(IoU >= 0.99) = UNetModel.set_precision('exact') -- fp32 activations, every conv / linear on the MFMA kernels over split "
                          "(hi, lo) operands, 3x the MFMA work -- with the dead work of the last step pruned (masks_only).  exact: the same precision, "
                          "every step in full (reported as `full_schedule` by the default run).  fp16: 16-bit activations, the reference's "
@@ -594,10 +595,6 @@ def main():
                     help="start the N ranks, form the process group, all-reduce a one per rank and print {n_gpus, rccl_ranks} -- no GPU "
                          "work (CPU test of the launcher: VIDSEG_DIST_BACKEND=gloo)")
     args = ap.parse_args()
-    args.parity = args.precision == "parity"
-    args.exact = args.precision in ("parity", "exact")
-    if args.parity:
-        args.masks_only = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` called directly: become the launcher -- one rank per GPU through torch.distributed.run, exactly
@@ -629,6 +626,12 @@ def main():
         assert rccl_ranks == dist.get_world_size() == args.gpus, (rccl_ranks, dist.get_world_size(), args.gpus)
 
     from vidseg_diffusion_amd import ops
+    if args.precision is None:
+        args.precision = "parity" if ops.act_dtype() == torch.float16 and not (args.fp8_attn or args.inversion) else "fp16"
+    args.parity = args.precision == "parity"
+    args.exact = args.precision in ("parity", "exact")
+    if args.parity:
+        args.masks_only = True
     svd = args.config == "svd"
     k_masks = args.masks or 20
     refine = True if svd else args.refine

@@ -289,6 +289,10 @@ int vidseg_linear_a16_rf32(const void* a, int K, long long M, const void* w, int
  * output projection's split operand image (ATT:89-96); w / bias interleaved like the 16-bit GEGLU weights */
 int vidseg_linear_a16_geglu_x3(const void* a, int K, long long M, const void* w, int N, const float* bias,
                                void* out_split3_f16 /* [M][3 * (N / 2)] */, vidseg_stream_t stream);
+/* the same projection on the 224 x 256 split tile (each plane of the operands staged once, k_gemm_p7x<4, true>): w / bias interleaved in
+ * 16-ROW value | gate groups instead of 32-row ones; K % 192 == 0 (K = 3 x the layer's width), N % 256 == 0 */
+int vidseg_linear_a16_geglu_x3g16(const void* a, int K, long long M, const void* w, int N, const float* bias,
+                                  void* out_split3_f16 /* [M][3 * (N / 2)] */, vidseg_stream_t stream);
 int vidseg_conv3x3_a16_rf32(const void* x, int C, int B, int Hin, int Win, int stride, int up, const void* w, int Cout, const float* bias,
                             const float* rowvec, int rv_stride, const float* residual_f32, float* out_f32, vidseg_stream_t stream);
 /* the same attention on the matrix pipe: three fp16 MFMA products of split operands per contraction (fp32 accuracy).  q fp32; k / v as

@@ -251,20 +251,28 @@ def test_geglu_projection_fused_into_the_gemm(X):
     image, against float64 and against the two-launch form (projection to fp32 + k_x_geglu_split3) on the same operands."""
     from vidseg_diffusion_amd import ops
     dev = torch.device("cuda:0")
-    for (M, K, inner) in ((300, 320, 1280), (7168, 1280, 5120), (1000, 640, 2560)):
-        a, w, b = rnd((M, K), 61, 1.5), rnd((2 * inner, K), 62, 0.03), rnd((2 * inner,), 63, 0.5)
-        a3 = X.split3(a.to(dev))
-        w3g, bg = X.pack_geglu_x(w, b, dev)
-        fused = X.geglu_linear_x(a3, w3g, bg).cpu()
-        two = X.geglu_split3(X.linear_x(a3, X.pack_linear_x(w, dev), ops.f32(b, dev))).cpu()
-        assert tuple(fused.shape) == (M, 3 * inner) and torch.equal(fused[:, :inner], fused[:, 2 * inner:])
-        y = a.double() @ w.double().t() + b.double()
-        ref = y[:, :inner] * TF.gelu(y[:, inner:])
-        got = fused[:, :inner].double() + fused[:, inner:2 * inner].double()
-        e, e2 = rel(got, ref), rel(two[:, :inner].double() + two[:, inner:2 * inner].double(), ref)
-        same = float((fused == two).double().mean())
-        print(f"fused GEGLU {M}x{2 * inner}x{K}: max err {e:.2e} (two launches {e2:.2e}); fp16 words identical to the two-launch form {same:.4f}")
-        assert e <= 5e-6, (M, K, inner, e)
+    tile0 = X._GEGLU_TILE
+    try:
+        for tile in ("p7x", "ph"):                                  # the 224 x 256 split tile (16-row groups) and the 256 x 256 phased tile (32-row groups)
+            X._GEGLU_TILE = tile
+            for (M, K, inner) in ((300, 320, 1280), (7168, 1280, 5120), (1000, 640, 2560), (230, 64, 96)):
+                a, w, b = rnd((M, K), 61, 1.5), rnd((2 * inner, K), 62, 0.03), rnd((2 * inner,), 63, 0.5)
+                a3 = X.split3(a.to(dev))
+                w3g, bg, grp = X.pack_geglu_x(w, b, dev)
+                assert grp == (16 if tile == "p7x" and (2 * inner) % 256 == 0 else 32)
+                fused = X.geglu_linear_x(a3, w3g, bg, grp).cpu()
+                two = X.geglu_split3(X.linear_x(a3, X.pack_linear_x(w, dev), ops.f32(b, dev))).cpu()
+                assert tuple(fused.shape) == (M, 3 * inner) and torch.equal(fused[:, :inner], fused[:, 2 * inner:])
+                y = a.double() @ w.double().t() + b.double()
+                ref = y[:, :inner] * TF.gelu(y[:, inner:])
+                got = fused[:, :inner].double() + fused[:, inner:2 * inner].double()
+                e, e2 = rel(got, ref), rel(two[:, :inner].double() + two[:, inner:2 * inner].double(), ref)
+                same = float((fused == two).double().mean())
+                print(f"fused GEGLU [{tile}, groups of {grp}] {M}x{2 * inner}x{K}: max err {e:.2e} (two launches {e2:.2e}); fp16 words identical to the "
+                      f"two-launch form {same:.4f}")
+                assert e <= 5e-6, (tile, M, K, inner, e)
+    finally:
+        X._GEGLU_TILE = tile0
 
 
 def test_split_survives_rounding_ties(X):

@@ -57,6 +57,7 @@ struct GemmParams {
     int tap_T, tap_S;        // >0: taps are written in the reference's temporal layout [(b s), t, c] (row permutation)
     const float* rowadd;     // per-row scalar added to every column before the residual (attention-output modulation
                              // lambda*mask[:,None], attention.py:646-663, 697-719) or nullptr
+    int geglu16;             // GEGLU weight rows interleaved in 16-row value | gate groups (k_gemm_p7x<4, true>) instead of 32-row ones
     int split2;              // exact mode: the operands are split images -- A rows [a_hi | a_lo | a_hi], W rows [w_hi | w_hi | w_lo] in the
                              // usual K order over the 3 * Cin channels (exact.py); k_gemm_p7x then stages each plane once
     int gn;                  // tile columns per panel of the launch order (map_tile)
@@ -1137,7 +1138,51 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
 // wave still issues 9 DMA instructions per K-tile.  A B block g is now the four 16-row strips {wn * 80 + g * 16 ..} that
 // phase g reads.  Phase j = B fragment column j over the whole BK = 64: 14 MFMAs (7 A fragments x 2 k-steps, 224 cycles).
 // ---------------------------------------------------------------------------------------------
-template <int MI, int NJ>
+// Phase 2 of the GEGLU projection on 16-wide fragments (k_gemm_p7x<4, true>): fragment columns (2 jj, 2 jj + 1) of a wave tile hold value
+// and gate of the same 16 output columns (weight rows interleaved in 16-row value | gate groups, exact.pack_geglu_x), staged side by
+// side.  A lane takes 8 consecutive product columns of one row per pass: (value + b) * gelu(gate + b) with libm's erf in the operation
+// order of k_x_geglu_split3, split into (hi, lo) and written as the consumer's operand image [hi | lo | hi].  A rolled loop of 8 erf
+// per pass: formed while staging (16 inlined erf per fragment pair, unrolled over the groups) it spilled into scratch.
+template <int NJ, int EP_LD>
+__device__ __forceinline__ void epilogue_rows_geglu16(const GemmParams& p, const float* stage, int mrow0, int nrows, int wcol_base, int lane) {
+    constexpr int NC8 = NJ;                                    // NJ / 2 pairs x 16 product columns = NJ cells of 8
+    const int ncell = nrows * NC8;
+#pragma nounroll
+    for (int cell = lane; cell < ncell; cell += 64) {
+        const int row = cell / NC8, pc = (cell - row * NC8) * 8;  // first product column of the cell inside the wave tile
+        const int jj = pc >> 4, c = pc & 15;
+        const int nv = wcol_base + jj * 32 + c;                 // GEMM column of the first value; its gate sits 16 columns further
+        const int m = mrow0 + row;
+        if (m >= (int)p.M || nv + 24 > p.N) continue;            // value columns nv .. nv + 7, gate columns nv + 16 .. nv + 23
+        const float* sv = stage + row * EP_LD + jj * 32 + c;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(sv), v1 = *reinterpret_cast<const f32x4*>(sv + 4);
+        f32x4 g0 = *reinterpret_cast<const f32x4*>(sv + 16), g1 = *reinterpret_cast<const f32x4*>(sv + 20);
+        if (p.bias) {
+            const f32x4 bv0 = *reinterpret_cast<const f32x4*>(p.bias + nv), bv1 = *reinterpret_cast<const f32x4*>(p.bias + nv + 4);
+            const f32x4 bg0 = *reinterpret_cast<const f32x4*>(p.bias + nv + 16), bg1 = *reinterpret_cast<const f32x4*>(p.bias + nv + 20);
+            v0 += bv0;
+            v1 += bv1;
+            g0 += bg0;
+            g1 += bg1;
+        }
+        f16x8 h8, l8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gt = e < 4 ? g0[e & 3] : g1[e & 3];
+            float x = (e < 4 ? v0[e & 3] : v1[e & 3]) * (0.5f * gt * (1.0f + erff(gt * 0.70710678118654752440f)));
+            asm volatile("" : "+v"(x));                         // one fp32 value for both lines (see exact_ops.hip: split_hl)
+            const f16 hh = (f16)x;
+            h8[e] = hh;
+            l8[e] = (f16)(x - (float)hh);
+        }
+        f16* o3 = p.out_split3 + (long long)m * 3 * p.ldo + (wcol_base >> 1) + pc;
+        *reinterpret_cast<f16x8*>(o3) = h8;
+        *reinterpret_cast<f16x8*>(o3 + p.ldo) = l8;
+        *reinterpret_cast<f16x8*>(o3 + 2 * p.ldo) = h8;
+    }
+}
+
+template <int MI, int NJ, bool G3 = false>
 __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc)[MI][NJ], char* smem, int mrow_base, int wcol_base, int lane,
                                                 int wave, int split) {
     constexpr int EP_LD = NJ * 16 + 4;                         // fp32 row stride of the staging tile
@@ -1145,6 +1190,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc
     float* stage = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
     const int l15 = lane & 15, q = lane >> 4;
     const bool fin = p.ksplit <= 1;                            // split-K partials carry no bias/emb/activation
+    static_assert(!G3 || NJ % 2 == 0, "GEGLU pairs fragment columns");
     __syncthreads();                                           // main-loop LDS reads are done
 #pragma nounroll
     for (int ig = 0; ig < NG; ++ig) {
@@ -1164,7 +1210,10 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        epilogue_rows<NJ * 2, EP_LD>(p, stage, mrow_base + ig * 32, nrows, wcol_base, p.N, lane, split, fin, true);
+        if constexpr (G3)
+            epilogue_rows_geglu16<NJ, EP_LD>(p, stage, mrow_base + ig * 32, nrows, wcol_base, lane);
+        else
+            epilogue_rows<NJ * 2, EP_LD>(p, stage, mrow_base + ig * 32, nrows, wcol_base, p.N, lane, split, fin, true);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
@@ -1454,11 +1503,15 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7(GemmParams p) {
 // Every piece overwrites a region whose last read lies at least one full phase back (A rows are read in phase 0 only, B block j in
 // phase j only; s2 reads no A rows), and lands at least two phases before it is read.  Counted waits (loads younger than the last
 // one the next phase needs): s0 5,5,6,6,3; s1 -,-,-,-,5; s2 5,5,5,5,5.  One source only (exact.py materialises channel concats).
+// <NJ = 4, G3>: the 224 x 256 instantiation for the GEGLU projection (wave tile 112 x 64 = 7 x 4 fragments, four phases per step, 16
+// pieces per wave and macro-tile: s0 A0.1 A0.2 | A0.3 | A1'.0 A1'.1 | A1'.2, waits 5,5,6,3; s1 B1.j then A1'.3, wait -,-,-,4; s2 B0'.j
+// then A0'.0, waits 4,4,4,4) with the GEGLU product formed in the epilogue and written as the split image (gemm_epilogue16<.., G3>).
 // ---------------------------------------------------------------------------------------------
+template <int NJ, bool G3>
 __global__ void __launch_bounds__(512, 2) k_gemm_p7x(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NJ = 5, MI = 7;
-    constexpr int BM = 224, BN = 320, RB = 128;
+    constexpr int MI = 7;
+    constexpr int BM = 224, BN = NJ * 64, WN = NJ * 16, RB = 128;     // NJ = 5: 224 x 320; NJ = 4: 224 x 256 (GEGLU pairs of fragment columns)
     constexpr int A_BYTES = 256 * RB, B_BYTES = BN * RB;                 // LDS map: A[0] A[1] B[0] B[1] (hi, lo, hi, lo)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1505,7 +1558,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7x(GemmParams p) {
         if (!ok) ih0 = -0x4000;
         a_hw[s4] = ((ih0 + 0x4000) << 16) | (iw0 + 0x4000);
     }
-    const int b_r0 = (wave >> 1) * 80 + (wave & 1) * 8;
+    const int b_r0 = (wave >> 1) * WN + (wave & 1) * 8;
     const int b_n = n0 + b_r0 + lrow;
     const unsigned b_off0 = (unsigned)((long long)b_n * p.K * 2) + swz16;
     const unsigned b_gstep = (unsigned)p.K * 32u;                            // 16 weight rows
@@ -1565,7 +1618,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7x(GemmParams p) {
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int sw = (l15 >> 1) & 7;
-    const int arow = (wm * 112 + l15) * RB, brow = 2 * A_BYTES + (wn * 80 + l15) * RB;
+    const int arow = (wm * 112 + l15) * RB, brow = 2 * A_BYTES + (wn * WN + l15) * RB;
 
     // prologue: what the steady state would have issued before s0(0), in its issue order
 #pragma unroll
@@ -1573,7 +1626,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7x(GemmParams p) {
 #pragma unroll
     for (int g = 0; g < NJ; ++g) stage_b(P0{}, g, 0);                         // B0(0)
     stage_a(P0{}, 0);                                                         // A0(0).0
-    wait_vmcnt<5>();
+    wait_vmcnt<NJ>();
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();
 
@@ -1593,21 +1646,38 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7x(GemmParams p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) fb[kk] = *reinterpret_cast<const bf16x8_t*>(B + j * 16 * RB + (((kk * 4 + l4) ^ sw) << 4));
             if (sk == 0) {
-                if (j <= 2) stage_a(P0{}, j + 1);                             // A0(kc).1..3
-                if (j >= 2) stage_a(P1{}, j - 2);                             // A1(kc+1).0..2
-                if (j <= 1) wait_vmcnt<5>();
-                else if (j <= 3) wait_vmcnt<6>();
-                else wait_vmcnt<3>();
+                if constexpr (NJ == 5) {
+                    if (j <= 2) stage_a(P0{}, j + 1);                         // A0(kc).1..3
+                    if (j >= 2) stage_a(P1{}, j - 2);                         // A1(kc+1).0..2
+                    if (j <= 1) wait_vmcnt<5>();
+                    else if (j <= 3) wait_vmcnt<6>();
+                    else wait_vmcnt<3>();
+                } else {                                                      // four phases: A0.1 A0.2 | A0.3 | A1'.0 A1'.1 | A1'.2; waits 5, 5, 6, 3
+                    if (j == 0) {
+                        stage_a(P0{}, 1);
+                        stage_a(P0{}, 2);
+                    } else if (j == 1) {
+                        stage_a(P0{}, 3);
+                    } else if (j == 2) {
+                        stage_a(P1{}, 0);
+                        stage_a(P1{}, 1);
+                    } else {
+                        stage_a(P1{}, 2);
+                    }
+                    if (j <= 1) wait_vmcnt<5>();
+                    else if (j == 2) wait_vmcnt<6>();
+                    else wait_vmcnt<3>();
+                }
             } else if (sk == 1) {
                 stage_b(P1{}, j, kc);                                         // B1(kc).j
-                if (j == 4) {
+                if (j == NJ - 1) {
                     stage_a(P1{}, 3);                                         // A1(kc+1).3
-                    wait_vmcnt<5>();
+                    wait_vmcnt<NJ>();
                 }
             } else {
                 stage_b(P0{}, j, kc + 1);                                     // B0(kc+1).j
-                if (j == 4) stage_a(P0{}, 0);                                 // A0(kc+1).0
-                wait_vmcnt<5>();
+                if (j == NJ - 1) stage_a(P0{}, 0);                            // A0(kc+1).0
+                wait_vmcnt<NJ>();
             }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -1639,7 +1709,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7x(GemmParams p) {
     wait_vmcnt<0>();
     if (grp == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
-    gemm_epilogue16<MI, NJ>(p, acc, smem, (int)m0 + wm * 112, n0 + wn * 80, lane, wave, split);
+    gemm_epilogue16<MI, NJ, G3>(p, acc, smem, (int)m0 + wm * 112, n0 + wn * WN, lane, wave, split);
 }
 
 // Split-K finish: sum the fp32 partials in split order (deterministic), then the same epilogue as above.
@@ -2433,12 +2503,25 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)k_gemm_ph<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
             attr3 = true;
         }
-        const long long tiles3 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         p.gn = (p.N + 255) / 256 < 8 ? (p.N + 255) / 256 : 8;
-        launch(k_gemm_ph<4, true>, dim3((unsigned)tiles3), 512, 2 * (256 + 256) * 128, p);
+        int kind3 = 1;
+        if (p.geglu16) {                                       // weights interleaved in 16-row value | gate groups: the split tile (224 x 256)
+            VS_REQUIRE(p.K % 192 == 0 && p.C0 == p.K && p.N % 256 == 0, "gemm: geglu16 needs K %% 192 == 0 and N %% 256 == 0 (K=%d N=%d)", p.K, p.N);
+            static bool attr4 = false;
+            if (!attr4) {
+                (void)hipFuncSetAttribute((const void*)k_gemm_p7x<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
+                attr4 = true;
+            }
+            const long long tiles4 = ((p.M + 223) / 224) * (p.N / 256);
+            launch(k_gemm_p7x<4, true>, dim3((unsigned)tiles4), 512, 2 * (256 + 256) * 128, p);
+            kind3 = 6;
+        } else {
+            const long long tiles3 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+            launch(k_gemm_ph<4, true>, dim3((unsigned)tiles3), 512, 2 * (256 + 256) * 128, p);
+        }
         if (g_prof.on) {
             if (!prof_ext) (void)hipEventRecord(ev1, st);
-            g_prof.shapes.push_back({p.M, p.N, p.K, p.ksize, p.up, p.stride, p.act, 1, 1, (double)p.x0_bytes + 2.0 * p.N * p.K + 6.0 * p.M * (p.N / 2)});
+            g_prof.shapes.push_back({p.M, p.N, p.K, p.ksize, p.up, p.stride, p.act, 1, kind3, (double)p.x0_bytes + 2.0 * p.N * p.K + 6.0 * p.M * (p.N / 2)});
         }
         VS_CHECK_LAUNCH("gemm_geglu_split3");
         return VS_OK;
@@ -2486,7 +2569,8 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)k_gemm_ph<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
             (void)hipFuncSetAttribute((const void*)k_gemm_p7<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
             (void)hipFuncSetAttribute((const void*)k_gemm_p7<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
-            (void)hipFuncSetAttribute((const void*)k_gemm_p7x, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
+            (void)hipFuncSetAttribute((const void*)k_gemm_p7x<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
+            (void)hipFuncSetAttribute((const void*)k_gemm_p7x<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
         }
         // Blocks run in rounds over the resident slots, so the last round's fill decides the efficiency.  Pick the K
         // split that maximises fill / (1 + cost of writing+reading the fp32 partials); deterministic finish kernel.
@@ -2529,7 +2613,10 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
                 const double fill7 = (double)items7 / (double)(((items7 + 255) / 256) * 256);
                 const double eff7 = fill7 * (double)p.M / (double)(tm7 * 224);
                 const double eff8 = fill * (double)p.M / (double)(((p.M + 255) / 256) * 256);
-                if (eff7 > eff8 * 1.04 || p7_mode == 2) {
+                // on split operands the 224-row tile has the native (hi, lo) staging (k_gemm_p7x: +13..17 % over the 3K walk, measured per
+                // shape, profiles/r04_b_p7x_vs_p7.txt), the 256-row tile has not: the SVD window's M = 28 * 72 * 128 fills both heights
+                const double x7 = (knobs().p7x && p.split2 && !p.x1 && p.C1 == 0 && p.K % 192 == 0 && p.C0 % 192 == 0) ? 1.15 : 1.0;
+                if (eff7 * x7 > eff8 * 1.04 || p7_mode == 2) {
                     p7 = true;
                     S = S7;
                     items = items7;
@@ -2572,7 +2659,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             // split operand images (exact mode): every plane staged once per 64 original channels (k_gemm_p7x); p7x=0 keeps the plain
             // walk over the 3K axis
             if (knobs().p7x && p.split2 && !p.x1 && p.C1 == 0 && p.K % 192 == 0 && p.C0 % 192 == 0 && (p.K / 192) / S >= 1) {
-                launch(k_gemm_p7x, dim3((unsigned)(tiles_7 * S)), 512, 2 * (256 + 320) * 128, p);
+                launch(k_gemm_p7x<5, false>, dim3((unsigned)(tiles_7 * S)), 512, 2 * (256 + 320) * 128, p);
                 kind = 6;
             } else {
                 if (p7_phases == 3)
@@ -2736,6 +2823,32 @@ int vidseg_linear_a16_geglu_x3(const void* a, int K, long long M, const void* w,
     p.out_split3 = (f16*)out_split3;
     p.ldo = N / 2;
     p.act = 2;
+    return launch_gemm(p, st);
+}
+
+// The same projection on the split tile (k_gemm_p7x<4, true>: every plane of the operands staged once): w / bias interleaved in 16-ROW
+// value | gate groups (exact.pack_geglu_x16) instead of 32-row ones; K %% 192 == 0 and N %% 256 == 0.
+int vidseg_linear_a16_geglu_x3g16(const void* a, int K, long long M, const void* w, int N, const float* bias, void* out_split3, hipStream_t st) {
+    VS_REQUIRE(out_split3 != nullptr && N % 256 == 0 && K % 192 == 0 && M >= 1, "linear_geglu_x3g16: N=%d K=%d M=%lld", N, K, M);
+    GemmParams p{};
+    p.x0 = (const bf16_t*)a;
+    p.C0 = K;
+    p.ksize = 1;
+    p.stride = 1;
+    p.up = 1;
+    p.Hin = p.Win = p.Hout = p.Wout = 1;
+    p.w = (const bf16_t*)w;
+    p.N = N;
+    p.K = K;
+    p.M = M;
+    p.x0_bytes = M * K * 2;
+    p.bias = bias;
+    p.rows_per_sample = 1;
+    p.out_split3 = (f16*)out_split3;
+    p.ldo = N / 2;
+    p.act = 2;
+    p.geglu16 = 1;
+    p.split2 = 1;
     return launch_gemm(p, st);
 }
 

@@ -39,6 +39,7 @@ _lib.register({
     "vidseg_x_groupnorm_rows_per_chunk": [_I],
     "vidseg_linear_a16_rf32": [_P, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
     "vidseg_linear_a16_geglu_x3": [_P, _I, _L, _P, _I, _P, _P, _P],
+    "vidseg_linear_a16_geglu_x3g16": [_P, _I, _L, _P, _I, _P, _P, _P],
     "vidseg_conv3x3_a16_rf32": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
     "vidseg_x_layernorm_split3": [_P, _L, _I, _P, _P, _F, _P, _P],
     "vidseg_x_attention_f32": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
@@ -64,27 +65,32 @@ def pack_linear_x(weight, device):
     return torch.cat([hi, hi, lo], dim=1).to(device).contiguous()
 
 
+_GEGLU_TILE = os.environ.get("VIDSEG_X_GEGLU_TILE", "p7x")    # "ph": the 256 x 256 phased tile on the 3K axis (k_gemm_ph<4, true>) everywhere
+
+
 def pack_geglu_x(weight, bias, device):
-    """GEGLU proj [2*inner, K] -> rows interleaved in 32-row value | gate groups (ops.pack_geglu), then [hi | hi | lo] along K; the
-    bias interleaved alike (fp32)."""
+    """GEGLU proj [2*inner, K] -> rows interleaved in value | gate groups, then [hi | hi | lo] along K; the bias interleaved alike
+    (fp32).  Groups of 16 rows where the 224 x 256 split tile takes the layer (k_gemm_p7x<4, true>: 2*inner a multiple of 256, K of
+    64), groups of 32 rows (ops.pack_geglu, k_gemm_ph<4, true>) otherwise.  Returns (w3g, bias_g, group)."""
     two_inner, K = weight.shape
     inner = two_inner // 2
     if inner % 32:
         raise VidsegError("pack_geglu_x: inner width must be a multiple of 32")
-    w = weight.detach().to(F32).view(2, inner // 32, 32, K).permute(1, 0, 2, 3).reshape(two_inner, K)
-    b = bias.detach().to(F32).view(2, inner // 32, 32).permute(1, 0, 2).reshape(two_inner)
-    return pack_linear_x(w, device), b.to(device).contiguous()
+    grp = 16 if (_GEGLU_TILE == "p7x" and two_inner % 256 == 0 and K % 64 == 0) else 32
+    w = weight.detach().to(F32).view(2, inner // grp, grp, K).permute(1, 0, 2, 3).reshape(two_inner, K)
+    b = bias.detach().to(F32).view(2, inner // grp, grp).permute(1, 0, 2).reshape(two_inner)
+    return pack_linear_x(w, device), b.to(device).contiguous(), grp
 
 
-def geglu_linear_x(a3, w3g, b_g):
+def geglu_linear_x(a3, w3g, b_g, grp=32):
     """split3(value * gelu_erf(gate)) of the GEGLU projection in ONE launch: the product is formed in fp32 inside the GEMM epilogue
-    and written as the FF output projection's operand image (a3: [.., 3K] fp16; w3g / b_g from pack_geglu_x).  -> [.., 3 * inner]."""
+    and written as the FF output projection's operand image (a3: [.., 3K] fp16; w3g / b_g / grp from pack_geglu_x).  -> [.., 3 * inner]."""
     ops.workspace(a3.device)
     K3 = a3.shape[-1]
     M = a3.numel() // K3
     N = w3g.shape[0]
     out = torch.empty(a3.shape[:-1] + (3 * (N // 2),), dtype=F16, device=a3.device)
-    call("vidseg_linear_a16_geglu_x3", ptr(a3), K3, M, ptr(w3g), N, ptr(b_g), ptr(out), stream())
+    call("vidseg_linear_a16_geglu_x3g16" if grp == 16 else "vidseg_linear_a16_geglu_x3", ptr(a3), K3, M, ptr(w3g), N, ptr(b_g), ptr(out), stream())
     return out
 
 
