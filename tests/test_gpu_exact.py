@@ -255,7 +255,8 @@ def test_geglu_projection_fused_into_the_gemm(X):
     try:
         for tile in ("p7x", "ph"):                                  # the 224 x 256 split tile (16-row groups) and the 256 x 256 phased tile (32-row groups)
             X._GEGLU_TILE = tile
-            for (M, K, inner) in ((300, 320, 1280), (7168, 1280, 5120), (1000, 640, 2560), (230, 64, 96)):
+            # (.., 64, 128) / (.., 128, 128): one and two macro-tiles on the split tile (prologue and tail of its staging schedule)
+            for (M, K, inner) in ((300, 320, 1280), (7168, 1280, 5120), (1000, 640, 2560), (230, 64, 96), (300, 64, 128), (5000, 128, 128)):
                 a, w, b = rnd((M, K), 61, 1.5), rnd((2 * inner, K), 62, 0.03), rnd((2 * inner,), 63, 0.5)
                 a3 = X.split3(a.to(dev))
                 w3g, bg, grp = X.pack_geglu_x(w, b, dev)

@@ -16,6 +16,8 @@ dev = torch.device("cuda:0")
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--quiet", action="store_true", help="no background stream")
+ap.add_argument("--exact", action="store_true", help="the exact mode's launches instead: split-operand conv / linear (k_gemm_p7x), the GEGLU projection on the "
+                                                   "split tile (k_gemm_p7x<4, true>), the split-operand attention")
 args = ap.parse_args()
 ad = ops.act_dtype()
 B = 28
@@ -51,6 +53,44 @@ def attn(N, H):
     cases.append((f"attention N{N} H{H}", lambda: ops.attention(q, k, v, H)))
 
 
+def xconv(H, Cin, Cout, up=1, stride=1, res=False, Bx=B):
+    from vidseg_diffusion_amd import exact as X
+    x3 = X.split3(rn(Bx, H, H, Cin))
+    w3 = X.pack_conv3x3_x(rn(Cout, Cin, 3, 3, s=0.02).cpu(), dev)
+    b = rn(Cout)
+    Ho = (H * up + 2 - 3) // stride + 1
+    r = rn(Bx, Ho, Ho, Cout) if res else None
+    cases.append((f"exact conv B{Bx} H{H} {Cin}->{Cout} up{up} s{stride} res{int(res)}", lambda: X.conv3x3_x(x3, w3, b, up=up, stride=stride, residual=r)))
+
+
+def xlin(M, K, N, res=False, geglu=False):
+    from vidseg_diffusion_amd import exact as X
+    a3 = X.split3(rn(M, K))
+    if geglu:
+        w3g, bg, grp = X.pack_geglu_x(rn(N, K, s=0.02).cpu(), rn(N).cpu(), dev)
+        cases.append((f"exact GEGLU M{M} K{K} N{N} (groups of {grp})", lambda: X.geglu_linear_x(a3, w3g, bg, grp)))
+        return
+    w3 = X.pack_linear_x(rn(N, K, s=0.02).cpu(), dev)
+    b = rn(N)
+    r = rn(M, N) if res else None
+    cases.append((f"exact linear M{M} K{K} N{N} res{int(res)}", lambda: X.linear_x(a3, w3, b, residual=r)))
+
+
+def xattn(N, H, Bx=B):
+    from vidseg_diffusion_amd import exact as X
+    q, kv = rn(Bx, N, H * 64), rn(Bx, N, 2 * H * 64)
+    cases.append((f"exact attention B{Bx} N{N} H{H}", lambda: X.attention_x(q, kv, H, Bx, N, N, split_out=True)))
+
+
+if args.exact:
+    xconv(64, 320, 320, res=True); xconv(64, 960, 320); xconv(32, 640, 640, res=True); xconv(32, 1920, 640); xconv(16, 1280, 1280, res=True)
+    xconv(16, 2560, 1280); xconv(8, 1280, 1280, res=True); xconv(32, 640, 640, up=2); xconv(64, 320, 320, stride=2); xconv(32, 640, 640, res=True, Bx=14)
+    xlin(114688, 320, 320, res=True); xlin(114688, 320, 960); xlin(114688, 1280, 320, res=True); xlin(28672, 640, 640, res=True); xlin(28672, 2560, 640, res=True)
+    xlin(7168, 1280, 1280, res=True); xlin(7168, 5120, 1280, res=True); xlin(3584, 1280, 1280, res=True); xlin(896, 1280, 1280, res=True)
+    xlin(114688, 320, 2560, geglu=True); xlin(28672, 640, 5120, geglu=True); xlin(7168, 1280, 10240, geglu=True); xlin(1792, 1280, 10240, geglu=True)
+    xlin(14336, 640, 5120, geglu=True); xlin(896, 1280, 10240, geglu=True)
+    xattn(4096, 5); xattn(1024, 10); xattn(1024, 10, Bx=14)
+    conv = lin = attn = lambda *a, **k: None                  # the 16-bit cases below are skipped
 conv(64, 320, 320, res=True); conv(64, 640, 320, 320); conv(32, 640, 640, res=True); conv(32, 1280, 640, 640); conv(16, 1280, 1280, res=True)
 conv(16, 1280, 1280, 1280); conv(8, 1280, 1280, res=True); conv(32, 640, 640, up=2); conv(16, 1280, 1280, up=2)
 lin(114688, 320, 320); lin(114688, 320, 320, res=True); lin(114688, 320, 960); lin(114688, 320, 2560, act=2); lin(114688, 1280, 320, res=True)
