@@ -33,3 +33,9 @@ head -16 $GRAFT_REPO_ROOT/gpurun_out/$T/bench_kernel_stats.md
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY -d /tmp/pm -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap --no-secondary > /tmp/pm.log 2>&1
 db=$(find /tmp/pm -name "*results.db" | head -1)
 python $GRAFT_REPO_ROOT/tools/pmc_mfma_util.py $db $GRAFT_REPO_ROOT/gpurun_out/$T/mfma_util.json | tail -24
+cd $GRAFT_REPO_ROOT
+timeout 900 python tools/race_stress.py --exact --iters 100 > gpurun_out/$T/race_stress_exact.txt 2>&1; tail -4 gpurun_out/$T/race_stress_exact.txt
+timeout 600 python tools/determinism_check.py --precision exact --overlap --windows 0-5 --reps 2 > gpurun_out/$T/determinism_exact_a.txt 2>&1
+timeout 600 python tools/determinism_check.py --precision exact --overlap --windows 0-5 --reps 2 > gpurun_out/$T/determinism_exact_b.txt 2>&1
+diff <(grep -v "^\[" gpurun_out/$T/determinism_exact_a.txt) <(grep -v "^\[" gpurun_out/$T/determinism_exact_b.txt) > gpurun_out/$T/determinism_exact_diff.txt && echo "determinism: two processes identical" || (echo "determinism: DIFF"; head -5 gpurun_out/$T/determinism_exact_diff.txt)
+tail -3 gpurun_out/$T/determinism_exact_a.txt
