@@ -757,9 +757,10 @@ def main():
             tr = pmc_traffic((["--refine"] if args.refine else []) + ["--precision", args.precision]) \
                 if os.environ.get("VIDSEG_BENCH_PMC", "1") != "0" else None
             dom = out["roofline"]["kernel"]
-            key = "k_gemm_p7" if dom.startswith("k_gemm_p7") else ("k_gemm_ph<5>" if dom.startswith("k_gemm_ph") else "k_gemm_dma<2>")
-            if tr and key not in tr:                                 # template instances: k_gemm_p7<5>
-                key = next((k for k in sorted(tr) if k.startswith(key)), key)
+            key = dom.split(" (")[0]                                  # the kind's name starts with the kernel's own (k_gemm_p7x<5, false>, ...)
+            if tr and key not in tr:                                 # kinds that cover several template instances: k_gemm_p7 -> k_gemm_p7<5>
+                base = "k_gemm_ph<5" if key.startswith("k_gemm_ph") else ("k_gemm_dma<2" if key.startswith("k_gemm_dma") else key)
+                key = next((k for k in sorted(tr) if k.startswith(base) and (base != "k_gemm_p7" or not k.startswith("k_gemm_p7x"))), key)
             if tr and key in tr:
                 out["roofline"]["traffic"] = int(tr[key][1])
                 out["roofline"]["traffic_how"] = (f"this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over one window of "

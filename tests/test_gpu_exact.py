@@ -136,9 +136,9 @@ def test_split_tile_stages_each_plane_once(X):
     print(f"split tile temporal conv T=14 128->320: max err {e:.2e}")
     assert e <= 5e-6, e
     ops.gemm_profile_end()
-    kinds = {n.split(" ")[0]: ln for (n, ms, fl, ln, ab) in ops.gemm_profile_kinds()}
+    kinds = {n.split(" (")[0]: ln for (n, ms, fl, ln, ab) in ops.gemm_profile_kinds()}
     print("launches by kernel:", kinds)
-    assert kinds.get("k_gemm_p7x", 0) >= 4, kinds                                           # the convolutions above must exercise the new tile (the N = 960 / split-K linears go to other tiles)
+    assert kinds.get("k_gemm_p7x<5, false>", 0) >= 4, kinds                                           # the convolutions above must exercise the new tile (the N = 960 / split-K linears go to other tiles)
 
 
 def test_fp32_glue_operators(X):

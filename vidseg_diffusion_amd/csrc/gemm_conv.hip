@@ -1987,7 +1987,8 @@ __global__ void __launch_bounds__(256) k_conv_out4_ws(const bf16_t* __restrict__
 // Kernel selection is a fixed function of the problem (the decision table in launch_gemm).  ONE override exists, for the per-kernel
 // tests and same-box A/B runs: VIDSEG_GEMM="key=value,key=value", read once per process.  Keys (default):
 //   big (1)   0 never / 1 where the table picks it / 2 whenever legal -- the 8-wave phased tiles (k_gemm_ph 256x320 / 256x256, k_gemm_p7 224x320)
-//   p7 (1)    0 / 1 / 2 likewise for the 224-row tile among the big ones;  p7x (1): 0 keeps k_gemm_p7 on split operands
+//   p7 (1)    0 / 1 / 2 likewise for the 224-row tile among the big ones;  p7x (1): 0 keeps k_gemm_p7 on split operands;
+//             xsmall (1): 0 = split operands obey the 16-bit thresholds of the big tile (fill >= 0.7, K / S >= 1440)
 //   p7ph (5)  phases per K-tile of k_gemm_p7 (5 or 3);  ph (1): 0 = the unphased k_gemm_tile for the big shapes
 //   mid (1)   0 / 1 / 2 the 128x320 tile;  dma (1): 0 = k_gemm_conv<128,128>, 3 = the 3-stage 128x128 everywhere;  tile (0): 128 forbids the narrow 256x64 tile
 //   ws (1)    0 / 1 / 2 the weight-stationary streaming kernel;  convout (1): 0 = the plain 4-channel output conv
@@ -1995,14 +1996,15 @@ __global__ void __launch_bounds__(256) k_conv_out4_ws(const bf16_t* __restrict__
 //   ext (1)   0 = hipEventRecord pairs instead of dispatch-packet timestamps (profiling);  fence (0): 1 = system-scope fence at the events
 //   shapes (0) 1 = one GEMMSHAPE line per profiled launch on stderr (tools/shape_summary.py)
 struct GemmKnobs {
-    int big = 1, p7 = 1, p7x = 1, p7ph = 5, ph = 1, mid = 1, dma = 1, tile = 0, ws = 1, convout = 1, split = 1, panel = 1, ext = 1, fence = 0, shapes = 0;
+    int big = 1, p7 = 1, p7x = 1, xsmall = 1, p7ph = 5, ph = 1, mid = 1, dma = 1, tile = 0, ws = 1, convout = 1, split = 1, panel = 1, ext = 1, fence = 0,
+        shapes = 0;
 };
 static const GemmKnobs& knobs() {
     static const GemmKnobs k = [] {
         GemmKnobs g;
         const char* e = getenv("VIDSEG_GEMM");
         if (!e) return g;
-        struct { const char* name; int* v; } tab[] = {{"big", &g.big}, {"p7", &g.p7}, {"p7x", &g.p7x}, {"p7ph", &g.p7ph}, {"ph", &g.ph}, {"mid", &g.mid},
+        struct { const char* name; int* v; } tab[] = {{"big", &g.big}, {"p7", &g.p7}, {"p7x", &g.p7x}, {"xsmall", &g.xsmall}, {"p7ph", &g.p7ph}, {"ph", &g.ph}, {"mid", &g.mid},
                                                       {"dma", &g.dma}, {"tile", &g.tile}, {"ws", &g.ws}, {"convout", &g.convout}, {"split", &g.split},
                                                       {"panel", &g.panel}, {"ext", &g.ext}, {"fence", &g.fence}, {"shapes", &g.shapes}};
         while (*e) {
@@ -2033,8 +2035,8 @@ struct GemmProf {
     std::vector<Shape> shapes;      // one per event pair
 };
 static GemmProf g_prof;
-static double g_kind_stats[21];
-static double g_kind_bytes[7];
+static double g_kind_stats[24];
+static double g_kind_bytes[8];
 
 static inline hipEvent_t prof_event() {
     if (g_prof.used == g_prof.ev.size()) {
@@ -2335,8 +2337,8 @@ int vidseg_gemm_profile_begin(void) {
 int vidseg_gemm_profile_end(double* out) {
     g_prof.on = false;
     double ms = 0.0;
-    for (int i = 0; i < 21; ++i) g_kind_stats[i] = 0.0;
-    for (int i = 0; i < 7; ++i) g_kind_bytes[i] = 0.0;
+    for (int i = 0; i < 24; ++i) g_kind_stats[i] = 0.0;
+    for (int i = 0; i < 8; ++i) g_kind_bytes[i] = 0.0;
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
         float t = 0.f;
         hipError_t e = hipEventSynchronize(g_prof.ev[i + 1]);
@@ -2345,7 +2347,7 @@ int vidseg_gemm_profile_end(double* out) {
         ms += t;
         if (i / 2 < g_prof.shapes.size()) {
             const GemmProf::Shape& h = g_prof.shapes[i / 2];
-            const int kd = h.kind >= 0 && h.kind < 7 ? h.kind : 0;
+            const int kd = h.kind >= 0 && h.kind < 8 ? h.kind : 0;
             g_kind_stats[kd * 3] += t;
             g_kind_stats[kd * 3 + 1] += 2.0 * (double)h.M * (double)h.N * (double)h.K;
             g_kind_stats[kd * 3 + 2] += 1.0;
@@ -2365,9 +2367,10 @@ int vidseg_gemm_profile_end(double* out) {
 
 // Per-kernel split of the last profiled region: out[k*3 + {0,1,2}] = {milliseconds, algorithmic FLOPs, launches} for
 // k = 0: k_gemm_dma (128x128), 1: k_gemm_ph big (256x320 / 256x256), 2: k_gemm_tile mid (128x320), 3: k_gemm_conv<256,64>,
-// 4: k_gemm_p7 (224x320), 5: k_gemm_ws (weight-stationary streaming, short K), 6: k_gemm_p7x (224x320 on split operands).
+// 4: k_gemm_p7 (224x320), 5: k_gemm_ws (weight-stationary streaming, short K), 6: k_gemm_p7x<5, false> (224x320 on split operands),
+// 7: k_gemm_p7x<4, true> (224x256 on split operands, GEGLU epilogue).
 int vidseg_gemm_profile_kinds(double* out) {
-    for (int i = 0; i < 21; ++i) out[i] = g_kind_stats[i];
+    for (int i = 0; i < 24; ++i) out[i] = g_kind_stats[i];
     return VS_OK;
 }
 
@@ -2375,7 +2378,7 @@ int vidseg_gemm_profile_kinds(double* out) {
 // reads (the whole input image for a conv: the 9 taps re-read it through L1/L2, not through memory), the weight matrix, the
 // residual, and every output it writes (16-bit result, fp32 result, fp16 taps); split-K partials are NOT algorithmic.
 int vidseg_gemm_profile_bytes(double* out) {
-    for (int i = 0; i < 7; ++i) out[i] = g_kind_bytes[i];
+    for (int i = 0; i < 8; ++i) out[i] = g_kind_bytes[i];
     return VS_OK;
 }
 
@@ -2514,7 +2517,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             }
             const long long tiles4 = ((p.M + 223) / 224) * (p.N / 256);
             launch(k_gemm_p7x<4, true>, dim3((unsigned)tiles4), 512, 2 * (256 + 256) * 128, p);
-            kind3 = 6;
+            kind3 = 7;
         } else {
             const long long tiles3 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
             launch(k_gemm_ph<4, true>, dim3((unsigned)tiles3), 512, 2 * (256 + 256) * 128, p);
@@ -2574,9 +2577,9 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         }
         // Blocks run in rounds over the resident slots, so the last round's fill decides the efficiency.  Pick the K
         // split that maximises fill / (1 + cost of writing+reading the fp32 partials); deterministic finish kernel.
-        auto pick_split = [&](long long tiles, int slots) {
+        auto pick_split = [&](long long tiles, int slots, int min_nk = 40) {
             int bestS = 1;
-            if (nosplit || nk < 40 || p.act == 2 || !g_ws || tiles >= 4 * slots) return bestS;
+            if (nosplit || nk < min_nk || p.act == 2 || !g_ws || tiles >= 4 * slots) return bestS;
             double best = 0.0;
             for (int S = 1; S <= 8; ++S) {
                 if (S > 1 && (nk / S < 8 || (long long)S * p.M * p.N > g_ws_floats)) break;
@@ -2598,7 +2601,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         // measured (tools/dbg/shape_summary.py): the 128 x 320 8-wave tile only beats 128 x 128 on the 32x32-level projections
         // (28672 x 640 x 640: 61 -> 50 us); K = 320 layers and under-filled grids lose
         const bool mid_ok = tiles_mid >= 448 && p.K >= 640 && p.N <= 640 && p.act == 0;
-        bool big = false, p7 = false;
+        bool big = false, p7 = false, xsmall = false;
         int S = 1;
         if (big_mode && p.M >= 256) {
             S = pick_split(tiles_b, 256);
@@ -2608,14 +2611,16 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             // M = 28 * H * W makes it 1.0 where the 256-row tile gives 0.875 (see k_gemm_p7)
             if (p7_mode && ph_mode && NJ == 5 && p.act != 2) {
                 const long long tm7 = (p.M + 223) / 224, tiles_7 = tm7 * ((p.N + 319) / 320);
-                const int S7 = pick_split(tiles_7, 256);
+                const bool x7ok = knobs().p7x && p.split2 && !p.x1 && p.C1 == 0 && p.K % 192 == 0 && p.C0 % 192 == 0;
+                xsmall = x7ok && knobs().xsmall;
+                const int S7 = pick_split(tiles_7, 256, xsmall ? 30 : 40);
                 const long long items7 = tiles_7 * S7;
                 const double fill7 = (double)items7 / (double)(((items7 + 255) / 256) * 256);
                 const double eff7 = fill7 * (double)p.M / (double)(tm7 * 224);
                 const double eff8 = fill * (double)p.M / (double)(((p.M + 255) / 256) * 256);
                 // on split operands the 224-row tile has the native (hi, lo) staging (k_gemm_p7x: +13..17 % over the 3K walk, measured per
                 // shape, profiles/r04_b_p7x_vs_p7.txt), the 256-row tile has not: the SVD window's M = 28 * 72 * 128 fills both heights
-                const double x7 = (knobs().p7x && p.split2 && !p.x1 && p.C1 == 0 && p.K % 192 == 0 && p.C0 % 192 == 0) ? 1.15 : 1.0;
+                const double x7 = x7ok ? 1.15 : 1.0;
                 if (eff7 * x7 > eff8 * 1.04 || p7_mode == 2) {
                     p7 = true;
                     S = S7;
@@ -2627,6 +2632,12 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             // measured per shape (tools/dbg/shape_summary.py): the big tile wins once the K loop is long enough to amortise its
             // unoverlapped prologue/epilogue (one block per CU) and the grid fills the chip
             big = big_mode == 2 || (fill >= 0.70 && p.K >= 960 && (S == 1 || p.K / S >= 1440));
+            // split operands on the 224-row tile (k_gemm_p7x): a K' / S of 960 is still five macro-tiles of three MFMA steps each, and
+            // half a round of these tiles beats the 128 x 128 kernel's 3K walk -- the small-M launches of the pruned last step
+            // (14 samples: 3584 / 896 rows at the 16^2 / 8^2 levels, 14336 x 640 at 32^2), measured per shape (tools/xsmall_bench.py)
+            // 3584 x 1280 x 3840 83 -> 65 us, the 8^2-level convolutions of 14 samples 132 -> 118 / 253 -> 207 us; K' = 960 launches lose 3 us
+            // and stay where they were (profiles/r04_i_xsmall_bench.txt; parity window 172.7 -> 171.3 ms in a same-box A/B)
+            if (!big && p7 && xsmall && fill >= 0.5 && p.K >= 1920 && (S == 1 || p.K / S >= 960)) big = true;
             // with the rolled epilogue (10 us fixed cost per tile instead of 27) the big tile also takes the short-K layers whose
             // grid is at least a full round of 256 CUs: 114688x960x320 161 -> 151 us, 28672x1920x640 118 -> 109, 114688x320x640 96 -> 77;
             // GEGLU and small-M shapes still lose (measured per shape, tools/dbg/shape_summary.py)

@@ -458,7 +458,8 @@ def gemm_profile_end():
 GEMM_KIND_NAMES = ("k_gemm_dma (128x128, LDS-DMA)", "k_gemm_ph<NJ> (256x320 / 256x256, LDS-DMA, phased)",
                    "k_gemm_tile<NJ,4,32,1> (128x320, LDS-DMA)", "k_gemm_conv<256,64>", "k_gemm_p7 (224x320, LDS-DMA, phased, 16x16x32 MFMA)",
                    "k_gemm_ws (weight-stationary streaming, K = 320 / 640)",
-                   "k_gemm_p7x (224x320 on split (hi, lo) operands: each plane staged once, 3 MFMA products per 64 channels)")
+                   "k_gemm_p7x<5, false> (224x320 on split (hi, lo) operands: each plane staged once, 3 MFMA products per 64 channels)",
+                   "k_gemm_p7x<4, true> (224x256 on split operands, GEGLU product in the epilogue, split-image output)")
 
 
 def gemm_profile_kinds():
