@@ -1,4 +1,4 @@
-# same-box A/B of the headline: bash tools/ab_bench.sh "ENV_A" "ENV_B" [extra bench args]   (env strings like "VIDSEG_SIDE_SKIP=0")
+# same-box A/B of the headline: bash tools/lab/ab_bench.sh "ENV_A" "ENV_B" [extra bench args]   (env strings like "VIDSEG_SIDE_SKIP=0")
 cd $GRAFT_REPO_ROOT
 A="$1"; B="$2"; shift 2
 for rep in 1 2; do

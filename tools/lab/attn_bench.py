@@ -1,11 +1,11 @@
-"""Time ops.attention at the window's self-attention sizes (GPU box).  python tools/attn_bench.py [--fp8]"""
+"""Time ops.attention at the window's self-attention sizes (GPU box).  python tools/lab/attn_bench.py [--fp8]"""
 import os
 import sys
 import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vidseg_diffusion_amd import ops  # noqa: E402
 

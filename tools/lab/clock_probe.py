@@ -1,5 +1,5 @@
 """Run one conv shape in a loop for a few seconds and sample rocm-smi (sclk, power) meanwhile: shows how far the chip
-clocks down under each kernel variant.  usage: python tools/clock_probe.py [seconds]"""
+clocks down under each kernel variant.  usage: python tools/lab/clock_probe.py [seconds]"""
 import subprocess
 import sys
 import threading

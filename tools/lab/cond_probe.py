@@ -7,8 +7,8 @@ and the label maps are written to gpurun_out/cond_probe_<act>.npz; run once per 
 with `--compare` (bf16 is a ~1e-2 perturbation of the taps).  Prints matched IoU / identical fraction between the variants
 and the agreement of `full` with the generating partition (region designs).
 
-    python tools/cond_probe.py            # writes gpurun_out/cond_probe_<act>.npz
-    python tools/cond_probe.py --compare  # f16 vs bf16 files
+    python tools/lab/cond_probe.py            # writes gpurun_out/cond_probe_<act>.npz
+    python tools/lab/cond_probe.py --compare  # f16 vs bf16 files
 """
 import argparse
 import os
@@ -17,7 +17,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from tools_metrics import matched_iou  # noqa: E402

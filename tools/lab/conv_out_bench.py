@@ -1,10 +1,10 @@
-"""Time the UNet's output conv (Cout = 4) at the window's size (GPU box): python tools/conv_out_bench.py  (VIDSEG_GEMM=convout=0/1)"""
+"""Time the UNet's output conv (Cout = 4) at the window's size (GPU box): python tools/lab/conv_out_bench.py  (VIDSEG_GEMM=convout=0/1)"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vidseg_diffusion_amd import ops  # noqa: E402
 

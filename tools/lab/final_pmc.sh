@@ -1,4 +1,4 @@
-# MFMA utilisation / effective clock of the final build (one PMC pass over one window of each precision mode): bash tools/final_pmc.sh [tag]
+# MFMA utilisation / effective clock of the final build (one PMC pass over one window of each precision mode): bash tools/lab/final_pmc.sh [tag]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 T=${1:-r03_d}

@@ -1,12 +1,12 @@
 """Fixed cost per round of the big GEMM tiles: time linears of growing K on a shape that is exactly one / two rounds of 256 tiles and
-fit t = a + b K (GPU box).  python tools/ksweep.py   (VIDSEG_GEMM=big=2,p7=2 forces the 224x320 tile)"""
+fit t = a + b K (GPU box).  python tools/lab/ksweep.py   (VIDSEG_GEMM=big=2,p7=2 forces the 224x320 tile)"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vidseg_diffusion_amd import ops  # noqa: E402
 

@@ -1,10 +1,10 @@
-"""Time the short-K linears of the window (GPU box): python tools/lin_bench.py   (VIDSEG_GEMM=ws=0/1 to compare)"""
+"""Time the short-K linears of the window (GPU box): python tools/lab/lin_bench.py   (VIDSEG_GEMM=ws=0/1 to compare)"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vidseg_diffusion_amd import ops  # noqa: E402
 

@@ -2,7 +2,7 @@
 with the REFERENCE's fp32 masks (tests/golden/c2_window.npz) and with the default variant: how much of the mask agreement is the
 kernels' accuracy and how much is the K-means / best-of-10 selection reacting to rounding-level changes of its input.
 
-    python tools/mask_sensitivity.py            (GPU box; VIDSEG_ACT=bf16 for the bf16 build)
+    python tools/lab/mask_sensitivity.py            (GPU box; VIDSEG_ACT=bf16 for the bf16 build)
 """
 import os
 import sys
@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from tools_metrics import matched_iou  # noqa: E402

@@ -1,6 +1,6 @@
-"""A few launches of one 3x3 conv shape (for rocprofv3 --pmc passes): python tools/one_conv.py B H W C0 C1 Cout [n]"""
+"""A few launches of one 3x3 conv shape (for rocprofv3 --pmc passes): python tools/lab/one_conv.py B H W C0 C1 Cout [n]"""
 import sys
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from vidseg_diffusion_amd import ops
 dev = torch.device("cuda:0")

@@ -1,5 +1,5 @@
 """A/B of the phased big tile (VIDSEG_GEMM=ph=1) against k_gemm_tile: bit-equality of outputs (same MFMA order), run-to-run
-stability (race screen) and time per launch.  usage: python tools/ph_bench.py            (spawns both modes)"""
+stability (race screen) and time per launch.  usage: python tools/lab/ph_bench.py            (spawns both modes)"""
 import os
 import subprocess
 import sys

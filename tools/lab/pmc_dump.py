@@ -1,5 +1,5 @@
 """Average per-dispatch PMC values (and the dispatch duration of the same pass) of the kernels whose name contains argv[2] from a
-rocprofv3 results db: python tools/pmc_dump.py <db> <substr>"""
+rocprofv3 results db: python tools/lab/pmc_dump.py <db> <substr>"""
 import collections, sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 acc = collections.defaultdict(lambda: [0, 0.0])

@@ -1,8 +1,8 @@
 """One 3x3 conv shape in a loop for a few seconds with rocm-smi sampled meanwhile: time per launch, TFLOP/s, shader clock, socket
 power.  The tile-selection knobs of the library are read once per process, so A/B two kernels with two invocations:
 
-    VIDSEG_GEMM=p7=0 python tools/power_probe.py 28 64 64 320 0 320      # B H W C0 C1 Cout [up] [seconds]
-    VIDSEG_GEMM=p7=1 python tools/power_probe.py 28 64 64 320 0 320
+    VIDSEG_GEMM=p7=0 python tools/lab/power_probe.py 28 64 64 320 0 320      # B H W C0 C1 Cout [up] [seconds]
+    VIDSEG_GEMM=p7=1 python tools/lab/power_probe.py 28 64 64 320 0 320
 """
 import re
 import subprocess

@@ -1,4 +1,4 @@
-# full GPU record of a build: bash tools/r3_full.sh <tag>   (GPU suite, headline bench, rocprofv3 kernel stats of the bench and of the exact mode)
+# full GPU record of a build: bash tools/lab/r3_full.sh <tag>   (GPU suite, headline bench, rocprofv3 kernel stats of the bench and of the exact mode)
 cd $GRAFT_REPO_ROOT
 T=${1:-r03_c}
 mkdir -p gpurun_out/$T

@@ -1,5 +1,5 @@
 # N repeats of the headline bench, per-window IoUs and (VIDSEG_DEBUG_HASH) feature / mask hashes of every analysed window:
-#   PROF_EXT=0 REPS=10 bash tools/rep_bench.sh      -> gpurun_out/rep/run_*.txt; differing hashes are reported at the end
+#   PROF_EXT=0 REPS=10 bash tools/lab/rep_bench.sh      -> gpurun_out/rep/run_*.txt; differing hashes are reported at the end
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/rep
 for i in $(seq 1 ${REPS:-6}); do

@@ -1,6 +1,6 @@
 """Steps 1-5 for one BASELINE configs[1] window at full size (SD 2.1 UNet + first stage, synthetic weights), everything in
 HBM: feature pass + masks, then the 2*K modulated passes, 2*K decodes, difference maps and arg-max.  Reported beside the
-headline metric, never inside it.  usage: python tools/step45_bench.py [K]"""
+headline metric, never inside it.  usage: python tools/lab/step45_bench.py [K]"""
 import os
 import sys
 import time
@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vidseg_diffusion_amd import feature_extraction as FE  # noqa: E402
 from vidseg_diffusion_amd import synthetic  # noqa: E402

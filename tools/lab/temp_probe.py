@@ -1,8 +1,8 @@
 """Why is a conv slower inside the UNet than in a hot loop?  Times ONE 3x3 conv shape (HIP events around the conv only) when
-  hot     the same input / output buffers every launch (what tools/power_probe.py measures)
+  hot     the same input / output buffers every launch (what tools/lab/power_probe.py measures)
   rotate  NSETS different input / output buffer sets in turn (working set >> the 256 MB Infinity Cache)
   gn+conv GroupNorm+SiLU writes the conv's input right before it (the UNet's pattern), rotating sets
-usage: python tools/temp_probe.py B H W C0 Cout [nsets]"""
+usage: python tools/lab/temp_probe.py B H W C0 Cout [nsets]"""
 import sys
 
 sys.path.insert(0, ".")

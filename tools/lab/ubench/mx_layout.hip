@@ -1,7 +1,7 @@
 // Verifies the operand layout assumed for v_mfma_scale_f32_32x32x64_f8f6f4 with fp8 (e4m3) inputs and unit scales:
 // lane l holds row (l & 31) of A (resp. column of B), k = 32*(l >> 5) + 0..31 (32 contiguous bytes = 8 VGPRs);
 // C/D as every 32x32 MFMA: col = l & 31, row = (r & 3) + 8*(r >> 2) + 4*(l >> 5).
-// build: hipcc --offload-arch=gfx950 -O2 tools/dbg/ubench/mx_layout.hip -o tools/dbg/ubench/mx_layout
+// build: hipcc --offload-arch=gfx950 -O2 tools/lab/ubench/mx_layout.hip -o tools/lab/ubench/mx_layout
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,11 +1,11 @@
 """Exact-mode attention at the window's sizes: k_x_attention_mfma (split operands on the matrix pipe) vs k_x_attention_f32
-(GPU box): python tools/x_attn_bench.py"""
+(GPU box): python tools/lab/x_attn_bench.py"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vidseg_diffusion_amd import exact as X  # noqa: E402
 

@@ -1,4 +1,4 @@
-"""Where does k_x_attention_mfma lose accuracy?  (GPU box)  python tools/x_attn_diag.py
+"""Where does k_x_attention_mfma lose accuracy?  (GPU box)  python tools/lab/x_attn_diag.py
 1. the split GEMM on all-positive operands of growing K (does a long MFMA accumulation chain into a large accumulator keep fp32 accuracy?)
 2. the attention error against float64 by key count, VIDSEG_ATTN=flush=0 / 1 (set before the process starts)."""
 import os
@@ -8,7 +8,7 @@ import numpy as np
 import torch
 import torch.nn.functional as TF
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vidseg_diffusion_amd import exact as X, ops  # noqa: E402
 

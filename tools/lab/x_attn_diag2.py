@@ -1,6 +1,6 @@
 import os, sys
 import numpy as np, torch, torch.nn.functional as TF
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vidseg_diffusion_amd import exact as X  # noqa: E402
 dev = torch.device("cuda:0")

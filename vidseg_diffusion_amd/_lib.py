@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # fp16 activations by default; VIDSEG_ACT=bf16 selects the bfloat16 build of the same sources (see csrc/common.h)
 LIB_PATH = os.path.join(_HERE, "libvidseg_hip_bf16.so" if os.environ.get("VIDSEG_ACT", "f16").lower() == "bf16" else "libvidseg_hip.so")
-if os.environ.get("VIDSEG_LIB"):                       # kernel experiments (tools/dbg/build_exp.sh): another build of the same C ABI
+if os.environ.get("VIDSEG_LIB"):                       # kernel experiments (tools/build_exp.py): another build of the same C ABI
     LIB_PATH = os.path.join(_HERE, os.environ["VIDSEG_LIB"])
 
 _P = ctypes.c_void_p

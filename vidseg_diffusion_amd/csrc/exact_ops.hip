@@ -23,7 +23,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int xu32x4;
 // per use: for x = a * s it emitted hi = v_cvt_pk_f16_f32(v_mul_f32(a, s)) for the operand image (two roundings) but
 // v_fma_mixlo_f16(a, s, 0) (one rounding of the exact product) as the hi that lo is taken against -- the two differ when the fp32
 // product sits on an fp16 rounding tie, and hi + lo is then one fp16 ulp (2^-12 relative) off: 6 of 10240 query rows of a
-// 1024-token attention came out 5e-5 wrong (tools/x_attn_diag2.py), every one holding such a tie.
+// 1024-token attention came out 5e-5 wrong (tools/lab/x_attn_diag2.py), every one holding such a tie.
 __device__ __forceinline__ void split_hl(float x, f16& hi, f16& lo) {
     asm volatile("" : "+v"(x));
     hi = (f16)x;

@@ -2598,7 +2598,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         const int NJ = (p.act != 2 && ((p.N + 319) / 320) * 320 <= ((p.N + 255) / 256) * 256) ? 5 : 4;
         const long long tiles_b = ((p.M + 255) / 256) * ((p.N + NJ * 64 - 1) / (NJ * 64));
         const long long tiles_mid = ((p.M + 127) / 128) * ((p.N + NJ * 64 - 1) / (NJ * 64));
-        // measured (tools/dbg/shape_summary.py): the 128 x 320 8-wave tile only beats 128 x 128 on the 32x32-level projections
+        // measured (tools/shape_summary.py): the 128 x 320 8-wave tile only beats 128 x 128 on the 32x32-level projections
         // (28672 x 640 x 640: 61 -> 50 us); K = 320 layers and under-filled grids lose
         const bool mid_ok = tiles_mid >= 448 && p.K >= 640 && p.N <= 640 && p.act == 0;
         bool big = false, p7 = false, xsmall = false;
@@ -2629,7 +2629,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
                 }
             }
             const long long tiles_sel = items / S;               // tile count of the chosen height
-            // measured per shape (tools/dbg/shape_summary.py): the big tile wins once the K loop is long enough to amortise its
+            // measured per shape (tools/shape_summary.py): the big tile wins once the K loop is long enough to amortise its
             // unoverlapped prologue/epilogue (one block per CU) and the grid fills the chip
             big = big_mode == 2 || (fill >= 0.70 && p.K >= 960 && (S == 1 || p.K / S >= 1440));
             // split operands on the 224-row tile (k_gemm_p7x): a K' / S of 960 is still five macro-tiles of three MFMA steps each, and
@@ -2640,7 +2640,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             if (!big && p7 && xsmall && fill >= 0.5 && p.K >= 1920 && (S == 1 || p.K / S >= 960)) big = true;
             // with the rolled epilogue (10 us fixed cost per tile instead of 27) the big tile also takes the short-K layers whose
             // grid is at least a full round of 256 CUs: 114688x960x320 161 -> 151 us, 28672x1920x640 118 -> 109, 114688x320x640 96 -> 77;
-            // GEGLU and small-M shapes still lose (measured per shape, tools/dbg/shape_summary.py)
+            // GEGLU and small-M shapes still lose (measured per shape, tools/shape_summary.py)
             if (!big && big_mode == 1 && p.act != 2 && S == 1 && fill >= 0.85 && tiles_sel >= 200 && p.K >= 320 && (p.N >= 640 || p.K >= 640))
                 big = true;
         }

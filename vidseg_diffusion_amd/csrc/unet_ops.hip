@@ -1,5 +1,5 @@
 // HIPCC_FLAGS: -fno-slp-vectorize
-// (packed fp32 VALU beside MFMAs costs ~10 cycles an instruction and does not overlap them: tools/ubench/mfma_valu.hip)
+// (packed fp32 VALU beside MFMAs costs ~10 cycles an instruction and does not overlap them: tools/lab/ubench/mfma_valu.hip)
 // Non-GEMM UNet operators for gfx950 on NHWC bf16 activations: GroupNorm(+SiLU) over an optional
 // two-source channel concat, LayerNorm, flash-style attention (head dim 64, MFMA), timestep embedding,
 // and the sampler's small elementwise steps.
@@ -559,7 +559,7 @@ __global__ void __launch_bounds__(256, 3) k_attention_fp8(const unsigned char* _
 
 // The same attention on the block-scaled instruction v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 operands, unit E8M0 scales): K = 64
 // per instruction at twice the 16-bit rate, so S^T of a 64-key tile is two MFMAs (d = 64 is one K) and O^T += V^T P^T two more,
-// instead of sixteen 32x32x16 ones.  Operand layout (checked on the device by tools/dbg/ubench/mx_layout.hip): lane l holds row
+// instead of sixteen 32x32x16 ones.  Operand layout (checked on the device by tools/lab/ubench/mx_layout.hip): lane l holds row
 // l & 31 and the 32 contiguous k of block l >> 5.  After S^T a lane owns the keys with bit 2 == hi of BOTH 32-key blocks; one
 // lane <-> lane+32 exchange of four words gives it all 32 keys of block hi, in natural order, which is how V^T is read.
 #define VT8M_LD 80   // Vt[d][key] row stride in bytes: 5 x 16, conflict-free ds_read_b128 across d rows
@@ -714,7 +714,7 @@ __global__ void __launch_bounds__(256, 3) k_attention_mx8(const unsigned char* _
 // TRV: the V tile stays row-major in LDS ([key][d], 192-B rows: two ds_write_b128 per thread instead of sixteen ds_write_b16) and
 // the V^T fragment of the PV MFMA comes from the gfx950 transpose read ds_read_b64_tr_b16: inside a 16-lane group, lane i passes
 // the address of row i >> 2, columns 4 (i & 3) .. +3 of a [4 keys][16 d] block and receives column i, keys 0..3
-// (tools/ubench/tr_layout.hip checks this on the device).  Row stride 48 dwords puts the 4 rows x 2 d-groups of a 32-lane half
+// (tools/lab/ubench/tr_layout.hip checks this on the device).  Row stride 48 dwords puts the 4 rows x 2 d-groups of a 32-lane half
 // on all 64 banks once.
 #define VR_LD 96
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -925,7 +925,7 @@ __global__ void __launch_bounds__(256, 2) k_attention2(const bf16_t* __restrict_
 }
 
 // k_attention2's tile schedule with a softmax whose common path is 32 exp2 + 16 packed adds + 16 conversions per 32 queries and
-// nothing else.  PMC on k_attention2 (tools/pmc_attn.sh): 279 VALU instructions per wave and K/V tile against 32 MFMAs -- the
+// nothing else.  PMC on k_attention2 (tools/lab/pmc_attn.sh): 279 VALU instructions per wave and K/V tile against 32 MFMAs -- the
 // kernel is bound by VALU issue slots (MFMA pipe 40 % busy), so the instructions that are not exp / row sum / conversion go:
 //   * Q is pre-multiplied by dim_head^-0.5 log2(e) once, in the prologue (one extra 16-bit rounding of Q);
 //   * the running reference m of a query is SUBTRACTED BY THE MATRIX PIPE: a fifth K-step per S block multiplies a constant
@@ -1133,7 +1133,7 @@ __global__ void __launch_bounds__(256, 2) k_attention3(const bf16_t* __restrict_
 
 // k_attention3 software-pipelined inside the wave.  PMC on k_attention2 / k_attention3: MFMA-busy + VALU-active = 93 % of the
 // cycles -- the two waves a SIMD holds were hardly ever in complementary phases (the hardware would overlap them:
-// tools/ubench/mfma_valu.hip).  Here the unit of work is a 32-key half tile u: while the matrix pipe computes S(u+1), the VALU
+// tools/lab/ubench/mfma_valu.hip).  Here the unit of work is a 32-key half tile u: while the matrix pipe computes S(u+1), the VALU
 // turns S(u) into P(u) in the same basic block (straight-line since k_attention3: exp2, row sum, conversion), then P(u) V(u).
 // K is staged two tiles ahead (ring of 3) because S(t+1, first half) runs before the end-of-tile barrier of tile t; V one (ring of 2).
 #ifdef VS_ATTN_STAMPS                                      /* experiment builds only: s_memtime at the phase boundaries of tiles 8..11 */

@@ -187,7 +187,7 @@ def region_clip(num_frames: int, h: int, w: int, num_regions: int = 20, seed: in
 # frame shows the same 20 drifting regions, so the frame-0-anchored clustering of Steps 3-3b (K-means over the window, labels
 # propagated from frame 0, feature_extraction.py:546-643) has K natural clusters -- through a network near the reference's own
 # initialisation (zero_gain): with the generic random network the K = 20 partition of the 6-blob clip was decided by the last
-# bits of the taps (16 % of the tokens moved under an fp16-rounding-level perturbation; tools/cond_probe.py measures this).
+# bits of the taps (16 % of the tokens moved under an fp16-rounding-level perturbation; tools/lab/cond_probe.py measures this).
 HEADLINE = dict(num_regions=20, amp=2.0, noise=0.05, zero_gain=0.3, protos="lattice")
 
 
