@@ -1,4 +1,4 @@
-"""smoke(): one narrow-width SD UNet forward on cuda:0 checked against the oracle.  Test infrastructure (it imports `oracle`):
+"""smoke(): one narrow-width SD UNet forward on cuda:0 in both precision modes, checked against the oracle.  Test infrastructure (it imports `oracle`):
 lives under tests/ and is called by __graft_entry__.smoke() only."""
 import numpy as np
 import torch
@@ -20,3 +20,9 @@ def run(dev):
     ref = UNetOracle(sd).forward(x, t, ctx)
     err = float((out - ref).norm() / ref.norm())
     assert err < 3e-2, f"smoke: UNet forward deviates {err:.3g} (normalised rms) from the fp32 oracle"
+    from vidseg_diffusion_amd import ops
+    if ops.act_dtype() == torch.float16:            # the precision mode bench.py quotes `value` on (exact.py; fp16 build only)
+        net.set_precision("exact")
+        out = net(x.to(dev), timesteps=t.to(dev), context=ctx.to(dev)).cpu()
+        err = float((out - ref).norm() / ref.norm())
+        assert err < 1e-4, f"smoke: exact-mode UNet forward deviates {err:.3g} (normalised rms) from the fp32 oracle"
