@@ -9,6 +9,7 @@ CONVS = [  # B, H, W, Cin, Cout, stride, up, residual
     (28, 64, 64, 320, 320, 1, 1, True), (28, 64, 64, 960, 320, 1, 1, False), (28, 32, 32, 640, 640, 1, 1, True), (28, 32, 32, 1920, 640, 1, 1, False),
     (28, 16, 16, 1280, 1280, 1, 1, True), (28, 16, 16, 2560, 1280, 1, 1, False), (28, 8, 8, 1280, 1280, 1, 1, True), (28, 64, 64, 320, 320, 2, 1, False),
     (28, 16, 16, 1280, 1280, 1, 2, False), (14, 32, 32, 640, 640, 1, 1, True), (3, 37, 29, 192, 320, 1, 1, False)]
+GEGLUS = [(114688, 320, 2560), (28672, 640, 5120), (7168, 1280, 10240), (57344, 320, 2560), (3584, 1280, 10240)]   # M, K, 2 * inner
 LINS = [  # M, K, N, residual
     (114688, 320, 320, True), (114688, 1280, 320, True), (28672, 640, 640, True), (28672, 2560, 640, True), (7168, 1280, 1280, True),
     (7168, 5120, 1280, True), (114688, 320, 960, False), (28672, 640, 1920, False), (7168, 1280, 3840, False), (2156, 1024, 1280, False), (999, 320, 640, False)]
@@ -58,6 +59,11 @@ def run(tag):
             e = float((outs[-1].double() - ref.double()).norm() / ref.double().norm())
             print(f"    vs float64 of the split operands: nrms {e:.2e}", flush=True)
             assert e < 2e-6, e
+    for (M, K, N) in GEGLUS:
+        g = torch.Generator(device="cpu").manual_seed(M + K + N)
+        a3 = X.split3(torch.randn((M, K), generator=g).to(dev))
+        w3g, bg, grp = X.pack_geglu_x(torch.randn((N, K), generator=g) * 0.03, torch.randn(N, generator=g), dev)
+        bench(f"GEGLU {M}x{N}x{K} (groups of {grp})", lambda: X.geglu_linear_x(a3, w3g, bg, grp), 2.0 * M * N * 3 * K)
     torch.save(outs, f"/tmp/p7x_{tag}.pt")
 
 
@@ -66,9 +72,10 @@ if __name__ == "__main__":
         run(sys.argv[1])
     else:
         import torch
-        for tag, env in (("p7", {"VIDSEG_GEMM": "p7x=0"}), ("p7x", {"VIDSEG_GEMM": "p7x=1"})):
+        modes = (("p7", {"VIDSEG_GEMM": "p7x=0"}), ("p7x", {"VIDSEG_GEMM": "p7x=1"}))
+        for tag, env in modes:
             subprocess.run([sys.executable, __file__, tag], env={**os.environ, **env}, check=True, timeout=900)
-        a, b = torch.load("/tmp/p7x_p7.pt"), torch.load("/tmp/p7x_p7x.pt")
+        a, b = torch.load(f"/tmp/p7x_{modes[0][0]}.pt"), torch.load(f"/tmp/p7x_{modes[1][0]}.pt")
         worst = 0.0
         for i, (x, y) in enumerate(zip(a, b)):
             e = float((x.double() - y.double()).norm() / x.double().norm())
