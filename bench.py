@@ -659,8 +659,13 @@ def main():
             else:                                                    # rank 0 holds the last step's label stack [world, F, N]
                 wins = out["config"]["windows_cycled"]
                 last = (args.warmup + args.steps - 1)
-                m = timed_masks_vs_reference([(wins[(last * world + r) % len(wins)], np.asarray(labels)[r]) for r in range(world)]
-                                             if not args.no_overlap else [], refine, k_masks)
+                # only rank 0's window is scored: the windows of ranks > 0 are CHAINED to it (4-NN label propagation, like windows > 0 of
+                # a clip), while every fixture holds its window's own K-means
+                m = timed_masks_vs_reference([(wins[(last * world) % len(wins)], np.asarray(labels)[0])] if not args.no_overlap else [],
+                                             refine, k_masks)
+                if m is not None:
+                    m["note"] += ("; N > 1: rank 0's window of the last step only -- the other ranks' windows are chained to it by 4-NN "
+                                  "propagation, the fixtures hold each window's own K-means")
             if m is not None:
                 out["mask_iou_vs_reference"] = m
         if world == 1 and ((args.masks_only and not args.parity) or args.fp8_attn):   # outside the timed region: the same window on the plain path
