@@ -239,21 +239,23 @@ int vidseg_cfg_euler_step(float* x, const float* net_out, int F, int C, int HW, 
                           vidseg_stream_t stream);
 int vidseg_add_noise(float* x, const float* eps, long long n, float sigma, float inv_scale, vidseg_stream_t stream);
 
-/* registers a caller-owned fp32 device scratch for split-K partials (optional; without it split-K is off):
-   set_workspace = default of the current device, bind_workspace = the scratch of launches on `stream` of the current device
-   (two streams must not share partials; the reference has no counterpart -- cuBLAS owns its workspaces, sgm/modules/attention.py
-   and openaimodel.py call F.linear / conv2d) */
-int vidseg_set_workspace(float* ws, long long floats);
+/* binds a caller-owned fp32 device scratch for split-K partials to the launches on `stream` of the current device (optional: a
+   stream without a binding runs without split-K; a null pointer unbinds; two streams must not share partials).  The reference has no
+   counterpart -- cuBLAS owns its workspaces, sgm/modules/attention.py and openaimodel.py call F.linear / conv2d.  There is no
+   process-wide default. */
 int vidseg_bind_workspace(vidseg_stream_t stream, float* ws, long long floats);
 
-/* opt-in HIP-event timing of the conv/linear MFMA kernel family (bench.py roofline); out = {ms, flops, launches} (host) */
-int vidseg_gemm_profile_begin(void);
-int vidseg_gemm_profile_end(double* out);
-/* per-kernel split of the same region: out[18] = {ms, flops, launches} x {128x128 LDS-DMA, 256-row big tile, mid tile, 256x64,
-   224-row big tile, weight-stationary streaming} */
-int vidseg_gemm_profile_kinds(double* out);
-/* algorithmic HBM bytes of the same region per kernel, out[6] (every operand and result once; no split-K partials) */
-int vidseg_gemm_profile_bytes(double* out);
+/* opt-in HIP-event timing of the conv/linear MFMA kernel family (bench.py roofline).  The profiler is a caller-owned handle: between
+   _begin(h) and _end(h) the launches of the CALLING THREAD are timed into h; _end: out = {ms, flops, launches} (host) */
+int vidseg_gemm_profiler_create(void** handle_out);
+int vidseg_gemm_profiler_destroy(void* handle);
+int vidseg_gemm_profile_begin(void* handle);
+int vidseg_gemm_profile_end(void* handle, double* out);
+/* per-kernel split of the region _end closed: out[24] = {ms, flops, launches} x {128x128 LDS-DMA, 256-row big tile, mid tile, 256x64,
+   224-row big tile, weight-stationary streaming, 224x320 split-operand tile, 224x256 split-operand GEGLU tile} */
+int vidseg_gemm_profile_kinds(void* handle, double* out);
+/* algorithmic HBM bytes of the same region per kernel, out[8] (every operand and result once; no split-K partials) */
+int vidseg_gemm_profile_bytes(void* handle, double* out);
 
 /* ---- "exact" mode of the UNet path (fp16 build; csrc/exact_ops.hip): every value is carried in fp32 and handed to the 16-bit MFMA
  * GEMM / conv entry points above as the operand image [hi | lo | hi] (hi = fp16(x), lo = fp16(x - hi)) against weights packed as

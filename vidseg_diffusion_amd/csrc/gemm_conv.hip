@@ -2033,10 +2033,14 @@ struct GemmProf {
     long long launches = 0;
     struct Shape { long long M; int N, K, ksize, up, stride, act, ksplit, kind; double alg_bytes; };
     std::vector<Shape> shapes;      // one per event pair
+    double kind_stats[24] = {0};    // per kernel kind: ms, flops, launches (filled by _end)
+    double kind_bytes[8] = {0};
 };
-static GemmProf g_prof;
-static double g_kind_stats[24];
-static double g_kind_bytes[8];
+// A profiler is a caller-owned handle (vidseg_gemm_profiler_create); between _begin(h) and _end(h) the GEMM launches of the CALLING
+// THREAD are timed into it.  No profiler state lives in the library beyond the per-thread pointer to the handle that is recording.
+static GemmProf g_off;                                          // the "not recording" profiler (on = false)
+static thread_local GemmProf* t_prof = &g_off;
+#define g_prof (*t_prof)
 
 static inline hipEvent_t prof_event() {
     if (g_prof.used == g_prof.ev.size()) {
@@ -2324,7 +2328,24 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
 
 extern "C" {
 
-int vidseg_gemm_profile_begin(void) {
+int vidseg_gemm_profiler_create(void** out) {
+    VS_REQUIRE(out != nullptr, "gemm_profiler_create: null output");
+    *out = new GemmProf();
+    return VS_OK;
+}
+
+int vidseg_gemm_profiler_destroy(void* h) {
+    GemmProf* gp = (GemmProf*)h;
+    if (!gp) return VS_OK;
+    if (t_prof == gp) t_prof = &g_off;
+    for (hipEvent_t e : gp->ev) (void)hipEventDestroy(e);
+    delete gp;
+    return VS_OK;
+}
+
+int vidseg_gemm_profile_begin(void* h) {
+    VS_REQUIRE(h != nullptr, "gemm_profile_begin: null profiler");
+    t_prof = (GemmProf*)h;
     g_prof.on = true;
     g_prof.used = 0;
     g_prof.flops = 0.0;
@@ -2334,34 +2355,37 @@ int vidseg_gemm_profile_begin(void) {
 }
 
 // out[0] = total kernel milliseconds, out[1] = algorithmic FLOPs, out[2] = launches
-int vidseg_gemm_profile_end(double* out) {
-    g_prof.on = false;
+int vidseg_gemm_profile_end(void* h, double* out) {
+    VS_REQUIRE(h != nullptr, "gemm_profile_end: null profiler");
+    GemmProf& gp = *(GemmProf*)h;
+    gp.on = false;
+    if (t_prof == &gp) t_prof = &g_off;
     double ms = 0.0;
-    for (int i = 0; i < 24; ++i) g_kind_stats[i] = 0.0;
-    for (int i = 0; i < 8; ++i) g_kind_bytes[i] = 0.0;
-    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+    for (int i = 0; i < 24; ++i) gp.kind_stats[i] = 0.0;
+    for (int i = 0; i < 8; ++i) gp.kind_bytes[i] = 0.0;
+    for (size_t i = 0; i + 1 < gp.used; i += 2) {
         float t = 0.f;
-        hipError_t e = hipEventSynchronize(g_prof.ev[i + 1]);
-        if (e == hipSuccess) e = hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
+        hipError_t e = hipEventSynchronize(gp.ev[i + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, gp.ev[i], gp.ev[i + 1]);
         if (e != hipSuccess) VS_FAIL(VS_ERR_HIP, "gemm_profile_end: %s", hipGetErrorString(e));
         ms += t;
-        if (i / 2 < g_prof.shapes.size()) {
-            const GemmProf::Shape& h = g_prof.shapes[i / 2];
-            const int kd = h.kind >= 0 && h.kind < 8 ? h.kind : 0;
-            g_kind_stats[kd * 3] += t;
-            g_kind_stats[kd * 3 + 1] += 2.0 * (double)h.M * (double)h.N * (double)h.K;
-            g_kind_stats[kd * 3 + 2] += 1.0;
-            g_kind_bytes[kd] += h.alg_bytes;
+        if (i / 2 < gp.shapes.size()) {
+            const GemmProf::Shape& sh = gp.shapes[i / 2];
+            const int kd = sh.kind >= 0 && sh.kind < 8 ? sh.kind : 0;
+            gp.kind_stats[kd * 3] += t;
+            gp.kind_stats[kd * 3 + 1] += 2.0 * (double)sh.M * (double)sh.N * (double)sh.K;
+            gp.kind_stats[kd * 3 + 2] += 1.0;
+            gp.kind_bytes[kd] += sh.alg_bytes;
         }
-        if (knobs().shapes && i / 2 < g_prof.shapes.size()) {
-            const GemmProf::Shape& h = g_prof.shapes[i / 2];
-            fprintf(stderr, "GEMMSHAPE M=%lld N=%d K=%d ks=%d up=%d st=%d act=%d split=%d us=%.1f kind=%d\n", h.M, h.N, h.K, h.ksize, h.up,
-                    h.stride, h.act, h.ksplit, t * 1e3, h.kind);
+        if (knobs().shapes && i / 2 < gp.shapes.size()) {
+            const GemmProf::Shape& sh = gp.shapes[i / 2];
+            fprintf(stderr, "GEMMSHAPE M=%lld N=%d K=%d ks=%d up=%d st=%d act=%d split=%d us=%.1f kind=%d\n", sh.M, sh.N, sh.K, sh.ksize, sh.up,
+                    sh.stride, sh.act, sh.ksplit, t * 1e3, sh.kind);
         }
     }
     out[0] = ms;
-    out[1] = g_prof.flops;
-    out[2] = (double)g_prof.launches;
+    out[1] = gp.flops;
+    out[2] = (double)gp.launches;
     return VS_OK;
 }
 
@@ -2369,69 +2393,60 @@ int vidseg_gemm_profile_end(double* out) {
 // k = 0: k_gemm_dma (128x128), 1: k_gemm_ph big (256x320 / 256x256), 2: k_gemm_tile mid (128x320), 3: k_gemm_conv<256,64>,
 // 4: k_gemm_p7 (224x320), 5: k_gemm_ws (weight-stationary streaming, short K), 6: k_gemm_p7x<5, false> (224x320 on split operands),
 // 7: k_gemm_p7x<4, true> (224x256 on split operands, GEGLU epilogue).
-int vidseg_gemm_profile_kinds(double* out) {
-    for (int i = 0; i < 24; ++i) out[i] = g_kind_stats[i];
+int vidseg_gemm_profile_kinds(void* h, double* out) {
+    VS_REQUIRE(h != nullptr, "gemm_profile_kinds: null profiler");
+    for (int i = 0; i < 24; ++i) out[i] = ((GemmProf*)h)->kind_stats[i];
     return VS_OK;
 }
 
 // Algorithmic HBM bytes of the same region per kernel (same order): every operand once -- the activation tensor(s) the launch
 // reads (the whole input image for a conv: the 9 taps re-read it through L1/L2, not through memory), the weight matrix, the
 // residual, and every output it writes (16-bit result, fp32 result, fp16 taps); split-K partials are NOT algorithmic.
-int vidseg_gemm_profile_bytes(double* out) {
-    for (int i = 0; i < 8; ++i) out[i] = g_kind_bytes[i];
+int vidseg_gemm_profile_bytes(void* h, double* out) {
+    VS_REQUIRE(h != nullptr, "gemm_profile_bytes: null profiler");
+    for (int i = 0; i < 8; ++i) out[i] = ((GemmProf*)h)->kind_bytes[i];
     return VS_OK;
 }
 
-// Split-K workspaces (caller-owned fp32 device memory).  One per (device, stream): two streams -- the two window lanes of
+// Split-K workspaces (caller-owned fp32 device memory), bound per (device, stream): two streams -- the two window lanes of
 // pipeline.WindowPipeline, or the two devices of one process -- must not share partials, and nothing orders their launches.
-// vidseg_bind_workspace registers the scratch the GEMMs launched on `stream` of the CURRENT device use; vidseg_set_workspace
-// registers the current device's default for streams without a binding.  The host keeps a scratch bound to a stream only while
-// every launch that uses it is ordered on that stream (ops.workspace does: one Workspace per (device, torch stream)).
+// vidseg_bind_workspace registers the scratch the GEMMs launched on `stream` of the CURRENT device use (a null pointer unbinds); a
+// launch on a stream without a binding runs without split-K.  The host keeps a scratch bound to a stream only while every launch that
+// uses it is ordered on that stream (ops.workspace does: one Workspace per (device, torch stream)).  There is no process-wide default.
 struct WsEntry {
     int dev;
     hipStream_t st;
-    bool any_stream;
     float* ws;
     long long floats;
 };
 static WsEntry g_ws_tab[64];
 static int g_ws_n = 0;
 
-static int ws_register(hipStream_t st, bool any_stream, float* ws, long long floats) {
+int vidseg_bind_workspace(hipStream_t st, float* ws, long long floats) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     for (int i = 0; i < g_ws_n; ++i)
-        if (g_ws_tab[i].dev == dev && g_ws_tab[i].any_stream == any_stream && (any_stream || g_ws_tab[i].st == st)) {
+        if (g_ws_tab[i].dev == dev && g_ws_tab[i].st == st) {
             g_ws_tab[i].ws = ws;
-            g_ws_tab[i].floats = floats;
+            g_ws_tab[i].floats = ws ? floats : 0;
             return VS_OK;
         }
     VS_REQUIRE(g_ws_n < 64, "workspace table full (%d bindings)", g_ws_n);
-    g_ws_tab[g_ws_n++] = WsEntry{dev, st, any_stream, ws, floats};
+    g_ws_tab[g_ws_n++] = WsEntry{dev, st, ws, ws ? floats : 0};
     return VS_OK;
 }
-
-int vidseg_set_workspace(float* ws, long long floats) { return ws_register(nullptr, true, ws, floats); }
-int vidseg_bind_workspace(hipStream_t stream, float* ws, long long floats) { return ws_register(stream, false, ws, floats); }
 
 static void ws_lookup(hipStream_t st, float*& ws, long long& floats) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     ws = nullptr;
     floats = 0;
-    for (int i = 0; i < g_ws_n; ++i) {
-        const WsEntry& e = g_ws_tab[i];
-        if (e.dev != dev) continue;
-        if (!e.any_stream && e.st == st) {
-            ws = e.ws;
-            floats = e.floats;
+    for (int i = 0; i < g_ws_n; ++i)
+        if (g_ws_tab[i].dev == dev && g_ws_tab[i].st == st) {
+            ws = g_ws_tab[i].ws;
+            floats = g_ws_tab[i].floats;
             return;
         }
-        if (e.any_stream && !ws) {
-            ws = e.ws;
-            floats = e.floats;
-        }
-    }
 }
 
 static int launch_gemm(const GemmParams& p_in, hipStream_t st) {

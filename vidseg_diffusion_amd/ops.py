@@ -44,17 +44,18 @@ _lib.register({
     "vidseg_euler_update": [_P, _P, _P, _P, _L, _L, _P, _P],
     "vidseg_axpy_f32": [_P, _P, _L, _F, _F, _P, _P],
     "vidseg_blend_f32": [_P, _P, _P, _L, _P, _P],
-    "vidseg_set_workspace": [_P, _L],
     "vidseg_bind_workspace": [_P, _P, _L],
     "vidseg_linear_a16_ttap": [_P, _L, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "vidseg_conv_temporal3_a16": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
     "vidseg_temporal_attention_a16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "vidseg_alpha_blend_a16": [_P, _P, _P, _L, _P, _P],
     "vidseg_add_rowvec_a16": [_P, _P, _L, _I, _I, _I, _P, _P],
-    "vidseg_gemm_profile_begin": [],
-    "vidseg_gemm_profile_end": [_P],
-    "vidseg_gemm_profile_kinds": [_P],
-    "vidseg_gemm_profile_bytes": [_P],
+    "vidseg_gemm_profiler_create": [_P],
+    "vidseg_gemm_profiler_destroy": [_P],
+    "vidseg_gemm_profile_begin": [_P],
+    "vidseg_gemm_profile_end": [_P, _P],
+    "vidseg_gemm_profile_kinds": [_P, _P],
+    "vidseg_gemm_profile_bytes": [_P, _P],
 })
 
 
@@ -443,16 +444,60 @@ def blend(x, y, m):
     return out
 
 
+class GemmProfiler:
+    """Caller-owned profiler handle of the C ABI (vidseg_gemm_profiler_create): between begin() and end() the conv / linear MFMA
+    launches of this thread are timed into it with HIP events riding on the dispatch packets (bench.py roofline)."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        call("vidseg_gemm_profiler_create", ctypes.byref(h))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _lib.lib().vidseg_gemm_profiler_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def begin(self):
+        call("vidseg_gemm_profile_begin", self.h)
+
+    def end(self):
+        """-> (kernel_ms_total, algorithmic_flops, launches)."""
+        out = (ctypes.c_double * 3)()
+        call("vidseg_gemm_profile_end", self.h, out)
+        return float(out[0]), float(out[1]), int(out[2])
+
+    def kinds(self):
+        """Per-kernel split of the region closed by end(): list of (name, ms, flops, launches, algorithmic_bytes)."""
+        nk = len(GEMM_KIND_NAMES)
+        out = (ctypes.c_double * (3 * nk))()
+        call("vidseg_gemm_profile_kinds", self.h, out)
+        ab = (ctypes.c_double * nk)()
+        call("vidseg_gemm_profile_bytes", self.h, ab)
+        return [(GEMM_KIND_NAMES[k], float(out[3 * k]), float(out[3 * k + 1]), int(out[3 * k + 2]), float(ab[k])) for k in range(nk)]
+
+
+_PROFILER = None
+
+
+def _profiler():
+    global _PROFILER
+    if _PROFILER is None:
+        _PROFILER = GemmProfiler()
+    return _PROFILER
+
+
 def gemm_profile_begin():
-    """Start HIP-event timing of every conv/linear MFMA launch (bench.py roofline)."""
-    call("vidseg_gemm_profile_begin")
+    """Start HIP-event timing of every conv/linear MFMA launch of this thread into the package's default GemmProfiler."""
+    _profiler().begin()
 
 
 def gemm_profile_end():
     """-> (kernel_ms_total, algorithmic_flops, launches)."""
-    out = (ctypes.c_double * 3)()
-    call("vidseg_gemm_profile_end", out)
-    return float(out[0]), float(out[1]), int(out[2])
+    return _profiler().end()
 
 
 GEMM_KIND_NAMES = ("k_gemm_dma (128x128, LDS-DMA)", "k_gemm_ph<NJ> (256x320 / 256x256, LDS-DMA, phased)",
@@ -464,12 +509,7 @@ GEMM_KIND_NAMES = ("k_gemm_dma (128x128, LDS-DMA)", "k_gemm_ph<NJ> (256x320 / 25
 
 def gemm_profile_kinds():
     """Per-kernel split of the region closed by gemm_profile_end: list of (name, ms, flops, launches, algorithmic_bytes)."""
-    nk = len(GEMM_KIND_NAMES)
-    out = (ctypes.c_double * (3 * nk))()
-    call("vidseg_gemm_profile_kinds", out)
-    ab = (ctypes.c_double * nk)()
-    call("vidseg_gemm_profile_bytes", ab)
-    return [(GEMM_KIND_NAMES[k], float(out[3 * k]), float(out[3 * k + 1]), int(out[3 * k + 2]), float(ab[k])) for k in range(nk)]
+    return _profiler().kinds()
 
 
 # ----------------------------------------------------------------------------- video (SVD) operators
