@@ -135,10 +135,25 @@ def test_split_tile_stages_each_plane_once(X):
     e = rel(out, ref)
     print(f"split tile temporal conv T=14 128->320: max err {e:.2e}")
     assert e <= 5e-6, e
+    # k_gemm_phx: the 256 x 320 tile with the same four-tile staging, for shapes whose M fills a round of 256-row tiles (M = 28 * 18 * 32
+    # = 63 tile rows x 4 tile columns = 252 of 256 CUs: the SVD window's 18x32 level): 3x3 conv + residual and a long-K linear
+    x, w, b = rnd((28, 18, 32, 128), 81), rnd((1280, 128, 3, 3), 82, 0.05), rnd((1280,), 83)
+    r = rnd((28, 18, 32, 1280), 84, 2.0)
+    out = X.conv3x3_x(X.split3(x.to(dev)), X.pack_conv3x3_x(w, dev), ops.f32(b, dev), residual=r.to(dev)).cpu()
+    ref = TF.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1).permute(0, 2, 3, 1) + r.double()
+    e = rel(out, ref)
+    print(f"split 256-row tile conv3x3 28x18x32 128->1280 + residual: max err {e:.2e}")
+    assert e <= 5e-6, e
+    M, K, N = 16128, 1280, 1280
+    a, w, b, r = rnd((M, K), 85), rnd((N, K), 86, 0.02), rnd((N,), 87), rnd((M, N), 88, 2.0)
+    out = X.linear_x(X.split3(a.to(dev)), X.pack_linear_x(w, dev), ops.f32(b, dev), residual=r.to(dev)).cpu()
+    e = rel(out, a.double() @ w.double().t() + b.double() + r.double())
+    print(f"split 256-row tile linear {M}x{N}x{K} + fp32 residual: max err {e:.2e}")
+    assert e <= 5e-6, e
     ops.gemm_profile_end()
     kinds = {n.split(" (")[0]: ln for (n, ms, fl, ln, ab) in ops.gemm_profile_kinds()}
     print("launches by kernel:", kinds)
-    assert kinds.get("k_gemm_p7x<5, false>", 0) >= 4, kinds                                           # the convolutions above must exercise the new tile (the N = 960 / split-K linears go to other tiles)
+    assert kinds.get("k_gemm_p7x<5, false>", 0) >= 4 and kinds.get("k_gemm_ph<NJ>", 0) >= 3, kinds                                           # the convolutions above must exercise the new tile (the N = 960 / split-K linears go to other tiles)
 
 
 def test_fp32_glue_operators(X):

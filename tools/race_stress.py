@@ -89,6 +89,7 @@ if args.exact:
     xlin(7168, 1280, 1280, res=True); xlin(7168, 5120, 1280, res=True); xlin(3584, 1280, 1280, res=True); xlin(896, 1280, 1280, res=True)
     xlin(114688, 320, 2560, geglu=True); xlin(28672, 640, 5120, geglu=True); xlin(7168, 1280, 10240, geglu=True); xlin(1792, 1280, 10240, geglu=True)
     xlin(14336, 640, 5120, geglu=True); xlin(896, 1280, 10240, geglu=True)
+    xconv(18, 1280, 1280, res=True); xconv(18, 2560, 1280); xlin(16128, 1280, 1280, res=True); xlin(16128, 5120, 1280, res=True)   # k_gemm_phx (256-row tile)
     xattn(4096, 5); xattn(1024, 10); xattn(1024, 10, Bx=14)
     conv = lin = attn = lambda *a, **k: None                  # the 16-bit cases below are skipped
 conv(64, 320, 320, res=True); conv(64, 640, 320, 320); conv(32, 640, 640, res=True); conv(32, 1280, 640, 640); conv(16, 1280, 1280, res=True)

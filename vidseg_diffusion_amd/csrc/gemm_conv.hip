@@ -1712,6 +1712,214 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7x(GemmParams p) {
     gemm_epilogue16<MI, NJ, G3>(p, acc, smem, (int)m0 + wm * 112, n0 + wn * WN, lane, wave, split);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_gemm_phx: the 256 x 320 phased tile (k_gemm_ph<5>: 4 x 2 waves, wave tile 64 x 160 of v_mfma_f32_32x32x16, B blocks of 32 rows)
+// on the exact mode's split operands with k_gemm_p7x's staging: the four distinct tiles of a 64-channel macro-tile (a_hi, a_lo, w_hi,
+// w_lo) staged once, three K-steps on them, the same schedule and counted waits (the piece counts per wave and tile are the same: four
+// A sets, five B blocks).  For the shapes whose M fills whole rounds of 256-row tiles -- the 36x64 and 18x32 levels of the SVD window.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 2) k_gemm_phx(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NJ = 5;
+    constexpr int BM = 256, BN = NJ * 64, RB = 128;
+    constexpr int A_BYTES = 256 * RB, B_BYTES = BN * RB;                 // LDS map: A[0] A[1] B[0] B[1] (hi, lo, hi, lo)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, grp = wave >> 2;
+    int split, tn;
+    long long tm;
+    map_tile(p, BM, BN, split, tm, tn);
+    const long long m0 = tm * BM;
+    const int n0 = tn * BN;
+
+    constexpr unsigned OOB = 0xF0000000u;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w), 0, (int)((long long)p.N * p.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x0), 0, (int)p.x0_bytes, 0x00020000);
+
+    const int Cin = p.C0 / 3;                                            // channels of the ORIGINAL operand; a pixel holds [hi | lo | hi] = 3 * Cin
+    const int HWo = p.Hout * p.Wout;
+    const int upsh = p.up - 1;
+    const int Hup = p.Hin << upsh, Wup = p.Win << upsh;
+    const int lrow = lane >> 3, lch = lane & 7;
+    const unsigned swz16 = (unsigned)((lch ^ (((wave & 1) << 2) | (lrow >> 1))) << 4);
+    const int hb = p.ksize == 1 ? 1 : (p.tmode ? p.T : Hup), wb = (p.ksize == 1 || p.tmode) ? 1 : Wup;
+    const int wmul = p.tmode ? HWo : p.Win;
+    int a_base[4], a_hw[4];                                            // a_hw = (ih0 + 0x4000) << 16 | (iw0 + 0x4000)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int r = (s4 >> 1) * 128 + (wave + 8 * (s4 & 1)) * 8 + lrow;
+        const long long m = m0 + r;
+        const bool ok = m < p.M;
+        const int mm = ok ? (int)m : 0;
+        int ih0 = 0, iw0 = 0;
+        if (p.ksize == 1) {
+            a_base[s4] = mm;
+        } else if (p.tmode) {
+            const int t = (mm / HWo) % p.T;
+            a_base[s4] = mm - t * HWo;
+            ih0 = t - 1;
+        } else {
+            const int b = mm / HWo, rem = mm - b * HWo;
+            const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
+            a_base[s4] = b * p.Hin * p.Win;
+            ih0 = oh * p.stride - p.pad;
+            iw0 = ow * p.stride - p.pad;
+        }
+        if (!ok) ih0 = -0x4000;
+        a_hw[s4] = ((ih0 + 0x4000) << 16) | (iw0 + 0x4000);
+    }
+    const int b_r0 = (wave >> 2) * (NJ * 32) + (wave & 3) * 8;           // first row of this wave's piece inside B block 0 (k_gemm_ph)
+    const int b_n = n0 + b_r0 + lrow;
+    const unsigned b_off0 = (unsigned)((long long)b_n * p.K * 2) + swz16;
+    const unsigned b_gstep = (unsigned)p.K * 64u;                            // 32 weight rows
+    const unsigned b_lo = (unsigned)(p.K / 3) * 4u;                          // w_lo = third plane of the row: 2 * (K / 3) elements further
+    const int kchunk = p.ksize == 1 ? Cin : 64;                              // K order of the ORIGINAL axis (chunk-major for convolutions)
+    const int nk_all = p.K / 192;                                            // macro-tiles: 64 channels of the original K
+    const int ks_begin = p.ksplit > 1 ? (int)((long long)nk_all * split / p.ksplit) : 0;
+    const int ks_end = p.ksplit > 1 ? (int)((long long)nk_all * (split + 1) / p.ksplit) : nk_all;
+    const int nk = ks_end - ks_begin;
+    // one K cursor per A plane: the hi plane runs one macro-tile behind the lo plane (see the schedule)
+    KCursor cur0, cur1;
+    cur0.init(ks_begin * 64, p.taps, kchunk);
+    cur1 = cur0;
+    int u0 = 0, u1 = 0;                                                       // macro-tile each cursor points at
+    int k0h = 0, k0w = 0, k0c = 0, k1h = 0, k1w = 0, k1c = 0;
+    bool live0 = false, live1 = false;
+    auto stage_a = [&](auto PL, int s4) {                                     // PL: 0 = hi plane -> A[0], 1 = lo plane -> A[1]
+        constexpr int pl = decltype(PL)::value;
+        KCursor& cur = pl ? cur1 : cur0;
+        int& kh = pl ? k1h : k0h;
+        int& kw = pl ? k1w : k0w;
+        int& cc = pl ? k1c : k0c;
+        bool& live = pl ? live1 : live0;
+        int& u = pl ? u1 : u0;
+        if (s4 == 0) {
+            live = u < nk;
+            ++u;
+            cc = cur.c0();
+            const int t3 = cur.tap / 3;
+            kh = p.tmode ? cur.tap : t3;
+            kw = p.tmode ? 0 : cur.tap - t3 * 3;
+            cur.advance(64, p.taps, kchunk);
+        }
+        char* dst = smem + pl * A_BYTES + ((s4 >> 1) * 128 + (wave + 8 * (s4 & 1)) * 8) * RB;
+        const int ih = (a_hw[s4] >> 16) - 0x4000 + kh, iw = (a_hw[s4] & 0xFFFF) - 0x4000 + kw;
+        const bool ok = live && (unsigned)ih < (unsigned)hb && (unsigned)iw < (unsigned)wb;
+        const int pix = a_base[s4] + (ih >> upsh) * wmul + (iw >> upsh);
+        const unsigned off = ok ? (unsigned)(pix * p.C0 + pl * Cin + cc) * 2u + swz16 : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+    };
+    auto stage_b = [&](auto PL, int g, int u) {                               // PL: 0 = w_hi -> B[0], 1 = w_lo -> B[1]; u = macro-tile
+        constexpr int pl = decltype(PL)::value;
+        const bool live = u < nk;
+        char* dst = smem + 2 * A_BYTES + pl * B_BYTES + (b_r0 + g * 32) * RB;
+        const unsigned off = (live && b_n + g * 32 < p.N) ? b_off0 + (unsigned)g * b_gstep + (pl ? b_lo : 0u) + (unsigned)(ks_begin + u) * 128u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int sw = lds_swz<64>(l31);
+    const int arow = (wm * 64 + l31) * RB, brow = 2 * A_BYTES + (wn * (NJ * 32) + l31) * RB;
+
+    // prologue: what the steady state would have issued before s0(0), in its issue order
+#pragma unroll
+    for (int g = 0; g < 4; ++g) stage_a(P1{}, g);                             // A1(0)
+#pragma unroll
+    for (int g = 0; g < NJ; ++g) stage_b(P0{}, g, 0);                         // B0(0)
+    stage_a(P0{}, 0);                                                         // A0(0).0
+    wait_vmcnt<NJ>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+
+    bf16x8_t fa[2][4];
+    auto step = [&](auto SK, int kc) {                                        // SK: 0 a_lo.w_hi, 1 a_hi.w_hi, 2 a_hi.w_lo of macro-tile kc
+        constexpr int sk = decltype(SK)::value;
+        const char* A = smem + (sk == 0 ? A_BYTES : 0) + arow;
+        const char* B = smem + (sk == 2 ? B_BYTES : 0) + brow;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            // ---- read section
+            bf16x8_t fb[4];
+            if (j == 0 && sk != 2) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fa[i][s4] = *reinterpret_cast<const bf16x8_t*>(A + i * 32 * RB + (((s4 * 2 + hi) ^ sw) << 4));
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) fb[s4] = *reinterpret_cast<const bf16x8_t*>(B + j * 32 * RB + (((s4 * 2 + hi) ^ sw) << 4));
+            if (sk == 0) {
+                if constexpr (NJ == 5) {
+                    if (j <= 2) stage_a(P0{}, j + 1);                         // A0(kc).1..3
+                    if (j >= 2) stage_a(P1{}, j - 2);                         // A1(kc+1).0..2
+                    if (j <= 1) wait_vmcnt<5>();
+                    else if (j <= 3) wait_vmcnt<6>();
+                    else wait_vmcnt<3>();
+                } else {                                                      // four phases: A0.1 A0.2 | A0.3 | A1'.0 A1'.1 | A1'.2; waits 5, 5, 6, 3
+                    if (j == 0) {
+                        stage_a(P0{}, 1);
+                        stage_a(P0{}, 2);
+                    } else if (j == 1) {
+                        stage_a(P0{}, 3);
+                    } else if (j == 2) {
+                        stage_a(P1{}, 0);
+                        stage_a(P1{}, 1);
+                    } else {
+                        stage_a(P1{}, 2);
+                    }
+                    if (j <= 1) wait_vmcnt<5>();
+                    else if (j == 2) wait_vmcnt<6>();
+                    else wait_vmcnt<3>();
+                }
+            } else if (sk == 1) {
+                stage_b(P1{}, j, kc);                                         // B1(kc).j
+                if (j == NJ - 1) {
+                    stage_a(P1{}, 3);                                         // A1(kc+1).3
+                    wait_vmcnt<NJ>();
+                }
+            } else {
+                stage_b(P0{}, j, kc + 1);                                     // B0(kc+1).j
+                if (j == NJ - 1) stage_a(P0{}, 0);                            // A0(kc+1).0
+                wait_vmcnt<NJ>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- matrix section
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][j] = mfma_32x32x16(fa[i][s4], fb[s4], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    for (int kc = 0; kc < nk; ++kc) {
+        step(S0{}, kc);
+        step(S1{}, kc);
+        step(S2{}, kc);
+    }
+    wait_vmcnt<0>();
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    gemm_epilogue<NJ, 2, true, false>(p, acc, smem, m0 + wm * 64, n0 + wn * (NJ * 32), lane, wave, split);
+}
+
 // Split-K finish: sum the fp32 partials in split order (deterministic), then the same epilogue as above.
 __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
     const long long i8 = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1988,7 +2196,8 @@ __global__ void __launch_bounds__(256) k_conv_out4_ws(const bf16_t* __restrict__
 // tests and same-box A/B runs: VIDSEG_GEMM="key=value,key=value", read once per process.  Keys (default):
 //   big (1)   0 never / 1 where the table picks it / 2 whenever legal -- the 8-wave phased tiles (k_gemm_ph 256x320 / 256x256, k_gemm_p7 224x320)
 //   p7 (1)    0 / 1 / 2 likewise for the 224-row tile among the big ones;  p7x (1): 0 keeps k_gemm_p7 on split operands;
-//             xsmall (1): 0 = split operands obey the 16-bit thresholds of the big tile (fill >= 0.7, K / S >= 1440)
+//             xsmall (1): 0 = split operands obey the 16-bit thresholds of the big tile (fill >= 0.7, K / S >= 1440);
+//             phx (1): 0 keeps k_gemm_ph<5> on split operands
 //   p7ph (5)  phases per K-tile of k_gemm_p7 (5 or 3);  ph (1): 0 = the unphased k_gemm_tile for the big shapes
 //   mid (1)   0 / 1 / 2 the 128x320 tile;  dma (1): 0 = k_gemm_conv<128,128>, 3 = the 3-stage 128x128 everywhere;  tile (0): 128 forbids the narrow 256x64 tile
 //   ws (1)    0 / 1 / 2 the weight-stationary streaming kernel;  convout (1): 0 = the plain 4-channel output conv
@@ -1996,7 +2205,7 @@ __global__ void __launch_bounds__(256) k_conv_out4_ws(const bf16_t* __restrict__
 //   ext (1)   0 = hipEventRecord pairs instead of dispatch-packet timestamps (profiling);  fence (0): 1 = system-scope fence at the events
 //   shapes (0) 1 = one GEMMSHAPE line per profiled launch on stderr (tools/shape_summary.py)
 struct GemmKnobs {
-    int big = 1, p7 = 1, p7x = 1, xsmall = 1, p7ph = 5, ph = 1, mid = 1, dma = 1, tile = 0, ws = 1, convout = 1, split = 1, panel = 1, ext = 1, fence = 0,
+    int big = 1, p7 = 1, p7x = 1, phx = 1, xsmall = 1, p7ph = 5, ph = 1, mid = 1, dma = 1, tile = 0, ws = 1, convout = 1, split = 1, panel = 1, ext = 1, fence = 0,
         shapes = 0;
 };
 static const GemmKnobs& knobs() {
@@ -2004,7 +2213,7 @@ static const GemmKnobs& knobs() {
         GemmKnobs g;
         const char* e = getenv("VIDSEG_GEMM");
         if (!e) return g;
-        struct { const char* name; int* v; } tab[] = {{"big", &g.big}, {"p7", &g.p7}, {"p7x", &g.p7x}, {"xsmall", &g.xsmall}, {"p7ph", &g.p7ph}, {"ph", &g.ph}, {"mid", &g.mid},
+        struct { const char* name; int* v; } tab[] = {{"big", &g.big}, {"p7", &g.p7}, {"p7x", &g.p7x}, {"phx", &g.phx}, {"xsmall", &g.xsmall}, {"p7ph", &g.p7ph}, {"ph", &g.ph}, {"mid", &g.mid},
                                                       {"dma", &g.dma}, {"tile", &g.tile}, {"ws", &g.ws}, {"convout", &g.convout}, {"split", &g.split},
                                                       {"panel", &g.panel}, {"ext", &g.ext}, {"fence", &g.fence}, {"shapes", &g.shapes}};
         while (*e) {
@@ -2698,7 +2907,14 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             p.ksplit = S;
             p.ws = S > 1 ? g_ws : nullptr;
             p.gn = pick_gn(256, NJ * 64, 32, S);
-            if (ph_mode && NJ == 5)
+            if (ph_mode && NJ == 5 && knobs().phx && p.split2 && !p.x1 && p.C1 == 0 && p.K % 192 == 0 && p.C0 % 192 == 0 && (p.K / 192) / S >= 1 && p.act != 2) {
+                static bool attrx = false;
+                if (!attrx) {
+                    (void)hipFuncSetAttribute((const void*)k_gemm_phx, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
+                    attrx = true;
+                }
+                launch(k_gemm_phx, dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 320) * 128, p);   // split operands: each plane staged once
+            } else if (ph_mode && NJ == 5)
                 launch(k_gemm_ph<5>, dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 320) * 128, p);
             else if (ph_mode)
                 launch(k_gemm_ph<4>, dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 256) * 128, p);
