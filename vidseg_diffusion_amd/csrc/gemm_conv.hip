@@ -2844,7 +2844,8 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
                 const double eff8 = fill * (double)p.M / (double)(((p.M + 255) / 256) * 256);
                 // on split operands the 224-row tile has the native (hi, lo) staging (k_gemm_p7x: +13..17 % over the 3K walk, measured per
                 // shape, profiles/r04_b_p7x_vs_p7.txt), the 256-row tile has not: the SVD window's M = 28 * 72 * 128 fills both heights
-                const double x7 = x7ok ? 1.15 : 1.0;
+                // (with k_gemm_phx the 256-row tile has it too: the bonus applies only where phx is switched off, or with phx=2 for A/B runs)
+                const double x7 = (x7ok && knobs().phx != 1) ? 1.15 : 1.0;
                 if (eff7 * x7 > eff8 * 1.04 || p7_mode == 2) {
                     p7 = true;
                     S = S7;
@@ -2907,7 +2908,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             p.ksplit = S;
             p.ws = S > 1 ? g_ws : nullptr;
             p.gn = pick_gn(256, NJ * 64, 32, S);
-            if (ph_mode && NJ == 5 && knobs().phx && p.split2 && !p.x1 && p.C1 == 0 && p.K % 192 == 0 && p.C0 % 192 == 0 && (p.K / 192) / S >= 1 && p.act != 2) {
+            if (ph_mode && NJ == 5 && knobs().phx != 0 && p.split2 && !p.x1 && p.C1 == 0 && p.K % 192 == 0 && p.C0 % 192 == 0 && (p.K / 192) / S >= 1 && p.act != 2) {
                 static bool attrx = false;
                 if (!attrx) {
                     (void)hipFuncSetAttribute((const void*)k_gemm_phx, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
