@@ -122,8 +122,7 @@ int vidseg_trajectory_vote(const int32_t* idx, const int32_t* labels, int F, int
 
 /* nn.Linear / 1x1 conv (ATT:274-280, 862, 886; OAI:317-324) as a bf16 MFMA GEMM: out = act(cat(a0,a1) @ w^T +
  * bias + rowvec[sample]) + residual.  act: 0 none, 1 SiLU (OAI:605-609 time_embed), 2 GEGLU (ATT:89-96; w/bias
- * packed in 32-row value|gate groups), 3 the same GEGLU with w/bias packed in 16-ROW groups (N % 256 == 0, one source, 16-bit output
- * only: the 224 x 256 tile k_gemm_p7g).  tap/tap2: fp16 copies of output columns [0,tap_cols) / [tap_cols,2*tap_cols)
+ * packed in 32-row value|gate groups).  tap/tap2: fp16 copies of output columns [0,tap_cols) / [tap_cols,2*tap_cols)
  * = the q / k dumps of ATT:330-331. */
 int vidseg_linear_a16(const void* a0, const void* a1, int C0, int C1, long long M, const void* w, int N, const float* bias,
                        const float* rowvec, int rv_stride, int rows_per_sample, const void* residual, int ldr, void* out,

@@ -49,7 +49,7 @@ struct GemmParams {
     int tap_cols, tap_ld;
     int tap_early;           // 1: the tap is taken after the bias, BEFORE the per-sample vector / activation (ResBlock.in_layers_features,
                              // openaimodel.py:349-350: in_layers(x) before `h + emb_out`); 0: after them, before the residual
-    int act;                 // 0 none, 1 SiLU, 2 GEGLU (32-column interleaved x|gate groups), 3 GEGLU with 16-column groups (k_gemm_p7g)
+    int act;                 // 0 none, 1 SiLU, 2 GEGLU (32-column interleaved x|gate groups)
     int ksplit;              // >1: K range split over `ksplit` blocks per tile, fp32 partials in ws[split][M][N]
     float* ws;
     int tmode, T;            // tmode: ksize 3 taps run over TIME (Conv3d kernel [3,1,1], video_model.py:45-58): row m is
@@ -1143,7 +1143,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
 // side.  A lane takes 8 consecutive product columns of one row per pass: (value + b) * gelu(gate + b) with libm's erf in the operation
 // order of k_x_geglu_split3, split into (hi, lo) and written as the consumer's operand image [hi | lo | hi].  A rolled loop of 8 erf
 // per pass: formed while staging (16 inlined erf per fragment pair, unrolled over the groups) it spilled into scratch.
-template <int NJ, int EP_LD, bool X3 = true>
+template <int NJ, int EP_LD>
 __device__ __forceinline__ void epilogue_rows_geglu16(const GemmParams& p, const float* stage, int mrow0, int nrows, int wcol_base, int lane) {
     constexpr int NC8 = NJ;                                    // NJ / 2 pairs x 16 product columns = NJ cells of 8
     const int ncell = nrows * NC8;
@@ -1165,31 +1165,24 @@ __device__ __forceinline__ void epilogue_rows_geglu16(const GemmParams& p, const
             g0 += bg0;
             g1 += bg1;
         }
-        if constexpr (X3) {
-            f16x8 h8, l8;
+        f16x8 h8, l8;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float gt = e < 4 ? g0[e & 3] : g1[e & 3];
-                float x = (e < 4 ? v0[e & 3] : v1[e & 3]) * (0.5f * gt * (1.0f + erff(gt * 0.70710678118654752440f)));
-                asm volatile("" : "+v"(x));                     // one fp32 value for both lines (see exact_ops.hip: split_hl)
-                const f16 hh = (f16)x;
-                h8[e] = hh;
-                l8[e] = (f16)(x - (float)hh);
-            }
-            f16* o3 = p.out_split3 + (long long)m * 3 * p.ldo + (wcol_base >> 1) + pc;
-            *reinterpret_cast<f16x8*>(o3) = h8;
-            *reinterpret_cast<f16x8*>(o3 + p.ldo) = l8;
-            *reinterpret_cast<f16x8*>(o3 + 2 * p.ldo) = h8;
-        } else {                                                // 16-bit mode: the GELU of the 16-bit GEGLU epilogues (gelu_erf), 16-bit result
-            bf16x8_t o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16((e < 4 ? v0[e & 3] : v1[e & 3]) * gelu_erf(e < 4 ? g0[e & 3] : g1[e & 3]));
-            *reinterpret_cast<bf16x8_t*>(p.out + (long long)m * p.ldo + (wcol_base >> 1) + pc) = o;
+        for (int e = 0; e < 8; ++e) {
+            const float gt = e < 4 ? g0[e & 3] : g1[e & 3];
+            float x = (e < 4 ? v0[e & 3] : v1[e & 3]) * (0.5f * gt * (1.0f + erff(gt * 0.70710678118654752440f)));
+            asm volatile("" : "+v"(x));                         // one fp32 value for both lines (see exact_ops.hip: split_hl)
+            const f16 hh = (f16)x;
+            h8[e] = hh;
+            l8[e] = (f16)(x - (float)hh);
         }
+        f16* o3 = p.out_split3 + (long long)m * 3 * p.ldo + (wcol_base >> 1) + pc;
+        *reinterpret_cast<f16x8*>(o3) = h8;
+        *reinterpret_cast<f16x8*>(o3 + p.ldo) = l8;
+        *reinterpret_cast<f16x8*>(o3 + 2 * p.ldo) = h8;
     }
 }
 
-template <int MI, int NJ, bool G3 = false, bool G16 = false>
+template <int MI, int NJ, bool G3 = false>
 __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc)[MI][NJ], char* smem, int mrow_base, int wcol_base, int lane,
                                                 int wave, int split) {
     constexpr int EP_LD = NJ * 16 + 4;                         // fp32 row stride of the staging tile
@@ -1197,7 +1190,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc
     float* stage = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
     const int l15 = lane & 15, q = lane >> 4;
     const bool fin = p.ksplit <= 1;                            // split-K partials carry no bias/emb/activation
-    static_assert(!(G3 || G16) || NJ % 2 == 0, "GEGLU pairs fragment columns");
+    static_assert(!G3 || NJ % 2 == 0, "GEGLU pairs fragment columns");
     __syncthreads();                                           // main-loop LDS reads are done
 #pragma nounroll
     for (int ig = 0; ig < NG; ++ig) {
@@ -1218,9 +1211,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         if constexpr (G3)
-            epilogue_rows_geglu16<NJ, EP_LD, true>(p, stage, mrow_base + ig * 32, nrows, wcol_base, lane);
-        else if constexpr (G16)
-            epilogue_rows_geglu16<NJ, EP_LD, false>(p, stage, mrow_base + ig * 32, nrows, wcol_base, lane);
+            epilogue_rows_geglu16<NJ, EP_LD>(p, stage, mrow_base + ig * 32, nrows, wcol_base, lane);
         else
             epilogue_rows<NJ * 2, EP_LD>(p, stage, mrow_base + ig * 32, nrows, wcol_base, p.N, lane, split, fin, true);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1491,196 +1482,6 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7(GemmParams p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
     gemm_epilogue16<MI, NJ>(p, acc, smem, (int)m0 + wm * 112, n0 + wn * 80, lane, wave, split);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_gemm_p7g: the GEGLU projection of the 16-bit mode (attention.py:89-96) on the 224-row tile: 224 x 256, wave tile 112 x 64 = 7 x 4
-// fragments of v_mfma_f32_16x16x32, four phases per K-tile, k_gemm_p7's LDS image / staging pieces / wave-group skew.  The weight
-// rows are interleaved in 16-row value | gate groups (ops.pack_geglu16), so fragment columns (2 jj, 2 jj + 1) of a wave tile hold
-// value and gate of the same 16 output columns; the accumulators are staged raw and phase 2 of the epilogue forms
-// (value + b) * gelu_erf(gate + b) eight columns per lane and pass (epilogue_rows_geglu16<.., false>).  These launches sat on the
-// 128 x 128 kernel (114688 x 2560 x 320: 301 us at 624 TFLOP/s) or the 256 x 256 tile, both leaving 1/8 of a round of CUs empty on a
-// window's M = 28 * 2^k rows.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512, 2) k_gemm_p7g(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NJ = 4, MI = 7, WN = NJ * 16;
-    constexpr int BM = 224, BN = NJ * 64, RB = 128;
-    constexpr int A_BYTES = 256 * RB, B_BYTES = BN * RB;                 // LDS map: A[0] A[1] B[0] B[1]; A keeps 256 rows (see above)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
-    int split, tn;
-    long long tm;
-    map_tile(p, BM, BN, split, tm, tn);
-    const long long m0 = tm * BM;
-    const int n0 = tn * BN;
-
-    constexpr unsigned OOB = 0xF0000000u;
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w), 0, (int)((long long)p.N * p.K * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x0), 0, (int)p.x0_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x1 ? p.x1 : p.x0), 0, (int)p.x1_bytes, 0x00020000);
-
-    const int HWo = p.Hout * p.Wout;
-    const int upsh = p.up - 1;
-    const int Hup = p.Hin << upsh, Wup = p.Win << upsh;
-    const int lrow = lane >> 3, lch = lane & 7;
-    const unsigned swz16 = (unsigned)((lch ^ (((wave & 1) << 2) | (lrow >> 1))) << 4);
-    const int hb = p.ksize == 1 ? 1 : (p.tmode ? p.T : Hup), wb = (p.ksize == 1 || p.tmode) ? 1 : Wup;
-    const int wmul = p.tmode ? HWo : p.Win;
-    int a_base[4], a_hw[4];                                            // a_hw = (ih0 + 0x4000) << 16 | (iw0 + 0x4000)
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-        const int r = (s4 >> 1) * 128 + (wave + 8 * (s4 & 1)) * 8 + lrow;
-        const long long m = m0 + r;
-        const bool ok = r < BM && m < p.M;                             // rows 224..255 of the LDS image belong to no tile
-        const int mm = ok ? (int)m : 0;
-        int ih0 = 0, iw0 = 0;
-        if (p.ksize == 1) {
-            a_base[s4] = mm;
-        } else if (p.tmode) {
-            const int t = (mm / HWo) % p.T;
-            a_base[s4] = mm - t * HWo;
-            ih0 = t - 1;
-        } else {
-            const int b = mm / HWo, rem = mm - b * HWo;
-            const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
-            a_base[s4] = b * p.Hin * p.Win;
-            ih0 = oh * p.stride - p.pad;
-            iw0 = ow * p.stride - p.pad;
-        }
-        if (!ok) ih0 = -0x4000;
-        a_hw[s4] = ((ih0 + 0x4000) << 16) | (iw0 + 0x4000);
-    }
-    // B block g = the 16-row strips wn * 80 + g * 16 .. of the four wave columns; piece `wave` = strip wave >> 1, rows (wave & 1) * 8 ..
-    const int b_r0 = (wave >> 1) * WN + (wave & 1) * 8;
-    const int b_n = n0 + b_r0 + lrow;                                        // + g*16: the weight row this lane stages for block g
-    const unsigned b_off0 = (unsigned)((long long)b_n * p.K * 2) + swz16;
-    const unsigned b_gstep = (unsigned)p.K * 32u;                            // 16 weight rows
-    const int nk_all = p.K / 64;
-    const int ks_begin = p.ksplit > 1 ? (int)((long long)nk_all * split / p.ksplit) : 0;
-    const int ks_end = p.ksplit > 1 ? (int)((long long)nk_all * (split + 1) / p.ksplit) : nk_all;
-    const int nk = ks_end - ks_begin;
-    KCursor cur;
-    cur.init(ks_begin * 64, p.taps, p.kchunk);
-    int t_kh = 0, t_kw = 0, t_Cs = 0, t_cc = 0;
-    bool a_second = false;
-    // One A set (s4: rows (s4 >> 1) * 128 + (wave + 8 * (s4 & 1)) * 8 .., one DMA instruction per wave) / one B block of tile u into
-    // buffer buf.  The K cursor moves when set 0 of a tile is staged; the sets of one tile are staged in order 0, 1, 2, 3.
-    auto stage_a = [&](int s4, int u, int buf) {
-        const bool live = u < nk;
-        if (s4 == 0) {
-            const int c0 = cur.c0();
-            a_second = c0 >= p.C0;
-            t_Cs = a_second ? p.C1 : p.C0;
-            t_cc = a_second ? c0 - p.C0 : c0;
-            const int t3 = cur.tap / 3;
-            t_kh = p.tmode ? cur.tap : t3;
-            t_kw = p.tmode ? 0 : cur.tap - t3 * 3;
-            cur.advance(64, p.taps, p.kchunk);
-        }
-        char* dst = smem + buf * A_BYTES + ((s4 >> 1) * 128 + (wave + 8 * (s4 & 1)) * 8) * RB;
-        const int ih = (a_hw[s4] >> 16) - 0x4000 + t_kh, iw = (a_hw[s4] & 0xFFFF) - 0x4000 + t_kw;
-        const bool ok = live && (unsigned)ih < (unsigned)hb && (unsigned)iw < (unsigned)wb;
-        const int pix = a_base[s4] + (ih >> upsh) * wmul + (iw >> upsh);
-        const unsigned off = ok ? (unsigned)(pix * t_Cs + t_cc) * 2u + swz16 : OOB;
-        if (a_second)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
-        else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
-    };
-    auto stage_b = [&](int g, int u, int buf) {
-        const bool live = u < nk;
-        char* dst = smem + 2 * A_BYTES + buf * B_BYTES + (b_r0 + g * 16) * RB;
-        const unsigned off = (live && b_n + g * 16 < p.N) ? b_off0 + (unsigned)g * b_gstep + (unsigned)(ks_begin + u) * 128u : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
-    };
-
-    f32x4 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int sw = (l15 >> 1) & 7;                                    // every fragment row is l15 + a multiple of 16
-    const int arow = (wm * 112 + l15) * RB, brow = 2 * A_BYTES + (wn * WN + l15) * RB;
-
-    bf16x8_t fa[MI][2];
-    // Schedule (four phases, eight pieces per wave and K-tile): phase j of tile t stages -- j = 0: (A2, B2), j = 1: (A3, B3) of tile t + 1
-    // into the other buffer (its A rows were read in phase (t-1, 0), its B block j + 2 two phases earlier); j = 2: (A0, B0), j = 3:
-    // (A1, B1) of tile t + 2 into tile t's own buffer.  Per-wave issue order of a tile's pieces: A0 B0 A1 B1 | A2 B2 A3 B3.  Counted
-    // waits: phase (t, 0) needs A3(t), issued first in (t-1, 1) -> B3(t) + A0 B0 A1 B1 (t+1) = 5 younger loads; B block j of tile t was
-    // issued five phases before phase (t, j) -> 10 younger loads.
-    // prologue: everything the steady state would have issued before phase (0, 0)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        stage_a(g, 0, 0);
-        stage_b(g, 0, 0);
-    }
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        stage_a(g, 1, 1);
-        stage_b(g, 1, 1);
-    }
-    wait_vmcnt<5>();
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-
-    auto tile = [&](int t, int buf) {
-        const char* A = smem + buf * A_BYTES + arow;
-        const char* B = smem + buf * B_BYTES + brow;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            // ---- read section
-            bf16x8_t fb[2];
-            if (j == 0) {
-                // only the first k-step's A fragments ahead of the barrier; the second k-step's are read inside the matrix section,
-                // under this wave's own first seven MFMAs (the A rows of tile t are not restaged before phase (t, 2)): -0.7 %
-#pragma unroll
-                for (int i = 0; i < MI; ++i) fa[i][0] = *reinterpret_cast<const bf16x8_t*>(A + i * 16 * RB + ((l4 ^ sw) << 4));
-            }
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fb[kk] = *reinterpret_cast<const bf16x8_t*>(B + j * 16 * RB + (((kk * 4 + l4) ^ sw) << 4));
-            if (j >= 2) {
-                stage_a(j - 2, t + 2, buf);
-                stage_b(j - 2, t + 2, buf);
-            } else {
-                stage_a(j + 2, t + 1, buf ^ 1);
-                stage_b(j + 2, t + 1, buf ^ 1);
-            }
-            if (j == NJ - 1)
-                wait_vmcnt<5>();
-            else
-                wait_vmcnt<10>();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- matrix section
-            if (j == 0) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) fa[i][1] = *reinterpret_cast<const bf16x8_t*>(A + i * 16 * RB + (((4 + l4) ^ sw) << 4));
-            }
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < MI; ++i) acc[i][j] = mfma_16x16x32(fa[i][kk], fb[kk], acc[i][j]);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    for (int t = 0; t < nk; t += 2) {
-        tile(t, 0);
-        if (t + 1 < nk) tile(t + 1, 1);
-    }
-    wait_vmcnt<0>();
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_barrier();
-    gemm_epilogue16<MI, NJ, false, true>(p, acc, smem, (int)m0 + wm * 112, n0 + wn * WN, lane, wave, split);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2921,25 +2722,6 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(i < 3 ? l320 : l640)) != hipSuccess) ws_fits = 0;
         (void)hipGetLastError();                                 // a refused attribute must not surface as this launch's error
     }
-    if (p.act == 3) {                                          // 16-bit GEGLU with 16-row value | gate groups: the 224 x 256 tile (k_gemm_p7g)
-        VS_REQUIRE(p.ksize == 1 && !p.x1 && p.C1 == 0 && p.out && !p.out_f32 && !p.residual && !p.tap && !p.rowvec && !p.rowadd && p.N % 256 == 0 &&
-                       p.K % 64 == 0 && p.ldo % 8 == 0,
-                   "gemm: GEGLU16 is the plain GEGLU linear with N %% 256 == 0 (N=%d K=%d)", p.N, p.K);
-        static bool attrg = false;
-        if (!attrg) {
-            (void)hipFuncSetAttribute((const void*)k_gemm_p7g, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
-            attrg = true;
-        }
-        p.gn = p.N / 256 < 8 ? p.N / 256 : 8;
-        const long long tilesg = ((p.M + 223) / 224) * (p.N / 256);
-        launch(k_gemm_p7g, dim3((unsigned)tilesg), 512, 2 * (256 + 256) * 128, p);
-        if (g_prof.on) {
-            if (!prof_ext) (void)hipEventRecord(ev1, st);
-            g_prof.shapes.push_back({p.M, p.N, p.K, p.ksize, p.up, p.stride, p.act, 1, 4, (double)p.x0_bytes + 2.0 * p.N * p.K + 2.0 * p.M * (p.N / 2)});
-        }
-        VS_CHECK_LAUNCH("gemm_geglu16");
-        return VS_OK;
-    }
     if (p.out_split3) {                                        // exact mode's GEGLU projection: always the 256 x 256 phased tile
         VS_REQUIRE(p.act == 2 && p.ksize == 1 && !p.out && !p.out_f32 && !p.residual && !p.tap && p.N % 64 == 0 && (p.ldo % 8) == 0,
                    "gemm: the split3 output exists for the plain GEGLU linear only");
@@ -3223,7 +3005,6 @@ int vidseg_linear_a16(const void* a0, const void* a1, int C0, int C1, long long 
     p.rowadd = rowadd;
     p.act = act;
     if (act == 2) VS_REQUIRE(N % 64 == 0 && out, "linear: GEGLU needs N %% 64 == 0 and a bf16 output");
-    if (act == 3) VS_REQUIRE(N % 256 == 0 && out && !a1, "linear: GEGLU16 needs N %% 256 == 0, one source and a 16-bit output");
     return launch_gemm(p, st);
 }
 

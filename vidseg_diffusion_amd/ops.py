@@ -72,7 +72,7 @@ def __getattr__(name):                                      # ops.ACT / ops.BF16
 
 
 F32 = torch.float32
-ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_GEGLU16 = 0, 1, 2, 3      # GEGLU16: weight rows in 16-row value | gate groups (pack_geglu(.., group=16))
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 
 
 # ----------------------------------------------------------------------------- weight packing
@@ -100,22 +100,16 @@ def pack_conv_out(weight: torch.Tensor, device) -> torch.Tensor:
     return weight.detach().permute(0, 2, 3, 1).to(device=device, dtype=act_dtype()).contiguous()
 
 
-def pack_geglu(weight: torch.Tensor, bias: torch.Tensor, device, group: int = 32):
+def pack_geglu(weight: torch.Tensor, bias: torch.Tensor, device):
     """GEGLU proj [2*inner, K]: rows [0,inner) = value, [inner, 2*inner) = gate (attention.py:92-96).
-    Interleave in `group`-row groups (value group, gate group, ...) so that one MFMA wave tile holds the
-    value and the gate of the same output column in the same lane: 32 rows for the 32x32 fragments of ACT_GEGLU, 16 rows for
-    the 16x16 fragments of the 224 x 256 tile (ACT_GEGLU16, k_gemm_p7g)."""
+    Interleave in 32-row groups (value group, gate group, ...) so that one MFMA wave tile holds the
+    value and the gate of the same output column in the same lane."""
     two_inner, K = weight.shape
     inner = two_inner // 2
-    assert inner % group == 0
-    w = weight.detach().view(2, inner // group, group, K).permute(1, 0, 2, 3).reshape(two_inner, K)
-    b = bias.detach().view(2, inner // group, group).permute(1, 0, 2).reshape(two_inner)
+    assert inner % 32 == 0
+    w = weight.detach().view(2, inner // 32, 32, K).permute(1, 0, 2, 3).reshape(two_inner, K)
+    b = bias.detach().view(2, inner // 32, 32).permute(1, 0, 2).reshape(two_inner)
     return w.to(device=device, dtype=act_dtype()).contiguous(), b.to(device=device, dtype=F32).contiguous()
-
-
-def geglu16_ok(two_inner: int, K: int) -> bool:
-    """The 224 x 256 GEGLU tile takes the layer: 2*inner a multiple of 256, K of 64."""
-    return two_inner % 256 == 0 and K % 64 == 0 and os.environ.get("VIDSEG_GEGLU_TILE", "p7g") == "p7g"
 
 
 def f32(t: torch.Tensor, device) -> torch.Tensor:
@@ -131,7 +125,7 @@ def linear(a, w, bias=None, *, a1=None, rowvec=None, rows_per_sample=0, residual
     C1 = a1.shape[-1] if a1 is not None else 0
     M = a.numel() // C0
     N = w.shape[0]
-    n_out = N // 2 if act in (ACT_GEGLU, ACT_GEGLU16) else N
+    n_out = N // 2 if act == ACT_GEGLU else N
     out = torch.empty(a.shape[:-1] + (n_out,), dtype=F32 if out_f32 else act_dtype(), device=a.device)
     call("vidseg_linear_a16", ptr(a), ptr(a1), C0, C1, M, ptr(w), N, ptr(bias), ptr(rowvec),
          rowvec.stride(0) if rowvec is not None else 0, rows_per_sample, ptr(residual),

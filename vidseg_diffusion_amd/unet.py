@@ -227,13 +227,11 @@ class FeedForward(nn.Module):
         self.net = nn.Sequential(GEGLU(dim, dim * mult), nn.Dropout(0.0), _meta(nn.Linear, dim * mult, dim))
 
     def pack(self, dev):
-        pw = self.net[0].proj.weight
-        self.g16 = ops.geglu16_ok(pw.shape[0], pw.shape[1])                # the 224 x 256 GEGLU tile (k_gemm_p7g): 16-row value | gate groups
-        self.w1, self.b1 = ops.pack_geglu(pw, self.net[0].proj.bias, dev, group=16 if self.g16 else 32)
+        self.w1, self.b1 = ops.pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias, dev)
         self.w2, self.b2 = ops.pack_linear(self.net[2].weight, dev), ops.f32(self.net[2].bias, dev)
 
     def run(self, x, residual, rowadd=None):
-        g = ops.linear(x, self.w1, self.b1, act=ops.ACT_GEGLU16 if self.g16 else ops.ACT_GEGLU)
+        g = ops.linear(x, self.w1, self.b1, act=ops.ACT_GEGLU)
         return ops.linear(g, self.w2, self.b2, residual=residual, rowadd=rowadd)
 
 
