@@ -460,7 +460,8 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, preb
                      "family": {"achieved": round(fam_tf, 2), "frac": round(fam_tf / 2500.0, 4),
                                 "launches_per_step": k_launches // max(steps, 1), "gemm_ms_per_step": round(k_ms / steps, 3),
                                 "by_kernel": {n: {"ms_per_step": round(ms / steps, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 else 0.0,
-                                                  "launches_per_step": ln // max(steps, 1)} for (n, ms, fl, ln, _b) in kinds if ln}}},
+                                                  "launches_per_step": ln // max(steps, 1),
+                                                  "algorithmic_bytes_per_launch": int(_b / ln)} for (n, ms, fl, ln, _b) in kinds if ln}}},
         "unique_labels": int(len(np.unique(labels))),
     }
     if not svd and not args.narrow:
