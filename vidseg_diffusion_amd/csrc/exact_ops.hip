@@ -1,3 +1,5 @@
+// HIPCC_FLAGS: -fno-slp-vectorize
+// (packed fp32 VALU beside MFMAs costs ~10 cycles an instruction and does not overlap them: profiles/r02_ubench_mfma_valu.txt)
 // "Exact" mode of the UNet path (fp16 build only): fp32-accurate evaluation on the SAME 16-bit MFMA GEMM / conv kernels.
 //
 // Why it exists: the reference's Step 3 is best-of-10 K-means++ on the dumped Q taps, and K-means++ seeding is chaotic in its
@@ -28,6 +30,22 @@ __device__ __forceinline__ void split_hl(float x, f16& hi, f16& lo) {
     asm volatile("" : "+v"(x));
     hi = (f16)x;
     lo = (f16)(x - (float)hi);
+}
+// Two values at once, packed the way the MFMA operand wants them (x0 in the low half): the same roundings as split_hl in 4 VALU
+// instructions instead of 11 -- v_cvt_pk_f16_f32 for the hi pair, x - hi as v_fma_mix_f32 (hi read as an fp16 half, the fma exact),
+// v_cvt_pk_f16_f32 for the lo pair.  For values with no foldable producer (the attention's probabilities come out of v_exp_f32).
+typedef __attribute__((ext_vector_type(2))) float xf32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 xf16x2;
+__device__ __forceinline__ void split_hl2(float x0, float x1, unsigned& hi2, unsigned& lo2) {
+    asm volatile("" : "+v"(x0), "+v"(x1));
+    const xf16x2 h = __builtin_convertvector(xf32x2{x0, x1}, xf16x2);
+    const unsigned hu = __builtin_bit_cast(unsigned, h);
+    float r0, r1;                                               // (hipcc turns fma(ext(h), -1, x) back into a conversion and a subtraction)
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hu), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hu), "v"(x1));
+    const xf16x2 l = __builtin_convertvector(xf32x2{r0, r1}, xf16x2);
+    hi2 = hu;
+    lo2 = __builtin_bit_cast(unsigned, l);
 }
 __device__ __forceinline__ float silu_x(float x) { return x / (1.0f + expf(-x)); }
 
@@ -563,11 +581,7 @@ __global__ void __launch_bounds__(256, 2) k_x_attention_mfma(const float* __rest
                 const float p0 = __builtin_amdgcn_exp2f(sacc[j][r] - mref), p1 = __builtin_amdgcn_exp2f(sacc[j][r + 1] - mref);
                 ps4[(r >> 1) & 1] += p0;
                 ps4[2 + ((r >> 1) & 1)] += p1;
-                f16 h0, h1, l0, l1;
-                split_hl(p0, h0, l0);
-                split_hl(p1, h1, l1);
-                pkh[j][r >> 1] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-                pkl[j][r >> 1] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                split_hl2(p0, p1, pkh[j][r >> 1], pkl[j][r >> 1]);
             }
         float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
         psum += __shfl_xor(psum, 32, 64);
