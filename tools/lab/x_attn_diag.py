@@ -1,6 +1,7 @@
 """Where does k_x_attention_mfma lose accuracy?  (GPU box)  python tools/lab/x_attn_diag.py
 1. the split GEMM on all-positive operands of growing K (does a long MFMA accumulation chain into a large accumulator keep fp32 accuracy?)
-2. the attention error against float64 by key count, VIDSEG_ATTN=flush=0 / 1 (set before the process starts)."""
+2. the attention error against float64 by key count (round 3 ran it with the PV products accumulated across tiles inside the MFMA
+   and with the per-tile flush that the kernel kept)."""
 import os
 import sys
 
@@ -24,7 +25,6 @@ def rel(got, ref):
     return float(np.abs(got - ref).max() / np.abs(ref).max()), float(np.sqrt(((got - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean()))
 
 
-print("flush =", os.environ.get("VIDSEG_ATTN", "default"))
 for K in (64, 320, 1280, 5120, 20480):
     for positive in (False, True):
         a, w = rnd((256, K), 3), rnd((320, K), 4)

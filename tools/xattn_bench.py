@@ -14,10 +14,12 @@ from vidseg_diffusion_amd import exact  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--first", action="store_true", help="the 64 x 64 level only (PMC passes)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 tag = os.environ.get("VIDSEG_LIB", "libvidseg_hip.so") + " " + os.environ.get("VIDSEG_ATTN", "")
-for B, H, N in ((28, 5, 4096), (14, 5, 4096), (28, 10, 1024), (28, 20, 256), (2, 5, 4000)):
+SHAPES = ((28, 5, 4096), (14, 5, 4096), (28, 10, 1024), (28, 20, 256), (2, 5, 4000))
+for B, H, N in SHAPES[:1] if args.first else SHAPES:
     C = H * 64
     g = torch.Generator().manual_seed(1)
     qkv = (torch.randn((B, N, 3 * C), generator=g) * 1.5).to(dev)

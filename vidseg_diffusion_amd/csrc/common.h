@@ -120,7 +120,7 @@ __device__ __forceinline__ void attn_block(int& bh, int& qb) {
 
 // Host-side override of a kernel-selection default, for tests and same-box A/B runs only: VAR="key=value,key=value".  The product
 // path sets none of them; every kernel choice is a fixed function of the problem.  (VIDSEG_GEMM: csrc/gemm_conv.hip, VIDSEG_ATTN: the
-// attention kernels of csrc/unet_ops.hip and csrc/exact_ops.hip.)
+// attention kernels of csrc/unet_ops.hip.)
 static inline int vs_knob(const char* var, const char* key, int dflt) {
     const char* e = getenv(var);
     const size_t kl = strlen(key);

@@ -16,6 +16,7 @@
 // 16-bit path.  Reference arithmetic followed: sgm/modules/diffusionmodules/util.py:276-278 (GroupNorm32 in fp32),
 // sgm/modules/attention.py:89-96 (GEGLU, erf GELU), :352-356 (scaled dot-product attention), torch.nn.LayerNorm (eps 1e-5).
 #include "common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) unsigned int xu32x4;
 
@@ -448,19 +449,29 @@ __global__ void __launch_bounds__(256) k_x_split_planes(const float* __restrict_
 // split in registers (p' = exp2(s - m + 8) <= 2^8, so the lo part of small probabilities stays clear of the fp16 subnormal quantum:
 // 2^-24 against a row sum >= 2^8).  The tile schedule is k_attention's (unet_ops.hip): block = 4 waves x 32 queries, 64-key tiles,
 // S computed transposed so a lane owns one query column and the softmax statistics are lane-local plus one lane <-> lane + 32
-// exchange; K tiles [key][d] with the 16-byte-slot XOR swizzle; V tiles stay row-major [key][d] (16-byte stores) and the V^T
+// exchange; K tiles [key][d] with the 16-byte-slot XOR swizzle (slot ^ ((row >> 1) & 7): the 16 lanes ds_read_b128 serves per cycle --
+// {0-3, 12-15, 20-27}, ... -- then cover all 16 slots of the 256-byte bank line; with row & 7 they covered 8, a 2-way conflict on
+// every K read, 24 % of the LDS cycles by SQ_LDS_BANK_CONFLICT); V tiles stay row-major [key][d] (16-byte stores) and the V^T
 // fragments come from ds_read_b64_tr_b16 (lane mapping as in k_attention3), rows 128 bytes with bit 6 of the byte column flipped on
 // rows 2, 3 (mod 4) so the 4 rows x 2 d-groups a 32-lane half reads cover all 64 banks once.  Double-buffered: 64 KB of LDS.
-// 48 MFMAs (32x32x16) per wave and tile against ~300 VALU instructions.  q: fp32 rows (stride ldq), head h at columns 64 h ..;
+// 48 MFMAs (32x32x16) per wave and tile against ~250 VALU instructions (P split two at a time: split_hl2).  q: fp32 rows (stride ldq), head h at columns 64 h ..;
 // kh / kl / vh / vl: fp16 planes, row stride ldkv; out fp32.  grid (ceil(Nq / 128), B * H).
 typedef __attribute__((ext_vector_type(4))) short xs16x4;
 __device__ __forceinline__ f32x16 xmfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-template <bool RAGGED, bool FLUSH>
+// Software-pipelined across key tiles: tile t + 1's S^T is computed by the matrix pipe WHILE the vector pipe runs tile t's softmax --
+// 24 fenced slices of one MFMA and its share of the softmax, so the in-order issue alternates the two -- and a wave keeps both pipes
+// busy by itself instead of hoping its SIMD partner is in the other phase (the un-pipelined form measured 51 % MFMA busy + 51 % VALU
+// active = no overlap: the phases of the two resident blocks drift into step).  Two S accumulators are alive (named A / B, swapped by
+// unrolling the loop twice: no runtime-indexed register arrays); K runs one tile ahead of V through the same two LDS buffers
+// (iteration t reads K(t+1) from buffer (t+1)&1 and V(t) from buffer t&1, then stores K(t+2) into t&1 and V(t+1) into (t+1)&1:
+// one barrier per tile).  Each tile's PV product is accumulated from zero inside the MFMA and added to the running O by the vector
+// pipe, d-block by d-block so the first block's adds run under the second's MFMAs.  244 VGPRs, no scratch.
+template <bool RAGGED>
 __global__ void __launch_bounds__(256, 2) k_x_attention_mfma(const float* __restrict__ q, int ldq, const f16* __restrict__ kh,
-                                                             const f16* __restrict__ kl, const f16* __restrict__ vh,
-                                                             const f16* __restrict__ vl, int ldkv, float* __restrict__ out, int ldo,
-                                                             f16* __restrict__ out3, int Nq, int Nk, int H, float scale_log2e) {
+                                                               const f16* __restrict__ kl, const f16* __restrict__ vh,
+                                                               const f16* __restrict__ vl, int ldkv, float* __restrict__ out, int ldo,
+                                                               f16* __restrict__ out3, int Nq, int Nk, int H, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) char smem[2][4][64 * 128];      // [buffer][K hi, K lo, V hi, V lo][64 keys x 128 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -471,7 +482,6 @@ __global__ void __launch_bounds__(256, 2) k_x_attention_mfma(const float* __rest
     const float* qp = q + (long long)b * Nq * ldq + h * 64;
     const long long kvoff = (long long)b * Nk * ldkv + h * 64;
 
-    // Q^T (scaled, split) as the MFMA B operand: lane holds query q0 + l31, d = s*16 + hi*8 .. +8
     f16x8 fqh[4], fql[4];
     {
         const int qi = min(q0 + l31, Nq - 1);
@@ -499,92 +509,127 @@ __global__ void __launch_bounds__(256, 2) k_x_attention_mfma(const float* __rest
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (Nk + 63) / 64;
-    xu32x4 rg[2][4];                                            // next tile's 16-byte pieces: [row half][K hi, K lo, V hi, V lo]
+    xu32x4 rg[2][4];                                            // [row half][K hi, K lo, V hi, V lo] of the tiles being fetched
     const int st_ch = tid & 7, st_r = tid >> 3;
-    auto stage_load = [&](int t) {
+    auto load_k = [&](int t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int key = min(t * 64 + st_r + 32 * i, Nk - 1);
-            const long long off = kvoff + (long long)key * ldkv + st_ch * 8;
+            const long long off = kvoff + (long long)min(t * 64 + st_r + 32 * i, Nk - 1) * ldkv + st_ch * 8;
             rg[i][0] = *reinterpret_cast<const xu32x4*>(kh + off);
             rg[i][1] = *reinterpret_cast<const xu32x4*>(kl + off);
+        }
+    };
+    auto load_v = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long off = kvoff + (long long)min(t * 64 + st_r + 32 * i, Nk - 1) * ldkv + st_ch * 8;
             rg[i][2] = *reinterpret_cast<const xu32x4*>(vh + off);
             rg[i][3] = *reinterpret_cast<const xu32x4*>(vl + off);
         }
     };
-    auto stage_store = [&](int buf) {
+    auto store_k = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = st_r + 32 * i;
-            const int ko = r * 128 + ((st_ch ^ (r & 7)) << 4), vo = r * 128 + ((st_ch << 4) ^ (((r >> 1) & 1) << 6));
+            const int r = st_r + 32 * i, ko = r * 128 + ((st_ch ^ ((r >> 1) & 7)) << 4);
             *reinterpret_cast<xu32x4*>(smem[buf][0] + ko) = rg[i][0];
             *reinterpret_cast<xu32x4*>(smem[buf][1] + ko) = rg[i][1];
+        }
+    };
+    auto store_v = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = st_r + 32 * i, vo = r * 128 + ((st_ch << 4) ^ (((r >> 1) & 1) << 6));
             *reinterpret_cast<xu32x4*>(smem[buf][2] + vo) = rg[i][2];
             *reinterpret_cast<xu32x4*>(smem[buf][3] + vo) = rg[i][3];
         }
     };
-    // transpose read of V: lane passes row 4 hi + ((lane & 15) >> 2) (+ 16-key slice, + 8), byte column ((lane >> 4) & 1) 32 + 8 (lane & 3) (+ 64 i)
-    const int vtr_base = (4 * hi + ((lane & 15) >> 2)) * 128 + ((lane >> 4) & 1) * 32 + 8 * (lane & 3);
-    const int vtr_swz = ((lane >> 3) & 1) << 6;
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const int k0 = t * 64;
-        const char* sKh = smem[t & 1][0];
-        const char* sKl = smem[t & 1][1];
-        const char* sVh = smem[t & 1][2];
-        const char* sVl = smem[t & 1][3];
-        stage_load(t + 1);                                      // unconditional (keys clamp to Nk - 1)
-        f32x16 sacc[2];                                         // S^T[j]: rows = keys j*32 + .., columns = queries; log2 units
+    auto qk = [&](int buf, f32x16 (&acc)[2]) {                  // S^T of the K tile in buffer buf; log2 units
+        const char* sKh = smem[buf][0];
+        const char* sKl = smem[buf][1];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             f16x8 fkh[2], fkl[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int r = j * 32 + l31, off = r * 128 + (((s * 2 + hi) ^ (r & 7)) << 4);
+                const int r = j * 32 + l31, off = r * 128 + (((s * 2 + hi) ^ ((r >> 1) & 7)) << 4);
                 fkh[j] = *reinterpret_cast<const f16x8*>(sKh + off);
                 fkl[j] = *reinterpret_cast<const f16x8*>(sKl + off);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                sacc[j] = xmfma(fkl[j], fqh[s], s == 0 ? f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f} : sacc[j]);
+                acc[j] = xmfma(fkl[j], fqh[s], s == 0 ? f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f} : acc[j]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) sacc[j] = xmfma(fkh[j], fql[s], sacc[j]);
+            for (int j = 0; j < 2; ++j) acc[j] = xmfma(fkh[j], fql[s], acc[j]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) sacc[j] = xmfma(fkh[j], fqh[s], sacc[j]);
+            for (int j = 0; j < 2; ++j) acc[j] = xmfma(fkh[j], fqh[s], acc[j]);
         }
-        // online softmax for this lane's query; key of sacc[j][r] = k0 + j*32 + (r&3) + 8*(r>>2) + 4*hi
+    };
+    const int vtr_base = (4 * hi + ((lane & 15) >> 2)) * 128 + ((lane >> 4) & 1) * 32 + 8 * (lane & 3);
+    const int vtr_swz = ((lane >> 3) & 1) << 6;
+
+    // one tile: PAR = t & 1 (compile time); cur = S^T(t), nxt <- S^T(t + 1)
+    auto tile = [&](auto PARc, int t, f32x16 (&cur)[2], f32x16 (&nxt)[2]) {
+        constexpr int PAR = decltype(PARc)::value;
+        const int k0 = t * 64;
+        load_k(t + 2);                                          // unconditional (keys clamp to Nk - 1)
+        load_v(t + 1);
         if (RAGGED && k0 + 64 > Nk) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = k0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= Nk) sacc[j][r] = -INFINITY;
+                    if (key >= Nk) cur[j][r] = -INFINITY;
                 }
         }
-        float mx = sacc[0][0];
+        // ---- the matrix pipe on tile t + 1, the vector pipe on tile t: 24 slices of one MFMA and its share of the softmax, fenced so
+        //      that the in-order issue alternates them (an MFMA holds the matrix pipe for 32 cycles; a slice carries up to 48 of VALU)
+        const char* sKh = smem[PAR ^ 1][0];
+        const char* sKl = smem[PAR ^ 1][1];
+        f16x8 fkh[2][2], fkl[2][2];                             // [s & 1][j]
+        auto ldk = [&](int s2) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float mref = m_new - 8.0f;                        // p' = 2^8 p
+            for (int j = 0; j < 2; ++j) {
+                const int r = j * 32 + l31, off = r * 128 + (((s2 * 2 + hi) ^ ((r >> 1) & 7)) << 4);
+                fkh[s2 & 1][j] = *reinterpret_cast<const f16x8*>(sKh + off);
+                fkl[s2 & 1][j] = *reinterpret_cast<const f16x8*>(sKl + off);
+            }
+        };
+        float mx = cur[0][0], mxb = cur[1][0], m_new = 0.f, mref = 0.f, psum = 0.f;
         float ps4[4] = {0.f, 0.f, 0.f, 0.f};
         unsigned pkh[2][8], pkl[2][8];
+        ldk(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int g = 0; g < 24; ++g) {
+            const int s2 = g / 6, w = g % 6, j = w & 1, c = w >> 1;
+            if (w == 0 && s2 < 3) ldk(s2 + 1);
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            nxt[j] = xmfma(c == 0 ? fkl[s2 & 1][j] : fkh[s2 & 1][j], c == 1 ? fql[s2] : fqh[s2], g < 2 ? zero : nxt[j]);
+            if (g == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(sacc[j][r] - mref), p1 = __builtin_amdgcn_exp2f(sacc[j][r + 1] - mref);
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, cur[0][r]);
+            } else if (g == 1) {
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mxb = fmaxf(mxb, cur[1][r]);
+                mx = fmaxf(mx, mxb);
+                mxb = __shfl_xor(mx, 32, 64);
+            } else if (g == 3) {
+                mx = fmaxf(mx, mxb);
+                m_new = fmaxf(m_run, mx);
+                mref = m_new - 8.0f;                            // p' = 2^8 p
+            } else if (g >= 4 && g < 20) {
+                const int u = g - 4, jj = u >> 3, r = 2 * (u & 7);
+                const float p0 = __builtin_amdgcn_exp2f(cur[jj][r] - mref), p1 = __builtin_amdgcn_exp2f(cur[jj][r + 1] - mref);
                 ps4[(r >> 1) & 1] += p0;
                 ps4[2 + ((r >> 1) & 1)] += p1;
-                split_hl2(p0, p1, pkh[j][r >> 1], pkl[j][r >> 1]);
+                split_hl2(p0, p1, pkh[jj][r >> 1], pkl[jj][r >> 1]);
+            } else if (g == 20) {
+                psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+                psum += __shfl_xor(psum, 32, 64);
             }
-        float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
-        psum += __shfl_xor(psum, 32, 64);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (__any(m_new != m_run)) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // 0 on the first tile (m_run = -inf)
             l_run *= alpha;
@@ -595,23 +640,21 @@ __global__ void __launch_bounds__(256, 2) k_x_attention_mfma(const float* __rest
             m_run = m_new;
         }
         l_run += psum;
-        // O^T[i] += V^T[d-block i] P^T: k-slices of 16 keys, the lane's 8 k-slots = keys base + {0..3, 8..11} + 4*hi
-        f32x16 otile[2];                                        // FLUSH: the tile's own product, added to oacc by the vector pipe
-        if (FLUSH) {
+        // ---- O^T[i] += V^T[d-block i] P^T, d-block by d-block: the tile's own product, added to oacc by the vector pipe
+        const char* sVh = smem[PAR][2];
+        const char* sVl = smem[PAR][3];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            f32x16 otile;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) otile[i][r] = 0.f;
-        }
+            for (int r = 0; r < 16; ++r) otile[r] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const xu32x4 ph = {pkh[j][s * 4 + 0], pkh[j][s * 4 + 1], pkh[j][s * 4 + 2], pkh[j][s * 4 + 3]};
-                const xu32x4 pl = {pkl[j][s * 4 + 0], pkl[j][s * 4 + 1], pkl[j][s * 4 + 2], pkl[j][s * 4 + 3]};
-                const f16x8 fph = __builtin_bit_cast(f16x8, ph), fpl = __builtin_bit_cast(f16x8, pl);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int s = 0; s < 2; ++s) {
+                    const xu32x4 ph = {pkh[j][s * 4 + 0], pkh[j][s * 4 + 1], pkh[j][s * 4 + 2], pkh[j][s * 4 + 3]};
+                    const xu32x4 pl = {pkl[j][s * 4 + 0], pkl[j][s * 4 + 1], pkl[j][s * 4 + 2], pkl[j][s * 4 + 3]};
+                    const f16x8 fph = __builtin_bit_cast(f16x8, ph), fpl = __builtin_bit_cast(f16x8, pl);
                     typedef __attribute__((address_space(3))) xs16x4* lds4_t;
                     const int a0 = vtr_base + (j * 32 + s * 16) * 128 + ((i * 64) ^ vtr_swz);
                     struct { xs16x4 a, b; } th = {__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(sVh + a0)),
@@ -619,27 +662,36 @@ __global__ void __launch_bounds__(256, 2) k_x_attention_mfma(const float* __rest
                     struct { xs16x4 a, b; } tl = {__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(sVl + a0)),
                                                   __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(sVl + a0 + 8 * 128))};
                     const f16x8 fvh = __builtin_bit_cast(f16x8, th), fvl = __builtin_bit_cast(f16x8, tl);
-                    if (FLUSH) {
-                        otile[i] = xmfma(fvl, fph, otile[i]);
-                        otile[i] = xmfma(fvh, fpl, otile[i]);
-                        otile[i] = xmfma(fvh, fph, otile[i]);
-                    } else {
-                        oacc[i] = xmfma(fvl, fph, oacc[i]);
-                        oacc[i] = xmfma(fvh, fpl, oacc[i]);
-                        oacc[i] = xmfma(fvh, fph, oacc[i]);
-                    }
+                    otile = xmfma(fvl, fph, otile);
+                    otile = xmfma(fvh, fpl, otile);
+                    otile = xmfma(fvh, fph, otile);
                 }
-            }
-        if (FLUSH) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[i][r] += otile[i][r];
+            for (int r = 0; r < 16; ++r) oacc[i][r] += otile[r];
         }
-        stage_store((t + 1) & 1);
+        store_k(PAR);
+        store_v(PAR ^ 1);
         __syncthreads();
+    };
+
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    load_k(0);
+    load_v(0);
+    store_k(0);
+    store_v(0);
+    load_k(1);
+    store_k(1);
+    __syncthreads();
+    f32x16 sA[2], sB[2];
+    qk(0, sA);
+    int t = 0;
+    for (; t + 1 < ntiles; t += 2) {
+        tile(P0{}, t, sA, sB);
+        tile(P1{}, t + 1, sB, sA);
     }
-    // write O: lane owns query q0 + l31; oacc[i][r] is d = i*32 + (r&3) + 8*(r>>2) + 4*hi
+    if (t < ntiles) tile(P0{}, t, sA, sB);
+
     const int qi = q0 + l31;
     if (qi < Nq) {
         const float inv = 1.0f / l_run;
@@ -767,12 +819,10 @@ int vidseg_x_attention_mfma(const float* q, int ldq, const void* k_hi, const voi
     if (B * H * Nq == 0) return VS_OK;
     const float scale_log2e = scale * 1.44269504088896340736f;
     const dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)(B * H));
-    static const int flush = vs_knob("VIDSEG_ATTN", "flush", 1);   // VIDSEG_ATTN="flush=0": the PV products accumulate across tiles inside the MFMA
-#define XA_LAUNCH(R, F) k_x_attention_mfma<R, F><<<grid, 256, 0, st>>>(q, ldq, (const f16*)k_hi, (const f16*)k_lo, (const f16*)v_hi, \
-                                                                        (const f16*)v_lo, ldkv, out, ldo, (f16*)out_split3, Nq, Nk, H, scale_log2e)
-    if (Nk % 64 == 0) { if (flush) XA_LAUNCH(false, true); else XA_LAUNCH(false, false); }
-    else { if (flush) XA_LAUNCH(true, true); else XA_LAUNCH(true, false); }
-#undef XA_LAUNCH
+    if (Nk % 64 == 0) k_x_attention_mfma<false><<<grid, 256, 0, st>>>(q, ldq, (const f16*)k_hi, (const f16*)k_lo, (const f16*)v_hi, (const f16*)v_lo, ldkv,
+                                                                      out, ldo, (f16*)out_split3, Nq, Nk, H, scale_log2e);
+    else k_x_attention_mfma<true><<<grid, 256, 0, st>>>(q, ldq, (const f16*)k_hi, (const f16*)k_lo, (const f16*)v_hi, (const f16*)v_lo, ldkv, out, ldo,
+                                                        (f16*)out_split3, Nq, Nk, H, scale_log2e);
     VS_CHECK_LAUNCH("x_attention_mfma");
     return VS_OK;
 }

@@ -207,7 +207,7 @@ template <bool RAGGED>
 __global__ void __launch_bounds__(256, 3) k_attention(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                    const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo, int Nq,
                                                    int Nk, int H, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) char sK2[2][64 * 128];          // K tile [key][d], 16-B slot XOR swizzle, double buffered
+    __shared__ __attribute__((aligned(16))) char sK2[2][64 * 128];          // K tile [key][d], 16-B slot ^ ((key >> 1) & 7): conflict-free ds_read_b128, double buffered
     __shared__ __attribute__((aligned(16))) bf16_t sVt2[2][64 * VT_LD];     // V tile transposed [d][key]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256, 3) k_attention(const bf16_t* __restrict__
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = (tid >> 3) + 32 * i;
-            *reinterpret_cast<u32x4*>(sK2[buf] + r * 128 + ((st_ch ^ (r & 7)) << 4)) = rk[i];
+            *reinterpret_cast<u32x4*>(sK2[buf] + r * 128 + ((st_ch ^ ((r >> 1) & 7)) << 4)) = rk[i];
 #pragma unroll
             for (int e = 0; e < 8; ++e) sVt2[buf][(st_ch * 8 + e) * VT_LD + r] = (bf16_t)rv[i][e];
         }
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256, 3) k_attention(const bf16_t* __restrict__
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int ch = s * 2 + hi;
-                const bf16x8_t fk = *reinterpret_cast<const bf16x8_t*>(sK + r * 128 + ((ch ^ (r & 7)) << 4));
+                const bf16x8_t fk = *reinterpret_cast<const bf16x8_t*>(sK + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
                 if (s == 0)                                            // C = inline 0: no accumulator initialisation moves
                     sacc[j] = mfma_32x32x16(fk, fq[s], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
                                                                                        0.f, 0.f, 0.f, 0.f, 0.f});
@@ -722,7 +722,7 @@ template <bool RAGGED, bool TRV>
 __global__ void __launch_bounds__(256, 2) k_attention2(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                    const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo, int Nq,
                                                    int Nk, int H, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) char sK2[2][64 * 128];          // K tile [key][d], 16-B slot XOR swizzle, double buffered
+    __shared__ __attribute__((aligned(16))) char sK2[2][64 * 128];          // K tile [key][d], 16-B slot ^ ((key >> 1) & 7): conflict-free ds_read_b128, double buffered
     __shared__ __attribute__((aligned(16))) bf16_t sVt2[2][64 * (TRV ? VR_LD : VT_LD)];     // V tile: transposed [d][key], or [key][d] (TRV)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -773,7 +773,7 @@ __global__ void __launch_bounds__(256, 2) k_attention2(const bf16_t* __restrict_
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = (tid >> 3) + 32 * i;
-            *reinterpret_cast<u32x4*>(sK2[buf] + r * 128 + ((st_ch ^ (r & 7)) << 4)) = rk[i];
+            *reinterpret_cast<u32x4*>(sK2[buf] + r * 128 + ((st_ch ^ ((r >> 1) & 7)) << 4)) = rk[i];
             if (TRV) {
                 *reinterpret_cast<bf16x8_t*>(sVt2[buf] + r * VR_LD + st_ch * 8) = rv[i];
             } else {
@@ -800,7 +800,7 @@ __global__ void __launch_bounds__(256, 2) k_attention2(const bf16_t* __restrict_
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int ch = s * 2 + hi;
-                const bf16x8_t fk = *reinterpret_cast<const bf16x8_t*>(sK + r * 128 + ((ch ^ (r & 7)) << 4));
+                const bf16x8_t fk = *reinterpret_cast<const bf16x8_t*>(sK + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     if (s == 0)
@@ -938,7 +938,7 @@ template <bool RAGGED>
 __global__ void __launch_bounds__(256, 2) k_attention3(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                    const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo, int Nq,
                                                    int Nk, int H, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) char sK2[2][64 * 128];          // K tile [key][d], 16-B slot XOR swizzle, double buffered
+    __shared__ __attribute__((aligned(16))) char sK2[2][64 * 128];          // K tile [key][d], 16-B slot ^ ((key >> 1) & 7): conflict-free ds_read_b128, double buffered
     __shared__ __attribute__((aligned(16))) bf16_t sV2[2][64 * VR_LD];      // V tile [key][d], read with ds_read_b64_tr_b16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -997,7 +997,7 @@ __global__ void __launch_bounds__(256, 2) k_attention3(const bf16_t* __restrict_
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = (tid >> 3) + 32 * i;
-            *reinterpret_cast<u32x4*>(sK2[buf] + r * 128 + ((st_ch ^ (r & 7)) << 4)) = rk[i];
+            *reinterpret_cast<u32x4*>(sK2[buf] + r * 128 + ((st_ch ^ ((r >> 1) & 7)) << 4)) = rk[i];
             *reinterpret_cast<bf16x8_t*>(sV2[buf] + r * VR_LD + st_ch * 8) = rv[i];
         }
     };
@@ -1023,7 +1023,7 @@ __global__ void __launch_bounds__(256, 2) k_attention3(const bf16_t* __restrict_
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int ch = s * 2 + hi;
-                const bf16x8_t fk = *reinterpret_cast<const bf16x8_t*>(sK + r * 128 + ((ch ^ (r & 7)) << 4));
+                const bf16x8_t fk = *reinterpret_cast<const bf16x8_t*>(sK + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) sacc[qb][j] = mfma_32x32x16(fk, fq[qb][s], sacc[qb][j]);
             }
@@ -1200,7 +1200,7 @@ __global__ void __launch_bounds__(256, OCC) k_attention4(const bf16_t* __restric
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = (tid >> 3) + 32 * i;
-            *reinterpret_cast<u32x4*>(sK3[slot] + r * 128 + ((st_ch ^ (r & 7)) << 4)) = rk[i];
+            *reinterpret_cast<u32x4*>(sK3[slot] + r * 128 + ((st_ch ^ ((r >> 1) & 7)) << 4)) = rk[i];
         }
     };
     auto store_v = [&](int slot) {
@@ -1218,7 +1218,7 @@ __global__ void __launch_bounds__(256, OCC) k_attention4(const bf16_t* __restric
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int ch = s * 2 + hi;
-            const bf16x8_t fk = *reinterpret_cast<const bf16x8_t*>(sK + r * 128 + ((ch ^ (r & 7)) << 4));
+            const bf16x8_t fk = *reinterpret_cast<const bf16x8_t*>(sK + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) sa[qb] = mfma_32x32x16(fk, fq[qb][s], sa[qb]);
         }
