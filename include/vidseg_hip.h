@@ -287,6 +287,17 @@ int vidseg_x_attention_f32(const float* q, int ldq, const float* k, int ldk, con
 int vidseg_linear_a16_rf32(const void* a, int K, long long M, const void* w, int N, const float* bias, const float* rowvec, int rv_stride,
                            int rows_per_sample, const float* residual_f32, int ldr, float* out_f32, int ldo, void* tap_f16, void* tap2_f16,
                            int tap_cols, int tap_ld, int act, vidseg_stream_t stream);
+/* the same linear writing the NEXT GEMM's operand image [hi | lo | hi] of its fp32 result instead of the fp32 tensor: for a result whose
+ * only consumer is another split-operand GEMM -- the FF output projection feeding proj_out when the transformer has one block
+ * (ATT:757 -> :921-927), which otherwise costs an fp32 round trip and a vidseg_x_split3 pass.  Same bits as that pair. */
+int vidseg_linear_a16_rf32_x3(const void* a, int K, long long M, const void* w, int N, const float* bias, const float* residual_f32, int ldr,
+                              void* out_split3_f16 /* [M][3 N] */, vidseg_stream_t stream);
+/* the fused q | k | v projection of a self-attention (ATT:636-650): columns [0, plane_col0) = q leave as fp32 [M][ldo], columns
+ * [plane_col0, N) = k | v as vidseg_x_attention_mfma's operand planes (hi = fp16(x), lo = fp16(x - hi), fp16 [M][plane_ld] each) -- the
+ * bits vidseg_x_split_planes makes of the fp32 k | v, without their fp32 round trip; q / k taps as in vidseg_linear_a16_rf32 */
+int vidseg_linear_a16_qkv_planes(const void* a, int K, long long M, const void* w, int N, const float* bias, float* q_f32, int ldo,
+                                 void* kv_hi_f16, void* kv_lo_f16, int plane_col0, int plane_ld, void* tap_f16, void* tap2_f16,
+                                 int tap_cols, int tap_ld, vidseg_stream_t stream);
 /* GEGLU projection of the exact mode with the product value * gelu_erf(gate) formed in fp32 inside the epilogue and written as the FF
  * output projection's split operand image (ATT:89-96); w / bias interleaved like the 16-bit GEGLU weights */
 int vidseg_linear_a16_geglu_x3(const void* a, int K, long long M, const void* w, int N, const float* bias,

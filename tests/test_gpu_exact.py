@@ -231,6 +231,30 @@ def test_fused_residual_and_split_outputs(X):
         e = rel(out, ref)
         print(f"linear_x + fp32 residual {M}x{N}x{K}: max err {e:.2e}")
         assert e <= 5e-6, (M, K, N, e)
+    # the same linear writing the next GEMM's operand image from its epilogue (vidseg_linear_a16_rf32_x3): the bits of split3(linear_x(..))
+    # on the 224 x 320 split tile, on a split-K shape (k_splitk_finish writes the image), on the small tile, with and without the residual
+    for (M, K, N, res) in ((28672, 1280, 320, True), (7168, 5120, 1280, True), (1792, 5120, 1280, True), (300, 320, 640, False), (114688, 1280, 320, True)):
+        a, w, b = rnd((M, K), 71), rnd((N, K), 72, 0.02), rnd((N,), 73)
+        r = rnd((M, N), 74, 2.0).to(dev) if res else None
+        a3, w3, bd = X.split3(a.to(dev)), X.pack_linear_x(w, dev), ops.f32(b, dev)
+        two = X.split3(X.linear_x(a3, w3, bd, residual=r))
+        one = X.linear_x(a3, w3, bd, residual=r, split_out=True)
+        assert tuple(one.shape) == (M, 3 * N) and torch.equal(one, two), (M, K, N, res)
+    # the fused q | k | v projection writing k | v as the attention kernel's planes (vidseg_linear_a16_qkv_planes): the bits of
+    # split_planes(linear_x(..)[..., Ci:]), q and both taps unchanged; the split tile, a split-K shape and the small tile
+    for (B, N, Ci) in ((7, 4096, 320), (4, 256, 1280), (28, 64, 1280), (1, 300, 64)):
+        a, w = rnd((B, N, Ci), 75), rnd((3 * Ci, Ci), 76, 0.03)
+        a3, w3 = X.split3(a.to(dev)), X.pack_linear_x(w, dev)
+        t1, t2 = torch.empty((B, N, Ci), dtype=torch.float16, device=dev), torch.empty((B, N, Ci), dtype=torch.float16, device=dev)
+        u1, u2 = torch.empty_like(t1), torch.empty_like(t2)
+        qkv = X.linear_x(a3, w3, tap=t1, tap2=t2, tap_cols=Ci)
+        hi0, lo0 = X.split_planes(qkv[..., Ci:])
+        q, (hi, lo) = X.linear_qkv_x(a3, w3, Ci, tap=u1, tap2=u2)
+        assert torch.equal(q, qkv[..., :Ci]) and torch.equal(hi, hi0) and torch.equal(lo, lo0) and torch.equal(t1, u1) and torch.equal(t2, u2), (B, N, Ci)
+        if N >= 128:
+            heads = Ci // 64
+            assert torch.equal(X.attention_x(q, None, heads, B, N, N, split_out=True, planes=(hi, lo)),
+                               X.attention_x(qkv[..., :Ci], qkv[..., Ci:], heads, B, N, N, split_out=True))
     x, w, b = rnd((2, 64, 12, 20), 45), rnd((128, 64, 3, 3), 46, 0.05), rnd((128,), 47)
     r = rnd((2, 12, 20, 128), 48, 3.0)
     out = X.conv3x3_x(X.split3(x.permute(0, 2, 3, 1).contiguous().to(dev)), X.pack_conv3x3_x(w, dev), ops.f32(b, dev), residual=r.to(dev)).cpu()

@@ -42,8 +42,11 @@ struct GemmParams {
     bf16_t* out;             // [M][ldo] or nullptr
     int ldo;
     float* out_f32;          // [M][ldo] or nullptr
-    f16* out_split3;         // exact mode, GEGLU only (k_gemm_ph<4, true>): the result as the consumer's split operand image
+    f16* out_split3;         // exact mode, plain or GEGLU linears: the result as the consumer's split operand image [hi | lo | hi]
                              // [M][3 * ldo] = [hi | lo | hi], hi = fp16(x), lo = fp16(x - hi); or nullptr
+    f16* plane_hi;           // exact mode, the fused q | k | v projection: columns >= plane_col0 leave as the attention kernel's K / V
+    f16* plane_lo;           // operand planes hi = fp16(x), lo = fp16(x - hi), [M][plane_ld] each, instead of going to out / out_f32
+    int plane_col0, plane_ld;
     f16* tap;                // fp16 copy of columns [0, tap_cols) with leading dim tap_ld, or nullptr
     f16* tap2;               // fp16 copy of columns [tap_cols, 2*tap_cols) (same leading dim), or nullptr
     int tap_cols, tap_ld;
@@ -266,6 +269,21 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
                 v[4 + e] += r1[e];
             }
         }
+        if (p.plane_hi && n >= p.plane_col0) {                  // k | v columns of the fused projection: the attention's operand planes
+            f16x8 h8, l8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = v[e];
+                asm volatile("" : "+v"(x));                     // one fp32 value for both lines (see exact_ops.hip: split_hl)
+                const f16 hh = (f16)x;
+                h8[e] = hh;
+                l8[e] = (f16)(x - (float)hh);
+            }
+            const long long po = (long long)m * p.plane_ld + (n - p.plane_col0);
+            *reinterpret_cast<f16x8*>(p.plane_hi + po) = h8;
+            *reinterpret_cast<f16x8*>(p.plane_lo + po) = l8;
+            continue;
+        }
         const long long oo = (long long)m * p.ldo + n;
         if (p.out) {
             bf16x8_t o;
@@ -277,22 +295,20 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
             *reinterpret_cast<f32x4*>(p.out_f32 + oo) = f32x4{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(p.out_f32 + oo + 4) = f32x4{v[4], v[5], v[6], v[7]};
         }
-        if constexpr (X3) {
-            if (p.out_split3) {
-                f16x8 h8, l8;
+        if (p.out_split3) {                                     // exact mode: the result as the next GEMM's split operand image
+            f16x8 h8, l8;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float x = v[e];
-                    asm volatile("" : "+v"(x));                 // one fp32 value for both lines (see exact_ops.hip: split_hl)
-                    const f16 hh = (f16)x;
-                    h8[e] = hh;
-                    l8[e] = (f16)(x - (float)hh);
-                }
-                f16* o3 = p.out_split3 + (long long)m * 3 * p.ldo + n;
-                *reinterpret_cast<f16x8*>(o3) = h8;
-                *reinterpret_cast<f16x8*>(o3 + p.ldo) = l8;
-                *reinterpret_cast<f16x8*>(o3 + 2 * p.ldo) = h8;
+            for (int e = 0; e < 8; ++e) {
+                float x = v[e];
+                asm volatile("" : "+v"(x));                     // one fp32 value for both lines (see exact_ops.hip: split_hl)
+                const f16 hh = (f16)x;
+                h8[e] = hh;
+                l8[e] = (f16)(x - (float)hh);
             }
+            f16* o3 = p.out_split3 + (long long)m * 3 * p.ldo + n;
+            *reinterpret_cast<f16x8*>(o3) = h8;
+            *reinterpret_cast<f16x8*>(o3 + p.ldo) = l8;
+            *reinterpret_cast<f16x8*>(o3 + 2 * p.ldo) = h8;
         }
         }
     }
@@ -1998,6 +2014,21 @@ __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
     }
+    if (p.plane_hi && n >= p.plane_col0) {                      // as in epilogue_rows
+        f16x8 h8, l8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = v[e];
+            asm volatile("" : "+v"(x));
+            const f16 hh = (f16)x;
+            h8[e] = hh;
+            l8[e] = (f16)(x - (float)hh);
+        }
+        const long long po = (long long)m * p.plane_ld + (n - p.plane_col0);
+        *reinterpret_cast<f16x8*>(p.plane_hi + po) = h8;
+        *reinterpret_cast<f16x8*>(p.plane_lo + po) = l8;
+        return;
+    }
     if (p.out) {
         bf16x8_t o;
 #pragma unroll
@@ -2008,6 +2039,21 @@ __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
         f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
         *reinterpret_cast<f32x4*>(p.out_f32 + (long long)m * p.ldo + n) = a;
         *reinterpret_cast<f32x4*>(p.out_f32 + (long long)m * p.ldo + n + 4) = b;
+    }
+    if (p.out_split3) {                                        // as in epilogue_rows
+        f16x8 h8, l8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = v[e];
+            asm volatile("" : "+v"(x));
+            const f16 hh = (f16)x;
+            h8[e] = hh;
+            l8[e] = (f16)(x - (float)hh);
+        }
+        f16* o3 = p.out_split3 + (long long)m * 3 * p.ldo + n;
+        *reinterpret_cast<f16x8*>(o3) = h8;
+        *reinterpret_cast<f16x8*>(o3 + p.ldo) = l8;
+        *reinterpret_cast<f16x8*>(o3 + 2 * p.ldo) = h8;
     }
 }
 
@@ -2722,9 +2768,15 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(i < 3 ? l320 : l640)) != hipSuccess) ws_fits = 0;
         (void)hipGetLastError();                                 // a refused attribute must not surface as this launch's error
     }
-    if (p.out_split3) {                                        // exact mode's GEGLU projection: always the 256 x 256 phased tile
-        VS_REQUIRE(p.act == 2 && p.ksize == 1 && !p.out && !p.out_f32 && !p.residual && !p.tap && p.N % 64 == 0 && (p.ldo % 8) == 0,
-                   "gemm: the split3 output exists for the plain GEGLU linear only");
+    if (p.plane_hi)
+        VS_REQUIRE(p.ksize == 1 && p.plane_lo && p.act == 0 && p.plane_col0 % 8 == 0 && p.plane_ld % 8 == 0 && p.plane_col0 > 0 &&
+                       p.plane_col0 < p.N && p.N - p.plane_col0 <= p.plane_ld && !p.residual,
+                   "gemm: k | v planes need a plain linear, plane_col0 / plane_ld multiples of 8");
+    if (p.out_split3 && p.act != 2)                            // a plain linear writing its consumer's operand image: any kernel below
+        VS_REQUIRE(p.ksize == 1 && !p.out && !p.out_f32 && p.N % 8 == 0 && (p.ldo % 8) == 0, "gemm: split3 output needs a plain linear, N %% 8 == 0");
+    if (p.out_split3 && p.act == 2) {                          // exact mode's GEGLU projection: always the 256 x 256 phased tile
+        VS_REQUIRE(p.ksize == 1 && !p.out && !p.out_f32 && !p.residual && !p.tap && p.N % 64 == 0 && (p.ldo % 8) == 0,
+                   "gemm: the GEGLU split3 output exists for the plain linear only");
         static bool attr3 = false;
         if (!attr3) {
             (void)hipFuncSetAttribute((const void*)k_gemm_ph<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
@@ -2961,7 +3013,9 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         double ab = (double)p.x0_bytes + (double)p.x1_bytes + 2.0 * (double)p.N * (double)p.K;
         if (p.residual) ab += (p.res_f32 ? 4.0 : 2.0) * (double)p.M * n_out;
         if (p.out) ab += 2.0 * (double)p.M * n_out;
-        if (p.out_f32) ab += 4.0 * (double)p.M * n_out;
+        if (p.out_f32) ab += 4.0 * (double)p.M * (p.plane_hi ? p.plane_col0 : n_out);
+        if (p.plane_hi) ab += 4.0 * (double)p.M * (n_out - p.plane_col0);
+        if (p.out_split3) ab += 6.0 * (double)p.M * n_out;
         if (p.tap) ab += 2.0 * (double)p.M * (double)p.tap_cols * (p.tap2 ? 2.0 : 1.0);
         g_prof.shapes.push_back({p.M, p.N, p.K, p.ksize, p.up, p.stride, p.act, p.ksplit, kind, ab});
     }
@@ -3041,6 +3095,70 @@ int vidseg_linear_a16_rf32(const void* a, int K, long long M, const void* w, int
     p.tap_ld = tap_ld;
     p.act = act;
     p.split2 = 1;                                              // the operands of this entry point ARE split images (header)
+    return launch_gemm(p, st);
+}
+
+// The fused q | k | v projection of a self-attention (attention.py:636-650; no bias there): columns [0, plane_col0) = q leave as fp32
+// [M][ldo] (the attention kernel splits its own queries), columns [plane_col0, N) = k | v as the attention kernel's operand planes
+// hi / lo fp16 [M][plane_ld] -- what vidseg_x_split_planes made of the fp32 k | v before, without their fp32 round trip.  Taps as usual.
+int vidseg_linear_a16_qkv_planes(const void* a, int K, long long M, const void* w, int N, const float* bias, float* q_f32, int ldo,
+                                 void* kv_hi, void* kv_lo, int plane_col0, int plane_ld, void* tap, void* tap2, int tap_cols, int tap_ld,
+                                 hipStream_t st) {
+    VS_REQUIRE(q_f32 != nullptr && kv_hi != nullptr && kv_lo != nullptr && ldo % 8 == 0 && ldo >= plane_col0,
+               "linear_qkv_planes: needs q, both planes, ldo %% 8 == 0 and >= plane_col0");
+    GemmParams p{};
+    p.x0 = (const bf16_t*)a;
+    p.C0 = K;
+    p.ksize = 1;
+    p.stride = 1;
+    p.up = 1;
+    p.Hin = p.Win = p.Hout = p.Wout = 1;
+    p.w = (const bf16_t*)w;
+    p.N = N;
+    p.K = K;
+    p.M = M;
+    p.x0_bytes = M * K * 2;
+    p.bias = bias;
+    p.rows_per_sample = 1;
+    p.out_f32 = q_f32;
+    p.ldo = ldo;
+    p.plane_hi = (f16*)kv_hi;
+    p.plane_lo = (f16*)kv_lo;
+    p.plane_col0 = plane_col0;
+    p.plane_ld = plane_ld;
+    p.tap = (f16*)tap;
+    p.tap2 = (f16*)tap2;
+    p.tap_cols = tap_cols;
+    p.tap_ld = tap_ld;
+    p.split2 = 1;
+    return launch_gemm(p, st);
+}
+
+// The same linear writing [hi | lo | hi] of its fp32 result (fp16 [M][3 N]) instead of the fp32 tensor: for results whose only consumer
+// is the next GEMM (the FF output projection feeding proj_out, attention.py:757 -> :921) -- saves the fp32 round trip and a split pass.
+int vidseg_linear_a16_rf32_x3(const void* a, int K, long long M, const void* w, int N, const float* bias, const float* residual_f32, int ldr,
+                              void* out_split3, hipStream_t st) {
+    VS_REQUIRE(out_split3 != nullptr && N % 8 == 0 && (!residual_f32 || ldr % 8 == 0), "linear_rf32_x3: needs an output image, N %% 8 == 0, ldr %% 8 == 0");
+    GemmParams p{};
+    p.x0 = (const bf16_t*)a;
+    p.C0 = K;
+    p.ksize = 1;
+    p.stride = 1;
+    p.up = 1;
+    p.Hin = p.Win = p.Hout = p.Wout = 1;
+    p.w = (const bf16_t*)w;
+    p.N = N;
+    p.K = K;
+    p.M = M;
+    p.x0_bytes = M * K * 2;
+    p.bias = bias;
+    p.rows_per_sample = 1;
+    p.residual = (const bf16_t*)residual_f32;
+    p.res_f32 = 1;
+    p.ldr = ldr;
+    p.out_split3 = (f16*)out_split3;
+    p.ldo = N;
+    p.split2 = 1;
     return launch_gemm(p, st);
 }
 

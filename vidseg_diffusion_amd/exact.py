@@ -38,6 +38,8 @@ _lib.register({
     "vidseg_x_groupnorm_split3": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _L, _P, _P],
     "vidseg_x_groupnorm_rows_per_chunk": [_I],
     "vidseg_linear_a16_rf32": [_P, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
+    "vidseg_linear_a16_rf32_x3": [_P, _I, _L, _P, _I, _P, _P, _I, _P, _P],
+    "vidseg_linear_a16_qkv_planes": [_P, _I, _L, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "vidseg_linear_a16_geglu_x3": [_P, _I, _L, _P, _I, _P, _P, _P],
     "vidseg_linear_a16_geglu_x3g16": [_P, _I, _L, _P, _I, _P, _P, _P],
     "vidseg_conv3x3_a16_rf32": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
@@ -181,12 +183,13 @@ def split_planes(x):
     return hi, lo
 
 
-def attention_mfma(q, kv, heads, B, Nq, Nk, split_out=False):
+def attention_mfma(q, kv, heads, B, Nq, Nk, split_out=False, planes=None):
     """softmax(q k^T / 8) v per 64-wide head at fp32 accuracy on the matrix pipe (three fp16 MFMA products of split operands per
-    contraction).  q: fp32 column slice [B, Nq, heads*64]; kv: fp32 [B, Nk, 2*heads*64] column slice holding k | v side by side.
+    contraction).  q: fp32 column slice [B, Nq, heads*64]; kv: fp32 [B, Nk, 2*heads*64] column slice holding k | v side by side, or
+    None with planes = its (hi, lo) fp16 planes (linear_qkv_x writes them from the projection's epilogue).
     split_out: return the consumer's split operand image [B, Nq, 3*heads*64] (fp16 [hi | lo | hi]) instead of the fp32 result."""
     C = heads * 64
-    hi, lo = split_planes(kv)
+    hi, lo = planes if planes is not None else split_planes(kv)
     out = torch.empty((B, Nq, 3 * C), dtype=F16, device=q.device) if split_out else torch.empty((B, Nq, C), dtype=F32, device=q.device)
     call("vidseg_x_attention_mfma", q.data_ptr(), q.stride(1), hi.data_ptr(), lo.data_ptr(), hi.data_ptr() + 2 * C, lo.data_ptr() + 2 * C, 2 * C,
          None if split_out else ptr(out), ptr(out) if split_out else None, C, B, heads, Nq, Nk, 0.125, stream())
@@ -196,29 +199,61 @@ def attention_mfma(q, kv, heads, B, Nq, Nk, split_out=False):
 _MFMA_MIN_Q = int(os.environ.get("VIDSEG_X_ATTN_MFMA_MINQ", "128"))   # below: k_x_attention_f32 (the 14-frame temporal attention); 0 disables
 
 
-def attention_x(q, kv, heads, B, Nq, Nk, split_out=False):
+def mfma_attention_for(Nq):
+    """attention_x runs Nq queries on the MFMA kernel (whose k | v operands are fp16 planes: linear_qkv_x can write them)."""
+    return bool(_MFMA_MIN_Q) and Nq >= _MFMA_MIN_Q
+
+
+def attention_x(q, kv, heads, B, Nq, Nk, split_out=False, planes=None):
     """The exact mode's attention: the MFMA kernel from 128 queries up (a block owns 128), the fp32 vector kernel below that."""
     C = heads * 64
-    if _MFMA_MIN_Q and Nq >= _MFMA_MIN_Q:
-        return attention_mfma(q, kv, heads, B, Nq, Nk, split_out)
+    if mfma_attention_for(Nq):
+        return attention_mfma(q, kv, heads, B, Nq, Nk, split_out, planes)
+    if planes is not None:
+        raise VidsegError("attention_x: the fp32 vector kernel takes fp32 k | v (ask mfma_attention_for(Nq) before projecting into planes)")
     a = attention_f32(q, kv[..., :C], kv[..., C:], heads, B, Nq, Nk)
     return split3(a) if split_out else a
 
 
-def linear_x(a3, w3, bias=None, *, rowvec=None, rows_per_sample=0, act=ops.ACT_NONE, tap=None, tap2=None, tap_cols=0, residual=None):
+def linear_x(a3, w3, bias=None, *, rowvec=None, rows_per_sample=0, act=ops.ACT_NONE, tap=None, tap2=None, tap_cols=0, residual=None,
+             split_out=False):
     """fp32 out = act(a . w^T + bias + rowvec[sample]) + residual on split operands (a3: [.., 3K] fp16, w3: [N, 3K] fp16; residual
-    fp32 [.., N], added inside the GEMM epilogue)."""
+    fp32 [.., N], added inside the GEMM epilogue).  split_out: the result as the next GEMM's operand image [.., 3N] (fp16
+    [hi | lo | hi], written by the epilogue: the bits of split3(linear_x(..))) instead of the fp32 tensor."""
     ops.workspace(a3.device)
     K3 = a3.shape[-1]
     M = a3.numel() // K3
     N = w3.shape[0]
-    out = torch.empty(a3.shape[:-1] + (N,), dtype=F32, device=a3.device)
     if residual is not None and (residual.dtype != F32 or residual.numel() != M * N or not residual.is_contiguous()):
         raise VidsegError("linear_x: residual must be a contiguous fp32 [.., N] tensor")
+    if split_out:
+        if rowvec is not None or act != ops.ACT_NONE or tap is not None or tap2 is not None:
+            raise VidsegError("linear_x: split_out is a plain linear (+ bias, + residual)")
+        out3 = torch.empty(a3.shape[:-1] + (3 * N,), dtype=F16, device=a3.device)
+        call("vidseg_linear_a16_rf32_x3", ptr(a3), K3, M, ptr(w3), N, ptr(bias), ptr(residual), N, ptr(out3), stream())
+        return out3
+    out = torch.empty(a3.shape[:-1] + (N,), dtype=F32, device=a3.device)
     call("vidseg_linear_a16_rf32", ptr(a3), K3, M, ptr(w3), N, ptr(bias), ptr(rowvec), rowvec.stride(0) if rowvec is not None else 0,
          rows_per_sample, ptr(residual), N, ptr(out), N, ptr(tap), ptr(tap2), tap_cols, tap.shape[-1] if tap is not None else 0, act,
          stream())                                                          # the split-operand entry point (residual optional)
     return out
+
+
+def linear_qkv_x(a3, w3, Ci, *, tap=None, tap2=None):
+    """The fused q | k | v projection (w3: [3 Ci, 3K]) with k | v written as the attention kernel's operand planes by the GEMM epilogue:
+    returns q fp32 [.., Ci] and (hi, lo) fp16 [.., 2 Ci] each = split_planes(linear_x(a3, w3)[..., Ci:]) bit for bit, without the fp32
+    k | v round trip.  tap / tap2: fp16 copies of q and k (the reference's dumps)."""
+    ops.workspace(a3.device)
+    K3 = a3.shape[-1]
+    M = a3.numel() // K3
+    if w3.shape[0] != 3 * Ci or Ci % 8:
+        raise VidsegError("linear_qkv_x: w3 must hold 3 * Ci rows, Ci a multiple of 8")
+    q = torch.empty(a3.shape[:-1] + (Ci,), dtype=F32, device=a3.device)
+    hi = torch.empty(a3.shape[:-1] + (2 * Ci,), dtype=F16, device=a3.device)
+    lo = torch.empty(a3.shape[:-1] + (2 * Ci,), dtype=F16, device=a3.device)
+    call("vidseg_linear_a16_qkv_planes", ptr(a3), K3, M, ptr(w3), 3 * Ci, None, ptr(q), Ci, ptr(hi), ptr(lo), Ci, 2 * Ci, ptr(tap), ptr(tap2),
+         Ci if tap is not None else 0, tap.shape[-1] if tap is not None else 0, stream())
+    return q, (hi, lo)
 
 
 def conv3x3_x(x3, w3, bias, *, stride=1, up=1, rowvec=None, residual=None):
@@ -446,8 +481,12 @@ class ExactRunner:
             # self-attention (ATT:636-672); q / k taps = fp16 of the fp32 projections (ATT:330-331)
             tq = torch.empty((B, N, Ci), dtype=F16, device=x.device) if dump else None
             tk = torch.empty((B, N, Ci), dtype=F16, device=x.device) if dump else None
-            qkv = linear_x(layernorm_split3(t, *bw["ln"][0]), bw["w_qkv"], tap=tq, tap2=tk, tap_cols=Ci)
-            a3 = attention_x(qkv[..., :Ci], qkv[..., Ci:], heads, B, N, N, split_out=True)
+            if mfma_attention_for(N):                                                                  # k | v straight into the attention's planes
+                q, planes = linear_qkv_x(layernorm_split3(t, *bw["ln"][0]), bw["w_qkv"], Ci, tap=tq, tap2=tk)
+                a3 = attention_x(q, None, heads, B, N, N, split_out=True, planes=planes)
+            else:
+                qkv = linear_x(layernorm_split3(t, *bw["ln"][0]), bw["w_qkv"], tap=tq, tap2=tk, tap_cols=Ci)
+                a3 = attention_x(qkv[..., :Ci], qkv[..., Ci:], heads, B, N, N, split_out=True)
             t = linear_x(a3, bw["w_o1"], bw["b_o1"], residual=t)
             if dump:
                 blk.attn1.q, blk.attn1.k = tq, tk
@@ -463,12 +502,13 @@ class ExactRunner:
                 blk.attn2.q, blk.attn2.k = tq, tk
             # GEGLU feed-forward (ATT:728-757, :89-115)
             g3 = self.geglu(layernorm_split3(t, *bw["ln"][2]), bw, "w_ff1", "b_ff1", "ff1g")
-            t = linear_x(g3, bw["w_ff2"], bw["b_ff2"], residual=t)
+            last = i == len(e["blocks"]) - 1 and "time" not in e                                      # t's only consumer is proj_out
+            t = linear_x(g3, bw["w_ff2"], bw["b_ff2"], residual=t, split_out=last)
             if "time" in e:                                                                            # VA:429-476
                 T = self.T
                 tm = self.time_block(m.time_stack[i], e["time"][i], add_rowvec(t, self.frame_emb(m, e, T), N), self.tctx3, T, dump)
                 t = blend(t, tm, e["alpha"])
-        out = linear_x(split3(t), e["w_out"], e["b_out"], residual=x.view(B, N, C))                    # ATT:921-927
+        out = linear_x(t if "time" not in e else split3(t), e["w_out"], e["b_out"], residual=x.view(B, N, C))   # ATT:921-927
         return out.view(B, H, W, C)
 
     def block(self, blk, x, x_skip, emb_all, ctx3, skip_resample=False):
