@@ -508,7 +508,7 @@ class ExactRunner:
                 T = self.T
                 tm = self.time_block(m.time_stack[i], e["time"][i], add_rowvec(t, self.frame_emb(m, e, T), N), self.tctx3, T, dump)
                 t = blend(t, tm, e["alpha"])
-        out = linear_x(t if "time" not in e else split3(t), e["w_out"], e["b_out"], residual=x.view(B, N, C))   # ATT:921-927
+        out = linear_x(t if t.dtype == F16 else split3(t), e["w_out"], e["b_out"], residual=x.view(B, N, C))   # ATT:921-927
         return out.view(B, H, W, C)
 
     def block(self, blk, x, x_skip, emb_all, ctx3, skip_resample=False):
