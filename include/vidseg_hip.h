@@ -260,6 +260,10 @@ int vidseg_gemm_profile_bytes(void* handle, double* out);
 /* ---- "exact" mode of the UNet path (fp16 build; csrc/exact_ops.hip): every value is carried in fp32 and handed to the 16-bit MFMA
  * GEMM / conv entry points above as the operand image [hi | lo | hi] (hi = fp16(x), lo = fp16(x - hi)) against weights packed as
  * [w_hi | w_hi | w_lo], i.e. one ordinary GEMM over a three-fold K axis with fp32 accumulation = a_hi w_hi + a_lo w_hi + a_hi w_lo.
+ * IMAGE FORMAT: rows of 3 C fp16 values, planes [hi | lo | third] at offsets 0, C, 2 C.  For C % 64 == 0 -- every width the GEMM / conv
+ * entry points accept -- the third plane is NEVER READ (the split tiles address planes 0, 1; every other GEMM kernel folds the last
+ * third of its walk back onto plane 0) and the producers below leave it UNWRITTEN: 4 bytes per value instead of 6 on HBM-bound
+ * passes.  For other widths they write [hi | lo | hi].  A caller that wants a full [hi | lo | hi] image copies plane 0 itself.
  * Replaces, at fp32 accuracy, the same reference operators as the 16-bit entry points: GroupNorm32 (+SiLU) DU:276-278 /
  * OAI:267-271, 302-315; LayerNorm ATT:609-759; GEGLU ATT:89-96; scaled-dot-product attention ATT:352-356.  The bf16 build exports
  * the symbols and returns VS_ERR_UNSUPPORTED. */

@@ -9,6 +9,7 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 os.environ.setdefault("VIDSEG_KEEP_LAST", "1")      # analysis.LAST_KMEANS / LAST_CENTER_IDS (restart-level parity tests); off in the product
+os.environ.setdefault("VIDSEG_X_POISON_PLANE3", "1")   # exact mode: NaN in the third plane of every operand image (no kernel may read it)
 
 
 def pytest_configure(config):

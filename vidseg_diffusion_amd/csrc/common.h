@@ -118,6 +118,12 @@ __device__ __forceinline__ void attn_block(int& bh, int& qb) {
     qb = (int)(id % gx);
 }
 
+// A split operand image has rows [hi | lo | third] of C values each (row stride 3 C).  Every GEMM consumer takes widths C % 64 == 0
+// only and never reads the third plane (k_gemm_p7x / k_gemm_phx address planes 0, 1; the 3 C walk of the other kernels folds its last
+// third back onto plane 0: GemmParams::a_fold), so the producers leave it unwritten there -- 4 instead of 6 bytes per value on
+// HBM-bound passes (same-box: 172.2 -> 163.7 ms per window with the stores compiled out).  Other widths keep [hi | lo | hi].
+#define VS_THIRD_PLANE(C) (((C) & 63) != 0)
+
 // Host-side override of a kernel-selection default, for tests and same-box A/B runs only: VAR="key=value,key=value".  The product
 // path sets none of them; every kernel choice is a fixed function of the problem.  (VIDSEG_GEMM: csrc/gemm_conv.hip, VIDSEG_ATTN: the
 // attention kernels of csrc/unet_ops.hip.)

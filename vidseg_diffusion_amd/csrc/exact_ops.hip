@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) k_x_split3(const float* __restrict__ x, l
     f16* o = out + m * 3 * C + c;
     *reinterpret_cast<f16x4*>(o) = h;
     *reinterpret_cast<f16x4*>(o + C) = l;
-    *reinterpret_cast<f16x4*>(o + 2 * C) = h;
+    if (VS_THIRD_PLANE(C)) *reinterpret_cast<f16x4*>(o + 2 * C) = h;
 }
 
 // the same for the channel concat of two sources (the ResBlock skip convolution's input, openaimodel.py:912): x0 [M][C0], x1 [M][C1]
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) k_x_split3_cat(const float* __restrict__ 
     f16* o = out + m * 3 * C + c;
     *reinterpret_cast<f16x4*>(o) = h;
     *reinterpret_cast<f16x4*>(o + C) = l;
-    *reinterpret_cast<f16x4*>(o + 2 * C) = h;
+    if (VS_THIRD_PLANE(C)) *reinterpret_cast<f16x4*>(o + 2 * C) = h;
 }
 
 // GEGLU (attention.py:89-96): y [M][2I] fp32, value = y[:, :I], gate = y[:, I:]  ->  split3(value * gelu_erf(gate)) [M][3I]
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256) k_x_geglu_split3(const float* __restrict_
     f16* o = out + m * 3 * I + c;
     *reinterpret_cast<f16x4*>(o) = h;
     *reinterpret_cast<f16x4*>(o + I) = l;
-    *reinterpret_cast<f16x4*>(o + 2 * I) = h;
+    if (VS_THIRD_PLANE(I)) *reinterpret_cast<f16x4*>(o + 2 * I) = h;
 }
 
 // out[(sample, row)][c] = x[(sample, row)][c] + vec[sample % nvec][c]   (the frame-index embedding of SpatialVideoTransformer,
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256) k_x_gn_apply_split3(const float* __restri
     f16* o = out + m * 3 * C + c;
     *reinterpret_cast<f16x4*>(o) = h;
     *reinterpret_cast<f16x4*>(o + C) = l;
-    *reinterpret_cast<f16x4*>(o + 2 * C) = h;
+    if (VS_THIRD_PLANE(C)) *reinterpret_cast<f16x4*>(o + 2 * C) = h;
 }
 
 // LayerNorm over the last dim of fp32 rows (C <= 2048, C % 4 == 0): one wave per row, two passes in registers -> split3
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(256) k_x_layernorm_split3(const float* __restr
             f16* o = out + row * 3 * C + c;
             *reinterpret_cast<f16x4*>(o) = h;
             *reinterpret_cast<f16x4*>(o + C) = l;
-            *reinterpret_cast<f16x4*>(o + 2 * C) = h;
+            if (VS_THIRD_PLANE(C)) *reinterpret_cast<f16x4*>(o + 2 * C) = h;
         }
     }
 }
@@ -712,7 +712,7 @@ __global__ void __launch_bounds__(256, 2) k_x_attention_mfma(const float* __rest
                     f16* o = op + i * 32 + 8 * g + 4 * hi;
                     *reinterpret_cast<f16x4*>(o) = vh4;
                     *reinterpret_cast<f16x4*>(o + ldo) = vl4;
-                    *reinterpret_cast<f16x4*>(o + 2 * ldo) = vh4;
+                    if (VS_THIRD_PLANE(ldo)) *reinterpret_cast<f16x4*>(o + 2 * ldo) = vh4;
                 }
         } else {
             float* op = out + ((long long)b * Nq + qi) * ldo + h * 64;

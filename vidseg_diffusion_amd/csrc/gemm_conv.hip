@@ -43,7 +43,7 @@ struct GemmParams {
     int ldo;
     float* out_f32;          // [M][ldo] or nullptr
     f16* out_split3;         // exact mode, plain or GEGLU linears: the result as the consumer's split operand image [hi | lo | hi]
-                             // [M][3 * ldo] = [hi | lo | hi], hi = fp16(x), lo = fp16(x - hi); or nullptr
+                             // [M][3 * ldo] = [hi | lo | third plane: unwritten for ldo % 64 == 0], hi = fp16(x), lo = fp16(x - hi); or nullptr
     f16* plane_hi;           // exact mode, the fused q | k | v projection: columns >= plane_col0 leave as the attention kernel's K / V
     f16* plane_lo;           // operand planes hi = fp16(x), lo = fp16(x - hi), [M][plane_ld] each, instead of going to out / out_f32
     int plane_col0, plane_ld;
@@ -61,8 +61,11 @@ struct GemmParams {
     const float* rowadd;     // per-row scalar added to every column before the residual (attention-output modulation
                              // lambda*mask[:,None], attention.py:646-663, 697-719) or nullptr
     int geglu16;             // GEGLU weight rows interleaved in 16-row value | gate groups (k_gemm_p7x<4, true>) instead of 32-row ones
-    int split2;              // exact mode: the operands are split images -- A rows [a_hi | a_lo | a_hi], W rows [w_hi | w_hi | w_lo] in the
-                             // usual K order over the 3 * Cin channels (exact.py); k_gemm_p7x then stages each plane once
+    int split2;              // exact mode: the operands are split images -- A rows [a_hi | a_lo | (unused)] with row stride 3 Cin, W rows
+                             // [w_hi | w_hi | w_lo] in the usual K order over 3 * Cin channels (exact.py); k_gemm_p7x / k_gemm_phx stage each plane
+                             // once, the other kernels walk the 3 Cin axis and fold its last third back onto plane 0 (a_fold)
+    int a_fold;              // split images carry TWO planes: channels [a_fold, 3 Cin / 3 * 3) of the K walk read plane 0 again (a_hi . w_lo);
+                             // = 2 * Cin for split2 launches (set by launch_gemm), 0 otherwise.  The third plane of an image is never read.
     int gn;                  // tile columns per panel of the launch order (map_tile)
     int taps, kchunk;        // K order of a conv weight row: k = (c / kchunk) * taps * kchunk + tap * kchunk + c % kchunk.
                              // kchunk = 64 (channel-chunk major: the taps of one 64-channel chunk are consecutive K-tiles, so the
@@ -121,6 +124,9 @@ struct KCursor {
 };
 
 #define BK 64
+
+// channel offset of a K-tile inside a split image's pixel: the last third of the 3 Cin walk (against w_lo) reads plane 0 (a_hi) again
+__device__ __forceinline__ int fold_c(const GemmParams& p, int c) { return (p.a_fold && c >= p.a_fold) ? c - p.a_fold : c; }
 
 __device__ __forceinline__ long long tap_row(const GemmParams& p, long long m) {
     if (p.tap_T <= 0) return m;
@@ -308,7 +314,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
             f16* o3 = p.out_split3 + (long long)m * 3 * p.ldo + n;
             *reinterpret_cast<f16x8*>(o3) = h8;
             *reinterpret_cast<f16x8*>(o3 + p.ldo) = l8;
-            *reinterpret_cast<f16x8*>(o3 + 2 * p.ldo) = h8;
+            if (VS_THIRD_PLANE(p.ldo)) *reinterpret_cast<f16x8*>(o3 + 2 * p.ldo) = h8;
         }
         }
     }
@@ -507,7 +513,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_conv(GemmParams p) {
                 a_off[i] = (unsigned)(pix * Cs + chunk * 8) * 2u;
             }
         }
-        const unsigned cbyte = (unsigned)(c0 >= p.C0 ? c0 - p.C0 : c0) * 2u;
+        const unsigned cbyte = (unsigned)fold_c(p, c0 >= p.C0 ? c0 - p.C0 : c0) * 2u;
         ld_k += BK;
         cur.advance(BK, p.taps, p.kchunk);
 #pragma unroll
@@ -682,7 +688,7 @@ __global__ void __launch_bounds__(256, NST == 2 ? 4 : 3) k_gemm_dma(GemmParams p
                 a_off[i] = ok ? (unsigned)(pix * Cs) * 2u + a_sw[i] : OOB;
             }
         }
-        const unsigned cbyte = (unsigned)(c0 >= p.C0 ? c0 - p.C0 : c0) * 2u;
+        const unsigned cbyte = (unsigned)fold_c(p, c0 >= p.C0 ? c0 - p.C0 : c0) * 2u;
         ld_k += DK;
         cur.advance(DK, p.taps, p.kchunk);
         char* A = smem + buf * BUF;
@@ -873,7 +879,7 @@ __global__ void __launch_bounds__(WM * 128, MI == 1 ? 4 : (WM == 4 ? 1 : 2)) k_g
                 a_off[i] = ok ? (unsigned)(pix * Cs) * 2u + (unsigned)((lch ^ lds_swz<BKT>(r)) * 16) : OOB;
             }
         }
-        const unsigned cbyte = (unsigned)(c0 >= p.C0 ? c0 - p.C0 : c0) * 2u;
+        const unsigned cbyte = (unsigned)fold_c(p, c0 >= p.C0 ? c0 - p.C0 : c0) * 2u;
         ld_k += BKT;
         cur.advance(BKT, p.taps, p.kchunk);
         char* A = smem + buf * BUF + wave * 1024;
@@ -1038,7 +1044,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
             const int c0 = cur.c0();
             a_second = c0 >= p.C0;
             t_Cs = a_second ? p.C1 : p.C0;
-            t_cc = a_second ? c0 - p.C0 : c0;
+            t_cc = fold_c(p, a_second ? c0 - p.C0 : c0);
             const int t3 = cur.tap / 3;
             t_kh = p.tmode ? cur.tap : t3;
             t_kw = p.tmode ? 0 : cur.tap - t3 * 3;
@@ -1194,7 +1200,7 @@ __device__ __forceinline__ void epilogue_rows_geglu16(const GemmParams& p, const
         f16* o3 = p.out_split3 + (long long)m * 3 * p.ldo + (wcol_base >> 1) + pc;
         *reinterpret_cast<f16x8*>(o3) = h8;
         *reinterpret_cast<f16x8*>(o3 + p.ldo) = l8;
-        *reinterpret_cast<f16x8*>(o3 + 2 * p.ldo) = h8;
+        if (VS_THIRD_PLANE(p.ldo)) *reinterpret_cast<f16x8*>(o3 + 2 * p.ldo) = h8;
     }
 }
 
@@ -1307,7 +1313,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_p7(GemmParams p) {
             const int c0 = cur.c0();
             a_second = c0 >= p.C0;
             t_Cs = a_second ? p.C1 : p.C0;
-            t_cc = a_second ? c0 - p.C0 : c0;
+            t_cc = fold_c(p, a_second ? c0 - p.C0 : c0);
             const int t3 = cur.tap / 3;
             t_kh = p.tmode ? cur.tap : t3;
             t_kw = p.tmode ? 0 : cur.tap - t3 * 3;
@@ -2053,7 +2059,7 @@ __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
         f16* o3 = p.out_split3 + (long long)m * 3 * p.ldo + n;
         *reinterpret_cast<f16x8*>(o3) = h8;
         *reinterpret_cast<f16x8*>(o3 + p.ldo) = l8;
-        *reinterpret_cast<f16x8*>(o3 + 2 * p.ldo) = h8;
+        if (VS_THIRD_PLANE(p.ldo)) *reinterpret_cast<f16x8*>(o3 + 2 * p.ldo) = h8;
     }
 }
 
@@ -2714,6 +2720,11 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     VS_REQUIRE(p.M > 0 && p.N > 0, "gemm: empty problem");
     p.taps = p.ksize == 1 ? 1 : (p.tmode ? 3 : 9);
     p.kchunk = p.ksize == 1 ? p.C0 + p.C1 : 64;                          // conv weights are packed chunk-major (see GemmParams)
+    p.a_fold = 0;
+    if (p.split2) {                                                      // C0 = 3 Cin with Cin % 64 == 0 (C0 % 64 == 0 above and 3 is odd)
+        VS_REQUIRE(!p.x1 && p.C1 == 0 && p.C0 % 3 == 0, "gemm: split operand images are single-source with 3 planes of channels (C0=%d)", p.C0);
+        p.a_fold = 2 * (p.C0 / 3);
+    }
     VS_REQUIRE(p.N % 8 == 0 && p.ldo % 8 == 0 && (!p.residual || p.ldr % 8 == 0) && (!p.tap || (p.tap_ld % 8 == 0 && p.tap_cols % 8 == 0)),
                "gemm: N=%d ldo=%d ldr=%d tap_ld=%d must be multiples of 8 (16-byte epilogue)", p.N, p.ldo, p.ldr, p.tap_ld);
     static bool attr = false;
@@ -3184,6 +3195,7 @@ int vidseg_linear_a16_geglu_x3(const void* a, int K, long long M, const void* w,
     p.out_split3 = (f16*)out_split3;
     p.ldo = N / 2;
     p.act = 2;
+    p.split2 = 1;                                              // a two-plane image: the 3 K walk of k_gemm_ph<4, true> folds (a_fold)
     return launch_gemm(p, st);
 }
 

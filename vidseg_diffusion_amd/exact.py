@@ -91,7 +91,7 @@ def geglu_linear_x(a3, w3g, b_g, grp=32):
     K3 = a3.shape[-1]
     M = a3.numel() // K3
     N = w3g.shape[0]
-    out = torch.empty(a3.shape[:-1] + (3 * (N // 2),), dtype=F16, device=a3.device)
+    out = _image(a3.shape[:-1] + (3 * (N // 2),), a3.device)
     call("vidseg_linear_a16_geglu_x3g16" if grp == 16 else "vidseg_linear_a16_geglu_x3", ptr(a3), K3, M, ptr(w3g), N, ptr(b_g), ptr(out), stream())
     return out
 
@@ -119,7 +119,7 @@ def pack_conv_out_x(weight, device):
 # ----------------------------------------------------------------------------- fp32 glue operators
 def split3(x, silu=False):
     C = x.shape[-1]
-    out = torch.empty(x.shape[:-1] + (3 * C,), dtype=F16, device=x.device)
+    out = _image(x.shape[:-1] + (3 * C,), x.device)
     call("vidseg_x_split3", ptr(x), x.numel() // C, C, int(silu), ptr(out), stream())
     return out
 
@@ -127,14 +127,14 @@ def split3(x, silu=False):
 def split3_cat(x0, x1):
     """split3 of the channel concat [x0 | x1] (fp32 [.., C0], [.., C1]) without materialising the concat."""
     C0, C1 = x0.shape[-1], x1.shape[-1]
-    out = torch.empty(x0.shape[:-1] + (3 * (C0 + C1),), dtype=F16, device=x0.device)
+    out = _image(x0.shape[:-1] + (3 * (C0 + C1),), x0.device)
     call("vidseg_x_split3_cat", ptr(x0), ptr(x1), x0.numel() // C0, C0, C1, ptr(out), stream())
     return out
 
 
 def geglu_split3(y):
     inner = y.shape[-1] // 2
-    out = torch.empty(y.shape[:-1] + (3 * inner,), dtype=F16, device=y.device)
+    out = _image(y.shape[:-1] + (3 * inner,), y.device)
     call("vidseg_x_geglu_split3", ptr(y), y.numel() // (2 * inner), inner, ptr(out), stream())
     return out
 
@@ -146,7 +146,7 @@ def groupnorm_split3(x0, gamma, beta, *, x1=None, eps=1e-5, silu=True):
     stats = torch.empty(B * 2 * (C0 + C1), dtype=F32, device=x0.device)
     rpc = _lib.lib().vidseg_x_groupnorm_rows_per_chunk(HW)                  # rows per block of the statistics pass
     part = torch.empty(B * (-(-HW // rpc)) * 2 * (C0 + C1), dtype=torch.float64, device=x0.device)
-    out = torch.empty(x0.shape[:-1] + (3 * (C0 + C1),), dtype=F16, device=x0.device)
+    out = _image(x0.shape[:-1] + (3 * (C0 + C1),), x0.device)
     call("vidseg_x_groupnorm_split3", ptr(x0), ptr(x1), C0, C1, B, HW, 32, ptr(gamma), ptr(beta), eps, int(silu), ptr(stats), stats.numel(),
          ptr(part), part.numel(), ptr(out), stream())
     return out
@@ -154,7 +154,7 @@ def groupnorm_split3(x0, gamma, beta, *, x1=None, eps=1e-5, silu=True):
 
 def layernorm_split3(x, gamma, beta, eps=1e-5):
     C = x.shape[-1]
-    out = torch.empty(x.shape[:-1] + (3 * C,), dtype=F16, device=x.device)
+    out = _image(x.shape[:-1] + (3 * C,), x.device)
     call("vidseg_x_layernorm_split3", ptr(x), x.numel() // C, C, ptr(gamma), ptr(beta), eps, ptr(out), stream())
     return out
 
@@ -167,6 +167,18 @@ def attention_f32(q, k, v, heads, B, Nq, Nk):
     out = torch.empty((B, Nq, heads * 64), dtype=F32, device=q.device)
     call("vidseg_x_attention_f32", q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), v.data_ptr(), v.stride(1), ptr(out), heads * 64,
          B, heads, Nq, Nk, 0.125, stream())
+    return out
+
+
+_POISON = os.environ.get("VIDSEG_X_POISON_PLANE3") == "1"     # tests: NaN in the never-written third plane -- any kernel reading it shows up
+
+
+def _image(shape, device):
+    """An operand image [.., 3 C] for a producer to fill: rows [hi | lo | third].  For C % 64 == 0 -- every width a GEMM takes -- the
+    producers leave the third plane unwritten and no consumer reads it (csrc/common.h: VS_THIRD_PLANE, GemmParams::a_fold)."""
+    out = torch.empty(shape, dtype=F16, device=device)
+    if _POISON:
+        out[..., 2 * (shape[-1] // 3):] = float("nan")
     return out
 
 
@@ -190,7 +202,7 @@ def attention_mfma(q, kv, heads, B, Nq, Nk, split_out=False, planes=None):
     split_out: return the consumer's split operand image [B, Nq, 3*heads*64] (fp16 [hi | lo | hi]) instead of the fp32 result."""
     C = heads * 64
     hi, lo = planes if planes is not None else split_planes(kv)
-    out = torch.empty((B, Nq, 3 * C), dtype=F16, device=q.device) if split_out else torch.empty((B, Nq, C), dtype=F32, device=q.device)
+    out = _image((B, Nq, 3 * C), q.device) if split_out else torch.empty((B, Nq, C), dtype=F32, device=q.device)
     call("vidseg_x_attention_mfma", q.data_ptr(), q.stride(1), hi.data_ptr(), lo.data_ptr(), hi.data_ptr() + 2 * C, lo.data_ptr() + 2 * C, 2 * C,
          None if split_out else ptr(out), ptr(out) if split_out else None, C, B, heads, Nq, Nk, 0.125, stream())
     return out
@@ -229,7 +241,7 @@ def linear_x(a3, w3, bias=None, *, rowvec=None, rows_per_sample=0, act=ops.ACT_N
     if split_out:
         if rowvec is not None or act != ops.ACT_NONE or tap is not None or tap2 is not None:
             raise VidsegError("linear_x: split_out is a plain linear (+ bias, + residual)")
-        out3 = torch.empty(a3.shape[:-1] + (3 * N,), dtype=F16, device=a3.device)
+        out3 = _image(a3.shape[:-1] + (3 * N,), a3.device)
         call("vidseg_linear_a16_rf32_x3", ptr(a3), K3, M, ptr(w3), N, ptr(bias), ptr(residual), N, ptr(out3), stream())
         return out3
     out = torch.empty(a3.shape[:-1] + (N,), dtype=F32, device=a3.device)
@@ -582,4 +594,6 @@ class ExactRunner:
                 return None
             h = self.block(blk, h, hs.pop(), emb_all, ctx3)                                            # OAI:911-948
         h3 = groupnorm_split3(h, self.out_g, self.out_beta, eps=1e-5, silu=True)
+        C = h.shape[-1]
+        h3[..., 2 * C:] = h3[..., :C]                 # the one consumer that walks all 3 C channels (k_conv_out4, once per evaluation)
         return ops.conv_out4(h3, self.out_w, self.out_b)
