@@ -2811,7 +2811,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         }
         if (g_prof.on) {
             if (!prof_ext) (void)hipEventRecord(ev1, st);
-            g_prof.shapes.push_back({p.M, p.N, p.K, p.ksize, p.up, p.stride, p.act, 1, kind3, (double)p.x0_bytes + 2.0 * p.N * p.K + 6.0 * p.M * (p.N / 2)});
+            g_prof.shapes.push_back({p.M, p.N, p.K, p.ksize, p.up, p.stride, p.act, 1, kind3, ((double)p.x0_bytes + 2.0 * p.N * p.K) * 2.0 / 3.0 + (VS_THIRD_PLANE(p.ldo) ? 6.0 : 4.0) * p.M * (p.N / 2)});
         }
         VS_CHECK_LAUNCH("gemm_geglu_split3");
         return VS_OK;
@@ -3022,11 +3022,12 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         if (!prof_ext) (void)hipEventRecord(ev1, st);
         const double n_out = p.act == 2 ? p.N / 2 : p.N;
         double ab = (double)p.x0_bytes + (double)p.x1_bytes + 2.0 * (double)p.N * (double)p.K;
+        if (p.split2) ab *= 2.0 / 3.0;                           // two distinct planes per operand: (a_hi, a_lo) and (w_hi, w_lo)
         if (p.residual) ab += (p.res_f32 ? 4.0 : 2.0) * (double)p.M * n_out;
         if (p.out) ab += 2.0 * (double)p.M * n_out;
         if (p.out_f32) ab += 4.0 * (double)p.M * (p.plane_hi ? p.plane_col0 : n_out);
         if (p.plane_hi) ab += 4.0 * (double)p.M * (n_out - p.plane_col0);
-        if (p.out_split3) ab += 6.0 * (double)p.M * n_out;
+        if (p.out_split3) ab += (VS_THIRD_PLANE(p.ldo) ? 6.0 : 4.0) * (double)p.M * n_out;
         if (p.tap) ab += 2.0 * (double)p.M * (double)p.tap_cols * (p.tap2 ? 2.0 : 1.0);
         g_prof.shapes.push_back({p.M, p.N, p.K, p.ksize, p.up, p.stride, p.act, p.ksplit, kind, ab});
     }
