@@ -115,15 +115,21 @@ def background(n):
                 (small @ small.t()).sum()                     # small f64 kernels: a few CUs at a time
 
 
+def live(t):
+    """the planes a split operand image carries: [hi | lo] of [.., 3 C] fp16 -- the third plane is unwritten for C % 64 == 0 (csrc/common.h)"""
+    c3 = t.shape[-1]
+    return t[..., :2 * (c3 // 3)] if args.exact and t.dtype == torch.float16 and c3 % 192 == 0 else t   # exact mode: fp16 results are images
+
+
 bad_total = 0
 for name, fn in cases:
-    ref = fn().clone()
+    ref = live(fn()).clone()
     torch.cuda.synchronize()
     bad = 0
     for it in range(args.iters):
         if not args.quiet and it % 4 == 0:
             background(2)
-        out = fn()
+        out = live(fn())
         if not torch.equal(out, ref):
             bad += 1
             if bad <= 2:
