@@ -319,12 +319,28 @@ int vidseg_x_split_planes(const float* x, int ld, long long rows, int cols, void
 int vidseg_x_attention_mfma(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* v_hi, const void* v_lo, int ldkv,
                             float* out /* fp32 [B][Nq][ldo], or NULL */, void* out_split3 /* f16 [B][Nq][3 ldo] = [hi | lo | hi], or NULL */,
                             int ldo, int B, int H, int Nq, int Nk, float scale, vidseg_stream_t stream);
+/* temporal self-attention of the VideoUNet's time stack at fp32 accuracy (sgm/modules/video_attention.py:171-199: rearrange
+ * `(b t) s c -> (b s) t c`, attention over the T <= 16 frames of every (video, location), rearrange back; ATT:352-356 per head of 64),
+ * read and written in the spatial row order: qkv fp32 rows (b T + t) S + s of `ld` floats holding q | k | v at columns 0 / 64 H / 128 H;
+ * result as fp32 [(b t) s][64 H] or as the output projection's split operand image [(b t) s][3 * 64 H]; optional fp16 taps of q / k in the
+ * reference's [(b s)][t][c] layout (ATT:330-331).  The permuted copies of the projection and of the result never exist. */
+int vidseg_x_temporal_attention(const float* qkv, int ld, int nvid, int T, int S, int H, float scale, float* out_f32 /* or NULL */,
+                                void* out_split3_f16 /* or NULL */, void* tap_q_f16 /* opt */, void* tap_k_f16 /* opt */,
+                                vidseg_stream_t stream);
 /* x + vec[sample % nvec] per row (the frame-index embedding add of SpatialVideoTransformer, VA:417-431), fp32 */
 int vidseg_x_add_rowvec_f32(const float* x, const float* vec, long long M, int C, int rows_per_sample, int nvec, float* out,
                             vidseg_stream_t stream);
 /* vidseg_conv_temporal3_a16 with the fp32 accumulators (+ bias + per-(b t) vector) stored as they are */
 int vidseg_conv_temporal3_a16_f32(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
                                    const float* rowvec, int rv_stride, float* out_f32, vidseg_stream_t stream);
+/* vidseg_linear_a16_rf32 / vidseg_conv_temporal3_a16_f32 followed inside the epilogue by the VideoUNet's AlphaBlender
+ * (sgm/modules/diffusionmodules/util.py:343-380, image_only_indicator = 0): out = alpha * blend + (1 - alpha) * (result + residual).
+ * The last linear of a time-stack transformer block (video_attention.py:281 -> :470-476) and the second temporal convolution of a
+ * VideoResBlock (video_model.py:66-89) write the mixed stream themselves. */
+int vidseg_linear_a16_rf32_blend(const void* a, int K, long long M, const void* w, int N, const float* bias, const float* residual_f32, int ldr,
+                                 const float* blend_f32 /* [M][N] */, float alpha, float* out_f32 /* [M][N] */, vidseg_stream_t stream);
+int vidseg_conv_temporal3_a16_f32_blend(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
+                                         const float* residual_f32, const float* blend_f32, float alpha, float* out_f32, vidseg_stream_t stream);
 /* input conv (OAI:638-644) with the fp32 accumulators stored as they are: fp32 NHWC [B][H][W][Cin] -> fp32 NHWC [B][H][W][Cout] */
 int vidseg_conv_in_f32(const float* x, const float* w, const float* bias, int B, int H, int W, int Cin, int Cout, float* out_f32_nhwc,
                        vidseg_stream_t stream);

@@ -395,6 +395,88 @@ def test_split_survives_rounding_ties(X):
     assert e <= 2e-6, e
 
 
+def test_temporal_attention_in_place(X):
+    """k_x_temporal_attention: the time stack's self-attention read and written in the spatial row order (b t) s against float64
+    attention through the reference's own rearranges (video_attention.py:171-199), for T = 14 (the drivers' window), short and
+    full-length (16) sequences, location counts that are no multiple of anything, one and several videos; fp32 and split-image
+    outputs agree bit for bit, the taps are fp16(q), fp16(k) in the reference's [(b s), t, c] layout."""
+    dev = torch.device("cuda:0")
+    for (nv, T, S, H, sc) in ((2, 14, 37, 5, 1.0), (1, 14, 144, 10, 1.0), (3, 3, 50, 1, 1.0), (1, 16, 9, 2, 3.0), (2, 1, 5, 1, 1.0), (1, 14, 2304, 5, 0.05)):
+        C = H * 64
+        qkv = rnd((nv * T, S, 3 * C), 30 + T, sc)
+        tq = torch.empty((nv * S, T, C), dtype=torch.float16, device=dev)
+        tk = torch.empty_like(tq)
+        out = X.temporal_attention_x(qkv.to(dev), nv, T, S, H, split_out=False).cpu()
+        img = X.temporal_attention_x(qkv.to(dev), nv, T, S, H, split_out=True, tap_q=tq, tap_k=tk).cpu()
+        perm = lambda t: t.view(nv, T, S, -1).permute(0, 2, 1, 3).reshape(nv * S, T, -1)             # noqa: E731  (b t) s c -> (b s) t c
+        q, k, v = (perm(qkv[..., i * C:(i + 1) * C].contiguous()) for i in range(3))
+        hd = lambda t: t.double().view(nv * S, T, H, 64).transpose(1, 2)                            # noqa: E731
+        ref = TF.scaled_dot_product_attention(hd(q), hd(k), hd(v)).transpose(1, 2).reshape(nv, S, T, C).permute(0, 2, 1, 3).reshape(nv * T, S, C)
+        e = rel(out, ref)
+        print(f"temporal attention videos={nv} T={T} S={S} H={H} scale={sc}: max err {e:.2e}")
+        assert e <= 2e-6 * max(1.0, sc * sc), (nv, T, S, H, e)
+        assert torch.equal(img[..., :C], out.half()) and torch.equal(img[..., :2 * C], X.split3(out.to(dev)).cpu()[..., :2 * C])
+        assert torch.equal(tq.cpu(), q.half()) and torch.equal(tk.cpu(), k.half())
+
+
+def test_alpha_blend_epilogues(X):
+    """AlphaBlender inside the GEMM epilogue (vidseg_linear_a16_rf32_blend, vidseg_conv_temporal3_a16_f32_blend; incl. a split-K
+    shape) against float64 of alpha * spatial + (1 - alpha) * (result + residual)."""
+    from vidseg_diffusion_amd import ops
+    dev = torch.device("cuda:0")
+    alpha = 0.3775
+    for (M, K, N) in ((448, 1280, 320), (7168, 5120, 1280), (300, 320, 640)):
+        a, w, b, r, sp = rnd((M, K), 41), rnd((N, K), 42, 0.03), rnd((N,), 43), rnd((M, N), 44), rnd((M, N), 45, 2.0)
+        out = X.linear_blend_x(X.split3(a.to(dev)), X.pack_linear_x(w, dev), ops.f32(b, dev), r.to(dev), sp.to(dev), alpha).cpu()
+        ref = alpha * sp.double() + (1 - alpha) * (a.double() @ w.double().t() + b.double() + r.double())
+        assert rel(out, ref) <= 5e-6, (M, K, N, rel(out, ref))
+    T, HW, C, Co = 7, 20, 64, 128
+    x, w, b = rnd((2 * T, 4, 5, C), 46), rnd((Co, C, 3, 1, 1), 47, 0.05), rnd((Co,), 48)
+    r, sp = rnd((2 * T, 4, 5, Co), 49), rnd((2 * T, 4, 5, Co), 50)
+    out = X.conv_temporal3_blend_x(X.split3(x.to(dev)), X.pack_conv_temporal3_x(w, dev), ops.f32(b, dev), T, r.to(dev), sp.to(dev), alpha).cpu()
+    x5 = x.double().view(2, T, 4, 5, C).permute(0, 4, 1, 2, 3)                                       # b c t h w
+    conv = TF.conv3d(x5, w.double(), b.double(), padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(2 * T, 4, 5, Co)
+    ref = alpha * sp.double() + (1 - alpha) * (conv + r.double())
+    assert rel(out, ref) <= 5e-6, rel(out, ref)
+
+
+def test_video_unet_fused_paths_equal_the_plain_ones(X):
+    """The round-5 fusions of the exact VideoUNet change no value beyond fp32 rounding order: (i) attention over a one-token context
+    taken as the identity on v (softmax of one score is exactly 1; norm2 / to_q / the attention are not evaluated, to_out(v) rides on
+    the preceding projection as a per-sample row vector), (ii) the temporal attention in place, (iii) AlphaBlender in the epilogues --
+    each against the full evaluation of the same network (VIDSEG_X_NK1 / _TEMPORAL / _BLEND = 0), and the dumped taps unchanged."""
+    from vidseg_diffusion_amd.video_unet import VideoUNet
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(os.path.dirname(G), "unet_svd_narrow.npz"))
+    net = VideoUNet(**synthetic.SVD_NARROW)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=4321).items()})
+    T = int(z["T"])
+    x, t, ctx, y = (torch.from_numpy(z[k]).to(dev) for k in ("fw_x", "fw_t", "fw_ctx", "fw_y"))
+    kw = dict(timesteps=t, context=ctx, y=y, num_video_frames=T, image_only_indicator=torch.zeros(2, T))
+    net.set_precision("exact")
+
+    def run():
+        out = net(x, **kw).cpu().double()
+        blk = net.output_blocks[7][1]
+        return out, [blk.transformer_blocks[0].attn1.q.cpu(), blk.time_stack[0].attn1.q.cpu(), blk.time_stack[0].attn1.k.cpu(),
+                     blk.time_stack[0].attn2.k.cpu()]
+    saved = (X._NK1_IDENTITY, X._TEMPORAL_FUSED, X._BLEND_FUSED)
+    try:
+        fused, ftaps = run()
+        for flag in ("_NK1_IDENTITY", "_TEMPORAL_FUSED", "_BLEND_FUSED"):
+            setattr(X, flag, False)
+            plain, ptaps = run()
+            setattr(X, flag, True)
+            e = float((fused - plain).norm() / plain.norm())
+            print(f"exact VideoUNet with {flag} off vs on: nrms {e:.2e}")
+            assert e <= 2e-6, (flag, e)
+            for a, b in zip(ftaps, ptaps):
+                assert a.shape == b.shape and float((a != b).float().mean()) <= 0.01, flag
+    finally:
+        X._NK1_IDENTITY, X._TEMPORAL_FUSED, X._BLEND_FUSED = saved
+
+
 def test_exact_unet_forward_vs_reference(X):
     """Narrow SD UNet in the exact mode against the REFERENCE's fp32 forward (tests/golden/unet_sd_narrow.npz): output and every
     dumped Q/K tap -- and the 16-bit mode of the same object on the same inputs, for the ratio."""

@@ -71,6 +71,57 @@ __global__ void __launch_bounds__(256) k_mean_normalize(BlockPtrs blocks, int nb
     }
 }
 
+// The same arithmetic for the shapes the windows have (nblk <= 4, C <= 1024), with every load of a row issued before the first
+// value is used: with the block count and the chunk count known at compile time a lane has NB x NCH independent 16-byte loads in
+// flight instead of walking them one round trip at a time (the generic kernel above: 56 us for the 73 MB of a configs[1] window =
+// 1.3 TB/s, six dependent HBM latencies per wave).  Same order of fp32 operations, same roundings, bit-identical output.
+template <int NB, int NCH>
+__global__ void __launch_bounds__(256) k_mean_normalize_fast(BlockPtrs blocks, int64_t row0, int64_t rows, int C, f16* __restrict__ out_mean,
+                                                             f16* __restrict__ out_norm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t off = (row0 + row) * (int64_t)C;
+    const float inv = (float)NB;
+    f16x8 v[NB][NCH];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = lane * 8 + ch * 512;
+            if (c < C) v[b][ch] = *reinterpret_cast<const f16x8*>(blocks.p[b] + off + c);
+        }
+    float vmax = 0.f;
+    f16x8 m[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = lane * 8 + ch * 512;
+        if (c < C) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float acc = (float)v[0][ch][j];
+#pragma unroll
+                for (int b = 1; b < NB; ++b) acc = acc + (float)v[b][ch][j];
+                const f16 h = (f16)(acc / inv);
+                m[ch][j] = h;
+                vmax = fmaxf(vmax, fabsf((float)h));
+            }
+        }
+    }
+    vmax = wave_max_f32(vmax);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = lane * 8 + ch * 512;
+        if (c < C) {
+            if (out_mean) *reinterpret_cast<f16x8*>(out_mean + row * (int64_t)C + c) = m[ch];
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)((float)m[ch][j] / vmax);
+            if (out_norm) *reinterpret_cast<f16x8*>(out_norm + row * (int64_t)C + c) = o;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // float64 64x64 tile product  D[s][j] = sum_c A[s][c] * B[j][c]  (256 threads, 4x4 per thread)
 // ---------------------------------------------------------------------------------------------
@@ -1401,7 +1452,21 @@ int vidseg_mean_normalize_f16(const void* const* blocks, int nblk, int64_t row0,
     if (rows == 0) return VS_OK;
     BlockPtrs bp;
     for (int i = 0; i < nblk; ++i) bp.p[i] = static_cast<const f16*>(blocks[i]);
-    k_mean_normalize<<<dim3((unsigned)cdiv64(rows, 4)), 256, 0, st>>>(bp, nblk, row0, rows, C, (f16*)out_mean, (f16*)out_norm);
+    const dim3 grid((unsigned)cdiv64(rows, 4));
+    f16* om = (f16*)out_mean;
+    f16* on = (f16*)out_norm;
+    const int nch = C <= 512 ? 1 : (C <= 1024 ? 2 : 0);
+#define VS_MN_FAST(NB, NCH) k_mean_normalize_fast<NB, NCH><<<grid, 256, 0, st>>>(bp, row0, rows, C, om, on)
+    if (nch == 1 && nblk == 1) VS_MN_FAST(1, 1);
+    else if (nch == 1 && nblk == 2) VS_MN_FAST(2, 1);
+    else if (nch == 1 && nblk == 3) VS_MN_FAST(3, 1);
+    else if (nch == 1 && nblk == 4) VS_MN_FAST(4, 1);
+    else if (nch == 2 && nblk == 1) VS_MN_FAST(1, 2);
+    else if (nch == 2 && nblk == 2) VS_MN_FAST(2, 2);
+    else if (nch == 2 && nblk == 3) VS_MN_FAST(3, 2);
+    else if (nch == 2 && nblk == 4) VS_MN_FAST(4, 2);
+    else k_mean_normalize<<<grid, 256, 0, st>>>(bp, nblk, row0, rows, C, om, on);
+#undef VS_MN_FAST
     VS_CHECK_LAUNCH("mean_normalize");
     return VS_OK;
 }

@@ -81,6 +81,53 @@ __device__ __forceinline__ f32x4 mfma_16x16x32(vs_s16x8 a, vs_s16x8 b, f32x4 c) 
 }
 #endif
 
+#if VIDSEG_ACT_IS_F16
+// ---- the exact mode's operand split: x -> hi = fp16(x), lo = fp16(x - hi)
+// x must be ONE fp32 value for both lines.  Without the barrier hipcc (-ffp-contract=fast) fuses the conversion with x's producer
+// per use: for x = a * s it emitted hi = v_cvt_pk_f16_f32(v_mul_f32(a, s)) for the operand image (two roundings) but
+// v_fma_mixlo_f16(a, s, 0) (one rounding of the exact product) as the hi that lo is taken against -- the two differ when the fp32
+// product sits on an fp16 rounding tie, and hi + lo is then one fp16 ulp (2^-12 relative) off: 6 of 10240 query rows of a
+// 1024-token attention came out 5e-5 wrong (tools/lab/x_attn_diag2.py), every one holding such a tie.
+__device__ __forceinline__ void split_hl(float x, f16& hi, f16& lo) {
+    asm volatile("" : "+v"(x));
+    hi = (f16)x;
+    lo = (f16)(x - (float)hi);
+}
+// Two values at once, packed the way the MFMA operand wants them (x0 in the low half): the same roundings as split_hl in 4 VALU
+// instructions instead of 11 -- v_cvt_pk_f16_f32 for the hi pair, x - hi as v_fma_mix_f32 (hi read as an fp16 half, the fma exact),
+// v_cvt_pk_f16_f32 for the lo pair.  For values with no foldable producer (the attention's probabilities come out of v_exp_f32).
+typedef __attribute__((ext_vector_type(2))) float xf32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 xf16x2;
+__device__ __forceinline__ void split_hl2(float x0, float x1, unsigned& hi2, unsigned& lo2) {
+    asm volatile("" : "+v"(x0), "+v"(x1));
+    const xf16x2 h = __builtin_convertvector(xf32x2{x0, x1}, xf16x2);
+    const unsigned hu = __builtin_bit_cast(unsigned, h);
+    float r0, r1;                                               // (hipcc turns fma(ext(h), -1, x) back into a conversion and a subtraction)
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hu), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hu), "v"(x1));
+    const xf16x2 l = __builtin_convertvector(xf32x2{r0, r1}, xf16x2);
+    hi2 = hu;
+    lo2 = __builtin_bit_cast(unsigned, l);
+}
+// Four / eight values at once as the image's 8- / 16-byte cells (the same roundings as split_hl, pair by pair through split_hl2).
+typedef __attribute__((ext_vector_type(2))) unsigned int vs_u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int vs_u32x4;
+__device__ __forceinline__ void split_hl4(const float (&x)[4], f16x4& hi, f16x4& lo) {
+    unsigned h0, l0, h1, l1;
+    split_hl2(x[0], x[1], h0, l0);
+    split_hl2(x[2], x[3], h1, l1);
+    hi = __builtin_bit_cast(f16x4, vs_u32x2{h0, h1});
+    lo = __builtin_bit_cast(f16x4, vs_u32x2{l0, l1});
+}
+__device__ __forceinline__ void split_hl8(const float (&x)[8], f16x8& hi, f16x8& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_hl2(x[2 * e], x[2 * e + 1], h[e], l[e]);
+    hi = __builtin_bit_cast(f16x8, vs_u32x4{h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(f16x8, vs_u32x4{l[0], l[1], l[2], l[3]});
+}
+#endif
+
 // acc + a.lo * b.lo + a.hi * b.hi on a packed pair of activations (one v_dot2c_f32_{f16,bf16})
 __device__ __forceinline__ float dot2_acc(unsigned a, unsigned b, float acc) {
 #if VIDSEG_ACT_IS_F16
@@ -104,6 +151,33 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// erf in fp32, branch-free, for the exact mode's GELU (sgm/modules/attention.py:89-96 -> F.gelu, erf form).  Two minimax fits --
+// |a| <= 0.9277: a + a p(a^2); beyond: 1 - exp(q(|a|)) -- both evaluated and selected per lane (a wave of gate values straddles the
+// switch point anyway, so libm's branches ran both sides under exec masks: ~45 VALU instructions per value in the GEGLU epilogue,
+// which made that epilogue, not the K loop, the longer half of a K' = 960 tile).  Max error 0.994 ulp against float64 erf over all
+// of [0, 6] (checked exhaustively on the host with the same fmaf sequence; libm's erff: 0.90 ulp); ~20 instructions.  The
+// exponential is v_exp_f32 of the product with log2 e: its argument's rounding is <= 0.5 ulp of a value whose result is <= 0.4, i.e.
+// < 3e-8 absolute on erf.
+__device__ __forceinline__ float erf_f32(float a) {
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    const float big = copysignf(1.0f - __builtin_amdgcn_exp2f(r * 1.44269504088896340736f), a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    q = fmaf(q, a, a);
+    return t > 0.927734375f ? big : q;
 }
 
 // Blocks reach the 8 XCDs round-robin by linear block id; give every XCD one contiguous chunk of the (head, query block) space so

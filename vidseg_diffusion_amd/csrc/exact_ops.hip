@@ -22,32 +22,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int xu32x4;
 
 #if VIDSEG_ACT_IS_F16
 
-// x must be ONE fp32 value for both lines.  Without the barrier hipcc (-ffp-contract=fast) fuses the conversion with x's producer
-// per use: for x = a * s it emitted hi = v_cvt_pk_f16_f32(v_mul_f32(a, s)) for the operand image (two roundings) but
-// v_fma_mixlo_f16(a, s, 0) (one rounding of the exact product) as the hi that lo is taken against -- the two differ when the fp32
-// product sits on an fp16 rounding tie, and hi + lo is then one fp16 ulp (2^-12 relative) off: 6 of 10240 query rows of a
-// 1024-token attention came out 5e-5 wrong (tools/lab/x_attn_diag2.py), every one holding such a tie.
-__device__ __forceinline__ void split_hl(float x, f16& hi, f16& lo) {
-    asm volatile("" : "+v"(x));
-    hi = (f16)x;
-    lo = (f16)(x - (float)hi);
-}
-// Two values at once, packed the way the MFMA operand wants them (x0 in the low half): the same roundings as split_hl in 4 VALU
-// instructions instead of 11 -- v_cvt_pk_f16_f32 for the hi pair, x - hi as v_fma_mix_f32 (hi read as an fp16 half, the fma exact),
-// v_cvt_pk_f16_f32 for the lo pair.  For values with no foldable producer (the attention's probabilities come out of v_exp_f32).
-typedef __attribute__((ext_vector_type(2))) float xf32x2;
-typedef __attribute__((ext_vector_type(2))) _Float16 xf16x2;
-__device__ __forceinline__ void split_hl2(float x0, float x1, unsigned& hi2, unsigned& lo2) {
-    asm volatile("" : "+v"(x0), "+v"(x1));
-    const xf16x2 h = __builtin_convertvector(xf32x2{x0, x1}, xf16x2);
-    const unsigned hu = __builtin_bit_cast(unsigned, h);
-    float r0, r1;                                               // (hipcc turns fma(ext(h), -1, x) back into a conversion and a subtraction)
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hu), "v"(x0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hu), "v"(x1));
-    const xf16x2 l = __builtin_convertvector(xf32x2{r0, r1}, xf16x2);
-    hi2 = hu;
-    lo2 = __builtin_bit_cast(unsigned, l);
-}
+// split_hl / split_hl2 / split_hl4 / split_hl8: csrc/common.h
 __device__ __forceinline__ float silu_x(float x) { return x / (1.0f + expf(-x)); }
 
 // out[m][0:C] = hi, out[m][C:2C] = lo, out[m][2C:3C] = hi   of f(x[m][c]);   f = identity or SiLU.  C % 4 == 0.
@@ -59,14 +34,10 @@ __global__ void __launch_bounds__(256) k_x_split3(const float* __restrict__ x, l
     const int c = (int)(i4 - m * c4n) * 4;
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + m * C + c);
     f16x4 h, l;
+    float f[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float f = silu ? silu_x(v[j]) : v[j];
-        f16 a, b;
-        split_hl(f, a, b);
-        h[j] = a;
-        l[j] = b;
-    }
+    for (int j = 0; j < 4; ++j) f[j] = silu ? silu_x(v[j]) : v[j];
+    split_hl4(f, h, l);
     f16* o = out + m * 3 * C + c;
     *reinterpret_cast<f16x4*>(o) = h;
     *reinterpret_cast<f16x4*>(o + C) = l;
@@ -84,13 +55,8 @@ __global__ void __launch_bounds__(256) k_x_split3_cat(const float* __restrict__ 
     const int c = (int)(i4 - m * c4n) * 4;
     const f32x4 v = c < C0 ? *reinterpret_cast<const f32x4*>(x0 + m * C0 + c) : *reinterpret_cast<const f32x4*>(x1 + m * C1 + (c - C0));
     f16x4 h, l;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f16 a, b;
-        split_hl(v[j], a, b);
-        h[j] = a;
-        l[j] = b;
-    }
+    const float f[4] = {v[0], v[1], v[2], v[3]};
+    split_hl4(f, h, l);
     f16* o = out + m * 3 * C + c;
     *reinterpret_cast<f16x4*>(o) = h;
     *reinterpret_cast<f16x4*>(o + C) = l;
@@ -106,14 +72,10 @@ __global__ void __launch_bounds__(256) k_x_geglu_split3(const float* __restrict_
     const int c = (int)(i4 - m * c4n) * 4;
     const f32x4 v = *reinterpret_cast<const f32x4*>(y + m * 2 * I + c), g = *reinterpret_cast<const f32x4*>(y + m * 2 * I + I + c);
     f16x4 h, l;
+    float f[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float f = v[j] * (0.5f * g[j] * (1.0f + erff(g[j] * 0.70710678118654752440f)));
-        f16 a, b;
-        split_hl(f, a, b);
-        h[j] = a;
-        l[j] = b;
-    }
+    for (int j = 0; j < 4; ++j) f[j] = v[j] * (0.5f * g[j] * (1.0f + erf_f32(g[j] * 0.70710678118654752440f)));
+    split_hl4(f, h, l);
     f16* o = out + m * 3 * I + c;
     *reinterpret_cast<f16x4*>(o) = h;
     *reinterpret_cast<f16x4*>(o + I) = l;
@@ -234,15 +196,13 @@ __global__ void __launch_bounds__(256) k_x_gn_apply_split3(const float* __restri
     const f32x4 v = c < C0 ? *reinterpret_cast<const f32x4*>(x0 + m * C0 + c) : *reinterpret_cast<const f32x4*>(x1 + m * C1 + (c - C0));
     const f32x4 sc = *reinterpret_cast<const f32x4*>(st + c), sh = *reinterpret_cast<const f32x4*>(st + C + c);
     f16x4 h, l;
+    float f[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float f = fmaf(v[j], sc[j], sh[j]);
-        if (silu) f = silu_x(f);
-        f16 a, bb;
-        split_hl(f, a, bb);
-        h[j] = a;
-        l[j] = bb;
+        f[j] = fmaf(v[j], sc[j], sh[j]);
+        if (silu) f[j] = silu_x(f[j]);
     }
+    split_hl4(f, h, l);
     f16* o = out + m * 3 * C + c;
     *reinterpret_cast<f16x4*>(o) = h;
     *reinterpret_cast<f16x4*>(o + C) = l;
@@ -286,14 +246,10 @@ __global__ void __launch_bounds__(256) k_x_layernorm_split3(const float* __restr
         if (c < C) {
             const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
             f16x4 h, l;
+            float f[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float f = fmaf((v[ch][j] - mean) * rstd, ga[j], be[j]);
-                f16 a, b;
-                split_hl(f, a, b);
-                h[j] = a;
-                l[j] = b;
-            }
+            for (int j = 0; j < 4; ++j) f[j] = fmaf((v[ch][j] - mean) * rstd, ga[j], be[j]);
+            split_hl4(f, h, l);
             f16* o = out + row * 3 * C + c;
             *reinterpret_cast<f16x4*>(o) = h;
             *reinterpret_cast<f16x4*>(o + C) = l;
@@ -421,6 +377,156 @@ __global__ void __launch_bounds__(256) k_x_attention_f32(const float* __restrict
     }
 }
 
+// Temporal self-attention of the exact VideoUNet (video_attention.py:171-199: `(b t) s c -> (b s) t c`, attention over the T frames of
+// every (video, location), and back): softmax(q k^T / 8) v in fp32 on the vector pipe for sequences of T <= 16 tokens, read and written
+// IN PLACE in the spatial row order (b t) s -- the two permuted copies of the [(b t) s, 3C] projection and of the result never exist,
+// and the result leaves as the output projection's split operand image.  One wave owns one (video, location, head): its 3 x T x 64
+// fp32 values are 42 rows of 256 contiguous bytes (a block's four waves take four neighbouring heads: 1 KB runs), staged through
+// 12.7 KB of LDS per wave; both contractions are register-blocked over lanes (frame, 4-key group) / (frame, 16-channel group); the
+// wave walks its items grid-stride with the next item's loads in flight under the current item's arithmetic.  HBM-bound by design:
+// 16 bytes per value of q | k | v | out against ~12 FMA.  (k_x_attention_f32 ran these as 64-query blocks holding 14 queries, after
+// two torch permute copies: 1.0 ms per launch on average in the SVD window.)
+// qkv: fp32 rows of `ld` floats, q | k | v at columns 0 / C / 2C, head h at 64 h; row of (video b, frame t, location s) = (b T + t) S + s.
+// tap_q / tap_k: optional fp16 copies of q / k in the reference's [(b s), t, c] layout (attention.py:330-331 through VA:171).
+#define TA_LD 68
+#define TA_PLD 20
+__global__ void __launch_bounds__(256) k_x_temporal_attention(const float* __restrict__ qkv, int ld, int nvid, int T, int S, int H, float scale,
+                                                              float* __restrict__ out, f16* __restrict__ out3, f16* __restrict__ tap_q,
+                                                              f16* __restrict__ tap_k) {
+    extern __shared__ __attribute__((aligned(16))) float ta_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, C = H * 64;
+    float* Qs = ta_smem + wave * (3 * T * TA_LD + 16 * TA_PLD);
+    float* Ks = Qs + T * TA_LD;
+    float* Vs = Ks + T * TA_LD;
+    float* Ps = Vs + T * TA_LD;
+    const long long nitems = (long long)nvid * S * H, nwaves = (long long)gridDim.x * 4;
+    const int g = lane >> 4, c4 = lane & 15;                   // load layout: frame 4 j + g, channels 4 c4 ..
+    const int tq = lane >> 2, sub = lane & 3;                  // compute layout: query frame, key group / channel group
+    const int tqc = min(tq, T - 1);
+    f32x4 rq[4], rk[4], rv[4];
+    auto load = [&](long long item) {
+        const int h = (int)(item % H);
+        const long long bs = item / H;
+        const int s = (int)(bs % S), b = (int)(bs / S);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = 4 * j + g;
+            rq[j] = rk[j] = rv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < T) {
+                const float* p = qkv + ((long long)(b * T + t) * S + s) * ld + h * 64 + c4 * 4;
+                rq[j] = *reinterpret_cast<const f32x4*>(p);
+                rk[j] = *reinterpret_cast<const f32x4*>(p + C);
+                rv[j] = *reinterpret_cast<const f32x4*>(p + 2 * C);
+            }
+        }
+    };
+    long long item = (long long)blockIdx.x * 4 + wave;
+    if (item < nitems) load(item);
+    for (; item < nitems; item += nwaves) {
+        const int h = (int)(item % H);
+        const long long bs = item / H;
+        const int s = (int)(bs % S), b = (int)(bs / S);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous item's LDS reads are done (same wave: in order)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = 4 * j + g;
+            if (t < T) {
+                *reinterpret_cast<f32x4*>(Qs + t * TA_LD + c4 * 4) = f32x4{rq[j][0] * scale, rq[j][1] * scale, rq[j][2] * scale, rq[j][3] * scale};
+                *reinterpret_cast<f32x4*>(Ks + t * TA_LD + c4 * 4) = rk[j];
+                *reinterpret_cast<f32x4*>(Vs + t * TA_LD + c4 * 4) = rv[j];
+                if (tap_q) {
+                    const long long to = ((long long)(b * S + s) * T + t) * C + h * 64 + c4 * 4;
+                    *reinterpret_cast<f16x4*>(tap_q + to) = f16x4{(f16)rq[j][0], (f16)rq[j][1], (f16)rq[j][2], (f16)rq[j][3]};
+                    *reinterpret_cast<f16x4*>(tap_k + to) = f16x4{(f16)rk[j][0], (f16)rk[j][1], (f16)rk[j][2], (f16)rk[j][3]};
+                }
+            }
+        }
+        if (item + nwaves < nitems) load(item + nwaves);       // in flight under this item's arithmetic
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // ---- scores of query frame tq against keys sub, sub + 4, sub + 8, sub + 12
+        float sc[4] = {0.f, 0.f, 0.f, 0.f};
+        int kr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kr[i] = min(sub + 4 * i, T - 1) * TA_LD;
+#pragma unroll
+        for (int d4 = 0; d4 < 16; ++d4) {
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(Qs + tqc * TA_LD + d4 * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(Ks + kr[i] + d4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sc[i] = fmaf(qv[e], kv[e], sc[i]);
+            }
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (sub + 4 * i >= T) sc[i] = -INFINITY;
+            m = fmaxf(m, sc[i]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 1, 64));
+        m = fmaxf(m, __shfl_xor(m, 2, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sc[i] = expf(sc[i] - m);                           // exp(-inf) = 0 for the keys beyond T
+            l += sc[i];
+        }
+        l += __shfl_xor(l, 1, 64);
+        l += __shfl_xor(l, 2, 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Ps[tq * TA_PLD + sub + 4 * i] = sc[i];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // ---- O[tq][16 sub ..] = sum_k P[tq][k] V[k][16 sub ..]
+        float pr[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(Ps + tq * TA_PLD + 4 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pr[4 * c + e] = pv[e];
+        }
+        float o[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int tk = 0; tk < 16; ++tk) {
+            if (tk < T) {                                       // uniform
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 vv = *reinterpret_cast<const f32x4*>(Vs + tk * TA_LD + sub * 16 + 4 * c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[4 * c + e] = fmaf(pr[tk], vv[e], o[4 * c + e]);
+                }
+            }
+        }
+        if (tq < T) {
+            const float inv = 1.0f / l;
+            const long long row = (long long)(b * T + tq) * S + s;
+            if (out3) {
+                f16* op = out3 + row * 3 * C + h * 64 + sub * 16;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float v8[8] = {o[8 * c + 0] * inv, o[8 * c + 1] * inv, o[8 * c + 2] * inv, o[8 * c + 3] * inv,
+                                         o[8 * c + 4] * inv, o[8 * c + 5] * inv, o[8 * c + 6] * inv, o[8 * c + 7] * inv};
+                    f16x8 h8, l8;
+                    split_hl8(v8, h8, l8);
+                    *reinterpret_cast<f16x8*>(op + 8 * c) = h8;
+                    *reinterpret_cast<f16x8*>(op + C + 8 * c) = l8;
+                    if (VS_THIRD_PLANE(C)) *reinterpret_cast<f16x8*>(op + 2 * C + 8 * c) = h8;
+                }
+            } else {
+                float* op = out + row * C + h * 64 + sub * 16;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    *reinterpret_cast<f32x4*>(op + 4 * c) = f32x4{o[4 * c + 0] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv};
+            }
+        }
+    }
+}
+
 // fp32 columns [0, cols) of rows with stride ld  ->  fp16 planes hi = fp16(x), lo = fp16(x - hi), [rows][cols] each (cols % 4 == 0).
 // The K / V operands of k_x_attention_mfma: every key row is re-read by Nq / 128 query blocks, so it is split once here.
 __global__ void __launch_bounds__(256) k_x_split_planes(const float* __restrict__ x, int ld, long long rows, int cols, f16* __restrict__ hi,
@@ -432,13 +538,8 @@ __global__ void __launch_bounds__(256) k_x_split_planes(const float* __restrict_
     const int c = (int)(i4 - m * c4n) * 4;
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + m * ld + c);
     f16x4 h, l;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f16 a, b;
-        split_hl(v[j], a, b);
-        h[j] = a;
-        l[j] = b;
-    }
+    const float f[4] = {v[0], v[1], v[2], v[3]};
+    split_hl4(f, h, l);
     *reinterpret_cast<f16x4*>(hi + m * cols + c) = h;
     *reinterpret_cast<f16x4*>(lo + m * cols + c) = l;
 }
@@ -685,6 +786,7 @@ __global__ void __launch_bounds__(256, 2) k_x_attention_mfma(const float* __rest
     __syncthreads();
     f32x16 sA[2], sB[2];
     qk(0, sA);
+    __syncthreads();                                            // tile 0 ends by storing K(2) over K(0): every wave must be out of qk(0) first
     int t = 0;
     for (; t + 1 < ntiles; t += 2) {
         tile(P0{}, t, sA, sB);
@@ -702,13 +804,8 @@ __global__ void __launch_bounds__(256, 2) k_x_attention_mfma(const float* __rest
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f16x4 vh4, vl4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        f16 a, c;
-                        split_hl(oacc[i][g * 4 + e] * inv, a, c);
-                        vh4[e] = a;
-                        vl4[e] = c;
-                    }
+                    const float o4[4] = {oacc[i][g * 4 + 0] * inv, oacc[i][g * 4 + 1] * inv, oacc[i][g * 4 + 2] * inv, oacc[i][g * 4 + 3] * inv};
+                    split_hl4(o4, vh4, vl4);
                     f16* o = op + i * 32 + 8 * g + 4 * hi;
                     *reinterpret_cast<f16x4*>(o) = vh4;
                     *reinterpret_cast<f16x4*>(o + ldo) = vl4;
@@ -804,6 +901,27 @@ int vidseg_x_attention_f32(const float* q, int ldq, const float* k, int ldk, con
     return VS_OK;
 }
 
+int vidseg_x_temporal_attention(const float* qkv, int ld, int nvid, int T, int S, int H, float scale, float* out, void* out_split3,
+                                void* tap_q, void* tap_k, hipStream_t st) {
+    VS_REQUIRE(T >= 1 && T <= 16 && H >= 1 && ld % 4 == 0 && ld >= 3 * H * 64, "x_temporal_attention: T=%d (1..16) H=%d ld=%d", T, H, ld);
+    VS_REQUIRE((out != nullptr) != (out_split3 != nullptr), "x_temporal_attention: exactly one of out / out_split3");
+    VS_REQUIRE((tap_q != nullptr) == (tap_k != nullptr), "x_temporal_attention: q and k taps come together");
+    const long long nitems = (long long)nvid * S * H;
+    if (nitems == 0) return VS_OK;
+    VS_REQUIRE((long long)nvid * T * S < (1LL << 31), "x_temporal_attention: too many rows");
+    const size_t lds = (size_t)4 * (3 * T * TA_LD + 16 * TA_PLD) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_x_temporal_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (3 * 16 * TA_LD + 16 * TA_PLD) * 4);
+        attr = true;
+    }
+    const long long blocks = (nitems + 3) / 4;
+    const unsigned grid = (unsigned)(blocks < 256 * 3 ? blocks : 256 * 3);     // persistent: three resident blocks per CU
+    k_x_temporal_attention<<<dim3(grid), 256, lds, st>>>(qkv, ld, nvid, T, S, H, scale, out, (f16*)out_split3, (f16*)tap_q, (f16*)tap_k);
+    VS_CHECK_LAUNCH("x_temporal_attention");
+    return VS_OK;
+}
+
 int vidseg_x_split_planes(const float* x, int ld, long long rows, int cols, void* hi16, void* lo16, hipStream_t st) {
     VS_REQUIRE(cols % 4 == 0 && ld % 4 == 0 && cols <= ld, "x_split_planes: cols=%d ld=%d", cols, ld);
     if (rows * cols == 0) return VS_OK;
@@ -844,6 +962,9 @@ int vidseg_x_layernorm_split3(const float*, long long, int, const float*, const 
 }
 int vidseg_x_attention_f32(const float*, int, const float*, int, const float*, int, float*, int, int, int, int, int, float, hipStream_t) {
     X_UNSUPPORTED("x_attention_f32");
+}
+int vidseg_x_temporal_attention(const float*, int, int, int, int, int, float, float*, void*, void*, void*, hipStream_t) {
+    X_UNSUPPORTED("x_temporal_attention");
 }
 int vidseg_x_split_planes(const float*, int, long long, int, void*, void*, hipStream_t) { X_UNSUPPORTED("x_split_planes"); }
 int vidseg_x_attention_mfma(const float*, int, const void*, const void*, const void*, const void*, int, float*, void*, int, int, int, int, int,

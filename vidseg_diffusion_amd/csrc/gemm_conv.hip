@@ -60,6 +60,8 @@ struct GemmParams {
     int tap_T, tap_S;        // >0: taps are written in the reference's temporal layout [(b s), t, c] (row permutation)
     const float* rowadd;     // per-row scalar added to every column before the residual (attention-output modulation
                              // lambda*mask[:,None], attention.py:646-663, 697-719) or nullptr
+    const float* blend;      // exact VideoUNet: after the residual, v = blend_a * blend[m][n] + blend_b * v (AlphaBlender, diffusionmodules/util.py:343-380:
+    float blend_a, blend_b;  // alpha * x_spatial + (1 - alpha) * x_temporal with x_temporal = this GEMM's result); fp32 [M][ldo] or nullptr
     int geglu16;             // GEGLU weight rows interleaved in 16-row value | gate groups (k_gemm_p7x<4, true>) instead of 32-row ones
     int split2;              // exact mode: the operands are split images -- A rows [a_hi | a_lo | (unused)] with row stride 3 Cin, W rows
                              // [w_hi | w_hi | w_lo] in the usual K order over 3 * Cin channels (exact.py); k_gemm_p7x / k_gemm_phx stage each plane
@@ -145,6 +147,22 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
+// one 8-column cell of fp32 results -> the (hi, lo) cells of a split operand image: hi = fp16(x), lo = fp16(x - hi) (common.h)
+__device__ __forceinline__ void split_cell8(const float (&v)[8], f16x8& h8, f16x8& l8) {
+#if VIDSEG_ACT_IS_F16
+    split_hl8(v, h8, l8);
+#else
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float x = v[e];
+        asm volatile("" : "+v"(x));
+        const f16 hh = (f16)x;
+        h8[e] = hh;
+        l8[e] = (f16)(x - (float)hh);
+    }
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // Shared epilogue of the MFMA GEMM kernels: accumulators of a 64 x (NJ*32) wave tile -> global memory.
 // `wcol_base` = first GEMM column of the wave, `mrow_base` = first row of the wave.
@@ -163,7 +181,7 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 // next to the 140 live accumulators) and picks its cell's registers by the uniform loop counter.  One cell at a time, every cell
 // paid its own residual round trip (the load sits behind the tap stores, which the compiler must assume may alias it) -- with the 8
 // waves of a CU all in the epilogue nothing else covered those ~1000 cycles, 20 times per tile.
-template <int NC8, int EP_LD, int U_ = (32 * NC8 + 63) / 64, bool PRELOAD = true, bool X3 = false>
+template <int NC8, int EP_LD, int U_ = (32 * NC8 + 63) / 64, bool PRELOAD = true, bool X3 = false, bool XMODE = true>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* stage, int mrow0, int nrows, int ocol0, int nout, int lane,
                                               int split, bool fin, bool pre) {
     constexpr int U = PRELOAD ? U_ : 1;                        // without the preload: the plain one-cell-at-a-time loop
@@ -171,8 +189,14 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
     const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
     const int ncell = nrows * NC8;
     const bool res16 = PRELOAD && fin && p.residual && !p.res_f32;    // PRELOAD = false: kernels capped at 128 registers (4 blocks per CU)
+    // XMODE = false (k_gemm_ws: 16-bit operands only, at 256 registers): the round-5 additions of the exact mode -- the fp32 residual
+    // preload and the blend -- are compiled out (launch_gemm never sends such a launch there); with them, or with the other exact-mode
+    // outputs removed as well, that kernel's allocation tips into scratch, which its hand-counted waits cannot see (tests/test_cabi.py)
+    const bool res32 = XMODE && PRELOAD && fin && p.residual && p.res_f32;
+    // fp32 residuals are taken two cells at a time (16 registers; five at a time spilled next to the live accumulators)
+    const int Ueff = res32 ? (U < 2 ? U : 2) : U;
 #pragma nounroll
-    for (int cell0 = lane; cell0 < ncell; cell0 += 64 * U) {
+    for (int cell0 = lane; cell0 < ncell; cell0 += 64 * Ueff) {
         bf16x8_t rr0 = {0, 0, 0, 0, 0, 0, 0, 0}, rr1 = rr0, rr2 = rr0, rr3 = rr0, rr4 = rr0;
         if (res16) {
             auto ld = [&](int u, bf16x8_t& r) {
@@ -187,8 +211,25 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
             ld(3, rr3);
             ld(4, rr4);
         }
+        // the exact mode's fp32 residual the same way, two cells at a time (round 5): it used to be loaded inside the cell loop, one HBM
+        // round trip per cell with nothing to cover it -- 17.5 of them per wave and 224 x 320 tile
+        f32x4 fa0 = {0.f, 0.f, 0.f, 0.f}, fb0 = fa0, fa1 = fa0, fb1 = fa0;
+        if (res32) {
+            auto ld = [&](int u, f32x4& a, f32x4& b) {
+                const int cell = cell0 + 64 * u;
+                const int row = cell / NC8, c8 = (cell - row * NC8) * 8;
+                const int n = ocol0 + c8, m = mrow0 + row;
+                if (u < Ueff && cell < ncell && n < nout && m < (int)p.M) {
+                    const float* rp = reinterpret_cast<const float*>(p.residual) + (long long)m * p.ldr + n;
+                    a = *reinterpret_cast<const f32x4*>(rp);
+                    b = *reinterpret_cast<const f32x4*>(rp + 4);
+                }
+            };
+            ld(0, fa0, fb0);
+            ld(1, fa1, fb1);
+        }
 #pragma nounroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < Ueff; ++u) {
         const int cell = cell0 + 64 * u;
         if (cell >= ncell) continue;
         const int row = cell / NC8, c8 = (cell - row * NC8) * 8;
@@ -197,6 +238,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
         const int m = mrow0 + row;                              // rows fit 31 bits (M * ldo may not: 64-bit only in the pointer math)
         if (m >= (int)p.M) continue;
         float v[8];
+        f32x4 rres0 = {0.f, 0.f, 0.f, 0.f}, rres1 = rres0;
         const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + c8);
         const f32x4 hi4 = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + c8 + 4);
 #pragma unroll
@@ -266,6 +308,16 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
             const bf16x8_t rr = *reinterpret_cast<const bf16x8_t*>(p.residual + (long long)m * p.ldr + n);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
+        } else if (res32) {
+            f32x4 ra = fa0, rb = fb0;                           // u is uniform: scalar selects
+            if (u == 1) { ra = fa1; rb = fb1; }
+            rres0 = ra;
+            rres1 = rb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] += ra[e];
+                v[4 + e] += rb[e];
+            }
         } else if (p.residual) {
             const float* rp = reinterpret_cast<const float*>(p.residual) + (long long)m * p.ldr + n;
             const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
@@ -275,16 +327,22 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
                 v[4 + e] += r1[e];
             }
         }
-        if (p.plane_hi && n >= p.plane_col0) {                  // k | v columns of the fused projection: the attention's operand planes
-            f16x8 h8, l8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float x = v[e];
-                asm volatile("" : "+v"(x));                     // one fp32 value for both lines (see exact_ops.hip: split_hl)
-                const f16 hh = (f16)x;
-                h8[e] = hh;
-                l8[e] = (f16)(x - (float)hh);
+        if (XMODE && p.blend) {                                 // AlphaBlender on the finished value (exact VideoUNet)
+            const float* bp = p.blend + (long long)m * p.ldo + n;
+            f32x4 s0 = rres0, s1 = rres1;
+            if (!(res32 && bp == reinterpret_cast<const float*>(p.residual) + (long long)m * p.ldr + n)) {   // VideoResBlock: blend source == skip source
+                s0 = *reinterpret_cast<const f32x4*>(bp);
+                s1 = *reinterpret_cast<const f32x4*>(bp + 4);
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = p.blend_a * s0[e] + p.blend_b * v[e];
+                v[4 + e] = p.blend_a * s1[e] + p.blend_b * v[4 + e];
+            }
+        }
+        if (p.plane_hi && n >= p.plane_col0) {         // k | v columns of the fused projection: the attention's operand planes
+            f16x8 h8, l8;
+            split_cell8(v, h8, l8);
             const long long po = (long long)m * p.plane_ld + (n - p.plane_col0);
             *reinterpret_cast<f16x8*>(p.plane_hi + po) = h8;
             *reinterpret_cast<f16x8*>(p.plane_lo + po) = l8;
@@ -301,16 +359,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
             *reinterpret_cast<f32x4*>(p.out_f32 + oo) = f32x4{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(p.out_f32 + oo + 4) = f32x4{v[4], v[5], v[6], v[7]};
         }
-        if (p.out_split3) {                                     // exact mode: the result as the next GEMM's split operand image
+        if (p.out_split3) {                            // exact mode: the result as the next GEMM's split operand image
             f16x8 h8, l8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float x = v[e];
-                asm volatile("" : "+v"(x));                     // one fp32 value for both lines (see exact_ops.hip: split_hl)
-                const f16 hh = (f16)x;
-                h8[e] = hh;
-                l8[e] = (f16)(x - (float)hh);
-            }
+            split_cell8(v, h8, l8);
             f16* o3 = p.out_split3 + (long long)m * 3 * p.ldo + n;
             *reinterpret_cast<f16x8*>(o3) = h8;
             *reinterpret_cast<f16x8*>(o3 + p.ldo) = l8;
@@ -359,9 +410,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if constexpr (X3) {                 // the exact mode's GELU: libm erf, the operation order of k_x_geglu_split3
+                        if constexpr (X3) {                 // the exact mode's GELU: erf_f32 (common.h), the operation order of k_x_geglu_split3
                             const float gt = acc[ki][2 * kg + 1][r] + bg;
-                            stage[row * EP_LD + l31] = (acc[ki][2 * kg][r] + bx) * (0.5f * gt * (1.0f + erff(gt * 0.70710678118654752440f)));
+                            stage[row * EP_LD + l31] = (acc[ki][2 * kg][r] + bx) * (0.5f * gt * (1.0f + erf_f32(gt * 0.70710678118654752440f)));
                         } else {
                             stage[row * EP_LD + l31] = (acc[ki][2 * kg][r] + bx) * gelu_erf(acc[ki][2 * kg + 1][r] + bg);
                         }
@@ -1162,7 +1213,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ph(GemmParams p) {
 // ---------------------------------------------------------------------------------------------
 // Phase 2 of the GEGLU projection on 16-wide fragments (k_gemm_p7x<4, true>): fragment columns (2 jj, 2 jj + 1) of a wave tile hold value
 // and gate of the same 16 output columns (weight rows interleaved in 16-row value | gate groups, exact.pack_geglu_x), staged side by
-// side.  A lane takes 8 consecutive product columns of one row per pass: (value + b) * gelu(gate + b) with libm's erf in the operation
+// side.  A lane takes 8 consecutive product columns of one row per pass: (value + b) * gelu(gate + b) with erf_f32 (common.h) in the operation
 // order of k_x_geglu_split3, split into (hi, lo) and written as the consumer's operand image [hi | lo | hi].  A rolled loop of 8 erf
 // per pass: formed while staging (16 inlined erf per fragment pair, unrolled over the groups) it spilled into scratch.
 template <int NJ, int EP_LD>
@@ -1188,15 +1239,13 @@ __device__ __forceinline__ void epilogue_rows_geglu16(const GemmParams& p, const
             g1 += bg1;
         }
         f16x8 h8, l8;
+        float pr[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float gt = e < 4 ? g0[e & 3] : g1[e & 3];
-            float x = (e < 4 ? v0[e & 3] : v1[e & 3]) * (0.5f * gt * (1.0f + erff(gt * 0.70710678118654752440f)));
-            asm volatile("" : "+v"(x));                         // one fp32 value for both lines (see exact_ops.hip: split_hl)
-            const f16 hh = (f16)x;
-            h8[e] = hh;
-            l8[e] = (f16)(x - (float)hh);
+            pr[e] = (e < 4 ? v0[e & 3] : v1[e & 3]) * (0.5f * gt * (1.0f + erf_f32(gt * 0.70710678118654752440f)));
         }
+        split_cell8(pr, h8, l8);                                // one fp32 value for both planes (common.h: split_hl)
         f16* o3 = p.out_split3 + (long long)m * 3 * p.ldo + (wcol_base >> 1) + pc;
         *reinterpret_cast<f16x8*>(o3) = h8;
         *reinterpret_cast<f16x8*>(o3 + p.ldo) = l8;
@@ -2020,16 +2069,18 @@ __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rr[e]);
     }
+    if (p.blend) {                                              // as in epilogue_rows
+        const float* bp = p.blend + (long long)m * p.ldo + n;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(bp), s1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = p.blend_a * s0[e] + p.blend_b * v[e];
+            v[4 + e] = p.blend_a * s1[e] + p.blend_b * v[4 + e];
+        }
+    }
     if (p.plane_hi && n >= p.plane_col0) {                      // as in epilogue_rows
         f16x8 h8, l8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float x = v[e];
-            asm volatile("" : "+v"(x));
-            const f16 hh = (f16)x;
-            h8[e] = hh;
-            l8[e] = (f16)(x - (float)hh);
-        }
+        split_cell8(v, h8, l8);
         const long long po = (long long)m * p.plane_ld + (n - p.plane_col0);
         *reinterpret_cast<f16x8*>(p.plane_hi + po) = h8;
         *reinterpret_cast<f16x8*>(p.plane_lo + po) = l8;
@@ -2048,14 +2099,7 @@ __global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
     }
     if (p.out_split3) {                                        // as in epilogue_rows
         f16x8 h8, l8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float x = v[e];
-            asm volatile("" : "+v"(x));
-            const f16 hh = (f16)x;
-            h8[e] = hh;
-            l8[e] = (f16)(x - (float)hh);
-        }
+        split_cell8(v, h8, l8);
         f16* o3 = p.out_split3 + (long long)m * 3 * p.ldo + n;
         *reinterpret_cast<f16x8*>(o3) = h8;
         *reinterpret_cast<f16x8*>(o3 + p.ldo) = l8;
@@ -2578,7 +2622,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(GemmParams p, int np, int cp
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                epilogue_rows<NJ * 2, EP_LD, (8 * NJ * 2 + 63) / 64>(p, stage, t * 32 + 16 * i + 8 * h, 8, pbase, p.N, lane, 0, true, true);
+                epilogue_rows<NJ * 2, EP_LD, (8 * NJ * 2 + 63) / 64, true, false, false>(p, stage, t * 32 + 16 * i + 8 * h, 8, pbase, p.N, lane, 0, true, true);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -2783,6 +2827,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         VS_REQUIRE(p.ksize == 1 && p.plane_lo && p.act == 0 && p.plane_col0 % 8 == 0 && p.plane_ld % 8 == 0 && p.plane_col0 > 0 &&
                        p.plane_col0 < p.N && p.N - p.plane_col0 <= p.plane_ld && !p.residual,
                    "gemm: k | v planes need a plain linear, plane_col0 / plane_ld multiples of 8");
+    if (p.blend) VS_REQUIRE(p.act != 2 && !p.plane_hi && (p.out_f32 || p.out_split3) && !p.out, "gemm: the blend epilogue belongs to fp32 / split-image results");
     if (p.out_split3 && p.act != 2)                            // a plain linear writing its consumer's operand image: any kernel below
         VS_REQUIRE(p.ksize == 1 && !p.out && !p.out_f32 && p.N % 8 == 0 && (p.ldo % 8) == 0, "gemm: split3 output needs a plain linear, N %% 8 == 0");
     if (p.out_split3 && p.act == 2) {                          // exact mode's GEGLU projection: always the 256 x 256 phased tile
@@ -2820,6 +2865,8 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     const int ws_np = p.N / ws_bn;
     const bool ws_ok = ws_mode && ws_fits && p.ksize == 1 && !p.x1 && p.C1 == 0 && p.C0 == p.K && (p.K == 320 || p.K == 640) && p.act != 2 &&
                        p.tmode == 0 && p.N % ws_bn == 0 && ws_np >= 1 && ws_np <= 32 && (32 % ws_np) <= 2 &&
+                       !p.split2 && !p.res_f32 && !p.blend && !p.plane_hi && !p.out_split3 &&   // its epilogue has no exact-mode outputs
+                      
                        (ws_mode == 2 || (p.M >= 16384 && p.K == 320));     // VIDSEG_GEMM_WS=2: whenever legal (tests); K = 640 is
                                                                             // slower than k_gemm_p7 so far (28672x640x640: 54 vs 44 us)
     if (ws_ok) {
@@ -3024,6 +3071,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         double ab = (double)p.x0_bytes + (double)p.x1_bytes + 2.0 * (double)p.N * (double)p.K;
         if (p.split2) ab *= 2.0 / 3.0;                           // two distinct planes per operand: (a_hi, a_lo) and (w_hi, w_lo)
         if (p.residual) ab += (p.res_f32 ? 4.0 : 2.0) * (double)p.M * n_out;
+        if (p.blend && p.blend != reinterpret_cast<const float*>(p.residual)) ab += 4.0 * (double)p.M * n_out;
         if (p.out) ab += 2.0 * (double)p.M * n_out;
         if (p.out_f32) ab += 4.0 * (double)p.M * (p.plane_hi ? p.plane_col0 : n_out);
         if (p.plane_hi) ab += 4.0 * (double)p.M * (n_out - p.plane_col0);
@@ -3107,6 +3155,38 @@ int vidseg_linear_a16_rf32(const void* a, int K, long long M, const void* w, int
     p.tap_ld = tap_ld;
     p.act = act;
     p.split2 = 1;                                              // the operands of this entry point ARE split images (header)
+    return launch_gemm(p, st);
+}
+
+// vidseg_linear_a16_rf32 followed, inside the epilogue, by the VideoUNet's AlphaBlender (diffusionmodules/util.py:343-380 with
+// image_only_indicator = 0): out = alpha * blend + (1 - alpha) * (a . w^T + bias + rowvec + residual).  The time stack's last linear
+// (video_attention.py:281 -> :470-476) writes the mixed stream itself; the fp32 pass over three tensors that did it is gone.
+int vidseg_linear_a16_rf32_blend(const void* a, int K, long long M, const void* w, int N, const float* bias, const float* residual_f32, int ldr,
+                                 const float* blend_f32, float alpha, float* out_f32, hipStream_t st) {
+    VS_REQUIRE(out_f32 != nullptr && blend_f32 != nullptr && (!residual_f32 || ldr % 8 == 0), "linear_rf32_blend: needs out, blend, ldr %% 8 == 0");
+    GemmParams p{};
+    p.x0 = (const bf16_t*)a;
+    p.C0 = K;
+    p.ksize = 1;
+    p.stride = 1;
+    p.up = 1;
+    p.Hin = p.Win = p.Hout = p.Wout = 1;
+    p.w = (const bf16_t*)w;
+    p.N = N;
+    p.K = K;
+    p.M = M;
+    p.x0_bytes = M * K * 2;
+    p.bias = bias;
+    p.rows_per_sample = 1;
+    p.residual = (const bf16_t*)residual_f32;
+    p.res_f32 = 1;
+    p.ldr = ldr;
+    p.out_f32 = out_f32;
+    p.ldo = N;
+    p.blend = blend_f32;
+    p.blend_a = alpha;
+    p.blend_b = 1.0f - alpha;
+    p.split2 = 1;
     return launch_gemm(p, st);
 }
 
@@ -3257,7 +3337,7 @@ int vidseg_linear_a16_ttap(const void* a0, long long M, int C0, const void* w, i
 // w packed [Cout][c/64][dt][c%64] (chunk-major K order, see GemmParams), + bias + per-sample emb vector + residual.
 static int conv_temporal3_impl(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
                                const float* rowvec, int rv_stride, const void* residual, void* out, float* out_f32, hipStream_t st,
-                               int split2 = 0) {
+                               int split2 = 0, int res_f32 = 0, const float* blend = nullptr, float alpha = 0.f) {
     VS_REQUIRE(T >= 1 && BT % T == 0, "conv_temporal3: BT=%d T=%d", BT, T);
     GemmParams p{};
     p.x0 = (const bf16_t*)x;
@@ -3284,6 +3364,10 @@ static int conv_temporal3_impl(const void* x, int C, int BT, int HW, int T, cons
     p.out_f32 = out_f32;
     p.ldo = Cout;
     p.split2 = split2;
+    p.res_f32 = res_f32;
+    p.blend = blend;
+    p.blend_a = alpha;
+    p.blend_b = 1.0f - alpha;
     return launch_gemm(p, st);
 }
 
@@ -3296,6 +3380,14 @@ int vidseg_conv_temporal3_a16_f32(const void* x, int C, int BT, int HW, int T, c
                                    const float* rowvec, int rv_stride, float* out_f32, hipStream_t st) {
     VS_REQUIRE(out_f32 != nullptr, "conv_temporal3_f32: output is null");
     return conv_temporal3_impl(x, C, BT, HW, T, w, Cout, bias, rowvec, rv_stride, nullptr, nullptr, out_f32, st, 1);   // split images (header)
+}
+
+// VideoResBlock's tail in one launch (video_model.py:66-89): the second [3,1,1] convolution of the time stack + its fp32 skip
+// (`x + h`, openaimodel.py:369) + the AlphaBlender: out = alpha * blend + (1 - alpha) * (conv + bias + residual).
+int vidseg_conv_temporal3_a16_f32_blend(const void* x, int C, int BT, int HW, int T, const void* w, int Cout, const float* bias,
+                                         const float* residual_f32, const float* blend_f32, float alpha, float* out_f32, hipStream_t st) {
+    VS_REQUIRE(out_f32 != nullptr && blend_f32 != nullptr, "conv_temporal3_f32_blend: needs out and blend");
+    return conv_temporal3_impl(x, C, BT, HW, T, w, Cout, bias, nullptr, 0, residual_f32, nullptr, out_f32, st, 1, 1, blend_f32, alpha);
 }
 
 // 3x3 convolution, padding 1, NHWC bf16 activations, weight packed [Cout][c/64][kh*3+kw][c%64] (chunk-major K order).

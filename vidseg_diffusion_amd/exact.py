@@ -46,10 +46,13 @@ _lib.register({
     "vidseg_x_layernorm_split3": [_P, _L, _I, _P, _P, _F, _P, _P],
     "vidseg_x_attention_f32": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     "vidseg_x_split_planes": [_P, _I, _L, _I, _P, _P, _P],
+    "vidseg_x_temporal_attention": [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],
     "vidseg_x_attention_mfma": [_P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "vidseg_conv_in_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "vidseg_x_add_rowvec_f32": [_P, _P, _L, _I, _I, _I, _P, _P],
     "vidseg_conv_temporal3_a16_f32": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P],
+    "vidseg_linear_a16_rf32_blend": [_P, _I, _L, _P, _I, _P, _P, _I, _P, _F, _P, _P],
+    "vidseg_conv_temporal3_a16_f32_blend": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _F, _P, _P],
 })
 
 F32, F16 = torch.float32, torch.float16
@@ -208,6 +211,27 @@ def attention_mfma(q, kv, heads, B, Nq, Nk, split_out=False, planes=None):
     return out
 
 
+def temporal_attention_x(qkv, nvid, T, S, heads, split_out=True, tap_q=None, tap_k=None):
+    """The time stack's self-attention (video_attention.py:171-199) on the fused projection qkv fp32 [(b t), S, 3C] IN the spatial row
+    order: softmax(q k^T / 8) v over the T frames of every (video, location, head); returns [(b t), S, C] fp32 or, split_out, the output
+    projection's operand image [(b t), S, 3C].  tap_q / tap_k: fp16 [(b s), T, C] buffers for the reference's dumps (attention.py:330-331)."""
+    C = heads * 64
+    if qkv.dtype != F32 or not qkv.is_contiguous() or qkv.shape[-1] != 3 * C or qkv.numel() != nvid * T * S * 3 * C:
+        raise VidsegError("temporal_attention_x: qkv must be a contiguous fp32 [(b t), S, 3 * heads * 64] tensor")
+    out = _image((nvid * T, S, 3 * C), qkv.device) if split_out else torch.empty((nvid * T, S, C), dtype=F32, device=qkv.device)
+    call("vidseg_x_temporal_attention", ptr(qkv), 3 * C, nvid, T, S, heads, 0.125, None if split_out else ptr(out), ptr(out) if split_out else None,
+         ptr(tap_q), ptr(tap_k), stream())
+    return out
+
+
+_TEMPORAL_FUSED = os.environ.get("VIDSEG_X_TEMPORAL", "1") != "0"    # 0: permuted copies + k_x_attention_f32 (the pre-round-5 path)
+# Attention over ONE key is the identity on v: softmax of a single score is exp(0) / 1 = 1.0 exactly, whatever q is, and 1.0 * v = v.
+# SVD's cross-attentions see a one-token context (the CLIP image embedding, svd_pipeline_vspw.py:300-311), so there norm2, to_q and the
+# attention itself produce nothing the output depends on: x + to_out(v) is a per-sample row vector added to every token, taken
+# along by the preceding output projection's epilogue.  VIDSEG_X_NK1=0 evaluates those layers in full (tests compare the two).
+_NK1_IDENTITY = os.environ.get("VIDSEG_X_NK1", "1") != "0"
+
+
 _MFMA_MIN_Q = int(os.environ.get("VIDSEG_X_ATTN_MFMA_MINQ", "128"))   # below: k_x_attention_f32 (the 14-frame temporal attention); 0 disables
 
 
@@ -293,6 +317,38 @@ def conv_temporal3_x(x3, w3, bias, T, *, rowvec=None):
     return out
 
 
+def linear_blend_x(a3, w3, bias, residual, blend_src, alpha):
+    """alpha * blend_src + (1 - alpha) * (a . w^T + bias + residual) in ONE launch: the time stack's last linear writing the
+    AlphaBlender's result (video_attention.py:281, :470-476; diffusionmodules/util.py:343-380).  fp32 [.., N]."""
+    ops.workspace(a3.device)
+    K3 = a3.shape[-1]
+    M = a3.numel() // K3
+    N = w3.shape[0]
+    for t in (residual, blend_src):
+        if t.dtype != F32 or t.numel() != M * N or not t.is_contiguous():
+            raise VidsegError("linear_blend_x: residual / blend_src must be contiguous fp32 [.., N] tensors")
+    out = torch.empty(a3.shape[:-1] + (N,), dtype=F32, device=a3.device)
+    call("vidseg_linear_a16_rf32_blend", ptr(a3), K3, M, ptr(w3), N, ptr(bias), ptr(residual), N, ptr(blend_src), float(alpha), ptr(out), stream())
+    return out
+
+
+def conv_temporal3_blend_x(x3, w3, bias, T, residual, blend_src, alpha):
+    """alpha * blend_src + (1 - alpha) * (temporal conv + bias + residual): VideoResBlock's tail (video_model.py:66-89) in one launch."""
+    ops.workspace(x3.device)
+    BT, H, W, C3 = x3.shape
+    Cout = w3.shape[0]
+    for t in (residual, blend_src):
+        if t.dtype != F32 or t.numel() != BT * H * W * Cout or not t.is_contiguous():
+            raise VidsegError("conv_temporal3_blend_x: residual / blend_src must be contiguous fp32 tensors of the output's shape")
+    out = torch.empty((BT, H, W, Cout), dtype=F32, device=x3.device)
+    call("vidseg_conv_temporal3_a16_f32_blend", ptr(x3), C3, BT, H * W, T, ptr(w3), Cout, ptr(bias), ptr(residual), ptr(blend_src), float(alpha),
+         ptr(out), stream())
+    return out
+
+
+_BLEND_FUSED = os.environ.get("VIDSEG_X_BLEND", "1") != "0"          # 0: separate axpy passes (the pre-round-5 path)
+
+
 def add_rowvec(x, vec, rows_per_sample):
     """x[(sample, row), :] + vec[sample % len(vec), :] in fp32."""
     C = x.shape[-1]
@@ -308,6 +364,10 @@ def add(a, b):
 def blend(a, b, alpha):
     """alpha * a + (1 - alpha) * b (AlphaBlender with image_only_indicator = 0, diffusionmodules/util.py:343-380), fp32."""
     return ops.axpy(a, b, (1.0 - alpha) / alpha, alpha)
+
+
+class _Slot:
+    """Holder for one ops.window_cached value."""
 
 
 # ----------------------------------------------------------------------------- the network
@@ -387,6 +447,8 @@ class ExactRunner:
             self.le = (pack_linear_x(le[0].weight, d), f(le[0].bias), pack_linear_x(le[2].weight, d), f(le[2].bias))
         self._temb = {}
         self._temb_dev = {}
+        self._nk1 = {}
+        self._kv = {}
         rbs = net._resblocks()
         off = 0
         self.emb_off = {}
@@ -429,6 +491,8 @@ class ExactRunner:
         h = groupnorm_split3(x.view(BT // T, T * H, W, C), ts["g1"], ts["b1"], eps=1e-5, silu=True).view(BT, H, W, 3 * C)
         h = conv_temporal3_x(h, ts["w1"], ts["cb1"], T, rowvec=rv)
         h = groupnorm_split3(h.view(BT // T, T * H, W, C), ts["g2"], ts["b2"], eps=1e-5, silu=True).view(BT, H, W, 3 * C)
+        if _BLEND_FUSED:                                                            # skip add + AlphaBlender inside the conv's epilogue
+            return conv_temporal3_blend_x(h, ts["w2"], ts["cb2"], T, x, x, e["alpha"])
         h = add(conv_temporal3_x(h, ts["w2"], ts["cb2"], T), x)
         return blend(x, h, e["alpha"])
 
@@ -452,34 +516,64 @@ class ExactRunner:
             self._temb[key] = linear_x(split3(linear_x(split3(te), w1, b1, act=ops.ACT_SILU)), w2, b2)
         return self._temb[key]
 
-    def time_block(self, tb, bw, x, tctx3, T, dump):
+    def single_key_out(self, bw, ctx3, Ci):
+        """to_out(v) of a cross-attention whose context holds ONE token (see _NK1_IDENTITY): fp32 [B, C], a pure function of the
+        step-constant context -- computed once per window."""
+        def make():
+            kv = linear_x(ctx3, bw["w_kv"])                                                         # [B, 1, 2 Ci]
+            v = kv[:, 0, Ci:].contiguous()
+            return linear_x(split3(v), bw["w_o2"], bw["b_o2"])
+        slot = self._nk1.setdefault(id(bw), _Slot())
+        return ops.window_cached(slot, "val", (ctx3,), make)
+
+    def time_block(self, tb, bw, x, tctx3, T, dump, blend_src=None, alpha=None):
         """VideoTransformerBlock._forward (video_attention.py:145-285) on rows kept in the spatial order (b t) s: ff_in, temporal
-        self-attention over the T frames of every (video, location), cross-attention to the first frame's context, ff."""
+        self-attention over the T frames of every (video, location), cross-attention to the first frame's context, ff.
+        blend_src / alpha: the caller's AlphaBlender (VA:470-476) applied by the last linear's epilogue."""
         BT, S, C = x.shape
         b = BT // T
         heads = tb.attn1.heads
         g3 = self.geglu(layernorm_split3(x, *bw["ln"]["norm_in"]), bw, "w_fi1", "b_fi1", "fi1g")     # VA:155-159
         x = linear_x(g3, bw["w_fi2"], bw["b_fi2"], residual=x)
-        qkv = linear_x(layernorm_split3(x, *bw["ln"]["norm1"]), bw["w_qkv"])                          # [(b t), S, 3C]
-        # (b t) s c -> (b s) t c (VA:171); .contiguous(): with ONE video (the taps-only evaluation of the conditional half) the reshape
-        # alone is a strided view, and the kernels take batches at Nq * ld
-        tqkv = qkv.view(b, T, S, 3 * C).permute(0, 2, 1, 3).contiguous().view(b * S, T, 3 * C)
-        a = attention_x(tqkv[..., :C], tqkv[..., C:], heads, b * S, T, T)
-        a = a.view(b, S, T, C).permute(0, 2, 1, 3).contiguous().view(BT, S, C)
-        if dump:
-            tb.attn1.q, tb.attn1.k = tqkv[..., :C].half(), tqkv[..., C:2 * C].half()                  # the reference's [(b s), t, c] layout
-        x = linear_x(split3(a), bw["w_o1"], bw["b_o1"], residual=x)                                  # VA:197-218
         L = tctx3.shape[1]
-        q2 = linear_x(layernorm_split3(x, *bw["ln"]["norm2"]), bw["w_q"])
-        tk = torch.empty((b, L, C), dtype=F16, device=x.device) if dump else None
-        kv = linear_x(tctx3, bw["w_kv"], tap=tk, tap_cols=C)
-        a23 = attention_x(q2.view(b, T * S, C), kv, heads, b, T * S, L, split_out=True)       # VA:224-250
-        x = linear_x(a23.view(BT, S, 3 * C), bw["w_o2"], bw["b_o2"], residual=x)
-        if dump:
-            tb.attn2.q = q2.view(b, T, S, C).permute(0, 2, 1, 3).contiguous().view(b * S, T, C).half()
-            tb.attn2.k = tk[:, None].expand(b, S, L, C).reshape(b * S, L, C)
+        nk1 = _NK1_IDENTITY and L == 1
+        cv = self.single_key_out(bw, tctx3, C) if nk1 else None                                      # [b, C]
+        fold = nk1 and not dump                                      # the cross-attention's row vector rides on attn1's output projection
+        qkv = linear_x(layernorm_split3(x, *bw["ln"]["norm1"]), bw["w_qkv"])                          # [(b t), S, 3C]
+        if _TEMPORAL_FUSED and T <= 16:
+            tq = torch.empty((b * S, T, C), dtype=F16, device=x.device) if dump else None
+            tk = torch.empty((b * S, T, C), dtype=F16, device=x.device) if dump else None
+            a3 = temporal_attention_x(qkv, b, T, S, heads, split_out=True, tap_q=tq, tap_k=tk)       # VA:171-199 without the rearranges
+            if dump:
+                tb.attn1.q, tb.attn1.k = tq, tk                                                      # the reference's [(b s), t, c] layout
+        else:
+            # (b t) s c -> (b s) t c (VA:171); .contiguous(): with ONE video (the taps-only evaluation of the conditional half) the reshape
+            # alone is a strided view, and the kernels take batches at Nq * ld
+            tqkv = qkv.view(b, T, S, 3 * C).permute(0, 2, 1, 3).contiguous().view(b * S, T, 3 * C)
+            a = attention_x(tqkv[..., :C], tqkv[..., C:], heads, b * S, T, T)
+            a3 = split3(a.view(b, S, T, C).permute(0, 2, 1, 3).contiguous().view(BT, S, C))
+            if dump:
+                tb.attn1.q, tb.attn1.k = tqkv[..., :C].half(), tqkv[..., C:2 * C].half()
+        x = linear_x(a3, bw["w_o1"], bw["b_o1"], residual=x, rowvec=cv if fold else None, rows_per_sample=T * S)   # VA:197-218
+        if not fold:
+            tk = torch.empty((b, L, C), dtype=F16, device=x.device) if dump else None
+            if nk1:                                                  # dump evaluation: q2 exists for its tap only
+                q2 = linear_x(layernorm_split3(x, *bw["ln"]["norm2"]), bw["w_q"])
+                linear_x(tctx3, bw["w_kv"], tap=tk, tap_cols=C)
+                x = add_rowvec(x, cv, T * S)
+            else:
+                q2 = linear_x(layernorm_split3(x, *bw["ln"]["norm2"]), bw["w_q"])
+                kv = linear_x(tctx3, bw["w_kv"], tap=tk, tap_cols=C)
+                a23 = attention_x(q2.view(b, T * S, C), kv, heads, b, T * S, L, split_out=True)       # VA:224-250
+                x = linear_x(a23.view(BT, S, 3 * C), bw["w_o2"], bw["b_o2"], residual=x)
+            if dump:
+                tb.attn2.q = q2.view(b, T, S, C).permute(0, 2, 1, 3).contiguous().view(b * S, T, C).half()
+                tb.attn2.k = tk[:, None].expand(b, S, L, C).reshape(b * S, L, C)
         g3 = self.geglu(layernorm_split3(x, *bw["ln"]["norm3"]), bw, "w_ff1", "b_ff1", "ff1g")        # VA:252-281
-        return linear_x(g3, bw["w_ff2"], bw["b_ff2"], residual=x)
+        if blend_src is not None and _BLEND_FUSED:
+            return linear_blend_x(g3, bw["w_ff2"], bw["b_ff2"], x, blend_src, alpha)
+        out = linear_x(g3, bw["w_ff2"], bw["b_ff2"], residual=x)
+        return out if blend_src is None else blend(blend_src, out, alpha)
 
     def transformer(self, m, x, ctx3, tap):
         e = self.w[self.names[id(m)]]
@@ -499,27 +593,37 @@ class ExactRunner:
             else:
                 qkv = linear_x(layernorm_split3(t, *bw["ln"][0]), bw["w_qkv"], tap=tq, tap2=tk, tap_cols=Ci)
                 a3 = attention_x(qkv[..., :Ci], qkv[..., Ci:], heads, B, N, N, split_out=True)
-            t = linear_x(a3, bw["w_o1"], bw["b_o1"], residual=t)
+            L = ctx3.shape[1]
+            nk1 = _NK1_IDENTITY and L == 1                                                             # one-token context: attention = identity on v
+            cv = self.single_key_out(bw, ctx3, Ci) if nk1 else None                                    # [B, C] = to_out(v)
+            fold = nk1 and not dump
+            t = linear_x(a3, bw["w_o1"], bw["b_o1"], residual=t, rowvec=cv if fold else None, rows_per_sample=N)
             if dump:
                 blk.attn1.q, blk.attn1.k = tq, tk
             # cross-attention to the (step-constant) context (ATT:689-726)
-            L = ctx3.shape[1]
-            tq = torch.empty((B, N, Ci), dtype=F16, device=x.device) if dump else None
-            q = linear_x(layernorm_split3(t, *bw["ln"][1]), bw["w_q"], tap=tq, tap_cols=Ci)
-            tk = torch.empty((B, L, Ci), dtype=F16, device=x.device) if dump else None
-            kv = linear_x(ctx3, bw["w_kv"], tap=tk, tap_cols=Ci)
-            a3 = attention_x(q, kv, heads, B, N, L, split_out=True)
-            t = linear_x(a3, bw["w_o2"], bw["b_o2"], residual=t)
-            if dump:
-                blk.attn2.q, blk.attn2.k = tq, tk
+            if not fold:
+                tq = torch.empty((B, N, Ci), dtype=F16, device=x.device) if dump else None
+                q = linear_x(layernorm_split3(t, *bw["ln"][1]), bw["w_q"], tap=tq, tap_cols=Ci)
+                tk = torch.empty((B, L, Ci), dtype=F16, device=x.device) if dump else None
+                if dump:
+                    kv = linear_x(ctx3, bw["w_kv"], tap=tk, tap_cols=Ci)
+                else:                                                  # to_k | to_v of the step-constant context: once per window (ATT:317-322)
+                    kv = ops.window_cached(self._kv.setdefault(id(bw), _Slot()), "val", (ctx3,), lambda: linear_x(ctx3, bw["w_kv"]))
+                if nk1:                                                                                # dump evaluation: q exists for its tap only
+                    t = add_rowvec(t, cv, N)
+                else:
+                    a3 = attention_x(q, kv, heads, B, N, L, split_out=True)
+                    t = linear_x(a3, bw["w_o2"], bw["b_o2"], residual=t)
+                if dump:
+                    blk.attn2.q, blk.attn2.k = tq, tk
             # GEGLU feed-forward (ATT:728-757, :89-115)
             g3 = self.geglu(layernorm_split3(t, *bw["ln"][2]), bw, "w_ff1", "b_ff1", "ff1g")
             last = i == len(e["blocks"]) - 1 and "time" not in e                                      # t's only consumer is proj_out
             t = linear_x(g3, bw["w_ff2"], bw["b_ff2"], residual=t, split_out=last)
             if "time" in e:                                                                            # VA:429-476
                 T = self.T
-                tm = self.time_block(m.time_stack[i], e["time"][i], add_rowvec(t, self.frame_emb(m, e, T), N), self.tctx3, T, dump)
-                t = blend(t, tm, e["alpha"])
+                t = self.time_block(m.time_stack[i], e["time"][i], add_rowvec(t, self.frame_emb(m, e, T), N), self.tctx3, T, dump,
+                                    blend_src=t, alpha=e["alpha"])
         out = linear_x(t if t.dtype == F16 else split3(t), e["w_out"], e["b_out"], residual=x.view(B, N, C))   # ATT:921-927
         return out.view(B, H, W, C)
 
