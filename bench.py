@@ -28,7 +28,10 @@ Prints ONE JSON line (rank 0).  Extra objects:
   cpu_baseline  the oracle ("port") timed on this box's host cores on a bounded sample (see `sample`), CPU model stated.
   mask_iou_vs_reference  the metric's second half on THIS config: masks of the timed run vs the reference's fp32 masks.
   chained_window  throughput when the windows are chained like one long clip (windows > 0: 14336^2 4-NN instead of K-means).
-  two_lanes     throughput with two feature passes in flight (--lanes 2); the headline keeps one so that per-launch times are clean.
+  single_lane   throughput with ONE feature pass in flight (the headline runs two, --lanes 2); the pass the roofline's per-launch HIP
+                events are recorded in, right after the timed region.
+  roofline_post_unet  the post-UNet kernels alone at the headline's sizes: bytes / time against 8 TB/s (k_mean_normalize, one Lloyd
+                E-step, 4-NN, dense tracking), the float64 contractions also against the f64 MFMA peak.
   full_schedule / fast_mode   the other precision / schedule modes on the same windows (see above), with their mask scores.
   secondary     BASELINE configs[2] (SVD 14x576x1024, t_start 17, refinement) measured after the headline, fewer steps, same
                 precision mode (+ its own fast_mode).
@@ -48,6 +51,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("VIDSEG_KEEP_LAST", "1")     # analysis.LAST_KMEANS: the ten restarts of every timed window (references only, read after the timing)
 
 F_WIN, LAT, NUM_STEPS = 14, 64, 25
 GOLDEN_C2 = os.path.join(ROOT, "tests", "golden", "c2_window.npz")
@@ -133,9 +137,11 @@ def timed_masks_vs_reference(timed, refine, k_masks, world=1, last_step_index=No
     from tools_metrics import matched_iou
     if k_masks != 20 or not timed:
         return None
+    from tools_metrics import P0, binom_min_successes, wilson
     per, first, same = {}, {}, True
-    for w, lab in timed:
-        lab = np.asarray(lab).reshape(-1)
+    for rec in timed:
+        w, lab = rec[0], np.asarray(rec[1]).reshape(-1)
+        runs = rec[2] if len(rec) > 2 else None
         if w in first:
             same = same and np.array_equal(first[w], lab)
             continue
@@ -146,13 +152,23 @@ def timed_masks_vs_reference(timed, refine, k_masks, world=1, last_step_index=No
         g = np.load(path)
         iou, exact = matched_iou(lab, g["corrected_labels" if refine else "match_labels"].astype(np.int64).reshape(-1), k_masks)
         per[w] = {"window": w, "iou": round(float(iou), 4), "identical_fraction": round(float(exact), 4)}
+        if runs is not None and "restart_labels" in g.files:         # the ten K-means restarts against the reference's ten, index by index
+            runs = runs.cpu().numpy().astype(np.int64)
+            per[w]["restarts_in_place"] = int(sum(matched_iou(runs[i], g["restart_labels"][i].astype(np.int64), k_masks)[0] >= 0.99
+                                                  for i in range(min(len(runs), len(g["restart_labels"])))))
     if not per:
         return None
     wins = [per[w] for w in sorted(per)]
     ious = np.array([x["iou"] for x in wins])
+    n_ok, n = int((ious >= 0.99).sum()), len(wins)
+    lo, hi = wilson(n_ok, n)
+    rip = [x["restarts_in_place"] for x in wins if "restarts_in_place" in x]
     return {"iou": wins[0]["iou"], "identical_fraction": wins[0]["identical_fraction"], "windows": wins,
             "mean_iou": round(float(ious.mean()), 4), "median_iou": round(float(np.median(ious)), 4), "min_iou": round(float(ious.min()), 4),
-            "windows_at_0.99": int((ious >= 0.99).sum()), "n_windows": len(wins),
+            "windows_at_0.99": n_ok, "n_windows": n,
+            "rate_at_0.99": round(n_ok / n, 4), "rate_95_interval": [round(lo, 4), round(hi, 4)],
+            "reference_rate_under_1e-6_noise": round(P0, 4), "rejected_below": binom_min_successes(n),
+            "mean_restarts_in_place": round(float(np.mean(rip)), 2) if rip else None,
             "mean_identical_fraction": round(float(np.mean([x["identical_fraction"] for x in wins])), 4),
             "repeats_identical": bool(same),
             "case": ("the masks of the TIMED steps (BASELINE configs[2] at full size: SVD 14x576x1024, K=20, t_start 17 = 8 CFG steps, full-width "
@@ -313,6 +329,56 @@ def fp8_attention_roofline(dev, B=28, H=5, N=9216, reps=10):
             "note": "kernel alone, back-to-back launches outside the window (in the window the quantisation of q, k, v adds three small launches)"}
 
 
+def post_unet_roofline(dev, F=F_WIN, fh=LAT // 2, fw=LAT // 2, C=640, K=20, reps=20):
+    """The post-UNet kernels alone at the headline's sizes ("HBM fraction for the post-UNet kernels"), torch
+    events on the launch stream, back-to-back launches on synthetic dumps: algorithmic bytes (every operand and result once) / time
+    against the 8 TB/s HBM peak, and for the float64 contractions their FLOPs against the 78.6 TFLOP/s f64 MFMA peak
+    (MI355X_MICROARCH.md) -- each kernel is priced against the roofline that bounds it (`bound`)."""
+    from vidseg_diffusion_amd import analysis as A
+    from vidseg_diffusion_amd import synthetic
+    N, n = fh * fw, F * fh * fw
+    blocks, _ = synthetic.attention_q_dumps(F, fh, fw, C, num_blocks=3, seed=1)
+    dumps = [torch.from_numpy(b).to(dev) for b in blocks]                       # [2F, N, C] fp16 each
+    _, feat = A.mean_normalize(dumps, n, n)
+    centers = feat[torch.randperm(n, generator=torch.Generator().manual_seed(3))[:K].to(dev)].double().contiguous()
+    ref_labels = torch.randint(0, K, (N,), generator=torch.Generator().manual_seed(4), dtype=torch.int32).to(dev)
+    cond7 = dumps[1][F:].contiguous()
+
+    def timeit(fn, r=reps):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(r):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / r                                      # microseconds per call
+
+    rows = []
+
+    def row(kernel, ref, bound, us, nbytes, flops=None):
+        gbs = nbytes / us / 1e3
+        d = {"kernel": kernel, "reference": ref, "bound": bound, "us": round(us, 1), "algorithmic_bytes": int(nbytes), "GB/s": round(gbs, 1),
+             "frac_hbm": round(gbs / 8000.0, 4)}
+        if flops is not None:
+            d.update({"f64_flops": int(flops), "f64_TFLOP/s": round(flops / us / 1e6, 2), "frac_f64_mfma": round(flops / us / 1e6 / 78.6, 4)})
+        rows.append(d)
+
+    row("k_mean_normalize", "FE:739-748, 550-555 (3-block mean + max-abs normalise, conditional half)", "hbm",
+        timeit(lambda: A.mean_normalize(dumps, n, n)), 3 * n * C * 2 + n * C * 2)
+    row("k_lloyd_assign (one full E-step, one restart)", "sklearn _kmeans.py lloyd_iter via FE:562-572", "f64 mfma / latency",
+        timeit(lambda: A.kmeans_predict(feat, centers)), n * C * 2 + K * C * 8 + n * 4, 2.0 * n * K * C)
+    row("k_knn (+ 2 row-norm passes): 4-NN of the window's tokens in frame 0", "FE:603-613", "f64 mfma",
+        timeit(lambda: A.knn_predict(feat[:N], ref_labels, feat), 5), (n + N) * C * 2 + n * 4, 2.0 * n * N * C)
+    row("k_track_normalize + 13 x (k_track_cos, k_row_select): dense tracking of block 7", "FE:176-364", "f64 mfma",
+        timeit(lambda: A.dense_tracking(cond7, F, fh, fw), 3), n * C * 2 * 2 + (F - 1) * (2 * N * C * 2 + N * N * 2), (F - 1) * 2.0 * 2.0 * N * N * C)
+    return {"peak_hbm_GB/s": 8000.0, "peak_f64_mfma_TFLOP/s": 78.6, "kernels": rows,
+            "note": "kernels alone, back-to-back on synthetic dumps of the headline's sizes (14 x 32 x 32 tokens, C = 640, K = 20); in the window they run "
+                    "on the analysis stream under the next window's UNet.  k_mean_normalize is the one pure streaming kernel of the stage; the "
+                    "others are float64 contractions (exactness is the point: bit-exact labels) priced against the f64 MFMA peak"}
+
+
 def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, prebuilt=None):
     """Time `steps` steps of one config; returns (out dict for rank 0 | None, sd_cpu, cfg, eng, labels)."""
     from vidseg_diffusion_amd import feature_extraction as FE
@@ -327,7 +393,9 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, preb
     # iteration counts, restarts and tie replays are data dependent, so one repeated window would time -- and score -- a single
     # draw.  SD headline: the windows for which the reference's labels are committed (tests/golden/c2_window*.npz), so that
     # `value` and `mask_iou_vs_reference` describe the same work; SVD: windows 0..2.  All inputs are resident in HBM beforehand.
-    if svd or args.narrow:
+    if svd and not args.narrow:
+        win_ids = sorted(int(np.load(p)["window_id"]) for p in glob.glob(os.path.join(ROOT, "tests", "golden", "c3_t17_w*.npz"))) or list(range(3))
+    elif args.narrow:
         win_ids = list(range(3))
     else:
         win_ids = sorted(int(np.load(p)["window_id"]) for p in glob.glob(os.path.join(ROOT, "tests", "golden", "c2_window*.npz"))) or [0]
@@ -346,6 +414,12 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, preb
     step_no = [0]
     record = []                                                      # (window id, labels) of every step run since the last reset
 
+    def last_restarts():
+        """The ten restarts' labels of the K-means that just ran (a reference to the device tensor: nothing is copied inside the timing)."""
+        from vidseg_diffusion_amd import analysis as A
+        km = A.LAST_KMEANS
+        return km.all_labels if km is not None else None
+
     def next_window():
         w = win_ids[(step_no[0] * world + rank) % len(win_ids)]
         step_no[0] += 1
@@ -363,10 +437,10 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, preb
                 fifo.append(w)
                 got = pipe.push(lat, cw, ucw, keep_all_steps=False, exp_name=nm, noise=noise, **fkw)
                 if got is not None:
-                    record.append((fifo.pop(0), got))
+                    record.append((fifo.pop(0), got, last_restarts()))
                     last = got
-            for got in pipe.drain():
-                record.append((fifo.pop(0), got))
+            for got in pipe.drain():                                 # (drain analyses one window after the other: the last K-means is the last window's)
+                record.append((fifo.pop(0), got, None))
                 last = got
             return last
     elif world > 1 and overlap:
@@ -391,7 +465,7 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, preb
                                                         is_aggre_attn=True, is_refine_mask=refine, seed=17, rank=rank, world=world,
                                                         masks_only=args.masks_only, inversion_type=fkw.get("inversion_type", "add_noise"))
                 if world == 1:
-                    record.append((w, last))
+                    record.append((w, last, last_restarts()))
             return last
 
     def barrier():
@@ -405,20 +479,42 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, preb
         run_steps(warmup)
     barrier()
     del record[:]
-    if os.environ.get("VIDSEG_BENCH_NOPROF") != "1":                      # A/B knob: what the per-launch HIP events cost the timed region
+    prof_in_region = lanes == 1 and os.environ.get("VIDSEG_BENCH_NOPROF") != "1"   # one lane: a launch's HIP-event time is its own
+    if prof_in_region:
         ops.gemm_profile_begin()
     t0 = time.perf_counter()
     labels = run_steps(steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    k_ms, k_flops, k_launches = ops.gemm_profile_end()
-    kinds = ops.gemm_profile_kinds()
+    prof_steps, single_lane = steps, None
+    if prof_in_region:
+        k_ms, k_flops, k_launches = ops.gemm_profile_end()
+        kinds = ops.gemm_profile_kinds()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     timed = list(record)                                            # (window id, labels) of exactly the timed steps, in order
+    if not prof_in_region and not args.pmc_child:
+        # the roofline's per-launch HIP events: a single-lane pass over the same windows, outside the timed region (two lanes share
+        # the chip, so inside it a launch's event time would include waiting for the other lane's kernels)
+        prof_steps = max(2, min(steps, 8)) if not svd else max(1, min(steps, 2))
+        run_steps(1, nl=1)
+        barrier()
+        ops.gemm_profile_begin()
+        t1 = time.perf_counter()
+        run_steps(prof_steps, nl=1)
+        barrier()
+        dt1 = time.perf_counter() - t1
+        k_ms, k_flops, k_launches = ops.gemm_profile_end()
+        kinds = ops.gemm_profile_kinds()
+        single_lane = {"value": round(F_WIN * world * prof_steps / dt1, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dt1 / prof_steps, 3),
+                       "steps": prof_steps,
+                       "note": "the same windows with ONE feature pass in flight (pipeline.WindowPipeline(lanes=1)) and the GEMM profiler's HIP "
+                               "events on every conv / linear launch: the pass the `roofline` object is measured in"}
+    elif args.pmc_child:
+        k_ms, k_flops, k_launches, kinds = 0.0, 0.0, 0, []
     if rank != 0 or args.pmc_child:
         return None, sd_cpu, cfg, eng, labels, run_steps, timed
 
@@ -452,28 +548,28 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, preb
                    else "none (each window's analysis follows its own feature pass)"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": round(achieved / 2500.0, 4), "traffic": None, "kernel": dom[0],
-                     "launches_per_step": dom[3] // max(steps, 1),
+                     "launches_per_step": dom[3] // max(prof_steps, 1),
                      "avg_launch_us": round(1e3 * dom[1] / max(dom[3], 1), 2),
-                     "ms_per_step": round(dom[1] / steps, 3),
+                     "ms_per_step": round(dom[1] / prof_steps, 3),
+                     "measured_in": ("the timed region (one lane)" if prof_in_region else
+                                     f"a single-lane pass of {prof_steps} steps over the same windows right after the timed region (`single_lane`)"),
                      "algorithmic_bytes": int(dom[4] / max(dom[3], 1)),
                      # every conv / linear of the UNet runs on this kernel family; the family-wide figures:
                      "family": {"achieved": round(fam_tf, 2), "frac": round(fam_tf / 2500.0, 4),
-                                "launches_per_step": k_launches // max(steps, 1), "gemm_ms_per_step": round(k_ms / steps, 3),
-                                "by_kernel": {n: {"ms_per_step": round(ms / steps, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 else 0.0,
-                                                  "launches_per_step": ln // max(steps, 1),
+                                "launches_per_step": k_launches // max(prof_steps, 1), "gemm_ms_per_step": round(k_ms / prof_steps, 3),
+                                "by_kernel": {n: {"ms_per_step": round(ms / prof_steps, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 else 0.0,
+                                                  "launches_per_step": ln // max(prof_steps, 1),
                                                   "algorithmic_bytes_per_launch": int(_b / ln)} for (n, ms, fl, ln, _b) in kinds if ln}}},
         "unique_labels": int(len(np.unique(labels))),
     }
     if not svd and not args.narrow:
-        out["flops"] = sd_flop_account(k_flops / max(steps, 1), evals)
+        out["flops"] = sd_flop_account(k_flops / max(prof_steps, 1), evals)
         if args.exact:
             out["flops"]["note"] += ("; precision exact: executed_gemm counts the three fp16 products per fp32-accurate product (K axis 3x)"
                                      + ("; masks_only: the last evaluation executes the conditional half up to decoder block 8 only, "
                                         "reference_equivalent still counts the three full CFG evaluations" if args.masks_only else ""))
-    if lanes > 1:
-        out["roofline"]["note"] = (f"{lanes} windows share the chip: a launch's HIP-event time includes the moments its blocks wait for "
-                                   f"CUs held by the other lane's kernels, so per-kernel TFLOP/s read lower than with --lanes 1 while the "
-                                   f"whole-job rate is higher")
+    if single_lane is not None:
+        out["single_lane"] = single_lane
     if args.masks_only:
         if not args.parity:
             out["metric"] += " [masks-only pruning]"
@@ -538,8 +634,11 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, preb
         out["roofline"]["note_flops"] = ("achieved / frac count the MFMA work the kernel executes (2*M*N*3K per launch: three fp16 products per "
                                          "fp32-accurate product); `fp32_equivalent` = the same launches counted as 2*M*N*K")
         out["roofline"]["fp32_equivalent"] = {"achieved": round(achieved / 3.0, 2), "frac_of_f16_mfma_peak": round(achieved / 3.0 / 2500.0, 4)}
+        out["roofline"]["frac_algorithmic"] = round(achieved / 3.0 / 2500.0, 4)     # reference-equivalent FLOPs (2*M*N*K) / time / peak
+        out["roofline"]["family"]["frac_algorithmic"] = round(fam_tf / 3.0 / 2500.0, 4)
     else:
         out["config"]["precision"] = "fp16"
+        out["roofline"]["frac_algorithmic"] = out["roofline"]["frac"]
         out["metric"] += " [precision=fp16: masks NOT at parity with the reference, see mask_iou_vs_reference]"
     if args.inversion:
         out["metric"] += " [inversion_type=inversion: 49 UNet evaluations per window]"
@@ -564,10 +663,11 @@ def main():
     ap.add_argument("--narrow", action="store_true", help="debug: narrow-width UNet (NOT the benchmark config)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run each window's analysis after its own feature pass instead of concurrently with the next ones'")
-    ap.add_argument("--lanes", type=int, default=1,
+    ap.add_argument("--lanes", type=int, default=2,
                     help="feature passes in flight at once, each on its own HIP stream (pipeline.WindowPipeline / parallel.ShardedPipeline). "
-                         "Default 1: every launch then has the chip to itself and its HIP-event time is its own (the roofline object); 2 is "
-                         "~4 %% faster end to end and is reported as `two_lanes`")
+                         "Default 2 (same launches, same masks, ~2 %% more throughput: a second window's kernels take the CUs a launch leaves "
+                         "idle).  With more than one lane the per-launch HIP events of the `roofline` object are recorded in a SINGLE-LANE pass "
+                         "over the same windows right after the timed region (`single_lane`), where a launch has the chip to itself")
     ap.add_argument("--vae", action="store_true", help="also time the first-stage encode of one window (reported beside the metric)")
     ap.add_argument("--config", default="sd", choices=["sd", "svd"],
                     help="sd = BASELINE configs[1] (headline); svd = configs[2]: SVD 14x576x1024, t_start 17, is_refine_mask")
@@ -662,7 +762,7 @@ def main():
                 last = (args.warmup + args.steps - 1)
                 # only rank 0's window is scored: the windows of ranks > 0 are CHAINED to it (4-NN label propagation, like windows > 0 of
                 # a clip), while every fixture holds its window's own K-means
-                m = timed_masks_vs_reference([(wins[(last * world) % len(wins)], np.asarray(labels)[0])] if not args.no_overlap else [],
+                m = timed_masks_vs_reference([(wins[(last * world) % len(wins)], np.asarray(labels)[0], None)] if not args.no_overlap else [],
                                              refine, k_masks)
                 if m is not None:
                     m["note"] += ("; N > 1: rank 0's window of the last step only -- the other ranks' windows are chained to it by 4-NN "
@@ -735,7 +835,8 @@ def main():
                     return {"value": round(F_WIN * n / dt, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n, 3), "steps": n,
                             "precision": prec, "masks_only": mo,
                             "mask_iou_vs_reference": {k: mm[k] for k in ("mean_iou", "median_iou", "min_iou", "windows_at_0.99", "n_windows",
-                                                                         "mean_identical_fraction")} if mm else None,
+                                                                         "rate_95_interval", "mean_restarts_in_place", "mean_identical_fraction")} if mm else None,
+                            "windows": [{k: x[k] for k in ("window", "iou", "restarts_in_place") if k in x} for x in mm["windows"]] if mm else None,
                             "note": note}
                 except Exception as e:
                     return {"error": repr(e)[:300]}
@@ -756,6 +857,12 @@ def main():
             else:
                 out["exact_mode"] = time_mode("exact", False, x_note + "Every step in full")
                 out["parity_mode"] = time_mode("exact", True, x_note + "Last step pruned to the conditional half / decoder blocks <= 8 (masks_only)")
+        if plain and not svd:
+            stage("post-UNet kernels alone")
+            try:
+                out["roofline_post_unet"] = post_unet_roofline(dev)
+            except Exception as e:                                   # never lose the headline line to a side measurement
+                out["roofline_post_unet"] = {"error": repr(e)[:300]}
         if args.vae:                                                 # outside the timed region, never part of `value`
             out["first_stage"] = first_stage_timing(dev, svd)
         if plain and not svd:
@@ -797,8 +904,8 @@ def main():
                 out["secondary"]["roofline"] = {k: sec["roofline"][k] for k in ("achieved", "frac", "kernel", "family")}
                 m2 = timed_masks_vs_reference(_t2, True, k_masks, svd=True)
                 if m2 is not None:
-                    out["secondary"]["mask_iou_vs_reference"] = {k: m2[k] for k in ("mean_iou", "min_iou", "windows_at_0.99", "n_windows",
-                                                                                    "mean_identical_fraction", "windows", "case")}
+                    out["secondary"]["mask_iou_vs_reference"] = {k: m2[k] for k in ("mean_iou", "min_iou", "windows_at_0.99", "n_windows", "rate_95_interval",
+                                                                                    "mean_restarts_in_place", "mean_identical_fraction", "windows", "case")}
                 if args.exact:                                       # the 16-bit mode of the same config beside it
                     stage("secondary: 16-bit mode")
                     net2 = eng2.model.diffusion_model

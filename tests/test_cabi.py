@@ -143,3 +143,33 @@ def test_hand_counted_kernels_have_no_scratch(tmp_path):
         assert len(sizes) >= 15, len(sizes)
         for name, size in sizes:
             assert int(size) == 0, (name, size, defines)
+
+
+def test_gemm_profiler_handle_is_bound_to_its_thread(lib):
+    """The profiler handle is caller-owned and records the launches of ONE thread (a thread-local pointer to it while recording):
+    ending or destroying it from another thread while it records is refused instead of leaving that pointer dangling (no HIP call is
+    involved: host-side bookkeeping only)."""
+    import threading
+    from vidseg_diffusion_amd import ops
+    p = ops.GemmProfiler()
+    p.begin()
+    res = {}
+
+    def other():
+        l = lib.lib()
+        out = (ctypes.c_double * 3)()
+        res["end"] = l.vidseg_gemm_profile_end(p.h, out)
+        res["destroy"] = l.vidseg_gemm_profiler_destroy(p.h)
+        res["msg"] = l.vidseg_last_error().decode()
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert res["end"] != 0 and res["destroy"] != 0 and "another thread" in res["msg"], res
+    ms, flops, launches = p.end()                                    # the owner ends it: an empty region
+    assert (ms, flops, launches) == (0.0, 0.0, 0)
+    q = ops.GemmProfiler()                                           # an idle handle may be destroyed from any thread
+    t = threading.Thread(target=lambda: res.__setitem__("idle", lib.lib().vidseg_gemm_profiler_destroy(q.h)))
+    t.start()
+    t.join()
+    q.h = None
+    assert res["idle"] == 0

@@ -15,41 +15,60 @@ pytestmark = pytest.mark.gpu
 F, K = 3, 5
 
 
-def _setup(dev):
-    from vidseg_diffusion_amd.pipeline import build_sd_engine
-    from vidseg_diffusion_amd.unet import UNetModel
-    net = UNetModel(**synthetic.SD21_NARROW)
+def _setup(dev, kind="sd", precision="fp16"):
+    """kind "sd": the narrow SD UNet; "svd": the narrow VideoUNet -- the unit of BASELINE configs[3] (SVD windows sharded one per GPU):
+    its temporal attention / convolution mix the frames of a window, which is why that config shards by WINDOW."""
+    from vidseg_diffusion_amd.pipeline import build_sd_engine, build_svd_engine
+    if kind == "svd":
+        from vidseg_diffusion_amd.video_unet import VideoUNet
+        net = VideoUNet(**synthetic.SVD_NARROW)
+    else:
+        from vidseg_diffusion_amd.unet import UNetModel
+        net = UNetModel(**synthetic.SD21_NARROW)
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, 1234).items()})
-    return build_sd_engine(net)
+    if precision != "fp16":
+        net.pack(dev)
+        net.set_precision(precision)
+    return build_svd_engine(net, num_frames=F) if kind == "svd" else build_sd_engine(net)
 
 
-def _inputs(win, dev):
+def _inputs(win, dev, kind="sd"):
     lat = torch.from_numpy(synthetic.latent_clip(F, 16, 16, seed=50 + win)).to(dev)
-    c = torch.from_numpy(np.random.Generator(np.random.PCG64(7)).standard_normal((F, 7, 64)).astype(np.float32)).to(dev)
     noise = torch.from_numpy(np.random.Generator(np.random.PCG64(90 + win)).standard_normal((F, 4, 16, 16)).astype(np.float32)).to(dev)
+    if kind == "svd":                                                    # svd_pipeline_vspw.py:300-311: one CLIP-image token, frame-0 latent, fps / motion vector
+        g = np.random.Generator(np.random.PCG64(7 + win))
+        ctx = torch.from_numpy(g.standard_normal((1, 1, 64)).astype(np.float32)).repeat(F, 1, 1).to(dev)
+        cat = lat[:1].repeat(F, 1, 1, 1) / 0.18215 * 0.2
+        vec = torch.from_numpy(g.standard_normal((1, 64)).astype(np.float32)).repeat(F, 1).to(dev)
+        c = {"crossattn": ctx, "concat": cat, "vector": vec}
+        uc = {"crossattn": torch.zeros_like(ctx), "concat": torch.zeros_like(cat), "vector": vec.clone()}
+        return lat, c, uc, noise
+    c = torch.from_numpy(np.random.Generator(np.random.PCG64(7)).standard_normal((F, 7, 64)).astype(np.float32)).to(dev)
     return lat, {"crossattn": c}, {"crossattn": torch.zeros_like(c)}, noise
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, kind="sd", precision="fp16"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     from vidseg_diffusion_amd import parallel
-    eng = _setup(dev)
-    lat, c, uc, noise = _inputs(rank, dev)
+    eng = _setup(dev, kind, precision)
+    lat, c, uc, noise = _inputs(rank, dev, kind)
+    mo = precision == "exact"                                            # the parity mode of bench.py: exact + masks_only
     labels = parallel.segment_windows_sharded(eng, lat, c, uc, noise=noise, num_masks=K, is_refine_mask=True, seed=17, rank=rank,
-                                              world=world, feature_folder="/nonexistent/par", exp_name=f"r{rank}")
+                                              world=world, feature_folder="/nonexistent/par", exp_name=f"r{rank}", masks_only=mo)
     # the overlapped form: two steps through ShardedPipeline (step 2's feature pass queued before step 1's cross-window stage)
+    fkw = dict(noise=noise, seed=17, feature_folder="/nonexistent/par", masks_only=mo)
     pipe = parallel.ShardedPipeline(eng, rank, world, num_masks=K, is_refine_mask=True)
-    assert pipe.push(lat, c, uc, noise=noise, seed=17, feature_folder="/nonexistent/par", exp_name=f"p{rank}a") is None
-    first = pipe.push(lat, c, uc, noise=noise, seed=17, feature_folder="/nonexistent/par", exp_name=f"p{rank}b")
+    assert pipe.push(lat, c, uc, exp_name=f"p{rank}a", **fkw) is None
+    first = pipe.push(lat, c, uc, exp_name=f"p{rank}b", **fkw)
     second = pipe.flush()
     assert np.array_equal(first, labels) and np.array_equal(second, labels), "overlapped sharded steps differ from the plain one"
     # two feature-pass lanes (two windows in flight on their own streams + scratch): same labels, delivered two pushes later
     pipe = parallel.ShardedPipeline(eng, rank, world, lanes=2, num_masks=K, is_refine_mask=True)
-    got = [pipe.push(lat, c, uc, noise=noise, seed=17, feature_folder="/nonexistent/par", exp_name=f"l{rank}{i}") for i in range(3)]
+    got = [pipe.push(lat, c, uc, exp_name=f"l{rank}{i}", **fkw) for i in range(3)]
     assert got[0] is None and got[1] is None and np.array_equal(got[2], labels)
     rest = pipe.drain()
     assert len(rest) == 2 and all(np.array_equal(r, labels) for r in rest), "two-lane sharded steps differ from the plain one"
@@ -58,17 +77,17 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_sequential_windows():
+def _two_ranks_vs_sequential(kind, precision):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, kind, precision)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=300) for _ in range(2))
+    res = dict(q.get(timeout=600) for _ in range(2))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -76,18 +95,35 @@ def test_two_ranks_equal_sequential_windows():
     from vidseg_diffusion_amd import feature_extraction as FE
     from vidseg_diffusion_amd.pipeline import WindowState, segment_window
     dev = torch.device("cuda:0")
-    eng = _setup(dev)
+    eng = _setup(dev, kind, precision)
     FE.FeatureStore.clear()
     FE.MaskStore.clear()
     state, seq = WindowState(), []
     for win in range(2):
-        lat, c, uc, noise = _inputs(win, dev)
+        lat, c, uc, noise = _inputs(win, dev, kind)
         labels, state = segment_window(eng, lat, c, uc, num_masks=K, is_refine_mask=True, seed=17, state=state, noise=noise,
-                                       feature_folder="/nonexistent/seq", exp_name=f"w{win}")
+                                       feature_folder="/nonexistent/seq", exp_name=f"w{win}", masks_only=(precision == "exact"))
         seq.append(labels)
     seq = np.stack(seq)
     for r in range(2):
-        assert np.array_equal(res[r], seq), f"rank {r}: sharded labels differ from the sequential window loop"
+        assert np.array_equal(res[r], seq), f"rank {r}: sharded labels differ from the sequential window loop ({kind}, {precision})"
+    FE.FeatureStore.clear()
+    FE.MaskStore.clear()
+
+
+def test_two_ranks_equal_sequential_windows():
+    _two_ranks_vs_sequential("sd", "fp16")
+
+
+def test_two_ranks_equal_sequential_svd_windows():
+    """BASELINE configs[3]'s unit: SVD windows, one per rank, through segment_windows_sharded / ShardedPipeline with the narrow
+    VideoUNet (temporal attention / temporal convolutions / AlphaBlender inside every window, one-token context) -- in the 16-bit
+    mode and in the parity mode bench.py quotes its SVD figures on (exact precision + masks_only); the gathered label chain must be the
+    sequential window loop's bit for bit."""
+    from vidseg_diffusion_amd import ops
+    _two_ranks_vs_sequential("svd", "fp16")
+    if ops.act_dtype() == torch.float16:
+        _two_ranks_vs_sequential("svd", "exact")
 
 
 def _rccl_worker(port, q):
@@ -154,6 +190,12 @@ def test_bench_gpus_flag_starts_the_ranks():
     out = lines[0]
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["scaling"] == "weak"
     assert abs(out["value"] - 2 * 14 * 2 / (out["ms_per_step"] * 2 / 1e3)) / out["value"] < 1e-2      # frames of BOTH ranks / max-rank time
+    # the same launch for configs[3]'s unit (SVD windows, one per rank)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--narrow", "--config", "svd", "--steps", "2", "--warmup", "1",
+                        "--no-secondary", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["rccl_ranks"] == 2 and "SVD" in lines[0]["metric"], r.stdout
 
 
 def _frames_worker(rank, world, port, q):

@@ -115,6 +115,12 @@ def test_bench_self_launch():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["rccl_ranks"] == 2, r.stdout
+    # the same launcher with the flags of BASELINE configs[3] (SVD windows, one per GPU)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "svd", "--steps", "2", "--warmup", "1",
+                        "--launch-dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["rccl_ranks"] == 2, r.stdout
     env["WORLD_SIZE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-dry-run"], env=env, capture_output=True,
                        text=True, timeout=120)
@@ -135,6 +141,16 @@ def test_frame_slices_cover_the_window():
             sl = frame_slices(F_, w)
             assert len(sl) == w and sl[0][0] == 0 and sl[-1][1] == F_ and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
             assert max(hi - lo for lo, hi in sl) - min(hi - lo for lo, hi in sl) <= 1
+
+
+def test_more_ranks_than_frames_is_refused_on_every_rank():
+    """The slice table is the same on every rank, so the refusal is too: no rank may enter a collective while another raises."""
+    from vidseg_diffusion_amd.parallel import _require_a_frame_per_rank, frame_slices
+    _require_a_frame_per_rank(frame_slices(14, 8))
+    _require_a_frame_per_rank(frame_slices(3, 3))
+    for rank_view in range(5):                                        # what each of 5 ranks computes for 3 frames: the same table, the same error
+        with pytest.raises(ValueError, match="at least one frame per rank"):
+            _require_a_frame_per_rank(frame_slices(3, 5))
 
 
 FF = 9                                                               # frames of the frame-sharded window: 8 ranks -> slices of 2,1,1,...

@@ -33,3 +33,30 @@ def clustering_objective(flat, labels):
         m = X[lab == l]
         tot += float(((m - m.mean(axis=0)) ** 2).sum())
     return tot
+
+
+# ---- the bar: a rate with an interval, not "all but two" --------------------------------------------------------------------------
+# What is known about the problem (profiles/r03_mask_knee_study_1e-6.txt: white noise of normalised rms 1e-6 -- another fp32
+# summation order -- on the REFERENCE's own fp32 taps, then the reference's own sklearn call): 46 of 48 runs keep the reference's
+# masks (IoU >= 0.99), i.e. p0 = 0.958 per window.  An fp32-accurate device evaluation is one more such summation order, so the
+# number of windows that keep the reference's masks must be compatible with Binomial(n, P0); the test rejects at the 1 % level.
+P0 = 46.0 / 48.0
+
+
+def binom_min_successes(n, p0=P0, alpha=0.01):
+    """Smallest k with P(K <= k - 1 | Binomial(n, p0)) < alpha <= P(K <= k): observing fewer than k successes rejects p >= p0."""
+    from math import comb
+    cdf = 0.0
+    for k in range(n + 1):
+        cdf += comb(n, k) * p0 ** k * (1.0 - p0) ** (n - k)
+        if cdf >= alpha:
+            return k
+    return n
+
+
+def wilson(k, n, z=1.96):
+    p = k / n
+    d = 1.0 + z * z / n
+    c = (p + z * z / (2 * n)) / d
+    h = z * np.sqrt(p * (1 - p) / n + z * z / (4 * n * n)) / d
+    return max(0.0, c - h), min(1.0, c + h)

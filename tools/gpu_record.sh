@@ -1,0 +1,55 @@
+# GPU record of a build: bash tools/gpu_record.sh <tag> [tests] [bench] [prof] [svdprof] [full] [final]
+#   tests    the exact-mode / analysis / window GPU tests (-x)             full   the whole GPU suite instead
+#   bench    python bench.py (default flags + steps 16 / warmup 3)         prof   rocprofv3 kernel stats of the SD parity window
+#   svdprof  rocprofv3 kernel stats of the SVD parity window               final  bf16 suite, MFMA-utilisation PMC pass, race stress, determinism
+# Everything lands under gpurun_out/<tag>/; the summaries worth keeping are copied to profiles/ by hand.
+cd $GRAFT_REPO_ROOT
+T=${1:-rec}
+shift
+mkdir -p gpurun_out/$T
+has() { for a in "$@"; do :; done; case " $ARGS " in *" $1 "*) return 0;; esac; return 1; }
+ARGS="$*"
+if has full; then
+  ( time timeout 3000 python -m pytest tests -m gpu -q -s > gpurun_out/$T/pytest_gpu.log 2>&1 ) 2> gpurun_out/$T/pytest_time.txt
+  tail -5 gpurun_out/$T/pytest_gpu.log; tail -3 gpurun_out/$T/pytest_time.txt
+elif has tests; then
+  ( time timeout 1500 python -m pytest tests/test_gpu_exact.py tests/test_gpu_analysis.py tests/test_gpu_c2_window.py tests/test_gpu_c3_window.py -m gpu -q -s -x > gpurun_out/$T/pytest_gpu.log 2>&1 ) 2> gpurun_out/$T/pytest_time.txt
+  tail -5 gpurun_out/$T/pytest_gpu.log; tail -3 gpurun_out/$T/pytest_time.txt
+fi
+grep -E "windows at IoU|reproduce the reference|window [0-9]+ (exact|parity|fp16)|nrms|max err" gpurun_out/$T/pytest_gpu.log 2>/dev/null | tail -40
+if has bench; then
+  timeout 1800 python bench.py --steps 16 --warmup 3 > gpurun_out/$T/bench.json 2> gpurun_out/$T/bench.err
+  tail -c 400 gpurun_out/$T/bench.err
+  python tools/bench_digest.py gpurun_out/$T/bench.json
+fi
+cd /tmp && export TMPDIR=/tmp
+if has prof; then
+  rm -rf /tmp/prof_d
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_d -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --lanes 1 > $GRAFT_REPO_ROOT/gpurun_out/$T/bench_under_rocprof.json 2>/tmp/prof_d.err
+  db=$(find /tmp/prof_d -name "*results.db" | head -1)
+  python $GRAFT_REPO_ROOT/tools/prof_summary.py $db "$T: python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --lanes 1 (parity mode) under rocprofv3 --kernel-trace --stats" > $GRAFT_REPO_ROOT/gpurun_out/$T/bench_kernel_stats.md
+  head -34 $GRAFT_REPO_ROOT/gpurun_out/$T/bench_kernel_stats.md
+fi
+if has svdprof; then
+  rm -rf /tmp/prof_s
+  timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o r -- python $GRAFT_REPO_ROOT/bench.py --config svd --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --lanes 1 > $GRAFT_REPO_ROOT/gpurun_out/$T/bench_svd_under_rocprof.json 2>/tmp/prof_s.err
+  db=$(find /tmp/prof_s -name "*results.db" | head -1)
+  python $GRAFT_REPO_ROOT/tools/prof_summary.py $db "$T: python bench.py --config svd --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --lanes 1 (parity mode) under rocprofv3 --kernel-trace --stats" > $GRAFT_REPO_ROOT/gpurun_out/$T/bench_svd_kernel_stats.md
+  head -44 $GRAFT_REPO_ROOT/gpurun_out/$T/bench_svd_kernel_stats.md
+  tail -c 300 /tmp/prof_s.err
+fi
+if has final; then
+  cd $GRAFT_REPO_ROOT
+  ( time VIDSEG_ACT=bf16 timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/$T/pytest_gpu_bf16.log 2>&1 ) 2>> gpurun_out/$T/pytest_time.txt
+  tail -2 gpurun_out/$T/pytest_gpu_bf16.log
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY -d /tmp/pm -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap --no-secondary > /tmp/pm.log 2>&1
+  db=$(find /tmp/pm -name "*results.db" | head -1)
+  python $GRAFT_REPO_ROOT/tools/pmc_mfma_util.py $db $GRAFT_REPO_ROOT/gpurun_out/$T/mfma_util.json | tail -24
+  cd $GRAFT_REPO_ROOT
+  timeout 900 python tools/race_stress.py --exact --iters 100 > gpurun_out/$T/race_stress_exact.txt 2>&1; tail -4 gpurun_out/$T/race_stress_exact.txt
+  timeout 600 python tools/determinism_check.py --precision exact --overlap --windows 0-5 --reps 2 > gpurun_out/$T/determinism_exact_a.txt 2>&1
+  timeout 600 python tools/determinism_check.py --precision exact --overlap --windows 0-5 --reps 2 > gpurun_out/$T/determinism_exact_b.txt 2>&1
+  diff <(grep -v "^\[" gpurun_out/$T/determinism_exact_a.txt) <(grep -v "^\[" gpurun_out/$T/determinism_exact_b.txt) > gpurun_out/$T/determinism_exact_diff.txt && echo "determinism: two processes identical" || (echo "determinism: DIFF"; head -5 gpurun_out/$T/determinism_exact_diff.txt)
+  tail -3 gpurun_out/$T/determinism_exact_a.txt
+fi

@@ -11,6 +11,7 @@
 // swizzle, global->register prefetch of the next K chunk issued before the MFMAs of the current one.
 #include "common.h"
 #include <hip/hip_ext.h>
+#include <thread>
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
@@ -2332,6 +2333,7 @@ static const GemmKnobs& knobs() {
 }
 struct GemmProf {
     bool on = false;
+    std::thread::id owner;           // the thread whose launches are being recorded (valid while on): its t_prof points here
     std::vector<hipEvent_t> ev;      // pairs
     size_t used = 0;
     double flops = 0.0;
@@ -2642,6 +2644,11 @@ int vidseg_gemm_profiler_create(void** out) {
 int vidseg_gemm_profiler_destroy(void* h) {
     GemmProf* gp = (GemmProf*)h;
     if (!gp) return VS_OK;
+    // a recording profiler is referenced by its owner thread's t_prof: freeing it from another thread would leave that pointer dangling
+    // (the owner's next launch_gemm reads g_prof.on through it).  The owner ends the recording first; on the owner itself destroy ends it.
+    VS_REQUIRE(!gp->on || gp->owner == std::this_thread::get_id(),
+               "gemm_profiler_destroy: the profiler is recording on another thread (call vidseg_gemm_profile_end there first)");
+    gp->on = false;
     if (t_prof == gp) t_prof = &g_off;
     for (hipEvent_t e : gp->ev) (void)hipEventDestroy(e);
     delete gp;
@@ -2650,7 +2657,9 @@ int vidseg_gemm_profiler_destroy(void* h) {
 
 int vidseg_gemm_profile_begin(void* h) {
     VS_REQUIRE(h != nullptr, "gemm_profile_begin: null profiler");
+    VS_REQUIRE(!((GemmProf*)h)->on || ((GemmProf*)h)->owner == std::this_thread::get_id(), "gemm_profile_begin: already recording on another thread");
     t_prof = (GemmProf*)h;
+    g_prof.owner = std::this_thread::get_id();
     g_prof.on = true;
     g_prof.used = 0;
     g_prof.flops = 0.0;
@@ -2663,6 +2672,7 @@ int vidseg_gemm_profile_begin(void* h) {
 int vidseg_gemm_profile_end(void* h, double* out) {
     VS_REQUIRE(h != nullptr, "gemm_profile_end: null profiler");
     GemmProf& gp = *(GemmProf*)h;
+    VS_REQUIRE(!gp.on || gp.owner == std::this_thread::get_id(), "gemm_profile_end: call it on the thread that called vidseg_gemm_profile_begin");
     gp.on = false;
     if (t_prof == &gp) t_prof = &g_off;
     double ms = 0.0;

@@ -657,6 +657,9 @@ class ExactRunner:
         key = (dim, tuple(ts.tolist()))
         if key not in self._temb_dev:
             if len(self._temb_dev) > 64:
+                # another lane's stream may still have kernels queued that read an entry (entries are allocated under whichever lane
+                # first saw the vector and shared without record_stream): nothing may be freed before the device is idle
+                torch.cuda.synchronize(self.dev)
                 self._temb_dev.clear()
             half = dim // 2
             freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=F32) / half)

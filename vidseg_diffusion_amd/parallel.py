@@ -255,7 +255,7 @@ def segment_windows_sharded(engine, latent, c, uc, *, noise=None, num_masks=20, 
 # ----------------------------------------------------------------------------------------------------------------------------------
 def frame_slices(num_frames: int, world: int):
     """Contiguous frame ranges [(lo, hi)] per rank, sizes differing by at most one (the first num_frames % world ranks hold one more);
-    ranks beyond the frame count hold an empty slice."""
+    ranks beyond the frame count hold an empty slice (which the frame-sharded entry points refuse, on every rank alike)."""
     base, extra = divmod(num_frames, world)
     out, lo = [], 0
     for r in range(world):
@@ -275,6 +275,13 @@ def gather_frames(local: torch.Tensor, slices, world: int) -> torch.Tensor:
     return torch.cat([allp[r, :hi - lo] for r, (lo, hi) in enumerate(slices)], 0)
 
 
+def _require_a_frame_per_rank(slices):
+    """More ranks than frames: decided from the slice table, which is identical on every rank, BEFORE any collective -- so every rank
+    raises (a check on the empty ranks alone left the others blocked in the all-gather until the collective timed out)."""
+    if any(hi == lo for lo, hi in slices):
+        raise ValueError(f"frame sharding needs at least one frame per rank: {slices[-1][1]} frames over {len(slices)} ranks")
+
+
 def frame_sharded_feature_pass(engine, latent, c, uc, *, noise=None, num_steps=25, t_start=22, seed=17, rank=0, world=1,
                                feature_folder="features_outputs_VSPW", exp_name=None, masks_only=False):
     """Steps 1-2 of ONE SD window on this rank's frame slice (`latent`, `c`, `uc`, `noise` are the WINDOW's full tensors, identical on
@@ -285,16 +292,15 @@ def frame_sharded_feature_pass(engine, latent, c, uc, *, noise=None, num_steps=2
         raise ValueError("frame-level sharding is for the per-sample SD UNet; the SVD VideoUNet shards by window (segment_windows_sharded)")
     F = latent.shape[0]
     sl = frame_slices(F, world)
+    _require_a_frame_per_rank(sl)                                         # every rank sees the same slices: all raise, none enters a collective
     lo, hi = sl[rank]
     if noise is None:
         seed_everything(seed)                                             # SDP:255, then add_noise's randn_like over the whole window (SAM:138)
         noise = torch.randn(latent.shape, dtype=latent.dtype, device=latent.device)
     exp_name = exp_name or f"frames{rank}"
     cut = lambda d: {k: v[lo:hi] for k, v in d.items()}                   # noqa: E731
-    h = None
-    if hi > lo:
-        h = sharded_feature_pass(engine, latent[lo:hi].contiguous(), cut(c), cut(uc), noise=noise[lo:hi].contiguous(), num_steps=num_steps,
-                                 t_start=t_start, seed=seed, rank=rank, feature_folder=feature_folder, exp_name=exp_name, masks_only=masks_only)
+    h = sharded_feature_pass(engine, latent[lo:hi].contiguous(), cut(c), cut(uc), noise=noise[lo:hi].contiguous(), num_steps=num_steps,
+                             t_start=t_start, seed=seed, rank=rank, feature_folder=feature_folder, exp_name=exp_name, masks_only=masks_only)
     return dict(h=h, F=F, fh=latent.shape[2] // 2, fw=latent.shape[3] // 2, slices=sl, seed=seed, feature_folder=feature_folder,
                 exp_name=exp_name, feature_timestep=num_steps - 1, device=latent.device)
 
@@ -309,35 +315,31 @@ def frame_sharded_resolve(engine, fh_, *, num_masks=20, is_aggre_attn=True, is_r
     F, fh, fw, sl = fh_["F"], fh_["fh"], fh_["fw"], fh_["slices"]
     N = fh * fw
     h = fh_["h"]
+    _require_a_frame_per_rank(sl)
     lo, hi = sl[rank]
     ts = fh_["feature_timestep"]
     names = (8, 7, 6) if is_aggre_attn else (7,)
     need = sorted(set(names) | ({7} if is_refine_mask else set()))
-    taps = {}
-    if h is not None:
+    try:
         torch.cuda.current_stream().wait_event(h["done"])
         store = FE.FeatureStore.folder(h["feature_folder"], h["exp_name"])
         Fr = hi - lo
-        for b in need:
-            taps[b] = store[f"output_block_{b}_spatial_self_attn_q_time_{ts}"][Fr:2 * Fr]       # conditional half (FE:550-551)
-    shape_c = next(iter(taps.values())).shape[1:] if taps else None
-    if world > 1:
-        if shape_c is None:                                               # a rank without frames still joins the collectives
-            raise ValueError("frame_sharded_resolve: more ranks than frames is not supported (every rank must hold >= 1 frame)")
-        taps = {b: gather_frames(taps[b].contiguous(), sl, world) for b in need}
-    if analysis is not None:
-        return analysis(taps, F, fh, fw, fh_["seed"])
-    _, feat = A.mean_normalize([taps[b].contiguous() for b in names], 0, F * N)          # the gathered stacks hold the conditional half only
-    np.random.seed(fh_["seed"])
-    km = A.kmeans_fit(feat, num_masks, n_init=10)
-    fake = A.kmeans_predict(feat[:N], km.centers)
-    labels = A.knn_predict(feat[:N].contiguous(), fake, feat)
-    if is_refine_mask:
-        tracks, _ = A.dense_tracking(taps[7].contiguous(), F, fh, fw)
-        labels = A.trajectory_vote(tracks.contiguous(), labels.view(F, N).contiguous(), fw).reshape(-1)
-    if h is not None:
+        taps = {b: store[f"output_block_{b}_spatial_self_attn_q_time_{ts}"][Fr:2 * Fr] for b in need}     # conditional half (FE:550-551)
+        if world > 1:
+            taps = {b: gather_frames(taps[b].contiguous(), sl, world) for b in need}
+        if analysis is not None:
+            return analysis(taps, F, fh, fw, fh_["seed"])
+        _, feat = A.mean_normalize([taps[b].contiguous() for b in names], 0, F * N)      # the gathered stacks hold the conditional half only
+        np.random.seed(fh_["seed"])
+        km = A.kmeans_fit(feat, num_masks, n_init=10)
+        fake = A.kmeans_predict(feat[:N], km.centers)
+        labels = A.knn_predict(feat[:N].contiguous(), fake, feat)
+        if is_refine_mask:
+            tracks, _ = A.dense_tracking(taps[7].contiguous(), F, fh, fw)
+            labels = A.trajectory_vote(tracks.contiguous(), labels.view(F, N).contiguous(), fw).reshape(-1)
+        return labels.view(F, N).cpu().numpy().astype(np.int64)
+    finally:                                                              # the rank's dumps leave the store on every path (hook, error)
         FE.FeatureStore.clear(h["feature_folder"], h["exp_name"])
-    return labels.view(F, N).cpu().numpy().astype(np.int64)
 
 
 def segment_window_frame_sharded(engine, latent, c, uc, *, rank=0, world=1, num_masks=20, is_aggre_attn=True, is_refine_mask=False,

@@ -456,13 +456,17 @@ class UNetModel(nn.Module):
         """"fp16": the 16-bit path of this file (activations stored in the library's 16-bit format; taps ~1.2e-3 from an fp32
         evaluation).  "exact": exact.ExactRunner -- fp32 activations, every conv / linear on the same MFMA kernels over split
         (hi, lo) operands, taps ~1e-5 from fp32: what best-of-10 K-means++ needs to return the reference's masks (3x the MFMA
-        work; feature-dump path of the SD UNet only)."""
+        work).
+
+        MEMORY: the exact runner packs its own weight images ([w_hi | w_hi | w_lo]: 3x the 16-bit weights, 5.2 GB for SD 2.1, 9.1 GB
+        for SVD) on first use and KEEPS them when the mode is switched back to "fp16" (bench.py and the tests flip modes per window);
+        a caller that is done with the exact mode calls `release_exact()` to free them."""
         if mode not in ("fp16", "exact"):
             raise ValueError(f"unknown precision {mode!r}")
         self.precision = mode                                       # the exact runner (its split weight images) stays cached: release_exact()
 
     def release_exact(self):
-        """Drop the exact mode's weight images (3x the 16-bit ones)."""
+        """Drop the exact mode's weight images (3x the 16-bit ones) and its per-window caches; the next exact forward packs them again."""
         self._exact = None
 
     def stash_resblock_features(self, on=True):
