@@ -406,7 +406,7 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, preb
     if not svd:                                                      # one conditioning for the clip (sd_conditioning(seed=1)): share the tensors
         inputs = {w: (v[0], c, uc, v[3]) for w, v in inputs.items()}
     torch.cuda.synchronize()
-    lanes = 1 if (args.no_overlap or args.pmc_child) else max(1, args.lanes)
+    lanes = 1 if (args.no_overlap or args.pmc_child) else max(1, args.lanes if args.lanes is not None else (1 if svd else 2))
     overlap = not args.no_overlap and not args.pmc_child
     fkw = dict(num_steps=NUM_STEPS, t_start=t_start, seed=17, masks_only=args.masks_only)
     if args.inversion:
@@ -663,11 +663,13 @@ def main():
     ap.add_argument("--narrow", action="store_true", help="debug: narrow-width UNet (NOT the benchmark config)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run each window's analysis after its own feature pass instead of concurrently with the next ones'")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=None,
                     help="feature passes in flight at once, each on its own HIP stream (pipeline.WindowPipeline / parallel.ShardedPipeline). "
-                         "Default 2 (same launches, same masks, ~2 %% more throughput: a second window's kernels take the CUs a launch leaves "
-                         "idle).  With more than one lane the per-launch HIP events of the `roofline` object are recorded in a SINGLE-LANE pass "
-                         "over the same windows right after the timed region (`single_lane`), where a launch has the chip to itself")
+                         "Default: 2 for --config sd (same launches, same masks, ~2 %% more throughput: a second window's kernels take the CUs a "
+                         "launch leaves idle -- 28 samples fill 7/8 of a round of tiles), 1 for --config svd (its launches fill the chip; two "
+                         "lanes measured 7 %% SLOWER there, profiles/r05_b).  With more than one lane the per-launch HIP events of the `roofline` "
+                         "object are recorded in a SINGLE-LANE pass over the same windows right after the timed region (`single_lane`), where a "
+                         "launch has the chip to itself")
     ap.add_argument("--vae", action="store_true", help="also time the first-stage encode of one window (reported beside the metric)")
     ap.add_argument("--config", default="sd", choices=["sd", "svd"],
                     help="sd = BASELINE configs[1] (headline); svd = configs[2]: SVD 14x576x1024, t_start 17, is_refine_mask")
@@ -799,7 +801,7 @@ def main():
                                      "note": "the same windows chained as one clip (sd_pipeline_vspw.py:381-401): window 0 of the chain runs "
                                              "K-means, every later one the 14336 x 14336 x 640 float64 4-NN against its predecessor "
                                              "(feature_extraction.py:603-613)"}
-        if plain and not args.no_overlap and args.lanes == 1:        # two feature passes in flight (outside the headline timing)
+        if plain and not args.no_overlap and args.lanes == 1 and not svd:   # two feature passes in flight (outside the headline timing)
             stage("two lanes")
             n = max(4, min(args.steps, 10))
             run_steps(3, nl=2)

@@ -279,6 +279,11 @@ int vidseg_x_groupnorm_split3(const float* x0, const float* x1 /* opt: channel c
 int vidseg_x_groupnorm_rows_per_chunk(int HW); /* rows per block of the statistics pass (sizes `part`) */
 int vidseg_x_layernorm_split3(const float* x, long long M, int C, const float* gamma, const float* beta, float eps,
                               void* out_f16 /* [M][3C] */, vidseg_stream_t stream);
+/* LayerNorm of x[row] + vec[(row / rows_per_sample) % nvec]: the time stack's frame-index embedding (VA:417-431) added on the way into
+ * norm_in (VA:155); x_sum (optional) receives the fp32 sum -- the block's residual stream -- so the separate add pass is gone */
+int vidseg_x_layernorm_rowvec_split3(const float* x, const float* vec, long long M, int C, int rows_per_sample, int nvec, const float* gamma,
+                                     const float* beta, float eps, float* x_sum /* [M][C] or NULL */, void* out_f16 /* [M][3C] */,
+                                     vidseg_stream_t stream);
 int vidseg_x_attention_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int B, int H,
                            int Nq, int Nk, float scale, vidseg_stream_t stream);
 /* linear / 3x3 conv of the exact mode with the fp32 residual added in the epilogue (ATT:636-757, 921-927; OAI:369): split operand
@@ -290,7 +295,10 @@ int vidseg_x_attention_f32(const float* q, int ldq, const float* k, int ldk, con
  * / vidseg_conv3x3_a16. */
 int vidseg_linear_a16_rf32(const void* a, int K, long long M, const void* w, int N, const float* bias, const float* rowvec, int rv_stride,
                            int rows_per_sample, const float* residual_f32, int ldr, float* out_f32, int ldo, void* tap_f16, void* tap2_f16,
-                           int tap_cols, int tap_ld, int act, vidseg_stream_t stream);
+                           int tap_cols, int tap_ld, int act,
+                           const float* rowadd /* opt: per-row scalar added to every column before the residual -- Step 4's lambda * mask on
+                                                  the attention / feed-forward outputs (ATT:646-663, 697-719, 733-755; VA:197-277) */,
+                           vidseg_stream_t stream);
 /* the same linear writing the NEXT GEMM's operand image [hi | lo | hi] of its fp32 result instead of the fp32 tensor: for a result whose
  * only consumer is another split-operand GEMM -- the FF output projection feeding proj_out when the transformer has one block
  * (ATT:757 -> :921-927), which otherwise costs an fp32 round trip and a vidseg_x_split3 pass.  Same bits as that pair. */

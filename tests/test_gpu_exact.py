@@ -231,6 +231,11 @@ def test_fp32_glue_operators(X):
         x, gg, bb = rnd((77, C), 15) * 2 + 0.3, rnd((C,), 16) * 0.3 + 1.0, rnd((C,), 17) * 0.1
         out = join(X.layernorm_split3(x.to(dev), ops.f32(gg, dev), ops.f32(bb, dev)), C)
         assert rel(out, TF.layer_norm(x.double(), (C,), gg.double(), bb.double(), 1e-5)) <= 2e-6, C
+    # the frame-embedding add folded into norm_in's pass: the bits of LayerNorm(add_rowvec(x, emb))
+    x, emb, gg, bb = rnd((6, 35, 320), 25), rnd((3, 320), 26), rnd((320,), 27) * 0.3 + 1.0, rnd((320,), 28) * 0.1
+    xs, img = X.layernorm_rowvec_split3(x.to(dev), emb.to(dev), 35, ops.f32(gg, dev), ops.f32(bb, dev))
+    ref_sum = X.add_rowvec(x.to(dev), emb.to(dev), 35)
+    assert torch.equal(xs, ref_sum) and torch.equal(img[..., :640], X.layernorm_split3(ref_sum, ops.f32(gg, dev), ops.f32(bb, dev))[..., :640])
     y = rnd((50, 2 * 256), 18, 1.5)
     out = join(X.geglu_split3(y.to(dev)), 256)
     v, gt = y.double().chunk(2, dim=-1)
@@ -475,6 +480,95 @@ def test_video_unet_fused_paths_equal_the_plain_ones(X):
                 assert a.shape == b.shape and float((a != b).float().mean()) <= 0.01, flag
     finally:
         X._NK1_IDENTITY, X._TEMPORAL_FUSED, X._BLEND_FUSED = saved
+
+
+def _step4_passes(X, kind, precision):
+    """Feature pass + the reference-style modulated / injected / latent-blended passes of tests/golden/{sd,svd}_modulated_narrow.npz
+    in the given precision; returns per pass (normalised rms of x after every step, of the final latent's DIFFERENCE from the
+    unmodulated one) against the reference's own run."""
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import build_sd_engine, build_svd_engine, save_feature_maps
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(os.path.dirname(G), f"{kind}_modulated_narrow.npz"))
+    g = {k: z[k] for k in z.files}
+    nrms = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / np.linalg.norm(np.asarray(b, np.float64)))   # noqa: E731
+    Fn = g["latent"].shape[0]
+    if kind == "svd":
+        from vidseg_diffusion_amd.video_unet import VideoUNet
+        net = VideoUNet(**synthetic.SVD_NARROW)
+        seed, T0 = 4321, 22
+    else:
+        from vidseg_diffusion_amd.unet import UNetModel
+        net = UNetModel(**synthetic.SD21_NARROW)
+        seed, T0 = 1234, 22
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=seed).items()})
+    net.pack(dev)
+    net.set_precision(precision)
+    if kind == "svd":
+        eng = build_svd_engine(net, num_frames=Fn)
+        c = {k[2:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith("c_")}
+        uc = {k[3:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith("uc_")}
+        extra = {"image_only_indicator": torch.zeros(2, Fn), "num_video_frames": Fn}
+        tags = [(k[4:-6], float(g[f"lam_{k[4:-6]}"])) for k in g if k.startswith("mod_") and k.endswith("_final")]
+        mkw = dict(modulate_block_idx=[8], modulate_layer_type=["spatial", "temporal"], modulate_attn_type=["self_attn"],
+                   injected_feature_types=["temporal_cross_attn_k", "temporal_cross_attn_q", "temporal_self_attn_k", "temporal_self_attn_q"],
+                   input_block_indices=[3, 4, 5, 6, 7, 8, 10, 11], latent_mask_end=25)
+    else:
+        eng = build_sd_engine(net)
+        c = {"crossattn": torch.from_numpy(g["c"]).to(dev)}
+        uc = {"crossattn": torch.zeros_like(c["crossattn"])}
+        extra = {}
+        tags = [("pos", 50.0), ("neg", -50.0)]
+        mkw = dict(modulate_block_idx=[7], modulate_layer_type=["spatial"], modulate_attn_type=["cross_attn"],
+                   injected_feature_types=["spatial_cross_attn_k", "spatial_cross_attn_q", "spatial_self_attn_k", "spatial_self_attn_q"],
+                   input_block_indices=[3, 4, 5, 6, 7, 8, 9, 10, 11], latent_mask_end=23)
+    noised = eng.sampler.add_noise(torch.from_numpy(g["latent"]).to(dev), cond=c, uc=uc, num_steps=25, noise_level=T0,
+                                   noise=torch.from_numpy(g["noise"]).to(dev))
+    FE.FeatureStore.clear()
+    base, exp = f"/nonexistent/x_step4_{kind}", "exp"
+
+    def denoiser(inp, sigma, cc, is_modulate_step=False, is_injected_step=False, modulate_params=None):
+        return eng.denoiser(eng.model, inp, sigma, cc, is_modulate_step=is_modulate_step, is_injected_step=is_injected_step,
+                            modulate_params=modulate_params, **extra)
+
+    feat = eng.sampler(denoiser, noised.clone(), cond=c, uc=uc, t_start=T0, img_callback=lambda xt, i: save_feature_maps(eng, base, exp, i, xt=xt))
+    out = {"feat": nrms(feat.cpu().numpy(), g["feat_final"])}
+    for tag, lam in tags:
+        mp = {"feature_masks": [torch.from_numpy(m).to(dev) for m in g["masks"]], "modulate_timestep": [T0], "modulate_schedule": "constant",
+              "modulate_lambda_start": lam, "modulate_lambda_end": lam, "num_frames": Fn, "modulate_uc": True, "is_injected_features": True,
+              "injected_block_types": ["output"], "output_block_indices": list(range(1, 12)), "feature_folder": base, "exp_name": exp,
+              "injected_features_group": {}, "modulate_layer_frames": {}, "modulate_block_frames": {}, "modulate_timestep_frames": {},
+              "modulate_lambda_layers": {}, "latent_mask_start": T0, **mkw}
+        xs = []
+        final = eng.sampler(denoiser, noised.clone(), cond=c, uc=uc, img_callback=lambda xt, i: xs.append(xt.cpu().numpy()), is_modulate=True,
+                            modulate_params=mp, t_start=T0, is_latent_blending=True, feature_height=8, feature_width=8, model=None)
+        ref = g[f"mod_{tag}_x_steps"]
+        assert len(xs) == ref.shape[0]
+        d_ref = g[f"mod_{tag}_final"] - g["feat_final"]
+        out[tag] = (max(nrms(xs[i], ref[i]) for i in range(len(xs))), nrms(final.cpu().numpy() - feat.cpu().numpy(), d_ref))
+    FE.FeatureStore.clear()
+    net.release_exact()
+    return out
+
+
+@pytest.mark.parametrize("kind", ["sd", "svd"])
+def test_exact_mode_step4_vs_reference(X, kind):
+    """Step 4 (a17) in the exact mode: the modulated + injected + latent-blended sampler passes of the narrow SD UNet (lambda * mask on
+    block 7's cross-attention output, injected spatial q / k) and of the narrow VideoUNet (block 8's spatial AND temporal self-attention
+    outputs, injected temporal q / k) against the REFERENCE's own run (tests/golden/{sd,svd}_modulated_narrow.npz).  The injected q / k are
+    the fp16 dumps of the feature pass here and fp32 tensors in the reference's CPU run, which bounds the agreement at the fp16
+    rounding of q / k (the CPU oracle with fp16 dumps reads the same); bars: x after every step <= 1e-3 normalised rms and the modulation's
+    EFFECT (modulated minus plain final latent) within 1 % of the reference's, both well inside the 16-bit mode's figures, which are
+    measured beside them."""
+    ex = _step4_passes(X, kind, "exact")
+    lo = _step4_passes(X, kind, "fp16")
+    for tag in [k for k in ex if k != "feat"]:
+        print(f"{kind} Step 4 pass {tag}: exact mode x-step nrms {ex[tag][0]:.2e}, effect nrms {ex[tag][1]:.2e}   (16-bit mode {lo[tag][0]:.2e}, {lo[tag][1]:.2e})")
+        assert ex[tag][0] <= 1e-3 and ex[tag][1] <= 1e-2, (kind, tag, ex[tag])
+        assert ex[tag][0] <= lo[tag][0] and ex[tag][1] <= lo[tag][1] * 1.05 + 1e-4, (kind, tag, ex[tag], lo[tag])
+    print(f"{kind} feature pass final latent: exact {ex['feat']:.2e}, 16-bit {lo['feat']:.2e}")
+    assert ex["feat"] <= 5e-5
 
 
 def test_exact_unet_forward_vs_reference(X):

@@ -3136,7 +3136,7 @@ int vidseg_linear_a16(const void* a0, const void* a1, int C0, int C1, long long 
 // (t + to_out(attn(..)), x + proj_out(..): attention.py:636-757, 921-927 -- the residual stream stays fp32, no separate add pass).
 int vidseg_linear_a16_rf32(const void* a, int K, long long M, const void* w, int N, const float* bias, const float* rowvec, int rv_stride,
                            int rows_per_sample, const float* residual_f32, int ldr, float* out_f32, int ldo, void* tap, void* tap2,
-                           int tap_cols, int tap_ld, int act, hipStream_t st) {
+                           int tap_cols, int tap_ld, int act, const float* rowadd, hipStream_t st) {
     VS_REQUIRE(out_f32 != nullptr && act != 2 && (!residual_f32 || ldr % 8 == 0), "linear_rf32: needs an fp32 output, act != GEGLU, ldr %% 8 == 0");
     GemmParams p{};
     p.x0 = (const bf16_t*)a;
@@ -3164,6 +3164,7 @@ int vidseg_linear_a16_rf32(const void* a, int K, long long M, const void* w, int
     p.tap_cols = tap_cols;
     p.tap_ld = tap_ld;
     p.act = act;
+    p.rowadd = rowadd;                                         // Step 4: lambda * mask on the rows of the modulated frames (ATT:646-663, VA:197-216)
     p.split2 = 1;                                              // the operands of this entry point ARE split images (header)
     return launch_gemm(p, st);
 }

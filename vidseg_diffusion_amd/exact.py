@@ -16,7 +16,9 @@ GroupNorm / LayerNorm / SiLU / GEGLU / softmax run in fp32 (csrc/exact_ops.hip) 
 capture at :330-331, :889-927 SpatialTransformer) and writes the same taps onto the same attention modules, so the drivers'
 dump protocol is unchanged.  The VideoUNet's time stack is covered the same way (video_model.py:15-89 VideoResBlock on the [3,1,1]
 temporal conv with split operands, video_attention.py:145-285 / :378-489 temporal transformer block, frame-index embedding and
-AlphaBlender in fp32; temporal taps in the reference's [(b s), t, c] layout).  Feature-dump path only: no modulation / injection.
+AlphaBlender in fp32; temporal taps in the reference's [(b s), t, c] layout).  Step 4's modulation / injection hooks (attention.py:616-755,
+video_attention.py:166-277) are carried too: injected q / k dumps replace the fp32 projections, lambda * mask rides in the output GEMMs'
+epilogues (GemmParams::rowadd).
 """
 from __future__ import annotations
 
@@ -37,13 +39,14 @@ _lib.register({
     "vidseg_x_split3_cat": [_P, _P, _L, _I, _I, _P, _P],
     "vidseg_x_groupnorm_split3": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _L, _P, _P],
     "vidseg_x_groupnorm_rows_per_chunk": [_I],
-    "vidseg_linear_a16_rf32": [_P, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
+    "vidseg_linear_a16_rf32": [_P, _I, _L, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _P],
     "vidseg_linear_a16_rf32_x3": [_P, _I, _L, _P, _I, _P, _P, _I, _P, _P],
     "vidseg_linear_a16_qkv_planes": [_P, _I, _L, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "vidseg_linear_a16_geglu_x3": [_P, _I, _L, _P, _I, _P, _P, _P],
     "vidseg_linear_a16_geglu_x3g16": [_P, _I, _L, _P, _I, _P, _P, _P],
     "vidseg_conv3x3_a16_rf32": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P],
     "vidseg_x_layernorm_split3": [_P, _L, _I, _P, _P, _F, _P, _P],
+    "vidseg_x_layernorm_rowvec_split3": [_P, _P, _L, _I, _I, _I, _P, _P, _F, _P, _P, _P],
     "vidseg_x_attention_f32": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     "vidseg_x_split_planes": [_P, _I, _L, _I, _P, _P, _P],
     "vidseg_x_temporal_attention": [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],
@@ -162,6 +165,17 @@ def layernorm_split3(x, gamma, beta, eps=1e-5):
     return out
 
 
+def layernorm_rowvec_split3(x, vec, rows_per_sample, gamma, beta, eps=1e-5):
+    """(x + vec[(row / rows_per_sample) % len(vec)], split3(LayerNorm(that sum))): the frame-index embedding add of the time stack
+    (video_attention.py:417-431, 155) inside the LayerNorm pass that reads x anyway."""
+    C = x.shape[-1]
+    xs = torch.empty_like(x)
+    out = _image(x.shape[:-1] + (3 * C,), x.device)
+    call("vidseg_x_layernorm_rowvec_split3", ptr(x), ptr(vec), x.numel() // C, C, rows_per_sample, vec.shape[0], ptr(gamma), ptr(beta), eps, ptr(xs),
+         ptr(out), stream())
+    return xs, out
+
+
 def attention_f32(q, k, v, heads, B, Nq, Nk):
     """softmax(q k^T / 8) v per 64-wide head; q / k / v: fp32 column slices [B, N, >= heads*64] of row-major buffers."""
     for t, n in ((q, Nq), (k, Nk), (v, Nk)):
@@ -252,18 +266,21 @@ def attention_x(q, kv, heads, B, Nq, Nk, split_out=False, planes=None):
 
 
 def linear_x(a3, w3, bias=None, *, rowvec=None, rows_per_sample=0, act=ops.ACT_NONE, tap=None, tap2=None, tap_cols=0, residual=None,
-             split_out=False):
-    """fp32 out = act(a . w^T + bias + rowvec[sample]) + residual on split operands (a3: [.., 3K] fp16, w3: [N, 3K] fp16; residual
-    fp32 [.., N], added inside the GEMM epilogue).  split_out: the result as the next GEMM's operand image [.., 3N] (fp16
-    [hi | lo | hi], written by the epilogue: the bits of split3(linear_x(..))) instead of the fp32 tensor."""
+             split_out=False, rowadd=None):
+    """fp32 out = act(a . w^T + bias + rowvec[sample]) + rowadd[row] + residual on split operands (a3: [.., 3K] fp16, w3: [N, 3K] fp16;
+    residual fp32 [.., N], added inside the GEMM epilogue; rowadd fp32 [rows]: Step 4's lambda * mask).  split_out: the result as the
+    next GEMM's operand image [.., 3N] (fp16 [hi | lo | hi], written by the epilogue: the bits of split3(linear_x(..))) instead of the
+    fp32 tensor."""
     ops.workspace(a3.device)
     K3 = a3.shape[-1]
     M = a3.numel() // K3
     N = w3.shape[0]
     if residual is not None and (residual.dtype != F32 or residual.numel() != M * N or not residual.is_contiguous()):
         raise VidsegError("linear_x: residual must be a contiguous fp32 [.., N] tensor")
+    if rowadd is not None and (rowadd.dtype != F32 or rowadd.numel() != M or not rowadd.is_contiguous()):
+        raise VidsegError("linear_x: rowadd must be a contiguous fp32 vector with one value per row")
     if split_out:
-        if rowvec is not None or act != ops.ACT_NONE or tap is not None or tap2 is not None:
+        if rowvec is not None or act != ops.ACT_NONE or tap is not None or tap2 is not None or rowadd is not None:
             raise VidsegError("linear_x: split_out is a plain linear (+ bias, + residual)")
         out3 = _image(a3.shape[:-1] + (3 * N,), a3.device)
         call("vidseg_linear_a16_rf32_x3", ptr(a3), K3, M, ptr(w3), N, ptr(bias), ptr(residual), N, ptr(out3), stream())
@@ -271,7 +288,7 @@ def linear_x(a3, w3, bias=None, *, rowvec=None, rows_per_sample=0, act=ops.ACT_N
     out = torch.empty(a3.shape[:-1] + (N,), dtype=F32, device=a3.device)
     call("vidseg_linear_a16_rf32", ptr(a3), K3, M, ptr(w3), N, ptr(bias), ptr(rowvec), rowvec.stride(0) if rowvec is not None else 0,
          rows_per_sample, ptr(residual), N, ptr(out), N, ptr(tap), ptr(tap2), tap_cols, tap.shape[-1] if tap is not None else 0, act,
-         stream())                                                          # the split-operand entry point (residual optional)
+         ptr(rowadd), stream())                                             # the split-operand entry point (residual optional)
     return out
 
 
@@ -526,20 +543,35 @@ class ExactRunner:
         slot = self._nk1.setdefault(id(bw), _Slot())
         return ops.window_cached(slot, "val", (ctx3,), make)
 
-    def time_block(self, tb, bw, x, tctx3, T, dump, blend_src=None, alpha=None):
+    def time_block(self, tb, bw, x, tctx3, T, dump, blend_src=None, alpha=None, mod=None, emb=None):
         """VideoTransformerBlock._forward (video_attention.py:145-285) on rows kept in the spatial order (b t) s: ff_in, temporal
         self-attention over the T frames of every (video, location), cross-attention to the first frame's context, ff.
-        blend_src / alpha: the caller's AlphaBlender (VA:470-476) applied by the last linear's epilogue."""
+        blend_src / alpha: the caller's AlphaBlender (VA:470-476) applied by the last linear's epilogue.
+        emb: the frame-index embedding [T, C] (VA:417-431): x + emb[frame] is formed inside norm_in's pass.
+        mod: None or (inject, rowadd) from unet.block_modulation(.., "temporal") -- Step 4 (VA:166-277): injected temporal_self_attn_{q,k,v}
+        dumps ([(b s), t, c] fp16) replace attn1's projections, rowadd[attn_type] = lambda_i * mask_i on the rows of frame i is added to
+        attn1_out / attn2_out / ff_out inside the output GEMMs' epilogues."""
         BT, S, C = x.shape
         b = BT // T
         heads = tb.attn1.heads
-        g3 = self.geglu(layernorm_split3(x, *bw["ln"]["norm_in"]), bw, "w_fi1", "b_fi1", "fi1g")     # VA:155-159
+        inj, ra = mod if mod is not None else (None, None)
+        inj, ra = inj or {}, ra or {}
+        pick = lambda sub: next((v for k, v in inj.items() if sub in k), None)                       # noqa: E731
+        if emb is not None:                                          # x + emb[frame] (VA:429-431) inside norm_in's pass
+            x, n_in = layernorm_rowvec_split3(x, emb, S, *bw["ln"]["norm_in"])
+        else:
+            n_in = layernorm_split3(x, *bw["ln"]["norm_in"])
+        g3 = self.geglu(n_in, bw, "w_fi1", "b_fi1", "fi1g")                                          # VA:155-159
         x = linear_x(g3, bw["w_fi2"], bw["b_fi2"], residual=x)
         L = tctx3.shape[1]
         nk1 = _NK1_IDENTITY and L == 1
         cv = self.single_key_out(bw, tctx3, C) if nk1 else None                                      # [b, C]
-        fold = nk1 and not dump                                      # the cross-attention's row vector rides on attn1's output projection
+        fold = nk1 and not dump and mod is None                      # the cross-attention's row vector rides on attn1's output projection
         qkv = linear_x(layernorm_split3(x, *bw["ln"]["norm1"]), bw["w_qkv"])                          # [(b t), S, 3C]
+        for j, name in enumerate(("temporal_self_attn_q", "temporal_self_attn_k", "temporal_self_attn_v")):
+            t16 = pick(name)
+            if t16 is not None:                                      # dump [(b s), t, c] -> rows (b t) s of the projection it replaces (VA:166-195)
+                qkv[..., j * C:(j + 1) * C] = t16.view(b, S, T, C).permute(0, 2, 1, 3).reshape(BT, S, C).float()
         if _TEMPORAL_FUSED and T <= 16:
             tq = torch.empty((b * S, T, C), dtype=F16, device=x.device) if dump else None
             tk = torch.empty((b * S, T, C), dtype=F16, device=x.device) if dump else None
@@ -554,80 +586,125 @@ class ExactRunner:
             a3 = split3(a.view(b, S, T, C).permute(0, 2, 1, 3).contiguous().view(BT, S, C))
             if dump:
                 tb.attn1.q, tb.attn1.k = tqkv[..., :C].half(), tqkv[..., C:2 * C].half()
-        x = linear_x(a3, bw["w_o1"], bw["b_o1"], residual=x, rowvec=cv if fold else None, rows_per_sample=T * S)   # VA:197-218
+        if pick("temporal_self_attn_q") is not None:
+            tb.attn1.q = pick("temporal_self_attn_q")                                               # ATT:330-331 stores what was used
+        if pick("temporal_self_attn_k") is not None:
+            tb.attn1.k = pick("temporal_self_attn_k")
+        x = linear_x(a3, bw["w_o1"], bw["b_o1"], residual=x, rowvec=cv if fold else None, rows_per_sample=T * S,
+                     rowadd=ra.get("self_attn"))                                                     # VA:197-218
         if not fold:
             tk = torch.empty((b, L, C), dtype=F16, device=x.device) if dump else None
-            if nk1:                                                  # dump evaluation: q2 exists for its tap only
-                q2 = linear_x(layernorm_split3(x, *bw["ln"]["norm2"]), bw["w_q"])
-                linear_x(tctx3, bw["w_kv"], tap=tk, tap_cols=C)
+            q2 = None
+            if nk1:                                                  # one key: the attention is the identity on v (see _NK1_IDENTITY)
+                if dump:                                             # q2 / k exist for their taps only
+                    q2 = linear_x(layernorm_split3(x, *bw["ln"]["norm2"]), bw["w_q"])
+                    linear_x(tctx3, bw["w_kv"], tap=tk, tap_cols=C)
                 x = add_rowvec(x, cv, T * S)
+                if ra.get("cross_attn") is not None:
+                    x = x + ra["cross_attn"].view(BT, S, 1)
             else:
                 q2 = linear_x(layernorm_split3(x, *bw["ln"]["norm2"]), bw["w_q"])
                 kv = linear_x(tctx3, bw["w_kv"], tap=tk, tap_cols=C)
                 a23 = attention_x(q2.view(b, T * S, C), kv, heads, b, T * S, L, split_out=True)       # VA:224-250
-                x = linear_x(a23.view(BT, S, 3 * C), bw["w_o2"], bw["b_o2"], residual=x)
+                x = linear_x(a23.view(BT, S, 3 * C), bw["w_o2"], bw["b_o2"], residual=x, rowadd=ra.get("cross_attn"))
             if dump:
                 tb.attn2.q = q2.view(b, T, S, C).permute(0, 2, 1, 3).contiguous().view(b * S, T, C).half()
                 tb.attn2.k = tk[:, None].expand(b, S, L, C).reshape(b * S, L, C)
         g3 = self.geglu(layernorm_split3(x, *bw["ln"]["norm3"]), bw, "w_ff1", "b_ff1", "ff1g")        # VA:252-281
-        if blend_src is not None and _BLEND_FUSED:
+        if blend_src is not None and _BLEND_FUSED and ra.get("ff_out") is None:
             return linear_blend_x(g3, bw["w_ff2"], bw["b_ff2"], x, blend_src, alpha)
-        out = linear_x(g3, bw["w_ff2"], bw["b_ff2"], residual=x)
+        out = linear_x(g3, bw["w_ff2"], bw["b_ff2"], residual=x, rowadd=ra.get("ff_out"))
         return out if blend_src is None else blend(blend_src, out, alpha)
 
-    def transformer(self, m, x, ctx3, tap):
+    def transformer(self, m, x, ctx3, tap, mod=None):
+        """SpatialTransformer / SpatialVideoTransformer.forward (ATT:889-927, VA:378-489).  mod: the block's (is_modulate_step,
+        is_injected_step, modulate_params) from UNetModel._block_mod, or None -- Step 4's hooks (ATT:616-755): injected q / k dumps replace
+        the projections, lambda * mask is added to the rows of attn1_out / attn2_out / ff_out."""
         e = self.w[self.names[id(m)]]
+        U = self.U
         B, H, W, C = x.shape
         N = H * W
         t = groupnorm_split3(x, e["g"], e["b"], eps=1e-6, silu=False).view(B, N, 3 * C)              # ATT:897-903
         t = linear_x(t, e["w_in"], e["b_in"])
+        bmod = U.block_modulation(mod, "spatial", N, x.device)                                       # ATT:906-915
+        inj, ra = bmod if bmod is not None else (None, None)
+        inj, ra = inj or {}, ra or {}
+        pick = lambda sub: next((v for k, v in inj.items() if sub in k), None)                       # noqa: E731
         for i, (blk, bw) in enumerate(zip(m.transformer_blocks, e["blocks"])):
             heads, Ci = blk.attn1.heads, blk.attn1.inner
             dump = tap and i == 0
             # self-attention (ATT:636-672); q / k taps = fp16 of the fp32 projections (ATT:330-331)
             tq = torch.empty((B, N, Ci), dtype=F16, device=x.device) if dump else None
             tk = torch.empty((B, N, Ci), dtype=F16, device=x.device) if dump else None
+            iq, ik = pick("spatial_self_attn_q"), pick("spatial_self_attn_k")
             if mfma_attention_for(N):                                                                  # k | v straight into the attention's planes
                 q, planes = linear_qkv_x(layernorm_split3(t, *bw["ln"][0]), bw["w_qkv"], Ci, tap=tq, tap2=tk)
+                if iq is not None:
+                    q = iq.float()                                                                     # ATT:305-315: the dump replaces the projection
+                if ik is not None:
+                    planes[0][..., :Ci] = ik                                                           # hi = the fp16 dump, lo = 0
+                    planes[1][..., :Ci] = 0
                 a3 = attention_x(q, None, heads, B, N, N, split_out=True, planes=planes)
             else:
                 qkv = linear_x(layernorm_split3(t, *bw["ln"][0]), bw["w_qkv"], tap=tq, tap2=tk, tap_cols=Ci)
+                if iq is not None:
+                    qkv[..., :Ci] = iq.float()
+                if ik is not None:
+                    qkv[..., Ci:2 * Ci] = ik.float()
                 a3 = attention_x(qkv[..., :Ci], qkv[..., Ci:], heads, B, N, N, split_out=True)
             L = ctx3.shape[1]
             nk1 = _NK1_IDENTITY and L == 1                                                             # one-token context: attention = identity on v
             cv = self.single_key_out(bw, ctx3, Ci) if nk1 else None                                    # [B, C] = to_out(v)
-            fold = nk1 and not dump
-            t = linear_x(a3, bw["w_o1"], bw["b_o1"], residual=t, rowvec=cv if fold else None, rows_per_sample=N)
+            fold = nk1 and not dump and bmod is None
+            t = linear_x(a3, bw["w_o1"], bw["b_o1"], residual=t, rowvec=cv if fold else None, rows_per_sample=N, rowadd=ra.get("self_attn"))
             if dump:
                 blk.attn1.q, blk.attn1.k = tq, tk
+            if iq is not None:
+                blk.attn1.q = iq                                                                       # ATT:330-331 stores what was used
+            if ik is not None:
+                blk.attn1.k = ik
             # cross-attention to the (step-constant) context (ATT:689-726)
             if not fold:
+                iq2, ik2 = pick("spatial_cross_attn_q"), pick("spatial_cross_attn_k")
                 tq = torch.empty((B, N, Ci), dtype=F16, device=x.device) if dump else None
-                q = linear_x(layernorm_split3(t, *bw["ln"][1]), bw["w_q"], tap=tq, tap_cols=Ci)
                 tk = torch.empty((B, L, Ci), dtype=F16, device=x.device) if dump else None
-                if dump:
-                    kv = linear_x(ctx3, bw["w_kv"], tap=tk, tap_cols=Ci)
-                else:                                                  # to_k | to_v of the step-constant context: once per window (ATT:317-322)
-                    kv = ops.window_cached(self._kv.setdefault(id(bw), _Slot()), "val", (ctx3,), lambda: linear_x(ctx3, bw["w_kv"]))
-                if nk1:                                                                                # dump evaluation: q exists for its tap only
+                if nk1:                                                                                # the attention is the identity on v
+                    if dump:                                                                           # q / k exist for their taps only
+                        linear_x(layernorm_split3(t, *bw["ln"][1]), bw["w_q"], tap=tq, tap_cols=Ci)
+                        linear_x(ctx3, bw["w_kv"], tap=tk, tap_cols=Ci)
                     t = add_rowvec(t, cv, N)
+                    if ra.get("cross_attn") is not None:
+                        t = t + ra["cross_attn"].view(B, N, 1)
                 else:
+                    q = linear_x(layernorm_split3(t, *bw["ln"][1]), bw["w_q"], tap=tq, tap_cols=Ci)
+                    if dump or ik2 is not None:
+                        kv = linear_x(ctx3, bw["w_kv"], tap=tk, tap_cols=Ci)
+                    else:                                              # to_k | to_v of the step-constant context: once per window (ATT:317-322)
+                        kv = ops.window_cached(self._kv.setdefault(id(bw), _Slot()), "val", (ctx3,), lambda: linear_x(ctx3, bw["w_kv"]))
+                    if iq2 is not None:
+                        q = iq2.float()
+                    if ik2 is not None:
+                        kv[..., :Ci] = ik2.float()
                     a3 = attention_x(q, kv, heads, B, N, L, split_out=True)
-                    t = linear_x(a3, bw["w_o2"], bw["b_o2"], residual=t)
+                    t = linear_x(a3, bw["w_o2"], bw["b_o2"], residual=t, rowadd=ra.get("cross_attn"))
                 if dump:
                     blk.attn2.q, blk.attn2.k = tq, tk
+                if iq2 is not None:
+                    blk.attn2.q = iq2
+                if ik2 is not None:
+                    blk.attn2.k = ik2
             # GEGLU feed-forward (ATT:728-757, :89-115)
             g3 = self.geglu(layernorm_split3(t, *bw["ln"][2]), bw, "w_ff1", "b_ff1", "ff1g")
-            last = i == len(e["blocks"]) - 1 and "time" not in e                                      # t's only consumer is proj_out
-            t = linear_x(g3, bw["w_ff2"], bw["b_ff2"], residual=t, split_out=last)
+            last = i == len(e["blocks"]) - 1 and "time" not in e and ra.get("ff_out") is None          # t's only consumer is proj_out
+            t = linear_x(g3, bw["w_ff2"], bw["b_ff2"], residual=t, split_out=last, rowadd=ra.get("ff_out"))
             if "time" in e:                                                                            # VA:429-476
                 T = self.T
-                t = self.time_block(m.time_stack[i], e["time"][i], add_rowvec(t, self.frame_emb(m, e, T), N), self.tctx3, T, dump,
-                                    blend_src=t, alpha=e["alpha"])
+                t = self.time_block(m.time_stack[i], e["time"][i], t, self.tctx3, T, dump, blend_src=t, alpha=e["alpha"],
+                                    mod=U.block_modulation(mod, "temporal", N, x.device), emb=self.frame_emb(m, e, T))
         out = linear_x(t if t.dtype == F16 else split3(t), e["w_out"], e["b_out"], residual=x.view(B, N, C))   # ATT:921-927
         return out.view(B, H, W, C)
 
-    def block(self, blk, x, x_skip, emb_all, ctx3, skip_resample=False):
+    def block(self, blk, x, x_skip, emb_all, ctx3, skip_resample=False, mod=None):
         U = self.U
         for layer in blk:
             if skip_resample and isinstance(layer, (U.Upsample, U.Downsample)):   # taps-only evaluation: nothing downstream reads this
@@ -636,7 +713,7 @@ class ExactRunner:
                 x = self.resblock(layer, x, x_skip, emb_all)
                 x_skip = None
             elif isinstance(layer, U.SpatialTransformer):
-                x = self.transformer(layer, x, ctx3, layer.tap)
+                x = self.transformer(layer, x, ctx3, layer.tap, mod)
             elif isinstance(layer, U.Upsample):
                 e = self.w[self.names[id(layer)]]
                 x = conv3x3_x(split3(x), e["w"], e["b"], up=2)
@@ -668,9 +745,12 @@ class ExactRunner:
             torch.cuda.current_stream().synchronize()                      # once per distinct vector: other lanes' streams read it too
         return self._temb_dev[key]
 
-    def forward(self, x_nchw, timesteps, context, y=None, num_video_frames=None, stop_after_block=None):
+    def forward(self, x_nchw, timesteps, context, y=None, num_video_frames=None, stop_after_block=None, is_modulate_step=False,
+                is_injected_step=False, modulate_params=None):
         """stop_after_block=b: taps-only evaluation (pipeline.feature_pass(masks_only=True)) -- output blocks 0..b run (b without its
-        Upsample), their Q/K taps are left on the attention modules and None is returned."""
+        Upsample), their Q/K taps are left on the attention modules and None is returned.
+        is_modulate_step / is_injected_step / modulate_params: Step 4 (openaimodel.py:884-937, video_model.py:480-545) -- the per-block
+        flags come from the network's own _block_mod, the hooks live in transformer() / time_block()."""
         net, dev = self.net, self.dev
         self.T = int(num_video_frames) if num_video_frames is not None else None
         if self.video and (y is None or self.T is None):
@@ -691,15 +771,16 @@ class ExactRunner:
         h = torch.empty((B, H, W, mc), dtype=F32, device=dev)
         call("vidseg_conv_in_f32", ptr(xn), ptr(self.cin_w), ptr(self.cin_b), B, H, W, Cin, mc, ptr(h), stream())
         hs = [h]
-        for blk in list(net.input_blocks)[1:]:
-            h = self.block(blk, h, None, emb_all, ctx3)
+        for i, blk in list(enumerate(net.input_blocks))[1:]:
+            h = self.block(blk, h, None, emb_all, ctx3, mod=net._block_mod("input", i, blk, False, is_injected_step, modulate_params, dev))
             hs.append(h)
         h = self.block(net.middle_block, h, None, emb_all, ctx3)
         for i, blk in enumerate(net.output_blocks):
+            mod = net._block_mod("output", i, blk, is_modulate_step, is_injected_step, modulate_params, dev)
             if stop_after_block is not None and i == stop_after_block:
-                self.block(blk, h, hs.pop(), emb_all, ctx3, skip_resample=True)
+                self.block(blk, h, hs.pop(), emb_all, ctx3, skip_resample=True, mod=mod)
                 return None
-            h = self.block(blk, h, hs.pop(), emb_all, ctx3)                                            # OAI:911-948
+            h = self.block(blk, h, hs.pop(), emb_all, ctx3, mod=mod)                                   # OAI:911-948
         h3 = groupnorm_split3(h, self.out_g, self.out_beta, eps=1e-5, silu=True)
         C = h.shape[-1]
         h3[..., 2 * C:] = h3[..., :C]                 # the one consumer that walks all 3 C channels (k_conv_out4, once per evaluation)

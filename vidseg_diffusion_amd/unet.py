@@ -576,8 +576,6 @@ class UNetModel(nn.Module):
         if not x.is_cuda:
             raise VidsegError("UNetModel runs on a HIP device only (no CPU fallback)")
         if self.precision == "exact":
-            if is_modulate_step or is_injected_step:
-                raise NotImplementedError("exact precision covers the feature-dump pass (no modulation / injection)")
             if any(rb.stash_features for rb in self._resblocks()):
                 raise NotImplementedError("exact precision does not produce ResBlock.in_layers_features / out_layers_features: "
                                           "stash_resblock_features(False) or set_precision('fp16')")
@@ -588,7 +586,8 @@ class UNetModel(nn.Module):
                         raise VidsegError("UNetModel has no weights: call load_state_dict() first")
                 self._set_taps()
                 self._exact = ExactRunner(self, x.device)
-            return self._exact.forward(x, timesteps, context, stop_after_block=stop_after_block)
+            return self._exact.forward(x, timesteps, context, stop_after_block=stop_after_block, is_modulate_step=is_modulate_step,
+                                       is_injected_step=is_injected_step, modulate_params=modulate_params)
         xn = x.float().permute(0, 2, 3, 1).contiguous()
         ctx = context if context.dtype == ops.act_dtype() else \
             ops.window_cached(self, "_ctx16", (context,), lambda: ops.to_bf16(context.float().contiguous()))

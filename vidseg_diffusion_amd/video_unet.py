@@ -377,8 +377,6 @@ class VideoUNet(UNetModel):
         if not x.is_cuda:
             raise VidsegError("VideoUNet runs on a HIP device only (no CPU fallback)")
         if self.precision == "exact":                                 # UNetModel.set_precision: exact.ExactRunner (fp32-accurate, 3x MFMA work)
-            if is_modulate_step or is_injected_step:
-                raise NotImplementedError("exact precision covers the feature-dump pass (no modulation / injection)")
             if self._exact is None:
                 from .exact import ExactRunner
                 for p in self.parameters():
@@ -386,7 +384,8 @@ class VideoUNet(UNetModel):
                         raise VidsegError("VideoUNet has no weights: call load_state_dict() first")
                 self._set_taps()
                 self._exact = ExactRunner(self, x.device)
-            return self._exact.forward(x, timesteps, context, y=y, num_video_frames=num_video_frames, stop_after_block=stop_after_block)
+            return self._exact.forward(x, timesteps, context, y=y, num_video_frames=num_video_frames, stop_after_block=stop_after_block,
+                                       is_modulate_step=is_modulate_step, is_injected_step=is_injected_step, modulate_params=modulate_params)
         xn = x.float().permute(0, 2, 3, 1).contiguous()
         ctx = context if context.dtype == ops.act_dtype() else ops.to_bf16(context.float().contiguous())
         return self.forward_nhwc(xn, timesteps, ctx, y, num_video_frames, is_modulate_step, is_injected_step, modulate_params,
