@@ -590,10 +590,9 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, preb
         # latent blending on, no feature injection), after an untimed window that keeps the x_t of every step in HBM for it.
         net4 = eng.model.diffusion_model
         prec4 = net4.precision
-        stage("step 4 (modulated passes, 16-bit mode)")
+        stage(f"step 4 (modulated passes, precision {prec4})")
         try:
             from vidseg_diffusion_amd.pipeline import modulation_sweep, segment_window
-            net4.set_precision("fp16")                               # the modulated / injected passes exist in the 16-bit mode only
             FE.FeatureStore.clear()
             FE.MaskStore.clear()
             lat, cw, ucw, noise = inputs[win_ids[0]]
@@ -614,12 +613,14 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, preb
             res = modulation_sweep(eng, lat, cw, ucw, [label], folder, **kw)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            out["step4_latent_blending"] = {"ms_per_modulated_pass": round(1e3 * dt / 2, 2), "passes_per_window": 2 * k_masks,
+            out["step4_latent_blending"] = {"ms_per_modulated_pass": round(1e3 * dt / 2, 2), "passes_per_window": 2 * k_masks, "precision": prec4,
                                             "finite": bool(all(torch.isfinite(v).all().item() for v in res.values())),
                                             "note": "one label's +lambda / -lambda modulated sampler passes (8 CFG evaluations each, lambda*mask added "
                                                     "to the spatial and temporal self-attention rows of decoder block 8 at step 17, latents blended "
                                                     "with the feature pass's x_t outside the mask at every step): the Step 4 unit of configs[2]; "
-                                                    "outside `value` (Steps 1-3b), which the metric is quoted on; 16-bit mode"}
+                                                    "outside `value` (Steps 1-3b), which the metric is quoted on; same precision mode as `value` (round 5: "
+                                                    "the exact runner carries the Step-4 hooks; tests/test_gpu_c3_window.py::test_step4_latent_blending_full_size "
+                                                    "pins these passes against the reference's own run at full size)"}
         except Exception as e:
             out["step4_latent_blending"] = {"error": repr(e)[:300]}
         finally:

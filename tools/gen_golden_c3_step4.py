@@ -9,7 +9,7 @@ at the modulation step (attention.py:646-663, video_attention.py:197-216), no fe
 pass's x_t outside the mask after every step (sampling.py:229-250).  The mask is the label the reference itself produced for this
 window: tests/golden/c3_t17_w0.npz `corrected_labels` == its smallest label (36x64 tokens = block 8's resolution).
 
-t_start = modulate_timestep = 22 (three Euler steps, 3 + 2 x 3 = 9 CFG evaluations, ~1.5 h and ~45 GB on the build host) instead
+t_start = modulate_timestep = 22 (three Euler steps, 3 + 2 x 3 = 9 CFG evaluations, ~45 min and ~40 GB on the build host) instead
 of the driver's 17 (3 x 8 = 24 evaluations, ~4 h): the hooks are step-independent and every one of them -- the row add on both
 layer types at the modulation step, the blend at every step from latent_mask_start on -- runs at full width.  The modulated
 evaluation runs the whole CFG batch in ONE network call (the hooks index the batch: rows i and i + num_masks / [:half_hw], [half_hw:]);
@@ -54,6 +54,19 @@ def main():
     from sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
     SAM.F = types.SimpleNamespace(to_pil_image=lambda t: None)      # torchvision stub: sampling.py:246 builds an unused PIL image
     torch.set_grad_enabled(False)
+    # Memory: the reference's attention is torch's math SDPA, which materialises the [frames x heads, tokens, tokens] scores -- 47.6 GB
+    # for the 28-frame CFG batch at 9216 tokens (the first attempt was OOM-killed at 65 GB).  The scores of different (frame, head)
+    # pairs never meet, so the same call on slices of the frame axis returns the same values slice by slice; the wrapper below hands
+    # torch's own kernel at most 7 frames at a time.
+    import torch.nn.functional as TF
+    sdpa = TF.scaled_dot_product_attention
+
+    def sdpa_by_frames(q, k, v, *a, **kw):
+        if q.dim() != 4 or q.shape[0] <= 7 or q.shape[2] < 1024 or a or kw.get("attn_mask") is not None:
+            return sdpa(q, k, v, *a, **kw)
+        return torch.cat([sdpa(q[i:i + 7], k[i:i + 7], v[i:i + 7], **kw) for i in range(0, q.shape[0], 7)], 0)
+
+    TF.scaled_dot_product_attention = sdpa_by_frames
     t_all = time.time()
     net = VideoUNet(use_checkpoint=False, spatial_transformer_attn_type="softmax", **synthetic.SVD_FULL).eval().to("cpu")
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
