@@ -271,7 +271,8 @@ def pmc_traffic(extra_args, timeout=240):
         for k, a in sums.items():
             n = a["FETCH_SIZE"][0]
             if n and n == a["WRITE_SIZE"][0]:
-                out[k] = (n, (2.0 * a["FETCH_SIZE"][1] + a["WRITE_SIZE"][1]) * 1024.0 / n)
+                out[k] = (n, (2.0 * a["FETCH_SIZE"][1] + a["WRITE_SIZE"][1]) * 1024.0 / n, 2.0 * a["FETCH_SIZE"][1] * 1024.0 / n,
+                          a["WRITE_SIZE"][1] * 1024.0 / n)
         return out or None
     except Exception:
         return None
@@ -583,7 +584,7 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, preb
         out["dtype"] += " + e4m3 attention (q, k, v, P; >= 1024 keys)"
         out["config"]["workload"] += "; BASELINE configs[4] attention path: OCP e4m3 MFMA on the spatial self-attentions"
     out["config"]["windows_cycled"] = win_ids
-    if svd and world == 1 and not args.narrow and (not args.masks_only or args.parity) and not args.fp8_attn:
+    if svd and world == 1 and not args.narrow and (not args.masks_only or args.parity) and not args.fp8_attn and not args.no_step4:
         # BASELINE configs[2] names "is_refine_mask + latent blending": the blending lives in Step 4's modulated sampler passes
         # (sampling.py:229-250; svd_pipeline_vspw.py:396-487 -- 2*K of them per window).  One label's +lambda / -lambda pair is run and
         # timed here with the SVD driver's defaults (block 8, spatial + temporal self-attention rows, modulate_timestep 17 = t_start,
@@ -682,6 +683,7 @@ def main():
                          "stops after decoder block 8 (pipeline.feature_pass(masks_only=True)); taps equal up to fp32 summation order")
     ap.add_argument("--masks", type=int, default=None, help="number of masks K (default 20; configs[4] uses 50)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the chained-window figure, the in-run PMC passes and the SVD secondary")
+    ap.add_argument("--no-step4", action="store_true", help="--config svd: skip the Step-4 pair timed after the headline (kernel-trace runs of the window alone)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # one window under rocprofv3 --pmc (see pmc_traffic)
     ap.add_argument("--precision", default=None, choices=["parity", "exact", "fp16"],
                     help="parity (default with the fp16 build of the library, the headline; the bf16 build has no exact mode and defaults to fp16): "
@@ -881,7 +883,8 @@ def main():
                 out["roofline"]["traffic"] = int(tr[key][1])
                 out["roofline"]["traffic_how"] = (f"this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over one window of "
                                                   f"the same workload, {key}: {tr[key][0]} launches, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches")
-                out["roofline"]["traffic_by_kernel"] = {k: {"launches": n, "bytes_per_launch": int(b)} for k, (n, b) in sorted(tr.items())}
+                out["roofline"]["traffic_by_kernel"] = {k: {"launches": v[0], "bytes_per_launch": int(v[1]), "read_bytes_per_launch": int(v[2]),
+                                                            "write_bytes_per_launch": int(v[3])} for k, v in sorted(tr.items())}
             else:
                 static = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
                 if static:

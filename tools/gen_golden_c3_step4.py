@@ -9,14 +9,11 @@ at the modulation step (attention.py:646-663, video_attention.py:197-216), no fe
 pass's x_t outside the mask after every step (sampling.py:229-250).  The mask is the label the reference itself produced for this
 window: tests/golden/c3_t17_w0.npz `corrected_labels` == its smallest label (36x64 tokens = block 8's resolution).
 
-t_start = modulate_timestep = 22 (three Euler steps, 3 + 2 x 3 = 9 CFG evaluations, ~45 min and ~40 GB on the build host) instead
-of the driver's 17 (3 x 8 = 24 evaluations, ~4 h): the hooks are step-independent and every one of them -- the row add on both
-layer types at the modulation step, the blend at every step from latent_mask_start on -- runs at full width.  The modulated
-evaluation runs the whole CFG batch in ONE network call (the hooks index the batch: rows i and i + num_masks / [:half_hw], [half_hw:]);
-the unmodulated ones are evaluated one video at a time as in tools/gen_golden_c3_window.py.
+t_start = modulate_timestep = 17, the SVD driver's own schedule (svd_pipeline_vspw.py:236-237, 598): eight Euler steps per pass, 3 x 8 = 24
+CFG evaluations of the whole 28-frame batch in ONE network call each (~65 min on the build host, 16 GB).
 
-The fixture holds, per pass, x after every step (every second latent row / column, fp32) with its full norm, and the final latent
-in full (+lambda pass; the -lambda pass subsampled like the steps); the mask; sha256 of every input.
+The fixture holds, per pass, x after every step (every fourth latent row / column, fp32) with its full norm, the final latent (every
+second row / column) with its norm; the mask; sha256 of every input.
 
     python tools/gen_golden_c3_step4.py [--threads N]
 """
@@ -38,7 +35,7 @@ from gen_golden_c3_window import F, LH, LW, NUM_STEPS, svd_inputs  # noqa: E402
 from ref_import import import_reference  # noqa: E402
 from vidseg_diffusion_amd import synthetic  # noqa: E402
 
-T_START, LAM, BLOCK = 22, 50.0, 8
+T_START, LAM, BLOCK = 17, 50.0, 8
 
 
 def main():
@@ -54,19 +51,6 @@ def main():
     from sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
     SAM.F = types.SimpleNamespace(to_pil_image=lambda t: None)      # torchvision stub: sampling.py:246 builds an unused PIL image
     torch.set_grad_enabled(False)
-    # Memory: the reference's attention is torch's math SDPA, which materialises the [frames x heads, tokens, tokens] scores -- 47.6 GB
-    # for the 28-frame CFG batch at 9216 tokens (the first attempt was OOM-killed at 65 GB).  The scores of different (frame, head)
-    # pairs never meet, so the same call on slices of the frame axis returns the same values slice by slice; the wrapper below hands
-    # torch's own kernel at most 7 frames at a time.
-    import torch.nn.functional as TF
-    sdpa = TF.scaled_dot_product_attention
-
-    def sdpa_by_frames(q, k, v, *a, **kw):
-        if q.dim() != 4 or q.shape[0] <= 7 or q.shape[2] < 1024 or a or kw.get("attn_mask") is not None:
-            return sdpa(q, k, v, *a, **kw)
-        return torch.cat([sdpa(q[i:i + 7], k[i:i + 7], v[i:i + 7], **kw) for i in range(0, q.shape[0], 7)], 0)
-
-    TF.scaled_dot_product_attention = sdpa_by_frames
     t_all = time.time()
     net = VideoUNet(use_checkpoint=False, spatial_transformer_attn_type="softmax", **synthetic.SVD_FULL).eval().to("cpu")
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
@@ -86,18 +70,26 @@ def main():
                latent_sha256=synthetic.sha256_of(lat.numpy()), noise_sha256=synthetic.sha256_of(noise.numpy()),
                ctx_sha256=synthetic.sha256_of(c["crossattn"].numpy()), vector_sha256=synthetic.sha256_of(c["vector"].numpy()))
 
+    # Memory: every attention / transformer / ResBlock module of the reference keeps its last q, k, v, attn1_out, attn2_out, ff_out ...
+    # as attributes (the dumps the driver's callback reads), ~3 GB per transformer at the 28-frame CFG batch: 65 GB over the network
+    # (three attempts were OOM-killed).  Step 4 with injection off reads none of them, so a forward hook drops each module's stash as
+    # soon as that module returns -- no arithmetic changes; the batch-28 evaluation then peaks at 15.5 GB and the whole CFG batch goes
+    # through ONE network call per evaluation (which the modulation hooks need: they index rows i and i + num_masks / [:half_hw], [half_hw:]).
+    stash = ("q", "k", "v", "attn1_out", "attn2_out", "ff_out", "features_after_temporal", "video_features", "in_layers_features",
+             "out_layers_features")
+
+    def drop(mod, inp, out):
+        for a in stash:
+            if isinstance(getattr(mod, a, None), torch.Tensor):
+                setattr(mod, a, None)
+
+    for m in net.modules():
+        m.register_forward_hook(drop)
     orig_forward = net.forward
 
-    def forward(x, timesteps=None, context=None, y=None, num_video_frames=None, image_only_indicator=None, **kw):
-        if kw.get("is_modulate_step"):                                # the hooks index the CFG batch: one call for both videos
-            out = orig_forward(x, timesteps=timesteps, context=context, y=y, num_video_frames=num_video_frames,
-                               image_only_indicator=image_only_indicator, **kw)
-        else:                                                         # per-video evaluation: no operator crosses the video axis
-            out = torch.cat([orig_forward(x[v * F:(v + 1) * F], timesteps=timesteps[v * F:(v + 1) * F], context=context[v * F:(v + 1) * F],
-                                          y=y[v * F:(v + 1) * F], num_video_frames=num_video_frames,
-                                          image_only_indicator=image_only_indicator[v:v + 1], **kw) for v in range(x.shape[0] // F)], 0)
-        print(f"  network evaluation done ({'modulated, batch 28' if kw.get('is_modulate_step') else 'two videos'}), {time.time() - t_all:.0f} s",
-              flush=True)
+    def forward(*a, **kw):
+        out = orig_forward(*a, **kw)
+        print(f"  network evaluation done ({'modulated' if kw.get('is_modulate_step') else 'plain'}, batch {out.shape[0]}), {time.time() - t_all:.0f} s", flush=True)
         return out
 
     net.forward = forward
@@ -129,7 +121,8 @@ def main():
 
     try:
         feat_final = sampler(denoiser, noised.clone(), cond=c, uc=uc, img_callback=dump_cb, t_start=T_START)
-        rec.update(feat_final=feat_final.numpy().astype(np.float32), feat_steps_sub=np.stack(feat_steps)[:, :, :, ::2, ::2].astype(np.float32),
+        rec.update(feat_final_sub=feat_final.numpy()[:, :, ::2, ::2].astype(np.float32), feat_final_norm=np.float64(np.linalg.norm(feat_final.double().numpy())),
+                   feat_steps_sub=np.stack(feat_steps)[:, :, :, ::4, ::4].astype(np.float32),
                    feat_step_norms=np.array([np.linalg.norm(x.astype(np.float64)) for x in feat_steps]))
         for tag, lam in (("pos", LAM), ("neg", -LAM)):
             mp = {"feature_masks": [torch.from_numpy(m) for m in masks_np], "modulate_block_idx": [BLOCK],
@@ -143,15 +136,12 @@ def main():
             final = sampler(denoiser, noised.clone(), cond=c, uc=uc, img_callback=lambda xt, i: xs.append(xt.clone().numpy()),
                             is_modulate=True, modulate_params=mp, t_start=T_START, is_latent_blending=True, feature_height=fh, feature_width=fw,
                             model=None)
-            rec[f"mod_{tag}_steps_sub"] = np.stack(xs)[:, :, :, ::2, ::2].astype(np.float32)
+            rec[f"mod_{tag}_steps_sub"] = np.stack(xs)[:, :, :, ::4, ::4].astype(np.float32)
             rec[f"mod_{tag}_step_norms"] = np.array([np.linalg.norm(x.astype(np.float64)) for x in xs])
             fin = final.numpy().astype(np.float32)
             rec[f"mod_{tag}_final_norm"] = np.float64(np.linalg.norm(fin.astype(np.float64)))
-            if tag == "pos":
-                rec["mod_pos_final"] = fin                              # in full; the -lambda pass keeps every second row / column
-            else:
-                rec["mod_neg_final_sub"] = fin[:, :, ::2, ::2]
-            d = np.abs(fin - rec["feat_final"]).mean() / np.abs(rec["feat_final"]).mean()
+            rec[f"mod_{tag}_final_sub"] = fin[:, :, ::2, ::2]
+            d = np.abs(fin - feat_final.numpy()).mean() / np.abs(feat_final.numpy()).mean()
             print(f"pass {tag}: modulated vs plain final latent, mean |difference| / mean |plain| = {d:.4f}", flush=True)
     finally:
         shutil.rmtree(base, ignore_errors=True)

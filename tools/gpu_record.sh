@@ -32,9 +32,9 @@ if has prof; then
 fi
 if has svdprof; then
   rm -rf /tmp/prof_s
-  timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o r -- python $GRAFT_REPO_ROOT/bench.py --config svd --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --lanes 1 > $GRAFT_REPO_ROOT/gpurun_out/$T/bench_svd_under_rocprof.json 2>/tmp/prof_s.err
+  timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o r -- python $GRAFT_REPO_ROOT/bench.py --config svd --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-step4 --lanes 1 > $GRAFT_REPO_ROOT/gpurun_out/$T/bench_svd_under_rocprof.json 2>/tmp/prof_s.err
   db=$(find /tmp/prof_s -name "*results.db" | head -1)
-  python $GRAFT_REPO_ROOT/tools/prof_summary.py $db "$T: python bench.py --config svd --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --lanes 1 (parity mode) under rocprofv3 --kernel-trace --stats" > $GRAFT_REPO_ROOT/gpurun_out/$T/bench_svd_kernel_stats.md
+  python $GRAFT_REPO_ROOT/tools/prof_summary.py $db "$T: python bench.py --config svd --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-step4 --lanes 1 (parity mode) under rocprofv3 --kernel-trace --stats" > $GRAFT_REPO_ROOT/gpurun_out/$T/bench_svd_kernel_stats.md
   head -44 $GRAFT_REPO_ROOT/gpurun_out/$T/bench_svd_kernel_stats.md
   tail -c 300 /tmp/prof_s.err
 fi

@@ -9,6 +9,6 @@ print(f"# {title}\n")
 print("rocprofv3 --kernel-trace --stats (durations in microseconds, whole process incl. warm-up)\n")
 print("| kernel | calls | total us | avg us | % |")
 print("|---|---|---|---|---|")
-for n, c, t, a, p in rows[:40]:
-    print(f"| `{n[:90]}` | {c} | {t:.0f} | {a:.1f} | {p:.2f} |")
+for n, c, t, a, p in rows[:48]:
+    print(f"| `{n[:260] if 'at::native' in n else n[:90]}` | {c} | {t:.0f} | {a:.1f} | {p:.2f} |")
 print(f"\ntotal kernel time: {sum(r[2] for r in rows):.0f} us over {sum(r[1] for r in rows)} dispatches")

@@ -82,7 +82,27 @@ def xattn(N, H, Bx=B):
     cases.append((f"exact attention B{Bx} N{N} H{H}", lambda: X.attention_x(q, kv, H, Bx, N, N, split_out=True)))
 
 
+def xtemporal(nv, S, H, T=14):
+    from vidseg_diffusion_amd import exact as X
+    qkv = rn(nv * T, S, 3 * H * 64)
+    cases.append((f"exact temporal attention videos{nv} T{T} S{S} H{H}", lambda: X.temporal_attention_x(qkv, nv, T, S, H, split_out=True)))
+
+
+def xblend(M, K, N):
+    from vidseg_diffusion_amd import exact as X
+    a3, w3, b, r, sp = X.split3(rn(M, K)), X.pack_linear_x(rn(N, K, s=0.02).cpu(), dev), rn(N), rn(M, N), rn(M, N)
+    cases.append((f"exact linear + blend M{M} K{K} N{N}", lambda: X.linear_blend_x(a3, w3, b, r, sp, 0.4)))
+
+
+def xrowvec(M, K, N, rows):
+    from vidseg_diffusion_amd import exact as X
+    a3, w3, b, r, rv = X.split3(rn(M, K)), X.pack_linear_x(rn(N, K, s=0.02).cpu(), dev), rn(N), rn(M, N), rn(M // rows, N)
+    cases.append((f"exact linear + row vector + residual M{M} K{K} N{N}", lambda: X.linear_x(a3, w3, b, residual=r, rowvec=rv, rows_per_sample=rows)))
+
+
 if args.exact:
+    xtemporal(2, 2304, 5); xtemporal(2, 576, 10); xtemporal(1, 2304, 5); xblend(64512, 2560, 640); xblend(16128, 5120, 1280); xrowvec(64512, 640, 640, 2304)
+    xattn(9216, 5, Bx=4)
     xconv(64, 320, 320, res=True); xconv(64, 960, 320); xconv(32, 640, 640, res=True); xconv(32, 1920, 640); xconv(16, 1280, 1280, res=True)
     xconv(16, 2560, 1280); xconv(8, 1280, 1280, res=True); xconv(32, 640, 640, up=2); xconv(64, 320, 320, stride=2); xconv(32, 640, 640, res=True, Bx=14)
     xlin(114688, 320, 320, res=True); xlin(114688, 320, 960); xlin(114688, 1280, 320, res=True); xlin(28672, 640, 640, res=True); xlin(28672, 2560, 640, res=True)

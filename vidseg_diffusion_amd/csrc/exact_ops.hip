@@ -795,6 +795,10 @@ __global__ void __launch_bounds__(256, 2) k_x_attention_mfma(const float* __rest
     store_k(1);
     __syncthreads();
     f32x16 sA[2], sB[2];
+#ifdef VS_XATTN_SKEW                                            // race hunting (tools/build_exp.py ab_xskew -DVS_XATTN_SKEW=1): wave 1 of every block
+    if (wave == VS_XATTN_SKEW)                                  // enters S(0) about one tile late -- without the barrier below its siblings' K(2)
+        for (int i = 0; i < 40; ++i) __builtin_amdgcn_s_sleep(127);   // stores would land on the K(0) it is still reading
+#endif
     qk(0, sA);
     __syncthreads();                                            // tile 0 ends by storing K(2) over K(0): every wave must be out of qk(0) first
     int t = 0;

@@ -2301,9 +2301,10 @@ __global__ void __launch_bounds__(256) k_conv_out4_ws(const bf16_t* __restrict__
 //   split (1) 0 = no split-K;  panel (1): 0 = row-major tile order
 //   ext (1)   0 = hipEventRecord pairs instead of dispatch-packet timestamps (profiling);  fence (0): 1 = system-scope fence at the events
 //   shapes (0) 1 = one GEMMSHAPE line per profiled launch on stderr (tools/shape_summary.py)
+//   gg / gn (0) > 0 = a fixed panel width of the tile order for the GEGLU tile / every other tile (tools/panel_sweep.py)
 struct GemmKnobs {
     int big = 1, p7 = 1, p7x = 1, phx = 1, xsmall = 1, p7ph = 5, ph = 1, mid = 1, dma = 1, tile = 0, ws = 1, convout = 1, split = 1, panel = 1, ext = 1, fence = 0,
-        shapes = 0;
+        shapes = 0, gg = 0, gn = 0;
 };
 static const GemmKnobs& knobs() {
     static const GemmKnobs k = [] {
@@ -2312,7 +2313,7 @@ static const GemmKnobs& knobs() {
         if (!e) return g;
         struct { const char* name; int* v; } tab[] = {{"big", &g.big}, {"p7", &g.p7}, {"p7x", &g.p7x}, {"phx", &g.phx}, {"xsmall", &g.xsmall}, {"p7ph", &g.p7ph}, {"ph", &g.ph}, {"mid", &g.mid},
                                                       {"dma", &g.dma}, {"tile", &g.tile}, {"ws", &g.ws}, {"convout", &g.convout}, {"split", &g.split},
-                                                      {"panel", &g.panel}, {"ext", &g.ext}, {"fence", &g.fence}, {"shapes", &g.shapes}};
+                                                      {"panel", &g.panel}, {"ext", &g.ext}, {"fence", &g.fence}, {"shapes", &g.shapes}, {"gg", &g.gg}, {"gn", &g.gn}};
         while (*e) {
             const char* eq = strchr(e, '=');
             if (!eq) break;
@@ -2849,6 +2850,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             attr3 = true;
         }
         p.gn = (p.N + 255) / 256 < 8 ? (p.N + 255) / 256 : 8;
+        if (knobs().gg > 0) p.gn = knobs().gg < (p.N + 255) / 256 ? knobs().gg : (p.N + 255) / 256;   // A/B: panel width of the GEGLU tile order
         int kind3 = 1;
         if (p.geglu16) {                                       // weights interleaved in 16-row value | gate groups: the split tile (224 x 256)
             VS_REQUIRE(p.K % 192 == 0 && p.C0 == p.K && p.N % 256 == 0, "gemm: geglu16 needs K %% 192 == 0 and N %% 256 == 0 (K=%d N=%d)", p.K, p.N);
@@ -2994,6 +2996,7 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         auto pick_gn = [&](int bm, int bn, int res, int split) {
             const int tn_all = (p.N + bn - 1) / bn;
             if (!panel_mode) return tn_all;
+            if (knobs().gn > 0) return knobs().gn < tn_all ? knobs().gn : tn_all;                     // A/B: a fixed panel width
             const double a_slab = (double)bm * (p.K / p.taps) * (p.stride * p.stride) / (double)(p.up * p.up);   // input bytes/2 behind a tile row
             const double w_slab = (double)bn * p.K / split;
             int best = tn_all;

@@ -312,7 +312,7 @@ class WindowPipeline:
             labels, state = analyse_window(self.engine, h, state=self.state if self.chain else WindowState(), **self.analysis_kw)
         if self.chain:
             self.state = state
-        if os.environ.get("VIDSEG_DEBUG_HASH"):                                      # run-to-run determinism hunts (tools/lab/rep_bench.sh)
+        if os.environ.get("VIDSEG_DEBUG_HASH"):                                      # run-to-run determinism hunts (tools/determinism_check.py)
             import hashlib
             import sys
             fm = state.ref_feature_map
