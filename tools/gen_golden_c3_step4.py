@@ -15,13 +15,11 @@ CFG evaluations of the whole 28-frame batch in ONE network call each (~65 min on
 The fixture holds, per pass, x after every step (every fourth latent row / column, fp32) with its full norm, the final latent (every
 second row / column) with its norm; the mask; sha256 of every input.
 
-    python tools/gen_golden_c3_step4.py [--threads N]
+    python tools/gen_golden_c3_step4.py [--threads N] [--state DIR]      # resumes from DIR pass by pass
 """
 import argparse
 import os
-import shutil
 import sys
-import tempfile
 import time
 import types
 
@@ -41,6 +39,7 @@ T_START, LAM, BLOCK = 17, 50.0, 8
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--state", default="/tmp/vidseg_c3_step4_state", help="directory that keeps the finished passes (the run resumes from it)")
     args = ap.parse_args()
     if args.threads:
         torch.set_num_threads(args.threads)
@@ -110,21 +109,31 @@ def main():
     noised = sampler.add_noise(lat.clone(), cond=c, uc=uc, num_steps=NUM_STEPS, noise_level=T_START)
     sig = sampler.discretization(NUM_STEPS, device="cpu")
     assert torch.equal(noised, (lat + noise * sig[T_START]) / torch.sqrt(1.0 + sig[0] ** 2.0)), "torch.randn_like under manual_seed != Generator draw"
-    base = tempfile.mkdtemp(prefix="vidseg_c3s4_")
+    # Resumable: every finished pass is kept under --state (the feature pass's xt_time_<i>.pt -- which the modulated passes read anyway --
+    # and one .npz per pass), so an interrupted run continues with the next pass instead of starting over.
+    base = args.state
     fm = os.path.join(base, "exp", "feature_maps")
-    os.makedirs(fm)
-    feat_steps = []
+    os.makedirs(fm, exist_ok=True)
 
-    def dump_cb(xt, i):                                           # the driver's callback keeps x_t of every step (SVP:123)
-        torch.save(xt.clone(), f"{fm}/xt_time_{i}.pt")
-        feat_steps.append(xt.clone().numpy())
+    def pass_file(tag):
+        return os.path.join(base, f"pass_{tag}.npz")
 
-    try:
+    if not os.path.exists(pass_file("feat")):
+        feat_steps = []
+
+        def dump_cb(xt, i):                                       # the driver's callback keeps x_t of every step (SVP:123)
+            torch.save(xt.clone(), f"{fm}/xt_time_{i}.pt")
+            feat_steps.append(xt.clone().numpy())
+
         feat_final = sampler(denoiser, noised.clone(), cond=c, uc=uc, img_callback=dump_cb, t_start=T_START)
-        rec.update(feat_final_sub=feat_final.numpy()[:, :, ::2, ::2].astype(np.float32), feat_final_norm=np.float64(np.linalg.norm(feat_final.double().numpy())),
-                   feat_steps_sub=np.stack(feat_steps)[:, :, :, ::4, ::4].astype(np.float32),
-                   feat_step_norms=np.array([np.linalg.norm(x.astype(np.float64)) for x in feat_steps]))
-        for tag, lam in (("pos", LAM), ("neg", -LAM)):
+        np.savez(pass_file("feat"), feat_final=feat_final.numpy(), feat_steps_sub=np.stack(feat_steps)[:, :, :, ::4, ::4].astype(np.float32),
+                 feat_step_norms=np.array([np.linalg.norm(x.astype(np.float64)) for x in feat_steps]))
+    pf = np.load(pass_file("feat"))
+    feat_final = pf["feat_final"]
+    rec.update(feat_final_sub=feat_final[:, :, ::2, ::2].astype(np.float32), feat_final_norm=np.float64(np.linalg.norm(feat_final.astype(np.float64))),
+               feat_steps_sub=pf["feat_steps_sub"], feat_step_norms=pf["feat_step_norms"])
+    for tag, lam in (("pos", LAM), ("neg", -LAM)):
+        if not os.path.exists(pass_file(tag)):
             mp = {"feature_masks": [torch.from_numpy(m) for m in masks_np], "modulate_block_idx": [BLOCK],
                   "modulate_layer_type": ["spatial", "temporal"], "modulate_attn_type": ["self_attn"], "modulate_timestep": [T_START],
                   "modulate_schedule": "constant", "modulate_lambda_start": lam, "modulate_lambda_end": lam, "num_frames": F,
@@ -136,15 +145,14 @@ def main():
             final = sampler(denoiser, noised.clone(), cond=c, uc=uc, img_callback=lambda xt, i: xs.append(xt.clone().numpy()),
                             is_modulate=True, modulate_params=mp, t_start=T_START, is_latent_blending=True, feature_height=fh, feature_width=fw,
                             model=None)
-            rec[f"mod_{tag}_steps_sub"] = np.stack(xs)[:, :, :, ::4, ::4].astype(np.float32)
-            rec[f"mod_{tag}_step_norms"] = np.array([np.linalg.norm(x.astype(np.float64)) for x in xs])
             fin = final.numpy().astype(np.float32)
-            rec[f"mod_{tag}_final_norm"] = np.float64(np.linalg.norm(fin.astype(np.float64)))
-            rec[f"mod_{tag}_final_sub"] = fin[:, :, ::2, ::2]
-            d = np.abs(fin - feat_final.numpy()).mean() / np.abs(feat_final.numpy()).mean()
-            print(f"pass {tag}: modulated vs plain final latent, mean |difference| / mean |plain| = {d:.4f}", flush=True)
-    finally:
-        shutil.rmtree(base, ignore_errors=True)
+            np.savez(pass_file(tag), steps_sub=np.stack(xs)[:, :, :, ::4, ::4].astype(np.float32),
+                     step_norms=np.array([np.linalg.norm(x.astype(np.float64)) for x in xs]), final_norm=np.float64(np.linalg.norm(fin.astype(np.float64))),
+                     final_sub=fin[:, :, ::2, ::2], effect=np.float64(np.abs(fin - feat_final).mean() / np.abs(feat_final).mean()))
+        pm = np.load(pass_file(tag))
+        rec[f"mod_{tag}_steps_sub"], rec[f"mod_{tag}_step_norms"] = pm["steps_sub"], pm["step_norms"]
+        rec[f"mod_{tag}_final_norm"], rec[f"mod_{tag}_final_sub"] = pm["final_norm"], pm["final_sub"]
+        print(f"pass {tag}: modulated vs plain final latent, mean |difference| / mean |plain| = {float(pm['effect']):.4f}", flush=True)
     rec["versions"] = np.array([f"torch {torch.__version__}", f"numpy {np.__version__}"])
     path = os.path.join(ROOT, "tests", "golden", "c3_step4_w0.npz")
     np.savez_compressed(path, **rec)
