@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(256) k_x_gn_apply_split3(const float* __restri
 // LayerNorm over the last dim of fp32 rows (C <= 2048, C % 4 == 0): one wave per row, two passes in registers -> split3
 // vec / rows_per_sample / nvec (optional): LayerNorm of x[row] + vec[(row / rows_per_sample) % nvec] -- the frame-index embedding of the
 // time stack (video_attention.py:417-431) added on the way in; x_sum (optional) receives that fp32 sum (the block's residual stream)
+template <bool RV>
 __global__ void __launch_bounds__(256) k_x_layernorm_split3(const float* __restrict__ x, long long M, int C, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, f16* __restrict__ out,
                                                             const float* __restrict__ vec, int rows_per_sample, int nvec,
@@ -222,13 +223,13 @@ __global__ void __launch_bounds__(256) k_x_layernorm_split3(const float* __restr
     constexpr int MAXCH = 8;                                   // 64 lanes * 4 * 8 = 2048 channels
     f32x4 v[MAXCH];
     float s = 0.f;
-    const float* vr = vec ? vec + (long long)((row / rows_per_sample) % nvec) * C : nullptr;
+    const float* vr = RV ? vec + (long long)((row / rows_per_sample) % nvec) * C : nullptr;
 #pragma unroll
     for (int ch = 0; ch < MAXCH; ++ch) {
         const int c = lane * 4 + ch * 256;
         if (c < C) {
             v[ch] = *reinterpret_cast<const f32x4*>(x + row * C + c);
-            if (vr) {
+            if constexpr (RV) {
                 const f32x4 e = *reinterpret_cast<const f32x4*>(vr + c);
                 v[ch] = f32x4{v[ch][0] + e[0], v[ch][1] + e[1], v[ch][2] + e[2], v[ch][3] + e[3]};
                 if (x_sum) *reinterpret_cast<f32x4*>(x_sum + row * C + c) = v[ch];
@@ -900,7 +901,7 @@ int vidseg_x_layernorm_split3(const float* x, long long M, int C, const float* g
                               hipStream_t st) {
     VS_REQUIRE(C % 4 == 0 && C <= 2048, "x_layernorm: C=%d", C);
     if (M == 0) return VS_OK;
-    k_x_layernorm_split3<<<dim3((unsigned)((M + 3) / 4)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16, nullptr, 1, 1, nullptr);
+    k_x_layernorm_split3<false><<<dim3((unsigned)((M + 3) / 4)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16, nullptr, 1, 1, nullptr);
     VS_CHECK_LAUNCH("x_layernorm_split3");
     return VS_OK;
 }
@@ -910,7 +911,7 @@ int vidseg_x_layernorm_rowvec_split3(const float* x, const float* vec, long long
     VS_REQUIRE(C % 4 == 0 && C <= 2048 && vec != nullptr && rows_per_sample > 0 && nvec > 0, "x_layernorm_rowvec: C=%d rows_per_sample=%d nvec=%d", C,
                rows_per_sample, nvec);
     if (M == 0) return VS_OK;
-    k_x_layernorm_split3<<<dim3((unsigned)((M + 3) / 4)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16, vec, rows_per_sample, nvec, x_sum);
+    k_x_layernorm_split3<true><<<dim3((unsigned)((M + 3) / 4)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16, vec, rows_per_sample, nvec, x_sum);
     VS_CHECK_LAUNCH("x_layernorm_rowvec_split3");
     return VS_OK;
 }

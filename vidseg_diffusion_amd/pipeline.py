@@ -182,8 +182,20 @@ def feature_pass(engine: Engine, latent: torch.Tensor, c: dict, uc: dict, *, num
         if keep_all_steps or want != num_steps - 1 or want < t_start:
             raise ValueError("masks_only needs keep_all_steps=False and feature_timestep = the last step")
         if want > t_start:
-            x = sampler(denoiser, x, cond=c, uc=uc, img_callback=None, is_modulate=False, modulate_params=None, uc_list=None,
-                        t_start=t_start, t_end=want - 1, is_latent_blending=False)
+            # nothing reads the Q / K taps of the steps before `want` (no callback): the fp16 tap copies of those evaluations are not
+            # written, and the exact mode's one-key cross-attentions fold into the preceding projection (exact._NK1_IDENTITY) -- round 5;
+            # the network's outputs do not depend on the taps
+            mode0 = getattr(net, "tap_mode", None)
+            if mode0 is not None:
+                net.tap_mode = "none"
+                net._set_taps()
+            try:
+                x = sampler(denoiser, x, cond=c, uc=uc, img_callback=None, is_modulate=False, modulate_params=None, uc_list=None,
+                            t_start=t_start, t_end=want - 1, is_latent_blending=False)
+            finally:
+                if mode0 is not None:
+                    net.tap_mode = mode0
+                    net._set_taps()
         else:                                                                       # one step only: the loop's entry scaling, SAM:45-59
             x, _, _, _, _, _ = sampler.prepare_sampling_loop(x, c, uc, num_steps)
         _taps_only_eval(engine, sampler, x, c, F, num_steps, want)
