@@ -10,7 +10,7 @@ mkdir -p gpurun_out/$T
 has() { for a in "$@"; do :; done; case " $ARGS " in *" $1 "*) return 0;; esac; return 1; }
 ARGS="$*"
 if has full; then
-  ( time timeout 3000 python -m pytest tests -m gpu -q -s > gpurun_out/$T/pytest_gpu.log 2>&1 ) 2> gpurun_out/$T/pytest_time.txt
+  ( time timeout 3000 python -m pytest tests -m gpu -q -s --durations=25 > gpurun_out/$T/pytest_gpu.log 2>&1 ) 2> gpurun_out/$T/pytest_time.txt
   tail -5 gpurun_out/$T/pytest_gpu.log; tail -3 gpurun_out/$T/pytest_time.txt
 elif has tests; then
   ( time timeout 1500 python -m pytest tests/test_gpu_exact.py tests/test_gpu_analysis.py tests/test_gpu_c2_window.py tests/test_gpu_c3_window.py -m gpu -q -s -x > gpurun_out/$T/pytest_gpu.log 2>&1 ) 2> gpurun_out/$T/pytest_time.txt
