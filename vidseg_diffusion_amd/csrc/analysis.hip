@@ -75,49 +75,57 @@ __global__ void __launch_bounds__(256) k_mean_normalize(BlockPtrs blocks, int nb
 // value is used: with the block count and the chunk count known at compile time a lane has NB x NCH independent 16-byte loads in
 // flight instead of walking them one round trip at a time (the generic kernel above: 56 us for the 73 MB of a configs[1] window =
 // 1.3 TB/s, six dependent HBM latencies per wave).  Same order of fp32 operations, same roundings, bit-identical output.
-template <int NB, int NCH>
+template <int NB, int NCH, int R>
 __global__ void __launch_bounds__(256) k_mean_normalize_fast(BlockPtrs blocks, int64_t row0, int64_t rows, int C, f16* __restrict__ out_mean,
                                                              f16* __restrict__ out_norm) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int64_t off = (row0 + row) * (int64_t)C;
+    const int64_t rbase = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;      // R consecutive rows per wave: R x NB x NCH loads in flight
+    if (rbase >= rows) return;
     const float inv = (float)NB;
-    f16x8 v[NB][NCH];
+    f16x8 v[R][NB][NCH];
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int r = 0; r < R; ++r) {
+        const int64_t off = (row0 + rbase + r) * (int64_t)C;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int c = lane * 8 + ch * 512;
+                if (c < C && rbase + r < rows) v[r][b][ch] = *reinterpret_cast<const f16x8*>(blocks.p[b] + off + c);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = rbase + r;
+        if (row >= rows) break;
+        float vmax = 0.f;
+        f16x8 m[NCH];
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int c = lane * 8 + ch * 512;
-            if (c < C) v[b][ch] = *reinterpret_cast<const f16x8*>(blocks.p[b] + off + c);
-        }
-    float vmax = 0.f;
-    f16x8 m[NCH];
+            if (c < C) {
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int c = lane * 8 + ch * 512;
-        if (c < C) {
+                for (int j = 0; j < 8; ++j) {
+                    float acc = (float)v[r][0][ch][j];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float acc = (float)v[0][ch][j];
-#pragma unroll
-                for (int b = 1; b < NB; ++b) acc = acc + (float)v[b][ch][j];
-                const f16 h = (f16)(acc / inv);
-                m[ch][j] = h;
-                vmax = fmaxf(vmax, fabsf((float)h));
+                    for (int b = 1; b < NB; ++b) acc = acc + (float)v[r][b][ch][j];
+                    const f16 h = (f16)(acc / inv);
+                    m[ch][j] = h;
+                    vmax = fmaxf(vmax, fabsf((float)h));
+                }
             }
         }
-    }
-    vmax = wave_max_f32(vmax);
+        vmax = wave_max_f32(vmax);
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int c = lane * 8 + ch * 512;
-        if (c < C) {
-            if (out_mean) *reinterpret_cast<f16x8*>(out_mean + row * (int64_t)C + c) = m[ch];
-            f16x8 o;
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = lane * 8 + ch * 512;
+            if (c < C) {
+                if (out_mean) *reinterpret_cast<f16x8*>(out_mean + row * (int64_t)C + c) = m[ch];
+                f16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (f16)((float)m[ch][j] / vmax);
-            if (out_norm) *reinterpret_cast<f16x8*>(out_norm + row * (int64_t)C + c) = o;
+                for (int j = 0; j < 8; ++j) o[j] = (f16)((float)m[ch][j] / vmax);
+                if (out_norm) *reinterpret_cast<f16x8*>(out_norm + row * (int64_t)C + c) = o;
+            }
         }
     }
 }
@@ -1452,11 +1460,12 @@ int vidseg_mean_normalize_f16(const void* const* blocks, int nblk, int64_t row0,
     if (rows == 0) return VS_OK;
     BlockPtrs bp;
     for (int i = 0; i < nblk; ++i) bp.p[i] = static_cast<const f16*>(blocks[i]);
-    const dim3 grid((unsigned)cdiv64(rows, 4));
     f16* om = (f16*)out_mean;
     f16* on = (f16*)out_norm;
     const int nch = C <= 512 ? 1 : (C <= 1024 ? 2 : 0);
-#define VS_MN_FAST(NB, NCH) k_mean_normalize_fast<NB, NCH><<<grid, 256, 0, st>>>(bp, row0, rows, C, om, on)
+    constexpr int MN_R = 1;                                            // rows per wave of the fast kernel (2 measured 21.2 against 20.1 us: no gain)
+    const dim3 grid((unsigned)cdiv64(rows, 4)), gridf((unsigned)cdiv64(rows, 4 * MN_R));
+#define VS_MN_FAST(NB, NCH) k_mean_normalize_fast<NB, NCH, MN_R><<<gridf, 256, 0, st>>>(bp, row0, rows, C, om, on)
     if (nch == 1 && nblk == 1) VS_MN_FAST(1, 1);
     else if (nch == 1 && nblk == 2) VS_MN_FAST(2, 1);
     else if (nch == 1 && nblk == 3) VS_MN_FAST(3, 1);
