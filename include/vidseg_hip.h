@@ -353,6 +353,31 @@ int vidseg_conv_temporal3_a16_f32_blend(const void* x, int C, int BT, int HW, in
 int vidseg_conv_in_f32(const float* x, const float* w, const float* bias, int B, int H, int W, int Cin, int Cout, float* out_f32_nhwc,
                        vidseg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Conditioner: the OpenCLIP ViT-H towers (sgm/modules/encoders/modules.py = MOD; csrc/clip_ops.hip)
+ * open_clip_torch 2.24.0's ResidualAttentionBlock / TextTransformer / VisionTransformer, reached through MOD:498-567 (text),
+ * MOD:570-728 (image), MOD:1028-1046 (SVD's image prediction embedder).  The towers' projections are vidseg_linear_a16_rf32 on split
+ * operand images; these entry points are the rest of their arithmetic, all fp32, a few hundred KB per call (once per clip).
+ * ---------------------------------------------------------------------------------------------------- */
+/* nn.MultiheadAttention's core: softmax(q k^T * scale [+ causal mask]) v per head of width d (<= 128, d % 4 == 0; ViT-H: 64 text,
+ * 80 image); q / k / v fp32 column slices with row strides ld*, head h at columns [d h, d h + d); Nk <= 1024; causal (Nq == Nk):
+ * keys above the diagonal are masked (open_clip's build_attention_mask, MOD:546 `attn_mask=self.model.attn_mask`). */
+int vidseg_clip_attention_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int B, int H,
+                              int Nq, int Nk, int d, float scale, int causal, vidseg_stream_t stream);
+/* torch.nn.LayerNorm, fp32 in / out (ln_pre, ln_post, ln_final: MOD:548); C % 4 == 0, C <= 2048 */
+int vidseg_clip_layernorm_f32(const float* x, long long M, int C, const float* gamma, const float* beta, float eps, float* out,
+                              vidseg_stream_t stream);
+/* erf GELU of the block's hidden layer (open_clip: mlp.gelu = nn.GELU) written as the next GEMM's operand image [M][3C] (fp16 build) */
+int vidseg_clip_gelu_split3(const float* x, long long M, int C, void* out_f16, vidseg_stream_t stream);
+/* one axis (1 = x, 0 = y) of kornia.filters.gaussian_blur2d(separable, border_type "reflect") on fp32 [planes][H][W]: the antialias
+ * pass of kornia.geometry.resize (kornia 0.7.2, MOD:623-629); taps: device fp32 [ks], ks odd */
+int vidseg_clip_blur_axis(const float* x, long long planes, int H, int W, const float* taps, int ks, int axis, float* out, vidseg_stream_t stream);
+/* bicubic (align_corners, A = -0.75) resize of fp32 NCHW [B][3][H][W] to S x S, (x + 1) / 2, (x - mean) / std (MOD:621-633;
+ * mean3 / std3: HOST pointers to 3 floats), stored as the patch matrix of the P x P stride-P convolution: row (b, py, px),
+ * column (c, ky, kx), row stride ldo >= 3 P P (columns beyond 3 P P are left as the caller set them) */
+int vidseg_clip_resize_patches(const float* x, int B, int H, int W, int S, int P, const float* mean3, const float* std3, float* out, int ldo,
+                               vidseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,7 @@ def _declared():
 
 
 def test_every_declared_symbol_is_exported(lib):
-    from vidseg_diffusion_amd import exact, ops, process_output  # noqa: F401  (register the UNet / exact-mode / Step 5 signatures)
+    from vidseg_diffusion_amd import exact, openclip, ops, process_output  # noqa: F401  (register the UNet / exact-mode / conditioner / Step 5 signatures)
     l = ctypes.CDLL(lib.LIB_PATH)
     names = _declared()
     assert len(names) >= 30

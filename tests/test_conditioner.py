@@ -69,6 +69,11 @@ def test_yaml_targets_resolve_to_the_mirror():
     assert cond({"fps_id": torch.tensor([1.0, 2.0])})["vector"].shape == (2, 8)
 
 
+# a narrow OpenCLIP config in open_clip's model_config schema (the `arch` parameter of the embedders accepts a name or such a dict)
+NARROW_CLIP = {"embed_dim": 64, "text": {"context_length": 77, "vocab_size": 49408, "width": 64, "heads": 1, "layers": 2},
+               "vision": {"image_size": 28, "patch_size": 14, "width": 128, "head_width": 64, "layers": 1, "mlp_ratio": 4.0}}
+
+
 def _narrow_model_config():
     """The schema of configs/inference/sd_2_1.yaml (own text, narrow sizes): every `target:` is the reference's dotted path."""
     dd = "sgm.modules.diffusionmodules."
@@ -84,7 +89,7 @@ def _narrow_model_config():
             channel_mult=[1, 2, 4, 4], num_head_channels=64, use_linear_in_transformer=True, transformer_depth=1, context_dim=64)},
         "conditioner_config": {"target": "sgm.modules.GeneralConditioner", "params": {"emb_models": [
             {"is_trainable": False, "input_key": "txt", "target": "sgm.modules.encoders.modules.FrozenOpenCLIPEmbedder",
-             "params": {"freeze": True, "layer": "penultimate"}}]}},
+             "params": {"freeze": True, "layer": "penultimate", "arch": NARROW_CLIP}}]}},
         "first_stage_config": {"target": "sgm.models.autoencoder.AutoencoderKL", "params": {
             "embed_dim": 4, "monitor": "val/rec_loss", "ddconfig": vae, "lossconfig": {"target": "torch.nn.Identity"}}},
         "sampler_config": {"target": dd + "sampling.EulerEDMSampler", "params": {
@@ -104,12 +109,17 @@ def test_diffusion_engine_from_reference_style_config():
     assert isinstance(eng.conditioner, conditioner.GeneralConditioner) and eng.conditioner.embedders[0].input_key == "txt"
     assert eng.scale_factor == 0.18215 and eng.en_and_decode_n_samples_a_time is None and eng.video is False
     assert len(list(eng.model.diffusion_model.output_blocks)) == 12 and callable(eng.encode_first_stage) and callable(eng.decode_first_stage)
-    # checkpoint-style keys are routed by prefix; the OpenCLIP tower's keys are ignored, strangers reported
+    # checkpoint-style keys are routed by prefix; the OpenCLIP tower's keys reach the text tower, strangers are reported
+    from vidseg_diffusion_amd import openclip
+    assert isinstance(eng.conditioner.embedders[0], openclip.FrozenOpenCLIPEmbedder) and eng.conditioner.embedders[0].layer == "penultimate"
     sd = {"model.diffusion_model." + k: torch.zeros(v.shape) for k, v in list(eng.model.diffusion_model.state_dict().items())[:3]}
-    sd["conditioner.embedders.0.model.ln_final.weight"] = torch.zeros(4)
+    sd["conditioner.embedders.0.model.ln_final.weight"] = torch.full((64,), 2.0)
     sd["something.else"] = torch.zeros(1)
     missing, unexpected = eng.load_state_dict(sd)
-    assert unexpected == ["something.else"] and len(missing) > 0 and all(k.startswith("model.diffusion_model.") for k in missing)
+    assert unexpected == ["something.else"] and len(missing) > 0
+    assert all(k.startswith("model.diffusion_model.") or k.startswith("conditioner.embedders.0.model.") for k in missing)
+    assert "conditioner.embedders.0.model.ln_final.weight" not in missing and "conditioner.embedders.0.model.ln_final.bias" in missing
+    assert torch.equal(eng.conditioner.embedders[0].model.ln_final.weight, torch.full((64,), 2.0))
     assert engine.engine_from_config(cfg).scale_factor == 0.18215
 
 
@@ -129,7 +139,8 @@ def _narrow_svd_config():
             use_spatial_context=True, merge_strategy="learned_with_images", video_kernel_size=[3, 1, 1])},
         "conditioner_config": {"target": "sgm.modules.GeneralConditioner", "params": {"emb_models": [
             {"is_trainable": False, "input_key": "cond_frames_without_noise", "target": emb + "FrozenOpenCLIPImagePredictionEmbedder",
-             "params": {"n_cond_frames": 1, "n_copies": 1, "open_clip_embedding_config": {"target": emb + "FrozenOpenCLIPImageEmbedder", "params": {"freeze": True}}}},
+             "params": {"n_cond_frames": 1, "n_copies": 1, "open_clip_embedding_config": {"target": emb + "FrozenOpenCLIPImageEmbedder",
+                                                                                    "params": {"freeze": True, "arch": NARROW_CLIP}}}},
             {"input_key": "fps_id", "is_trainable": False, "target": emb + "ConcatTimestepEmbedderND", "params": {"outdim": 32}},
             {"input_key": "motion_bucket_id", "is_trainable": False, "target": emb + "ConcatTimestepEmbedderND", "params": {"outdim": 32}},
             {"input_key": "cond_frames", "is_trainable": False, "target": emb + "VideoPredictionEmbedderWithEncoder", "params": {
@@ -158,7 +169,7 @@ def test_svd_style_config_builds_the_video_engine():
     assert isinstance(eng.first_stage_model, vae.AutoencodingEngine) and eng.first_stage_model.decoder.video
     assert isinstance(eng.sampler.guider, sampling.LinearPredictionGuider)
     kinds = [type(e).__name__ for e in eng.conditioner.embedders]
-    assert kinds == ["PrecomputedEmbedder", "ConcatTimestepEmbedderND", "ConcatTimestepEmbedderND", "VideoPredictionEmbedderWithEncoder",
+    assert kinds == ["FrozenOpenCLIPImagePredictionEmbedder", "ConcatTimestepEmbedderND", "ConcatTimestepEmbedderND", "VideoPredictionEmbedderWithEncoder",
                      "ConcatTimestepEmbedderND"]
     assert isinstance(eng.conditioner.embedders[3].encoder, vae.AutoencoderKL)
     # the vector conditioning the video UNet's label_emb takes: three 32-wide sinusoids = adm_in_channels 96
@@ -179,7 +190,15 @@ def _prefixed_checkpoint(eng, seed=3):
             shapes = {k: tuple(v.shape) for k, v in emb.encoder.state_dict().items()}
             sd.update({f"conditioner.embedders.{i}.encoder.{k}": torch.from_numpy(v)
                        for k, v in synthetic.fill_state_dict(shapes, seed=seed + 1).items()})
-    sd["conditioner.embedders.0.model.ln_final.weight"] = torch.zeros(4)          # an OpenCLIP tower key: ignored
+    from vidseg_diffusion_amd import openclip
+    e0 = eng.conditioner.embedders[0]                                             # the OpenCLIP tower (text: SD, image: SVD)
+    assert isinstance(e0, (openclip.FrozenOpenCLIPEmbedder, openclip.FrozenOpenCLIPImagePredictionEmbedder))
+    shapes = {k: tuple(v.shape) for k, v in e0.state_dict().items()}
+    sd.update({"conditioner.embedders.0." + k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=seed + 2).items()})
+    if isinstance(e0, openclip.FrozenOpenCLIPImagePredictionEmbedder):
+        # what `del model.transformer` (modules.py:596) leaves of the text half in the released SVD checkpoints: not the image tower's, not reported
+        sd["conditioner.embedders.0.open_clip.model.positional_embedding"] = torch.zeros(77, 64)
+        sd["conditioner.embedders.0.open_clip.model.logit_scale"] = torch.zeros(())
     return sd
 
 

@@ -1,0 +1,99 @@
+"""oracle/openclip.py pinned against an independent implementation of the same published architecture: transformers' CLIP classes (the
+ones the HF conversion of OpenCLIP ViT-H-14 loads into) on the same weights.  open_clip / kornia themselves are absent (see the
+oracle's header).  CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import openclip as O  # noqa: E402
+from tools_openclip import fill, text_shapes, visual_shapes  # noqa: E402
+
+transformers = pytest.importorskip("transformers")
+
+
+def _hf_layers(sd, hf, pre_hf, layers, W):
+    for i in range(layers):
+        p, q = f"transformer.resblocks.{i}.", f"{pre_hf}encoder.layers.{i}."
+        wq, wk, wv = sd[p + "attn.in_proj_weight"].chunk(3, 0)
+        bq, bk, bv = sd[p + "attn.in_proj_bias"].chunk(3, 0)
+        hf.update({q + "self_attn.q_proj.weight": wq, q + "self_attn.k_proj.weight": wk, q + "self_attn.v_proj.weight": wv,
+                   q + "self_attn.q_proj.bias": bq, q + "self_attn.k_proj.bias": bk, q + "self_attn.v_proj.bias": bv,
+                   q + "self_attn.out_proj.weight": sd[p + "attn.out_proj.weight"], q + "self_attn.out_proj.bias": sd[p + "attn.out_proj.bias"],
+                   q + "layer_norm1.weight": sd[p + "ln_1.weight"], q + "layer_norm1.bias": sd[p + "ln_1.bias"],
+                   q + "layer_norm2.weight": sd[p + "ln_2.weight"], q + "layer_norm2.bias": sd[p + "ln_2.bias"],
+                   q + "mlp.fc1.weight": sd[p + "mlp.c_fc.weight"], q + "mlp.fc1.bias": sd[p + "mlp.c_fc.bias"],
+                   q + "mlp.fc2.weight": sd[p + "mlp.c_proj.weight"], q + "mlp.fc2.bias": sd[p + "mlp.c_proj.bias"]})
+
+
+@pytest.mark.parametrize("layer", ["penultimate", "last"])
+def test_text_tower_vs_transformers_clip(layer):
+    from transformers import CLIPTextConfig, CLIPTextModel
+    vocab, ctx, W, heads, layers = 600, 77, 128, 2, 4
+    sd = fill(text_shapes(vocab, ctx, W, layers, 64), 5)
+    cfg = CLIPTextConfig(vocab_size=vocab, hidden_size=W, intermediate_size=4 * W, num_hidden_layers=layers, num_attention_heads=heads,
+                         max_position_embeddings=ctx, hidden_act="gelu", layer_norm_eps=1e-5, eos_token_id=vocab - 1, bos_token_id=vocab - 2,
+                         pad_token_id=0, attn_implementation="eager")
+    m = CLIPTextModel(cfg).eval()
+    tp = "text_model." if any(k.startswith("text_model.") for k in m.state_dict()) else ""        # the prefix differs between versions
+    hf = {tp + "embeddings.token_embedding.weight": sd["token_embedding.weight"],
+          tp + "embeddings.position_embedding.weight": sd["positional_embedding"],
+          tp + "final_layer_norm.weight": sd["ln_final.weight"], tp + "final_layer_norm.bias": sd["ln_final.bias"]}
+    _hf_layers(sd, hf, tp, layers, W)
+    missing, unexpected = m.load_state_dict(hf, strict=False)
+    assert not unexpected and all("position_ids" in k for k in missing), (missing, unexpected)
+    g = torch.Generator().manual_seed(3)
+    tokens = torch.randint(1, vocab - 2, (3, ctx), generator=g)
+    tokens[:, 0] = vocab - 2
+    tokens[0, 1] = vocab - 1
+    tokens[0, 2:] = 0                                               # the empty prompt's pattern: start, end, zeros
+    with torch.no_grad():
+        out = m(input_ids=tokens, output_hidden_states=True)
+        fln = (m.text_model if hasattr(m, "text_model") else m).final_layer_norm
+        ref = out.last_hidden_state if layer == "last" else fln(out.hidden_states[-2])
+        got = O.text_encode(sd, tokens, heads, layer)
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+
+
+def test_visual_tower_vs_transformers_clip():
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    W, heads, layers, patch, size, embed = 160, 2, 3, 14, 56, 48          # head width 80, as ViT-H's
+    grid = size // patch
+    sd = fill(visual_shapes(W, layers, patch, grid, embed), 6)
+    cfg = CLIPVisionConfig(hidden_size=W, intermediate_size=4 * W, num_hidden_layers=layers, num_attention_heads=heads, image_size=size,
+                           patch_size=patch, hidden_act="gelu", layer_norm_eps=1e-5, projection_dim=embed, attn_implementation="eager")
+    m = CLIPVisionModelWithProjection(cfg).eval()
+    hf = {"vision_model.embeddings.class_embedding": sd["class_embedding"], "vision_model.embeddings.patch_embedding.weight": sd["conv1.weight"],
+          "vision_model.embeddings.position_embedding.weight": sd["positional_embedding"],
+          "vision_model.pre_layrnorm.weight": sd["ln_pre.weight"], "vision_model.pre_layrnorm.bias": sd["ln_pre.bias"],
+          "vision_model.post_layernorm.weight": sd["ln_post.weight"], "vision_model.post_layernorm.bias": sd["ln_post.bias"],
+          "visual_projection.weight": sd["proj"].t().contiguous()}
+    _hf_layers(sd, hf, "vision_model.", layers, W)
+    missing, unexpected = m.load_state_dict(hf, strict=False)
+    assert not unexpected and all("position_ids" in k for k in missing), (missing, unexpected)
+    x = torch.randn(2, 3, size, size, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        ref = m(pixel_values=x).image_embeds
+        got = O.visual_forward(sd, x, heads, patch)
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+
+
+def test_preprocess_pieces():
+    """The bicubic step is torch's own call; the gaussian taps sum to one and follow exp(-x^2 / 2 sigma^2); a constant image stays
+    constant through blur + resize; without shrinking no blur is applied (kornia: `antialias and max(factors) > 1`)."""
+    t = O.gaussian_taps(7, 1.786)
+    assert abs(t.sum().item() - 1) < 1e-6 and torch.allclose(t, t.flip(0)) and abs((t[4] / t[3]).item() - np.exp(-1 / (2 * 1.786 ** 2))) < 1e-6
+    img = torch.full((1, 3, 90, 160), 0.25)
+    out = O.preprocess(img, 28)
+    for c in range(3):
+        assert torch.allclose(out[0, c], torch.full((28, 28), ((0.25 + 1) / 2 - O.CLIP_MEAN[c]) / O.CLIP_STD[c]), atol=1e-6)
+    small = torch.randn(1, 3, 20, 24, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(O.kornia_resize(small, 28), torch.nn.functional.interpolate(small, size=(28, 28), mode="bicubic", align_corners=True))
+    # 576 x 1024 -> 224: sigma (0.786, 1.786), windows 3 and 7 (int(max(4 sigma, 3)), made odd)
+    fy, fx = 576 / 224, 1024 / 224
+    assert (int(max(4 * (fy - 1) / 2, 3)), int(max(4 * (fx - 1) / 2, 3))) == (3, 7)

@@ -7,9 +7,9 @@
     VideoPredictionEmbedderWithEncoder  :951-1031 SVD's `cond_frames`: (optionally noise-augmented) conditioning frame through
                                                   the first stage's encoder (posterior MODE, AutoencoderKLModeOnly), repeated over frames
 
-The OpenCLIP text / image embedders (FrozenOpenCLIPEmbedder, FrozenOpenCLIPImagePredictionEmbedder) are pretrained ViT-H networks whose
-definition lives in the `open_clip` package, absent here: `PrecomputedEmbedder` stands in for them -- it returns the tensor
-the caller computed elsewhere, so the rest of the conditioner (keys, concatenation, zeroing) still follows the reference.
+The OpenCLIP text / image embedders (FrozenOpenCLIPEmbedder, FrozenOpenCLIPImageEmbedder, FrozenOpenCLIPImagePredictionEmbedder) live in
+`openclip.py` (the ViT-H towers on the HIP path); an embedding computed elsewhere still passes through them unchanged, and
+`PrecomputedEmbedder` remains as the explicit stand-in for any pretrained embedder.
 The sinusoid is evaluated in fp32 with torch on the device the inputs live on (a few hundred numbers: plumbing, not a kernel).
 """
 from __future__ import annotations
@@ -105,9 +105,15 @@ class VideoPredictionEmbedderWithEncoder(AbstractEmbModel):
 _TARGETS = {
     "sgm.modules.encoders.modules.ConcatTimestepEmbedderND": ConcatTimestepEmbedderND,
     "sgm.modules.encoders.modules.VideoPredictionEmbedderWithEncoder": VideoPredictionEmbedderWithEncoder,
-    "sgm.modules.encoders.modules.FrozenOpenCLIPEmbedder": PrecomputedEmbedder,
-    "sgm.modules.encoders.modules.FrozenOpenCLIPImagePredictionEmbedder": PrecomputedEmbedder,
 }
+_CLIP_TARGETS = ("FrozenOpenCLIPEmbedder", "FrozenOpenCLIPImageEmbedder", "FrozenOpenCLIPImagePredictionEmbedder")
+
+
+def __getattr__(name):                                      # sgm.modules.encoders.modules.FrozenOpenCLIP* -> openclip.py (imports this module)
+    if name in _CLIP_TARGETS:
+        from . import openclip
+        return getattr(openclip, name)
+    raise AttributeError(name)
 
 
 class GeneralConditioner(nn.Module):
@@ -124,6 +130,8 @@ class GeneralConditioner(nn.Module):
                 emb = cfg
             elif tgt in _TARGETS:
                 emb = _TARGETS[tgt](**cfg.get("params", {}))
+            elif tgt and tgt.startswith("sgm.modules.encoders.modules.") and tgt.rsplit(".", 1)[1] in _CLIP_TARGETS:
+                emb = __getattr__(tgt.rsplit(".", 1)[1])(**cfg.get("params", {}))
             else:
                 emb = instantiate_from_config(cfg)
             if not isinstance(emb, nn.Module) or not hasattr(emb, "forward"):
