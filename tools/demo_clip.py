@@ -16,6 +16,11 @@ from vidseg_diffusion_amd import synthetic, util  # noqa: E402
 from vidseg_diffusion_amd.pipeline import segment_window, segmentation_map_window  # noqa: E402
 
 
+# open_clip model-config schema, narrow: the text tower's width is the narrow UNet's context_dim
+NARROW_CLIP = {"embed_dim": 64, "text": {"context_length": 77, "vocab_size": 49408, "width": 64, "heads": 1, "layers": 2},
+               "vision": {"image_size": 28, "patch_size": 14, "width": 128, "head_width": 64, "layers": 1, "mlp_ratio": 4.0}}
+
+
 def model_config(full):
     dd = "sgm.modules.diffusionmodules."
     mc, ctx, ch = (320, 1024, 128) if full else (64, 64, 64)
@@ -30,7 +35,8 @@ def model_config(full):
             use_checkpoint=True, in_channels=4, out_channels=4, model_channels=mc, attention_resolutions=[4, 2, 1], num_res_blocks=2,
             channel_mult=[1, 2, 4, 4], num_head_channels=64, use_linear_in_transformer=True, transformer_depth=1, context_dim=ctx)},
         "conditioner_config": {"target": "sgm.modules.GeneralConditioner", "params": {"emb_models": [
-            {"is_trainable": False, "input_key": "txt", "target": "sgm.modules.encoders.modules.FrozenOpenCLIPEmbedder", "params": {}}]}},
+            {"is_trainable": False, "input_key": "txt", "target": "sgm.modules.encoders.modules.FrozenOpenCLIPEmbedder",
+             "params": {"freeze": True, "layer": "penultimate", "arch": "ViT-H-14" if full else NARROW_CLIP}}]}},
         "first_stage_config": {"target": "sgm.models.autoencoder.AutoencoderKL", "params": {"embed_dim": 4, "ddconfig": vae}},
         "sampler_config": {"target": dd + "sampling.EulerEDMSampler", "params": {
             "num_steps": 25, "discretization_config": {"target": dd + "discretizer.LegacyDDPMDiscretization"},
@@ -47,7 +53,8 @@ def main():
     dev = torch.device("cuda:0")
     eng = util.instantiate_from_config(model_config(a.full))
     sd = {}
-    for prefix, mod, seed in (("model.diffusion_model.", eng.model.diffusion_model, 1234), ("first_stage_model.", eng.first_stage_model, 99)):
+    for prefix, mod, seed in (("model.diffusion_model.", eng.model.diffusion_model, 1234), ("first_stage_model.", eng.first_stage_model, 99),
+                              ("conditioner.embedders.0.", eng.conditioner.embedders[0], 7)):        # the OpenCLIP text tower's keys
         shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
         sd.update({prefix + k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=seed).items()})
     missing, unexpected = eng.load_state_dict(sd)
@@ -55,9 +62,11 @@ def main():
     F, S = a.frames, a.size
     g = np.random.Generator(np.random.PCG64(3))
     frames = torch.from_numpy(np.clip(g.standard_normal((F, 3, S, S)) * 0.4, -1, 1).astype(np.float32)).to(dev)
-    ctx = eng.model.diffusion_model.context_dim if hasattr(eng.model.diffusion_model, "context_dim") else (1024 if a.full else 64)
-    txt = torch.from_numpy(g.standard_normal((F, 77, ctx)).astype(np.float32)).to(dev)       # what the OpenCLIP text tower would return
-    c, uc = eng.conditioner.get_unconditional_conditioning({"txt": txt}, force_uc_zero_embeddings=["txt"])
+    tc = time.perf_counter()
+    # the drivers' conditioning (sd_pipeline_vspw.py:270-318): the empty prompt through the OpenCLIP text tower, zeros for the unconditional half
+    c, uc = eng.conditioner.get_unconditional_conditioning({"txt": [""] * F}, batch_uc={"txt": [""] * F}, force_uc_zero_embeddings=["txt"])
+    torch.cuda.synchronize()
+    print(f"conditioner: crossattn {tuple(c['crossattn'].shape)} in {1e3 * (time.perf_counter() - tc):.1f} ms (incl. packing the tower's weights)")
     t0 = time.perf_counter()
     z = eng.encode_first_stage(frames)
     torch.cuda.synchronize()
