@@ -635,7 +635,10 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, preb
                                       "16-bit mode; the mode whose masks are the reference's (`mask_iou_vs_reference`)")
         out["roofline"]["note_flops"] = ("achieved / frac count the MFMA work the kernel executes (2*M*N*3K per launch: three fp16 products per "
                                          "fp32-accurate product); `fp32_equivalent` = the same launches counted as 2*M*N*K")
-        out["roofline"]["fp32_equivalent"] = {"achieved": round(achieved / 3.0, 2), "frac_of_f16_mfma_peak": round(achieved / 3.0 / 2500.0, 4)}
+        out["roofline"]["fp32_equivalent"] = {"achieved": round(achieved / 3.0, 2), "frac_of_f16_mfma_peak": round(achieved / 3.0 / 2500.0, 4),
+                                              # the chip's own fp32-input matrix rate (v_mfma_f32_32x32x2_f32: 157.3 TFLOP/s dense, MI355X_MICROARCH.md)
+                                              # is what an fp32 GEMM of the reference's precision could reach without the split
+                                              "vs_f32_mfma_peak_157.3": round(achieved / 3.0 / 157.3, 2)}
         out["roofline"]["frac_algorithmic"] = round(achieved / 3.0 / 2500.0, 4)     # reference-equivalent FLOPs (2*M*N*K) / time / peak
         out["roofline"]["family"]["frac_algorithmic"] = round(fam_tf / 3.0 / 2500.0, 4)
     else:
