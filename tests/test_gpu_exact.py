@@ -208,6 +208,39 @@ def test_no_kernel_reads_the_third_plane(X):
     assert len(seen) >= 6, seen
 
 
+def test_layernorm_rows_per_wave_is_a_schedule_not_an_arithmetic(X):
+    """LayerNorm -> split image with several rows per wave (csrc/exact_ops.hip: k_x_layernorm_split3_rows, taken for M >= 4096) against
+    the one-row-per-wave kernel the masks were pinned with: the same bits (a second process with VIDSEG_X_LN_ROWS=1 runs the old schedule)."""
+    import subprocess
+    import sys
+    import tempfile
+    dev = torch.device("cuda:0")
+    code = (
+        "import sys, torch, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from vidseg_diffusion_amd import exact as X\n"
+        "out = {}\n"
+        "for M, C in ((4096, 320), (4099, 320), (114688, 320), (28672, 640), (5000, 1024), (7168, 1280), (4100, 64), (4097, 512)):\n"
+        "    g = np.random.Generator(np.random.PCG64(M + C))\n"
+        "    x = torch.from_numpy((g.standard_normal((M, C)) * 2.0 + 0.3).astype(np.float32)).cuda()\n"
+        "    ga = torch.from_numpy((1 + 0.1 * g.standard_normal(C)).astype(np.float32)).cuda()\n"
+        "    be = torch.from_numpy((0.05 * g.standard_normal(C)).astype(np.float32)).cuda()\n"
+        "    y = X.layernorm_split3(x, ga, be)\n"
+        "    out[f'{M}x{C}'] = y[:, :2 * C].contiguous().cpu().numpy().view(np.uint16)\n"
+        "np.savez(sys.argv[1], **out)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        res = {}
+        for knob in ("0", "1"):
+            path = os.path.join(d, f"ln{knob}.npz")
+            env = dict(os.environ, VIDSEG_X_LN_ROWS=knob, VIDSEG_X_POISON_PLANE3="0")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=300)
+            res[knob] = np.load(path)
+        assert sorted(res["0"].files) == sorted(res["1"].files) and len(res["0"].files) == 8
+        for k in res["0"].files:
+            assert np.array_equal(res["0"][k], res["1"][k]), k
+    _ = X, dev
+
+
 def test_fp32_glue_operators(X):
     from vidseg_diffusion_amd import ops
     dev = torch.device("cuda:0")

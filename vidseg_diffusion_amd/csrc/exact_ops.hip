@@ -269,6 +269,79 @@ __global__ void __launch_bounds__(256) k_x_layernorm_split3(const float* __restr
     }
 }
 
+// The same LayerNorm with R rows per wave (C <= 256 * MAXCH): the lane <-> channel map and every row's arithmetic (the per-lane partial
+// sums, the xor butterflies, the fma chain of the variance) are those of k_x_layernorm_split3<false>, so the result is the same bit
+// for bit; only the schedule differs -- the loads of R rows are issued before the first reduction and the R shuffle chains interleave.
+// (One row per wave keeps 1.28 KB of a C = 320 row in flight per wave and then waits on a dependent chain: 80 us for 114688 rows,
+// 3.7 TB/s, against 6 TB/s of the plain split of the same bytes.)
+template <int MAXCH, int R>
+__global__ void __launch_bounds__(256) k_x_layernorm_split3_rows(const float* __restrict__ x, long long M, int C, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps, f16* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= M) return;
+    f32x4 v[R][MAXCH];
+    float s[R], q[R], mean[R], rstd[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        s[r] = 0.f;
+        const long long row = min(row0 + r, M - 1);                  // a tail wave repeats the last row (stores are guarded)
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch) {
+            const int c = lane * 4 + ch * 256;
+            if (c < C) v[r][ch] = *reinterpret_cast<const f32x4*>(x + row * C + c);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch) {
+            const int c = lane * 4 + ch * 256;
+            if (c < C) s[r] += (v[r][ch][0] + v[r][ch][1]) + (v[r][ch][2] + v[r][ch][3]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) mean[r] = wave_sum_f32(s[r]) / (float)C;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        q[r] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch) {
+            const int c = lane * 4 + ch * 256;
+            if (c < C) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[r][ch][j] - mean[r];
+                    q[r] = fmaf(d, d, q[r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) rstd[r] = 1.0f / sqrtf(wave_sum_f32(q[r]) / (float)C + eps);
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+        const int c = lane * 4 + ch * 256;
+        if (c < C) {
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (row0 + r < M) {
+                    f16x4 h, l;
+                    float f[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[j] = fmaf((v[r][ch][j] - mean[r]) * rstd[r], ga[j], be[j]);
+                    split_hl4(f, h, l);
+                    f16* o = out + (row0 + r) * 3 * C + c;
+                    *reinterpret_cast<f16x4*>(o) = h;
+                    *reinterpret_cast<f16x4*>(o + C) = l;
+                    if (VS_THIRD_PLANE(C)) *reinterpret_cast<f16x4*>(o + 2 * C) = h;
+                }
+            }
+        }
+    }
+}
+
 // fp32 attention, head dim 64, on the vector FMA pipe (packed fp32): a 256-thread block owns 64 queries of one (sample, head) and
 // walks the keys 64 at a time.  Both contractions are register-blocked outer products -- thread (ty, tx) holds the 4 x 4 block
 // S[4ty.., 4tx..] of the scores and the 4 x 4 block O[4ty.., 4tx..] of the output -- so one pair of 16-byte LDS reads feeds 16
@@ -901,7 +974,16 @@ int vidseg_x_layernorm_split3(const float* x, long long M, int C, const float* g
                               hipStream_t st) {
     VS_REQUIRE(C % 4 == 0 && C <= 2048, "x_layernorm: C=%d", C);
     if (M == 0) return VS_OK;
-    k_x_layernorm_split3<false><<<dim3((unsigned)((M + 3) / 4)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16, nullptr, 1, 1, nullptr);
+    static const int rows_knob = [] {                             // VIDSEG_X_LN_ROWS=1: one row per wave everywhere (A/B of the schedule; same bits)
+        const char* e = getenv("VIDSEG_X_LN_ROWS");
+        return e ? atoi(e) : 0;
+    }();
+    if (rows_knob != 1 && C <= 512 && M >= 4096)
+        k_x_layernorm_split3_rows<2, 4><<<dim3((unsigned)((M + 15) / 16)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16);
+    else if (rows_knob != 1 && C <= 1024 && M >= 4096)
+        k_x_layernorm_split3_rows<4, 2><<<dim3((unsigned)((M + 7) / 8)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16);
+    else
+        k_x_layernorm_split3<false><<<dim3((unsigned)((M + 3) / 4)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16, nullptr, 1, 1, nullptr);
     VS_CHECK_LAUNCH("x_layernorm_split3");
     return VS_OK;
 }
