@@ -227,6 +227,10 @@ def test_layernorm_rows_per_wave_is_a_schedule_not_an_arithmetic(X):
         "    be = torch.from_numpy((0.05 * g.standard_normal(C)).astype(np.float32)).cuda()\n"
         "    y = X.layernorm_split3(x, ga, be)\n"
         "    out[f'{M}x{C}'] = y[:, :2 * C].contiguous().cpu().numpy().view(np.uint16)\n"
+        "    vec = torch.from_numpy(g.standard_normal((14, C)).astype(np.float32)).cuda()\n"
+        "    xs, y2 = X.layernorm_rowvec_split3(x, vec, 37, ga, be)\n"
+        "    out[f'{M}x{C}rv'] = y2[:, :2 * C].contiguous().cpu().numpy().view(np.uint16)\n"
+        "    out[f'{M}x{C}sum'] = xs.cpu().numpy().view(np.uint32)\n"
         "np.savez(sys.argv[1], **out)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as d:
         res = {}
@@ -235,7 +239,7 @@ def test_layernorm_rows_per_wave_is_a_schedule_not_an_arithmetic(X):
             env = dict(os.environ, VIDSEG_X_LN_ROWS=knob, VIDSEG_X_POISON_PLANE3="0")
             subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=300)
             res[knob] = np.load(path)
-        assert sorted(res["0"].files) == sorted(res["1"].files) and len(res["0"].files) == 8
+        assert sorted(res["0"].files) == sorted(res["1"].files) and len(res["0"].files) == 24
         for k in res["0"].files:
             assert np.array_equal(res["0"][k], res["1"][k]), k
     _ = X, dev

@@ -274,9 +274,11 @@ __global__ void __launch_bounds__(256) k_x_layernorm_split3(const float* __restr
 // for bit; only the schedule differs -- the loads of R rows are issued before the first reduction and the R shuffle chains interleave.
 // (One row per wave keeps 1.28 KB of a C = 320 row in flight per wave and then waits on a dependent chain: 80 us for 114688 rows,
 // 3.7 TB/s, against 6 TB/s of the plain split of the same bytes.)
-template <int MAXCH, int R>
+template <bool RV, int MAXCH, int R>
 __global__ void __launch_bounds__(256) k_x_layernorm_split3_rows(const float* __restrict__ x, long long M, int C, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, float eps, f16* __restrict__ out) {
+                                                                 const float* __restrict__ beta, float eps, f16* __restrict__ out,
+                                                                 const float* __restrict__ vec, int rows_per_sample, int nvec,
+                                                                 float* __restrict__ x_sum) {
     const int lane = threadIdx.x & 63;
     const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= M) return;
@@ -286,10 +288,18 @@ __global__ void __launch_bounds__(256) k_x_layernorm_split3_rows(const float* __
     for (int r = 0; r < R; ++r) {
         s[r] = 0.f;
         const long long row = min(row0 + r, M - 1);                  // a tail wave repeats the last row (stores are guarded)
+        const float* vr = RV ? vec + (long long)((row / rows_per_sample) % nvec) * C : nullptr;
 #pragma unroll
         for (int ch = 0; ch < MAXCH; ++ch) {
             const int c = lane * 4 + ch * 256;
-            if (c < C) v[r][ch] = *reinterpret_cast<const f32x4*>(x + row * C + c);
+            if (c < C) {
+                v[r][ch] = *reinterpret_cast<const f32x4*>(x + row * C + c);
+                if constexpr (RV) {
+                    const f32x4 e = *reinterpret_cast<const f32x4*>(vr + c);
+                    v[r][ch] = f32x4{v[r][ch][0] + e[0], v[r][ch][1] + e[1], v[r][ch][2] + e[2], v[r][ch][3] + e[3]};
+                    if (x_sum && row0 + r < M) *reinterpret_cast<f32x4*>(x_sum + row * C + c) = v[r][ch];
+                }
+            }
         }
     }
 #pragma unroll
@@ -970,18 +980,23 @@ int vidseg_x_groupnorm_split3(const float* x0, const float* x1, int C0, int C1, 
     return VS_OK;
 }
 
+static int ln_rows_knob() {                                       // VIDSEG_X_LN_ROWS=1: one row per wave everywhere (A/B of the schedule; same bits)
+    static const int k = [] {
+        const char* e = getenv("VIDSEG_X_LN_ROWS");
+        return e ? atoi(e) : 0;
+    }();
+    return k;
+}
+
 int vidseg_x_layernorm_split3(const float* x, long long M, int C, const float* gamma, const float* beta, float eps, void* out16,
                               hipStream_t st) {
     VS_REQUIRE(C % 4 == 0 && C <= 2048, "x_layernorm: C=%d", C);
     if (M == 0) return VS_OK;
-    static const int rows_knob = [] {                             // VIDSEG_X_LN_ROWS=1: one row per wave everywhere (A/B of the schedule; same bits)
-        const char* e = getenv("VIDSEG_X_LN_ROWS");
-        return e ? atoi(e) : 0;
-    }();
+    const int rows_knob = ln_rows_knob();
     if (rows_knob != 1 && C <= 512 && M >= 4096)
-        k_x_layernorm_split3_rows<2, 4><<<dim3((unsigned)((M + 15) / 16)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16);
+        k_x_layernorm_split3_rows<false, 2, 4><<<dim3((unsigned)((M + 15) / 16)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16, nullptr, 1, 1, nullptr);
     else if (rows_knob != 1 && C <= 1024 && M >= 4096)
-        k_x_layernorm_split3_rows<4, 2><<<dim3((unsigned)((M + 7) / 8)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16);
+        k_x_layernorm_split3_rows<false, 4, 2><<<dim3((unsigned)((M + 7) / 8)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16, nullptr, 1, 1, nullptr);
     else
         k_x_layernorm_split3<false><<<dim3((unsigned)((M + 3) / 4)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16, nullptr, 1, 1, nullptr);
     VS_CHECK_LAUNCH("x_layernorm_split3");
@@ -993,7 +1008,13 @@ int vidseg_x_layernorm_rowvec_split3(const float* x, const float* vec, long long
     VS_REQUIRE(C % 4 == 0 && C <= 2048 && vec != nullptr && rows_per_sample > 0 && nvec > 0, "x_layernorm_rowvec: C=%d rows_per_sample=%d nvec=%d", C,
                rows_per_sample, nvec);
     if (M == 0) return VS_OK;
-    k_x_layernorm_split3<true><<<dim3((unsigned)((M + 3) / 4)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16, vec, rows_per_sample, nvec, x_sum);
+    const int rows_knob = ln_rows_knob();
+    if (rows_knob != 1 && C <= 512 && M >= 4096)
+        k_x_layernorm_split3_rows<true, 2, 4><<<dim3((unsigned)((M + 15) / 16)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16, vec, rows_per_sample, nvec, x_sum);
+    else if (rows_knob != 1 && C <= 1024 && M >= 4096)
+        k_x_layernorm_split3_rows<true, 4, 2><<<dim3((unsigned)((M + 7) / 8)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16, vec, rows_per_sample, nvec, x_sum);
+    else
+        k_x_layernorm_split3<true><<<dim3((unsigned)((M + 3) / 4)), 256, 0, st>>>(x, M, C, gamma, beta, eps, (f16*)out16, vec, rows_per_sample, nvec, x_sum);
     VS_CHECK_LAUNCH("x_layernorm_rowvec_split3");
     return VS_OK;
 }
