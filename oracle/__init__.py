@@ -16,5 +16,8 @@ oracle is pinned against outputs of the reference itself, run in the build conta
 Third-party arithmetic restated here (absent from /root/reference, pinned in
 requirements/pt2.txt): scikit-learn ``KMeans``/``KNeighborsClassifier`` (pinned 1.5.0 by the
 reference, 1.7.2 in the build container -- fixtures were generated with 1.7.2), numpy
-``argpartition`` tie-breaking (2.0.0 pinned, 2.2.6 here).
+``argpartition`` tie-breaking (2.0.0 pinned, 2.2.6 here); ``oracle/openclip.py``: open_clip_torch
+2.24.0's ViT-H text / image towers and kornia 0.7.2's antialiased resize (both absent from this
+image) -- pinned against transformers' CLIP classes on the same weights instead of against the
+reference run (tests/test_oracle_openclip.py); kornia's gaussian pass: parity unpinned.
 """
