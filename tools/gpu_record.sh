@@ -18,6 +18,7 @@ elif has tests; then
 fi
 grep -E "windows at IoU|reproduce the reference|window [0-9]+ (exact|parity|fp16)|nrms|max err" gpurun_out/$T/pytest_gpu.log 2>/dev/null | tail -40
 if has bench; then
+  ( time timeout 1200 python bench.py > gpurun_out/$T/bench_default.json 2> gpurun_out/$T/bench_default.err ) 2> gpurun_out/$T/bench_default_time.txt; tail -3 gpurun_out/$T/bench_default_time.txt
   timeout 1800 python bench.py --steps 16 --warmup 3 > gpurun_out/$T/bench.json 2> gpurun_out/$T/bench.err
   tail -c 400 gpurun_out/$T/bench.err
   python tools/bench_digest.py gpurun_out/$T/bench.json

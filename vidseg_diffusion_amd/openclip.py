@@ -356,7 +356,10 @@ class FrozenOpenCLIPEmbedder(AbstractEmbModel):
         return self.encode_with_transformer(tokens.to(self.device))
 
     def encode_with_transformer(self, text):
-        return self.model.encode(text, self.layer_idx)
+        # the drivers hand one prompt per frame ([prompt] * num_frames, sd_pipeline_vspw.py:536): evaluate each distinct row once
+        rows, inverse = torch.unique(text, dim=0, return_inverse=True)
+        z = self.model.encode(rows.contiguous(), self.layer_idx)
+        return z if rows.shape[0] == text.shape[0] and bool((inverse == torch.arange(text.shape[0], device=text.device)).all()) else z[inverse]
 
     def encode(self, text):
         return self(text)
