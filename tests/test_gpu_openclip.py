@@ -180,3 +180,52 @@ def test_general_conditioner_with_the_towers(C):
     c, uc = cond.get_unconditional_conditioning(batch, force_uc_zero_embeddings=["cond_frames_without_noise"])
     assert tuple(c["crossattn"].shape) == (1, 1, 64) and c["crossattn"].abs().max() > 0 and not uc["crossattn"].any()
     assert torch.equal(c["vector"], uc["vector"]) and tuple(c["vector"].shape) == (1, 32)
+
+
+def _engine(kind):
+    """A narrow engine from a reference-schema config (tests/test_conditioner.py) with every parameter -- the towers' included --
+    restored through the checkpoint key route."""
+    import test_conditioner as TC
+    from vidseg_diffusion_amd import util
+    cfg = TC._narrow_model_config()["model"] if kind == "sd" else TC._narrow_svd_config()
+    eng = util.instantiate_from_config(cfg)
+    sd = TC._prefixed_checkpoint(eng)
+    missing, unexpected = eng.load_state_dict(sd)
+    assert not missing and not unexpected
+    return eng, sd
+
+
+def test_sd_driver_conditioning_block(C):
+    """sd_pipeline_vspw.py:268-318: [""] * num_frames through the conditioner -> crossattn [F, 77, context_dim], zeros for the
+    unconditional half; the rows are the text tower's embedding of the empty prompt (oracle)."""
+    from oracle import openclip as O
+    from vidseg_diffusion_amd.pipeline import sd_window_conditioning
+    eng, sd = _engine("sd")
+    c, uc = sd_window_conditioning(eng.conditioner, 5, device=DEV)
+    assert set(c) == {"crossattn"} and tuple(c["crossattn"].shape) == (5, 77, 64) and not uc["crossattn"].any()
+    tower = {k[len("conditioner.embedders.0.model."):]: v for k, v in sd.items() if k.startswith("conditioner.embedders.0.model.")}
+    ref = O.text_encode(tower, C.tokenize([""]), 1, "penultimate")
+    assert rel(c["crossattn"][3:4], ref) <= 2e-5 and torch.equal(c["crossattn"][0], c["crossattn"][4])
+
+
+def test_svd_driver_conditioning_block(C):
+    """svd_pipeline_vspw.py:263-302: first frame -> image tower (crossattn) and noise-augmented first-stage latent (concat), the three
+    scalars -> vector; both image embeddings zeroed in the unconditional half; crossattn / concat repeated over the frames."""
+    from oracle import openclip as O
+    from vidseg_diffusion_amd.pipeline import svd_window_conditioning
+    eng, sd = _engine("svd")
+    T = 6
+    frames = torch.tanh(rnd((T, 3, 64, 96), 9)).to(DEV)
+    noise = rnd((1, 3, 64, 96), 10).to(DEV)
+    c, uc, extra = svd_window_conditioning(eng.conditioner, frames, fps_id=6, motion_bucket_id=127, cond_aug=0.02, noise=noise)
+    assert tuple(c["crossattn"].shape) == (T, 1, 64) and tuple(c["vector"].shape) == (T, 96) and tuple(c["concat"].shape) == (T, 4, 8, 12)
+    assert not uc["crossattn"].any() and not uc["concat"].any() and torch.equal(uc["vector"], c["vector"])
+    assert tuple(extra["image_only_indicator"].shape) == (2, T) and extra["num_video_frames"] == T
+    pre = "conditioner.embedders.0.open_clip.model.visual."
+    tower = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    import test_conditioner as TC
+    v = TC.NARROW_CLIP["vision"]
+    ref = O.image_embed(tower, frames[:1].cpu(), v["width"] // v["head_width"], v["patch_size"], v["image_size"])
+    assert rel(c["crossattn"][2], ref) <= 2e-5 and torch.equal(c["crossattn"][0], c["crossattn"][T - 1])
+    lat = eng.conditioner.embedders[3](frames[:1] + 0.02 * noise)                  # the `cond_frames` embedder on its own
+    assert torch.equal(c["concat"][T - 1], lat[0]) and torch.equal(c["vector"][0], c["vector"][T - 1])

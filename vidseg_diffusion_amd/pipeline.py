@@ -398,6 +398,64 @@ def segment_clip(engine, latents, c_fn, *, batch_size=14, overlap=True, lanes=1,
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# The drivers' conditioning block: value_dict -> get_batch -> conditioner.get_unconditional_conditioning -> per-frame repeat
+# ----------------------------------------------------------------------------------------------------------------------
+def get_unique_embedder_keys_from_conditioner(conditioner):
+    """sd_pipeline_vspw.py:527-528 (a list in embedder order here: the set's order is arbitrary and nothing downstream depends on it)."""
+    seen = []
+    for e in conditioner.embedders:
+        if e.input_key not in seen:
+            seen.append(e.input_key)
+    return seen
+
+
+def sd_window_conditioning(conditioner, num_frames, *, prompt="", negative_prompt="", device="cuda"):
+    """The SD driver's conditioning of one window (sd_pipeline_vspw.py:268-318 with get_batch :530-551): `txt` = [prompt] * num_frames
+    through the conditioner (the OpenCLIP text tower), the unconditional half forced to zeros; T is None in that driver, so nothing is
+    repeated over frames.  Returns (c, uc) with `crossattn` [num_frames, 77, context_dim] on `device`."""
+    batch = {"txt": [prompt] * num_frames}
+    batch_uc = {"txt": [negative_prompt] * num_frames}
+    c, uc = conditioner.get_unconditional_conditioning(batch, batch_uc=batch_uc, force_uc_zero_embeddings=["txt"], force_cond_zero_embeddings=None)
+    for k in c:
+        if k != "crossattn":                                                 # SDP:310-313 (`math.prod(1)` rows of the other keys)
+            c[k], uc[k] = c[k][:1].to(device), uc[k][:1].to(device)
+    return c, uc
+
+
+def svd_window_conditioning(conditioner, frames, num_frames=None, *, fps_id=6, motion_bucket_id=127, cond_aug=0.02, noise=None):
+    """The SVD driver's conditioning of one window (svd_pipeline_vspw.py:263-302 with get_batch :510-541): the window's first frame is
+    the conditioning image -- `cond_frames_without_noise` (OpenCLIP image tower -> crossattn) and `cond_frames` = image + cond_aug * noise
+    (first-stage encoder -> concat) --, fps / motion bucket / cond_aug as the `vector` of N = num_frames rows; the unconditional half
+    zeroes both image embeddings; crossattn and concat are then repeated over the frames.  frames: fp32 [T, 3, H, W] in [-1, 1] on the
+    device.  `noise`: the N(0, 1) draw of SVP:279 (torch.randn_like(image) under the driver's seed) or None to draw it here.
+    Returns (c, uc, additional_model_inputs)."""
+    T = frames.shape[0] if num_frames is None else num_frames
+    dev = frames.device
+    image = frames[:1].contiguous()
+    if noise is None:
+        noise = torch.randn(image.shape, device=dev, dtype=image.dtype)
+    value = {"motion_bucket_id": motion_bucket_id, "fps_id": fps_id, "cond_aug": cond_aug, "cond_frames_without_noise": image,
+             "cond_frames": image + cond_aug * noise}
+    N = (1, T)
+    batch = {}
+    for key in get_unique_embedder_keys_from_conditioner(conditioner):
+        if key in ("fps_id", "motion_bucket_id", "cond_aug"):
+            batch[key] = torch.tensor([value[key]], device=dev).repeat(N[0] * N[1])
+        elif key in ("cond_frames", "cond_frames_without_noise"):
+            batch[key] = value[key].expand(N[0], -1, -1, -1).contiguous()       # "1 ... -> b ...", b = N[0]
+        else:
+            batch[key] = value[key]
+    batch_uc = {k: v.clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
+    c, uc = conditioner.get_unconditional_conditioning(batch, batch_uc=batch_uc,
+                                                       force_uc_zero_embeddings=["cond_frames", "cond_frames_without_noise"])
+    for k in ("crossattn", "concat"):                                       # "b ... -> b t ..." then "(b t) ..." (SVP:297-301)
+        for d in (c, uc):
+            d[k] = d[k][:, None].expand(-1, T, *d[k].shape[1:]).reshape(-1, *d[k].shape[1:]).contiguous()
+    extra = {"image_only_indicator": torch.zeros(2, T, device=dev), "num_video_frames": T}
+    return c, uc, extra
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # Step 4 of sample(): the modulation sweep (sd_pipeline_vspw.py:412-507, svd_pipeline_vspw.py:396-487)
 # ----------------------------------------------------------------------------------------------------------------------
 _BLOCK_SCALE = {0: 1, 1: 1, 2: 1, 3: 2, 4: 2, 5: 2, 6: 4, 7: 4, 8: 4, 9: 8, 10: 8, 11: 8}
