@@ -97,3 +97,36 @@ def test_preprocess_pieces():
     # 576 x 1024 -> 224: sigma (0.786, 1.786), windows 3 and 7 (int(max(4 sigma, 3)), made odd)
     fy, fx = 576 / 224, 1024 / 224
     assert (int(max(4 * (fy - 1) / 2, 3)), int(max(4 * (fx - 1) / 2, 3))) == (3, 7)
+
+
+def test_simple_tokenizer_vs_transformers_clip_tokenizer(tmp_path):
+    """vidseg_diffusion_amd.openclip.SimpleTokenizer (open_clip's byte-level BPE, restated) against transformers' CLIPTokenizer -- an
+    independent implementation of the same algorithm -- on a synthetic merges file (the real one is not in this image), plus
+    open_clip.tokenize's framing: <start_of_text> ids <end_of_text>, zero padding, truncation that keeps the end token."""
+    import gzip
+    import json
+    from transformers import CLIPTokenizer
+    from vidseg_diffusion_amd import openclip as C
+    merges = ["t h", "th e</w>", "c a", "ca t</w>", "p h", "ph o", "pho t", "phot o</w>", "o f</w>", "i n", "in g</w>", "r i", "ri d", "rid ing</w>",
+              "a n</w>", "p i", "pi g</w>", "' s</w>", "1 0</w>", "s t", "st r", "str e", "e t</w>", "stre et</w>"]
+    bpe = tmp_path / "bpe.txt.gz"
+    bpe.write_bytes(gzip.compress(("#version: 0.2\n" + "\n".join(merges) + "\n").encode()))
+    tok = C.SimpleTokenizer(str(bpe))
+    assert (tok.sot, tok.eot) == (512 + len(merges), 513 + len(merges))
+    vocab = {("<|startoftext|>" if t == "<start_of_text>" else "<|endoftext|>" if t == "<end_of_text>" else t): i for t, i in tok.encoder.items()}
+    (tmp_path / "vocab.json").write_text(json.dumps(vocab))
+    (tmp_path / "merges.txt").write_text("#version: 0.2\n" + "\n".join(merges) + "\n")
+    hf = CLIPTokenizer(str(tmp_path / "vocab.json"), str(tmp_path / "merges.txt"))
+    texts = ["A photo of the cat", "an astronaut riding a pig", "the cat's street,  the   street 10 cats", "", "thethe  PHOTO", "café in the street"]
+    got = tok(texts, 77)
+    for row, t in zip(got, texts):
+        ids = hf(t)["input_ids"]
+        assert row[:len(ids)].tolist() == ids and not row[len(ids):].any(), t
+    assert got[3].tolist() == [tok.sot, tok.eot] + [0] * 75
+    long = tok(["the cat " * 60], 77)[0]
+    assert long[0] == tok.sot and long[-1] == tok.eot and (long != 0).all()
+    # the module-level entry point: a merges file by path, token tensors as they are, the empty prompt without any file
+    assert torch.equal(C.tokenize(texts, 77, str(bpe)), got) and torch.equal(C.tokenize(got), got)
+    assert C.tokenize([""])[0, :3].tolist() == [49406, 49407, 0]
+    with pytest.raises(C.VidsegError, match="BPE vocabulary"):
+        C.tokenize(["a cat"])

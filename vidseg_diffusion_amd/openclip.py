@@ -19,9 +19,10 @@ GELU / attention in fp32 (csrc/exact_ops.hip, csrc/clip_ops.hip) -- because the 
 constant; SVD: one frame), so their cost is nothing and their accuracy is the UNet's input.  No CPU path: tensors live on the HIP
 device, a missing library raises.
 
-Tokenisation: open_clip's BPE vocabulary file is part of the absent package.  The drivers' prompt is the empty string
+Tokenisation: open_clip's BPE merges file is part of the absent package.  The drivers' prompt is the empty string
 (sd_pipeline_vspw.py:35, 280-281), whose tokenisation is [<start_of_text> = 49406, <end_of_text> = 49407, 0 x 75]; that and
-pre-tokenised int tensors are accepted, any other string raises with that explanation.
+pre-tokenised int tensors need no file.  Other prompts go through `SimpleTokenizer` (the byte-level BPE restated) once the merges file's
+path is given (`bpe_path=` / VIDSEG_OPENCLIP_BPE); without it they raise with that explanation.
 """
 from __future__ import annotations
 
@@ -314,16 +315,110 @@ class VisualTower(_Tower):
         return X.linear_x(X.split3(pooled), pk.extra["proj"])
 
 
-def tokenize(text: Union[str, Sequence[str], torch.Tensor], context_length=77) -> torch.Tensor:
-    """open_clip.tokenize for what can be tokenised without the package's BPE vocabulary: the empty string, or token tensors."""
+def _bytes_to_unicode():
+    """The byte -> printable-character table of the CLIP byte-level BPE (open_clip/tokenizer.py: bytes_to_unicode)."""
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("\u00a1"), ord("\u00ac") + 1)) + list(range(ord("\u00ae"), ord("\u00ff") + 1))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    return dict(zip(bs, (chr(c) for c in cs)))
+
+
+class SimpleTokenizer:
+    """open_clip.tokenizer.SimpleTokenizer (2.24.0; OpenAI CLIP's byte-level BPE) over a merges file in the package's format
+    (`bpe_simple_vocab_16e6.txt.gz`: a header line, then one merge per line; gzip or plain text).  The file itself is not in this image:
+    pass its path (`bpe_path=` of FrozenOpenCLIPEmbedder, or VIDSEG_OPENCLIP_BPE).  Vocabulary: 256 byte symbols, the same with the
+    end-of-word mark, one entry per merge (the first 48894 of the file), <start_of_text>, <end_of_text> -- 49408 with the real file.
+    Text cleaning: html.unescape twice, whitespace collapsed, lower-cased; ftfy's mojibake repair (absent here) is skipped.
+    Pinned against transformers' CLIPTokenizer on a synthetic merges file (tests/test_oracle_openclip.py)."""
+
+    def __init__(self, bpe_path, max_merges=49152 - 256 - 2):
+        import gzip
+        import regex
+        with open(bpe_path, "rb") as fh:
+            raw = fh.read()
+        text = (gzip.decompress(raw) if raw[:2] == b"\x1f\x8b" else raw).decode("utf-8")
+        merges = [tuple(m.split()) for m in text.split("\n")[1:max_merges + 1] if len(m.split()) == 2]
+        self.byte_encoder = _bytes_to_unicode()
+        vocab = list(self.byte_encoder.values())
+        vocab = vocab + [v + "</w>" for v in vocab] + ["".join(m) for m in merges] + ["<start_of_text>", "<end_of_text>"]
+        self.encoder = {t: i for i, t in enumerate(vocab)}
+        self.bpe_ranks = {m: i for i, m in enumerate(merges)}
+        self.cache = {"<start_of_text>": "<start_of_text>", "<end_of_text>": "<end_of_text>"}
+        self.pat = regex.compile(r"""<start_of_text>|<end_of_text>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+""", regex.IGNORECASE)
+        self.sot, self.eot = self.encoder["<start_of_text>"], self.encoder["<end_of_text>"]
+
+    def bpe(self, token):
+        if token in self.cache:
+            return self.cache[token]
+        word = tuple(token[:-1]) + (token[-1] + "</w>",)
+        while len(word) > 1:
+            pairs = {(a, b) for a, b in zip(word, word[1:])}
+            best = min(pairs, key=lambda p: self.bpe_ranks.get(p, float("inf")))
+            if best not in self.bpe_ranks:
+                break
+            a, b = best
+            merged, i = [], 0
+            while i < len(word):
+                if i < len(word) - 1 and word[i] == a and word[i + 1] == b:
+                    merged.append(a + b)
+                    i += 2
+                else:
+                    merged.append(word[i])
+                    i += 1
+            word = tuple(merged)
+        out = " ".join(word)
+        self.cache[token] = out
+        return out
+
+    def encode(self, text):
+        import html
+        import re
+        text = re.sub(r"\s+", " ", html.unescape(html.unescape(text)).strip()).strip().lower()
+        ids = []
+        for tok in self.pat.findall(text):
+            tok = "".join(self.byte_encoder[b] for b in tok.encode("utf-8"))
+            ids.extend(self.encoder[t] for t in self.bpe(tok).split(" "))
+        return ids
+
+    def __call__(self, texts, context_length=77):
+        """open_clip.tokenize: <start_of_text> ids <end_of_text>, zero-padded; a longer text is cut and ends with <end_of_text>."""
+        texts = [texts] if isinstance(texts, str) else list(texts)
+        out = torch.zeros((len(texts), context_length), dtype=torch.long)
+        for i, t in enumerate(texts):
+            ids = [self.sot] + self.encode(t) + [self.eot]
+            if len(ids) > context_length:
+                ids = ids[:context_length]
+                ids[-1] = self.eot
+            out[i, :len(ids)] = torch.tensor(ids)
+        return out
+
+
+_TOKENIZERS: Dict[str, SimpleTokenizer] = {}
+
+
+def tokenize(text: Union[str, Sequence[str], torch.Tensor], context_length=77, bpe_path: Optional[str] = None) -> torch.Tensor:
+    """open_clip.tokenize.  Token tensors pass through; with a merges file (`bpe_path` or VIDSEG_OPENCLIP_BPE) any text is tokenised by
+    SimpleTokenizer; without one only the empty string -- the drivers' prompt -- can be, as [49406, 49407, 0, ...]."""
+    import os
     if isinstance(text, torch.Tensor):
         if text.dtype not in (torch.int32, torch.int64) or text.dim() != 2 or text.shape[1] != context_length:
             raise VidsegError(f"tokenize: token tensors are int [B, {context_length}]")
         return text.long()
     texts = [text] if isinstance(text, str) else list(text)
+    bpe_path = bpe_path or os.environ.get("VIDSEG_OPENCLIP_BPE")
+    if bpe_path:
+        if bpe_path not in _TOKENIZERS:
+            _TOKENIZERS[bpe_path] = SimpleTokenizer(bpe_path)
+        return _TOKENIZERS[bpe_path](texts, context_length)
     if any(t.strip() != "" for t in texts):
         raise VidsegError("tokenize: open_clip's BPE vocabulary (bpe_simple_vocab_16e6.txt.gz) is part of the absent open_clip package; "
-                          "only the empty prompt (the drivers' default, sd_pipeline_vspw.py:35) or pre-tokenised int tensors are accepted")
+                          "pass its path (bpe_path= / VIDSEG_OPENCLIP_BPE), or use the empty prompt (the drivers' default, "
+                          "sd_pipeline_vspw.py:35) or pre-tokenised int tensors")
     out = torch.zeros((len(texts), context_length), dtype=torch.long)
     out[:, 0], out[:, 1] = SOT, EOT
     return out
@@ -335,10 +430,11 @@ class FrozenOpenCLIPEmbedder(AbstractEmbModel):
     LAYERS = ["last", "penultimate"]
 
     def __init__(self, arch="ViT-H-14", version="laion2b_s32b_b79k", device="cuda", max_length=77, freeze=True, layer="last",
-                 state_dict: Optional[Dict[str, torch.Tensor]] = None):
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None, bpe_path: Optional[str] = None):
         super().__init__()
         if layer not in self.LAYERS:
             raise AssertionError(layer)
+        self.bpe_path = bpe_path
         self.model = TextTower(arch)
         self.device, self.max_length, self.layer = device, max_length, layer
         self.layer_idx = 0 if layer == "last" else 1
@@ -352,7 +448,7 @@ class FrozenOpenCLIPEmbedder(AbstractEmbModel):
     def forward(self, text):
         if isinstance(text, torch.Tensor) and text.is_floating_point():
             return text                                               # an embedding computed elsewhere ([B, 77, W]) passes through
-        tokens = tokenize(text, self.max_length)
+        tokens = tokenize(text, self.max_length, self.bpe_path)
         return self.encode_with_transformer(tokens.to(self.device))
 
     def encode_with_transformer(self, text):
