@@ -215,10 +215,10 @@ def test_svd_driver_conditioning_block(C):
     from vidseg_diffusion_amd.pipeline import svd_window_conditioning
     eng, sd = _engine("svd")
     T = 6
-    frames = torch.tanh(rnd((T, 3, 64, 96), 9)).to(DEV)
-    noise = rnd((1, 3, 64, 96), 10).to(DEV)
+    frames = torch.tanh(rnd((T, 3, 64, 128), 9)).to(DEV)       # 8 x 16 latent: the first stage's mid attention takes token counts % 64 == 0
+    noise = rnd((1, 3, 64, 128), 10).to(DEV)
     c, uc, extra = svd_window_conditioning(eng.conditioner, frames, fps_id=6, motion_bucket_id=127, cond_aug=0.02, noise=noise)
-    assert tuple(c["crossattn"].shape) == (T, 1, 64) and tuple(c["vector"].shape) == (T, 96) and tuple(c["concat"].shape) == (T, 4, 8, 12)
+    assert tuple(c["crossattn"].shape) == (T, 1, 64) and tuple(c["vector"].shape) == (T, 96) and tuple(c["concat"].shape) == (T, 4, 8, 16)
     assert not uc["crossattn"].any() and not uc["concat"].any() and torch.equal(uc["vector"], c["vector"])
     assert tuple(extra["image_only_indicator"].shape) == (2, T) and extra["num_video_frames"] == T
     pre = "conditioner.embedders.0.open_clip.model.visual."
