@@ -120,3 +120,25 @@ def test_asymmetric_downsample_and_softmax_ops():
     lg = torch.randn(37, 256, generator=gen) * 8
     p = ops.softmax_rows(lg.to(dev), 0.25).float().cpu()
     assert (p - torch.softmax(lg * 0.25, -1)).abs().max() < 4e-3
+
+
+def test_mid_attention_with_a_token_count_that_is_not_a_gemm_width():
+    """model.py:161-202 on a 8 x 12 latent (96 tokens): P @ V contracts over the tokens, so the device pads that axis with zero columns to
+    the next multiple of 64 -- an exact operation; against the fp32 formula within the 16-bit mode's bar."""
+    from vidseg_diffusion_amd import ops
+    from vidseg_diffusion_amd.vae import AttnBlock
+    dev = torch.device("cuda:0")
+    C, H, W = 64, 8, 12
+    blk = AttnBlock(C)
+    shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=5).items()}
+    blk.load_state_dict(sd, assign=True)
+    blk.pack(dev)
+    x = torch.randn(2, H, W, C, generator=torch.Generator().manual_seed(6))
+    got = blk.run(x.to(ops.act_dtype()).to(dev)).float().cpu()
+    xn = x.permute(0, 3, 1, 2)
+    h = torch.nn.functional.group_norm(xn, 32, sd["norm.weight"], sd["norm.bias"], 1e-6)
+    q, k, v = (torch.nn.functional.conv2d(h, sd[n + ".weight"], sd[n + ".bias"]).reshape(2, C, H * W).transpose(1, 2) for n in "qkv")
+    a = torch.softmax(q @ k.transpose(1, 2) * C ** -0.5, -1) @ v
+    ref = xn + torch.nn.functional.conv2d(a.transpose(1, 2).reshape(2, C, H, W), sd["proj_out.weight"], sd["proj_out.bias"])
+    assert nrms(got.permute(0, 3, 1, 2), ref) <= 2 * act_mode()[1]

@@ -124,12 +124,15 @@ class AttnBlock(nn.Module):
         t = ops.groupnorm(x, self.g, self.b, eps=1e-6, silu=False).view(B, N, C)
         qkv = ops.linear(t, self.w_qkv, self.b_qkv)                                   # [B, N, 3C]
         att = torch.empty((B, N, C), dtype=ops.act_dtype(), device=x.device)
+        Np = -(-N // 64) * 64                                                          # P @ V contracts over the tokens: a GEMM K, % 64
         for b in range(B):                                                             # one frame at a time: N x N fp32 logits
             q = qkv[b, :, :C].contiguous()
             k = qkv[b, :, C:2 * C].contiguous()
             vt = qkv[b, :, 2 * C:].t().contiguous()                                    # [C, N]: the K-contiguous "weight" of P @ V
             logits = ops.linear(q, k, out_f32=True)                                    # q k^T, fp32 [N, N]
             p = ops.softmax_rows(logits, float(C) ** -0.5)                             # SDPA's default scale (model.py:189-191)
+            if Np != N:                                                                # e.g. a 64 x 96 frame: 96 tokens -> zero columns up to 128 (exact)
+                p, vt = torch.nn.functional.pad(p, (0, Np - N)), torch.nn.functional.pad(vt, (0, Np - N))
             att[b] = ops.linear(p, vt)
         out = ops.linear(att, self.w_o, self.b_o, residual=x.view(B, N, C))
         return out.view(B, H, W, C)
