@@ -216,13 +216,14 @@ class _Tower(nn.Module):
         pk = self._packed
         if pk.dev != dev:
             pk.dev, pk.blocks, pk.extra = dev, [_pack_block(b, dev) for b in resblocks], {}
+            torch.cuda.synchronize(dev)          # the copies outlive this call and may be read from another stream (a pipeline lane) later
         return pk
 
     OPTIONAL = ("text_projection", "logit_scale")                   # carried by checkpoints, read by nobody on this path
 
     def load_state_dict(self, state_dict, strict=False, assign=True):
         """The host masters of the parameters (fp32, CPU); the device copies are rebuilt on the next call."""
-        self._packed = _Packed()
+        self.release()
         sd = {k: v.detach().to(device="cpu", dtype=F32) for k, v in state_dict.items()}
         return super().load_state_dict(sd, strict=strict, assign=True)
 
@@ -230,7 +231,9 @@ class _Tower(nn.Module):
         return self
 
     def release(self):
-        """Drop the device copies (they are rebuilt on the next call)."""
+        """Drop the device copies (they are rebuilt on the next call); waits for the kernels that may still read them."""
+        if self._packed.dev is not None:
+            torch.cuda.synchronize(self._packed.dev)
         self._packed = _Packed()
 
 
@@ -264,6 +267,7 @@ class TextTower(_Tower):
         if not pk.extra:
             f = lambda p: p.detach().to(device=dev, dtype=F32).contiguous()   # noqa: E731
             pk.extra = dict(tok=f(self.token_embedding.weight), pos=f(self.positional_embedding), lnf=(f(self.ln_final.weight), f(self.ln_final.bias)))
+            torch.cuda.synchronize(dev)
         x = (pk.extra["tok"][tokens.long()] + pk.extra["pos"]).reshape(B * N, -1).contiguous()     # gather + add of 77 rows: plumbing
         x = run_blocks(x, pk.blocks[:len(pk.blocks) - skip_last], B, N, t["heads"], causal=True)
         return layernorm(x, *pk.extra["lnf"]).reshape(B, N, -1)
@@ -303,6 +307,7 @@ class VisualTower(_Tower):
             pk.extra = dict(conv=X.pack_linear_x(wc, dev), cls=f(self.class_embedding), pos=f(self.positional_embedding),
                             pre=(f(self.ln_pre.weight), f(self.ln_pre.bias)), post=(f(self.ln_post.weight), f(self.ln_post.bias)),
                             proj=X.pack_linear_x(self.proj.detach().t().contiguous(), dev))
+            torch.cuda.synchronize(dev)
         B = img.shape[0]
         G2, W = self.grid ** 2, v["width"]
         patches = preprocess_patches(img, v["image_size"], v["patch_size"], self.k_pad, antialias)
