@@ -130,6 +130,50 @@ __global__ void __launch_bounds__(256) k_mean_normalize_fast(BlockPtrs blocks, i
     }
 }
 
+// C % 128 == 0 (the 640-channel taps of decoder blocks 6-8): 16 lanes per row, four rows per wave, NQ = C / 128 chunks of 8 per lane.
+// Every lane is busy on every load (the map above leaves 48 of 64 lanes idle on the second 512-channel chunk of a 640-channel row) and a
+// wave has 4 x NB x NQ loads in flight.  The only cross-lane operation is the row's max |.|, which is exact in any order: same bits.
+template <int NB, int NQ>
+__global__ void __launch_bounds__(256) k_mean_normalize_rows16(BlockPtrs blocks, int64_t row0, int64_t rows, int C, f16* __restrict__ out_mean,
+                                                               f16* __restrict__ out_norm) {
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool live = row < rows;
+    const float inv = (float)NB;
+    f16x8 v[NB][NQ];
+    const int64_t off = (row0 + (live ? row : rows - 1)) * (int64_t)C;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int qd = 0; qd < NQ; ++qd) v[b][qd] = *reinterpret_cast<const f16x8*>(blocks.p[b] + off + (qd * 16 + sub) * 8);
+    float vmax = 0.f;
+    f16x8 m[NQ];
+#pragma unroll
+    for (int qd = 0; qd < NQ; ++qd) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float acc = (float)v[0][qd][j];
+#pragma unroll
+            for (int b = 1; b < NB; ++b) acc = acc + (float)v[b][qd][j];
+            const f16 h = (f16)(acc / inv);
+            m[qd][j] = h;
+            vmax = fmaxf(vmax, fabsf((float)h));
+        }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));     // within the row's 16 lanes
+    if (!live) return;
+#pragma unroll
+    for (int qd = 0; qd < NQ; ++qd) {
+        const int c = (qd * 16 + sub) * 8;
+        if (out_mean) *reinterpret_cast<f16x8*>(out_mean + row * (int64_t)C + c) = m[qd];
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)((float)m[qd][j] / vmax);
+        if (out_norm) *reinterpret_cast<f16x8*>(out_norm + row * (int64_t)C + c) = o;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // float64 64x64 tile product  D[s][j] = sum_c A[s][c] * B[j][c]  (256 threads, 4x4 per thread)
 // ---------------------------------------------------------------------------------------------
@@ -1466,7 +1510,13 @@ int vidseg_mean_normalize_f16(const void* const* blocks, int nblk, int64_t row0,
     constexpr int MN_R = 1;                                            // rows per wave of the fast kernel (2 measured 21.2 against 20.1 us: no gain)
     const dim3 grid((unsigned)cdiv64(rows, 4)), gridf((unsigned)cdiv64(rows, 4 * MN_R));
 #define VS_MN_FAST(NB, NCH) k_mean_normalize_fast<NB, NCH, MN_R><<<gridf, 256, 0, st>>>(bp, row0, rows, C, om, on)
-    if (nch == 1 && nblk == 1) VS_MN_FAST(1, 1);
+    static const bool rows16 = [] {                                    // VIDSEG_MN_ROWS16=0: the one-row-per-wave map (A/B; same bits)
+        const char* e = getenv("VIDSEG_MN_ROWS16");
+        return !(e && e[0] == '0');
+    }();
+    if (rows16 && C == 640 && nblk == 3 && rows > 0)
+        k_mean_normalize_rows16<3, 5><<<dim3((unsigned)cdiv64(rows, 16)), 256, 0, st>>>(bp, row0, rows, C, om, on);
+    else if (nch == 1 && nblk == 1) VS_MN_FAST(1, 1);
     else if (nch == 1 && nblk == 2) VS_MN_FAST(2, 1);
     else if (nch == 1 && nblk == 3) VS_MN_FAST(3, 1);
     else if (nch == 1 && nblk == 4) VS_MN_FAST(4, 1);
