@@ -123,6 +123,47 @@ def test_diffusion_engine_from_reference_style_config():
     assert engine.engine_from_config(cfg).scale_factor == 0.18215
 
 
+def test_engine_follows_the_drivers_to_eval_calls():
+    """`instantiate_from_config(config.model).to(device).eval()` (svd_pipeline_vspw.py:566-569) and `.half()`: the engine's parameters are
+    host masters -- still meta before a checkpoint arrives --, so moving / casting the module is a no-op that hands the engine back."""
+    from vidseg_diffusion_amd import util
+    eng = util.instantiate_from_config(_narrow_model_config()["model"])
+    assert eng.to("cuda").eval() is eng and eng.half() is eng and eng.cuda() is eng
+    assert any(p.is_meta for p in eng.parameters())                      # nothing was materialised or moved
+
+
+@pytest.mark.parametrize("name", ["sd_2_1", "svd"])
+def test_the_reference_yaml_files_build_the_engine(name):
+    """The reference's own configs/inference/{sd_2_1,svd}.yaml (read-only, build container only: skipped where /root/reference is absent)
+    with the drivers' patches (svd_pipeline_vspw.py:556-565: init_device, num_steps, guider num_frames) go through instantiate_from_config
+    unchanged: every `target:` resolves to this package, at full size, nothing materialised (parameters on the meta device)."""
+    path = f"/root/reference/configs/inference/{name}.yaml"
+    if not os.path.exists(path):
+        pytest.skip("the reference tree is not on this box")
+    yaml = pytest.importorskip("yaml")
+    from vidseg_diffusion_amd import engine, openclip, unet, util, video_unet
+    with open(path) as fh:
+        cfg = yaml.safe_load(fh)["model"]
+    p = cfg["params"]
+    p.pop("ckpt_path", None)
+    if name == "svd":
+        p["conditioner_config"]["params"]["emb_models"][0]["params"]["open_clip_embedding_config"]["params"]["init_device"] = "cuda"
+        p["sampler_config"]["params"]["num_steps"] = 25
+        p["sampler_config"]["params"]["guider_config"]["params"]["num_frames"] = 14
+    eng = util.instantiate_from_config(cfg).to("cuda").eval()
+    assert isinstance(eng, engine.DiffusionEngine)
+    net = eng.model.diffusion_model
+    if name == "svd":
+        assert isinstance(net, video_unet.VideoUNet) and eng.video
+        assert isinstance(eng.conditioner.embedders[0], openclip.FrozenOpenCLIPImagePredictionEmbedder) and len(eng.conditioner.embedders) == 5
+        assert eng.conditioner.embedders[0].open_clip.model.visual.cfg["width"] == 1280
+    else:
+        assert isinstance(net, unet.UNetModel) and not eng.video
+        e0 = eng.conditioner.embedders[0]
+        assert isinstance(e0, openclip.FrozenOpenCLIPEmbedder) and e0.layer == "penultimate" and e0.model.cfg["layers"] == 24
+    assert sum(p.numel() for p in net.parameters()) > 8e8
+
+
 def _narrow_svd_config():
     """The schema of configs/inference/svd.yaml (own text, narrow sizes)."""
     dd = "sgm.modules.diffusionmodules."

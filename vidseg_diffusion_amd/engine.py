@@ -40,6 +40,12 @@ class DiffusionEngine(nn.Module):
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path)
 
+    def _apply(self, fn, recurse=True):
+        """`.to(device)` / `.cuda()` / `.half()` as the drivers call them on the engine (svd_pipeline_vspw.py:566-569, `load_model`):
+        no-ops that return the engine.  The parameters are host masters (fp32, possibly still on the meta device before a checkpoint is
+        loaded); the kernels' device copies are packed from them on first use, on the device the inputs live on."""
+        return self
+
     # ------------------------------------------------------------------ checkpoints (diffusion.py:85-101)
     def init_from_ckpt(self, path: str):
         """diffusion.py:85-101: the RAW checkpoint dict (Lightning prefixes kept: `model.diffusion_model.*`, `first_stage_model.*`,
