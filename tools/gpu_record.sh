@@ -19,9 +19,11 @@ fi
 grep -E "windows at IoU|reproduce the reference|window [0-9]+ (exact|parity|fp16)|nrms|max err" gpurun_out/$T/pytest_gpu.log 2>/dev/null | tail -40
 if has bench; then
   ( time timeout 1200 python bench.py > gpurun_out/$T/bench_default.json 2> gpurun_out/$T/bench_default.err ) 2> gpurun_out/$T/bench_default_time.txt; tail -3 gpurun_out/$T/bench_default_time.txt
+  cp bench_full.json gpurun_out/$T/bench_default_full.json; wc -c gpurun_out/$T/bench_default.json
   timeout 1800 python bench.py --steps 16 --warmup 3 > gpurun_out/$T/bench.json 2> gpurun_out/$T/bench.err
   tail -c 400 gpurun_out/$T/bench.err
-  python tools/bench_digest.py gpurun_out/$T/bench.json
+  cp bench_full.json gpurun_out/$T/bench_full.json; wc -c gpurun_out/$T/bench.json
+  python tools/bench_digest.py gpurun_out/$T/bench_full.json
 fi
 cd /tmp && export TMPDIR=/tmp
 if has prof; then
