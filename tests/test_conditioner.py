@@ -132,6 +132,68 @@ def test_engine_follows_the_drivers_to_eval_calls():
     assert any(p.is_meta for p in eng.parameters())                      # nothing was materialised or moved
 
 
+def test_sd21_checkpoint_layout_fills_the_text_tower():
+    """the checkpoint the SD driver loads (v2-1_512-ema-pruned.safetensors, sd_pipeline_vspw.py:663) is in the LDM layout:
+    `model.diffusion_model.*`, `first_stage_model.*` and the text encoder under `cond_stage_model.model.*` (open_clip names, with the
+    `attn_mask` buffer).  Those keys must reach the first FrozenOpenCLIPEmbedder's tower -- every parameter of it, nothing left on meta."""
+    from vidseg_diffusion_amd import util
+    eng = util.instantiate_from_config(_narrow_model_config()["model"])
+    tower = eng.conditioner.embedders[0].model
+    g = torch.Generator().manual_seed(3)
+    sd = {"cond_stage_model.model." + k: torch.randn(v.shape, generator=g) for k, v in tower.state_dict().items()}
+    sd["cond_stage_model.model.attn_mask"] = torch.zeros(77, 77)
+    sd.update({"model.diffusion_model." + k: torch.zeros(v.shape) for k, v in eng.model.diffusion_model.state_dict().items()})
+    sd.update({"first_stage_model." + k: torch.zeros(v.shape) for k, v in eng.first_stage_model.state_dict().items()})
+    sd["model_ema.decay"] = torch.zeros(1)
+    missing, unexpected = eng.load_state_dict(sd)
+    assert missing == [] and unexpected == ["model_ema.decay"]
+    assert not any(p.is_meta for p in tower.parameters())
+    assert torch.equal(tower.ln_final.weight, sd["cond_stage_model.model.ln_final.weight"])
+    assert torch.equal(tower.transformer.resblocks[1].mlp.c_fc.weight, sd["cond_stage_model.model.transformer.resblocks.1.mlp.c_fc.weight"])
+    # a checkpoint that ALSO carries the embedder's own keys keeps those; the legacy copy is then reported, not loaded
+    eng2 = util.instantiate_from_config(_narrow_model_config()["model"])
+    sd2 = {"cond_stage_model.model.ln_final.weight": torch.full((64,), 5.0), "conditioner.embedders.0.model.ln_final.weight": torch.full((64,), 2.0)}
+    _, unexpected2 = eng2.load_state_dict(sd2)
+    assert unexpected2 == ["cond_stage_model.model.ln_final.weight"]
+    assert torch.equal(eng2.conditioner.embedders[0].model.ln_final.weight, torch.full((64,), 2.0))
+
+
+def test_engine_to_moves_ordinary_torch_embedders_only():
+    """`.to()` / `.half()` on the engine leave the host-master modules (UNet, first stage, OpenCLIP towers) alone but must
+    still reach an ordinary torch embedder that GeneralConditioner built through instantiate_from_config and that owns real parameters."""
+    from vidseg_diffusion_amd import util
+    cfg = _narrow_model_config()
+    cfg["model"]["params"]["conditioner_config"]["params"]["emb_models"].append(
+        {"is_trainable": False, "input_key": "vec", "ucg_rate": 0.0, "target": "tests_plain_embedder.PlainEmbedder", "params": {"dim": 8}})
+    import sys
+    import types
+    from vidseg_diffusion_amd.conditioner import AbstractEmbModel
+
+    class PlainEmbedder(AbstractEmbModel):
+        def __init__(self, dim):
+            super().__init__()
+            self.proj = torch.nn.Linear(dim, dim)
+            self.register_buffer("scale", torch.ones(dim))
+
+        def forward(self, x):
+            return self.proj(x) * self.scale
+
+    mod = types.ModuleType("tests_plain_embedder")
+    mod.PlainEmbedder = PlainEmbedder
+    sys.modules["tests_plain_embedder"] = mod
+    try:
+        eng = util.instantiate_from_config(cfg["model"])
+    finally:
+        del sys.modules["tests_plain_embedder"]
+    plain = eng.conditioner.embedders[1]
+    assert plain.proj.weight.dtype == torch.float32
+    assert eng.double() is eng
+    assert plain.proj.weight.dtype == torch.float64 and plain.proj.bias.dtype == torch.float64 and plain.scale.dtype == torch.float64
+    assert any(p.is_meta for p in eng.model.diffusion_model.parameters())              # the host masters were not touched
+    assert all(p.is_meta for p in eng.conditioner.embedders[0].model.parameters())
+    assert eng.float() is eng and plain.proj.weight.dtype == torch.float32
+
+
 @pytest.mark.parametrize("name", ["sd_2_1", "svd"])
 def test_the_reference_yaml_files_build_the_engine(name):
     """The reference's own configs/inference/{sd_2_1,svd}.yaml (read-only, build container only: skipped where /root/reference is absent)

@@ -1571,7 +1571,8 @@ int vidseg_kpp_round_v2(const void* x16, const double* mean, const double* xsq, 
     const int ntiles = (int)cdiv64(n, TS);
     RowsF16 X{(const f16*)x16, nullptr, mean, n, C};
     if (c > 0) {
-        static int lds_ok = -1;                                        // 0: the device refused 120 KB of dynamic LDS -> distances stay in global memory
+        static VsPerDeviceFlag lds_flag;                               // 0: the device refused 120 KB of dynamic LDS -> distances stay in global memory
+        signed char& lds_ok = lds_flag.here();
         if (lds_ok < 0) {
             lds_ok = hipFuncSetAttribute((const void*)k_kpp_pick, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
             (void)hipGetLastError();
@@ -1618,10 +1619,10 @@ int vidseg_lloyd_iter(const void* x16, const double* mean, int64_t n, int C, int
         const int nblk = (int)cdiv64(n, chunk);
         const size_t lds = (size_t)K * 256 * 8 + (size_t)chunk * 4 + (size_t)K * 4;
         VS_REQUIRE(lds <= 160 * 1024, "lloyd_iter: LDS %zu too large", lds);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static VsOncePerDevice attr_set;
+        if (attr_set.needs()) {
             (void)hipFuncSetAttribute((const void*)k_lloyd_accum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
+            attr_set.mark();
         }
         k_lloyd_accum<<<dim3(nblk, nslots), 256, lds, st>>>(X, labels, R, K, d_active, slots, chunk, psum, pcnt, nblk);
         VS_CHECK_LAUNCH("lloyd_accum");

@@ -31,6 +31,29 @@ extern thread_local char g_vs_err[512];
         if (e_ != hipSuccess) VS_FAIL(VS_ERR_HIP, "%s: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
+// One-time setup that is PER DEVICE (hipFuncSetAttribute: a process that drives several GPUs needs it on each one) and safe to race on:
+// two threads may both run the setup, which is idempotent; nobody launches before `mark()` of its own pass.
+struct VsOncePerDevice {
+    unsigned long long done = 0;
+    static unsigned long long bit() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return 1ull << (d & 63);
+    }
+    bool needs() const { return !(__atomic_load_n(&done, __ATOMIC_ACQUIRE) & bit()); }
+    void mark() { __atomic_fetch_or(&done, bit(), __ATOMIC_RELEASE); }
+};
+// A per-device tri-state cache (-1 unknown, 0 no, 1 yes) for "does this device accept the attribute".
+struct VsPerDeviceFlag {
+    signed char v[64];
+    VsPerDeviceFlag() { memset(v, -1, sizeof(v)); }
+    signed char& here() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return v[d & 63];
+    }
+};
+
 typedef _Float16 f16;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;

@@ -1038,10 +1038,10 @@ int vidseg_x_temporal_attention(const float* qkv, int ld, int nvid, int T, int S
     if (nitems == 0) return VS_OK;
     VS_REQUIRE((long long)nvid * T * S < (1LL << 31), "x_temporal_attention: too many rows");
     const size_t lds = (size_t)4 * (3 * T * TA_LD + 16 * TA_PLD) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static VsOncePerDevice attr;
+    if (attr.needs()) {
         (void)hipFuncSetAttribute((const void*)k_x_temporal_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (3 * 16 * TA_LD + 16 * TA_PLD) * 4);
-        attr = true;
+        attr.mark();
     }
     const long long blocks = (nitems + 3) / 4;
     const unsigned grid = (unsigned)(blocks < 256 * 3 ? blocks : 256 * 3);     // persistent: three resident blocks per CU

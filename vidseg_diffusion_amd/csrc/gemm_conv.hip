@@ -2782,11 +2782,11 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     }
     VS_REQUIRE(p.N % 8 == 0 && p.ldo % 8 == 0 && (!p.residual || p.ldr % 8 == 0) && (!p.tap || (p.tap_ld % 8 == 0 && p.tap_cols % 8 == 0)),
                "gemm: N=%d ldo=%d ldr=%d tap_ld=%d must be multiples of 8 (16-byte epilogue)", p.N, p.ldo, p.ldr, p.tap_ld);
-    static bool attr = false;
-    if (!attr) {
+    static VsOncePerDevice attr;
+    if (attr.needs()) {
         (void)hipFuncSetAttribute((const void*)k_gemm_conv<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         (void)hipFuncSetAttribute((const void*)k_gemm_conv<256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
-        attr = true;
+        attr.mark();
     }
     const int force = knobs().tile;
     bool narrow = p.N <= 64 && p.act != 2 && p.M >= 256;
@@ -2821,7 +2821,8 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     // k_gemm_ws is written for this chip: a fixed grid of 256 persistent blocks laid out over 8 XCDs and ~142 KB of dynamic LDS.  On
     // a device that does not offer that (fewer CUs, less LDS per block) or when the attribute call is refused, the launch goes to
     // the tiled kernels instead of failing (or idling half a larger chip).
-    static int ws_fits = -1;
+    static VsPerDeviceFlag ws_flag;
+    signed char& ws_fits = ws_flag.here();
     if (ws_fits < 0) {
         int dev = 0, cus = 0, lds = 0;
         ws_fits = hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
@@ -2844,20 +2845,20 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
     if (p.out_split3 && p.act == 2) {                          // exact mode's GEGLU projection: always the 256 x 256 phased tile
         VS_REQUIRE(p.ksize == 1 && !p.out && !p.out_f32 && !p.residual && !p.tap && p.N % 64 == 0 && (p.ldo % 8) == 0,
                    "gemm: the GEGLU split3 output exists for the plain linear only");
-        static bool attr3 = false;
-        if (!attr3) {
+        static VsOncePerDevice attr3;
+        if (attr3.needs()) {
             (void)hipFuncSetAttribute((const void*)k_gemm_ph<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
-            attr3 = true;
+            attr3.mark();
         }
         p.gn = (p.N + 255) / 256 < 8 ? (p.N + 255) / 256 : 8;
         if (knobs().gg > 0) p.gn = knobs().gg < (p.N + 255) / 256 ? knobs().gg : (p.N + 255) / 256;   // A/B: panel width of the GEGLU tile order
         int kind3 = 1;
         if (p.geglu16) {                                       // weights interleaved in 16-row value | gate groups: the split tile (224 x 256)
             VS_REQUIRE(p.K % 192 == 0 && p.C0 == p.K && p.N % 256 == 0, "gemm: geglu16 needs K %% 192 == 0 and N %% 256 == 0 (K=%d N=%d)", p.K, p.N);
-            static bool attr4 = false;
-            if (!attr4) {
+            static VsOncePerDevice attr4;
+            if (attr4.needs()) {
                 (void)hipFuncSetAttribute((const void*)k_gemm_p7x<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
-                attr4 = true;
+                attr4.mark();
             }
             const long long tiles4 = ((p.M + 223) / 224) * (p.N / 256);
             launch(k_gemm_p7x<4, true>, dim3((unsigned)tiles4), 512, 2 * (256 + 256) * 128, p);
@@ -2905,9 +2906,9 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
         const int nosplit = !knobs().split, use_dma = knobs().dma, big_mode = knobs().big, mid_mode = knobs().mid, ph_mode = knobs().ph,
                   p7_mode = knobs().p7, p7_phases = knobs().p7ph;
         constexpr int MID_LDS = 8 * 32 * 68 * 4;               // epilogue staging of 8 waves (69.6 KiB) > 2 x (128+320) x 64 B
-        static bool attr2 = false;
-        if (!attr2) {
-            attr2 = true;
+        static VsOncePerDevice attr2;
+        if (attr2.needs()) {
+            attr2.mark();
             (void)hipFuncSetAttribute((const void*)k_gemm_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 36864);
             (void)hipFuncSetAttribute((const void*)k_gemm_dma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
             (void)hipFuncSetAttribute((const void*)k_gemm_tile<4, 4, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS);
@@ -3032,10 +3033,10 @@ static int launch_gemm(const GemmParams& p_in, hipStream_t st) {
             p.ws = S > 1 ? g_ws : nullptr;
             p.gn = pick_gn(256, NJ * 64, 32, S);
             if (ph_mode && NJ == 5 && knobs().phx != 0 && p.split2 && !p.x1 && p.C1 == 0 && p.K % 192 == 0 && p.C0 % 192 == 0 && (p.K / 192) / S >= 1 && p.act != 2) {
-                static bool attrx = false;
-                if (!attrx) {
+                static VsOncePerDevice attrx;
+                if (attrx.needs()) {
                     (void)hipFuncSetAttribute((const void*)k_gemm_phx, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 320) * 128);
-                    attrx = true;
+                    attrx.mark();
                 }
                 launch(k_gemm_phx, dim3((unsigned)(tiles_b * S)), 512, 2 * (256 + 320) * 128, p);   // split operands: each plane staged once
             } else if (ph_mode && NJ == 5)
@@ -3482,10 +3483,10 @@ static int conv_in_impl(const float* x, const float* w, const float* bias, int B
     if (npix == 0 || Cout == 0) return VS_OK;
     VS_REQUIRE(Cout % 8 == 0 && Cout <= 2048 && 9 * Cin * Cout * 4 <= 160 * 1024 && W % 4 == 0, "conv_in: Cin=%d Cout=%d W=%d", Cin, Cout, W);
     const size_t lds = (size_t)9 * Cin * Cout * 4;
-    static bool attr = false;
-    if (!attr) {
+    static VsOncePerDevice attr;
+    if (attr.needs()) {
         (void)hipFuncSetAttribute((const void*)k_conv_in, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
+        attr.mark();
     }
     const long long nquad = npix / 4;
     k_conv_in<<<dim3((unsigned)((nquad + CONV_IN_QUADS - 1) / CONV_IN_QUADS)), 256, lds, st>>>(x, w, bias, B, H, W, Cin, Cout,

@@ -1890,10 +1890,10 @@ int vidseg_temporal_attention_a16(const void* q, int ldq, const void* k, int ldk
     VS_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "temporal_attention: strides must be multiples of 8");
     const long long total = (long long)Bv * T * S * H;
     if (total == 0) return VS_OK;
-    static bool attr = false;
-    if (!attr) {
+    static VsOncePerDevice attr;
+    if (attr.needs()) {
         (void)hipFuncSetAttribute((const void*)k_temporal_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
+        attr.mark();
     }
     const size_t lds = (size_t)2 * T * TA_LOC * 64 * 2;
     k_temporal_attention<<<dim3((unsigned)((S + TA_LOC - 1) / TA_LOC), H, Bv), 256, lds, st>>>(

@@ -41,9 +41,20 @@ class DiffusionEngine(nn.Module):
             self.init_from_ckpt(ckpt_path)
 
     def _apply(self, fn, recurse=True):
-        """`.to(device)` / `.cuda()` / `.half()` as the drivers call them on the engine (svd_pipeline_vspw.py:566-569, `load_model`):
-        no-ops that return the engine.  The parameters are host masters (fp32, possibly still on the meta device before a checkpoint is
-        loaded); the kernels' device copies are packed from them on first use, on the device the inputs live on."""
+        """`.to(device)` / `.cuda()` / `.half()` as the drivers call them on the engine (svd_pipeline_vspw.py:566-569, `load_model`).
+        The modules that hold HOST MASTERS (class flag `HOST_MASTERS`: the UNet, the first stage, the OpenCLIP towers -- fp32 on the
+        host, possibly still on the meta device before a checkpoint is loaded; the kernels' device copies are packed from them on first
+        use, on the device the inputs live on) are left alone.  Everything else -- e.g. an ordinary torch embedder that
+        GeneralConditioner built through `instantiate_from_config` and that owns real parameters -- follows the call as in torch."""
+        def walk(m):
+            for child in m.children():
+                if getattr(child, "HOST_MASTERS", False):
+                    continue
+                walk(child)
+                if any(p.is_meta for p in child.parameters(recurse=False)):
+                    continue                                              # a named slot that no checkpoint has filled yet
+                nn.Module._apply(child, fn, recurse=False)
+        walk(self)
         return self
 
     # ------------------------------------------------------------------ checkpoints (diffusion.py:85-101)
@@ -63,11 +74,12 @@ class DiffusionEngine(nn.Module):
     def load_state_dict(self, state_dict, strict=False, assign=True):
         """Keys as in the released checkpoints, routed by prefix: `model.diffusion_model.*` -> the network,
         `first_stage_model.*` -> the first stage, `conditioner.embedders.N.*` -> embedder N when it owns parameters (SVD's
-        `VideoPredictionEmbedderWithEncoder.encoder`, svd.yaml:66-91).  Keys of embedders that are stand-ins here (the OpenCLIP
+        `VideoPredictionEmbedderWithEncoder.encoder`, svd.yaml:66-91), `cond_stage_model.*` (the LDM layout of the SD 2.1 checkpoint) ->
+        the first FrozenOpenCLIPEmbedder.  Keys of embedders that are stand-ins here (the OpenCLIP
         towers, `PrecomputedEmbedder`) and `denoiser.*` buffers are ignored; anything else is reported as unexpected.
         Returns (missing, unexpected) with the checkpoint's full key names."""
         parts = {"model.diffusion_model.": {}, "first_stage_model.": {}}
-        cond = {}
+        cond, legacy = {}, {}
         unexpected = []
         for k, v in state_dict.items():
             for pre, d in parts.items():
@@ -81,9 +93,25 @@ class DiffusionEngine(nn.Module):
                         cond.setdefault(int(idx), {})[rest] = v
                     else:
                         unexpected.append(k)
+                elif k.startswith("cond_stage_model."):
+                    legacy[k[len("cond_stage_model."):]] = v
                 elif not k.startswith("conditioner.") and not k.startswith("denoiser."):
                     unexpected.append(k)
         missing = []
+        embedders = list(getattr(self.conditioner, "embedders", []))
+        if legacy:
+            # The SD 2.1 checkpoint the SD driver loads (v2-1_512-ema-pruned.safetensors, sd_pipeline_vspw.py:663) is in the LDM layout:
+            # the text encoder sits under `cond_stage_model.model.*` (open_clip names).  The reference reports those keys as unexpected
+            # and takes the same weights from open_clip's pretrained download (modules.py:511-516), which this image cannot do -- so they
+            # are routed to the first FrozenOpenCLIPEmbedder (whose `model.*` they are), unless the checkpoint also carries that
+            # embedder's own `conditioner.embedders.N.*` keys.
+            idx = next((i for i, e in enumerate(embedders) if type(e).__name__ == "FrozenOpenCLIPEmbedder"), None)
+            if idx is None or idx in cond:
+                unexpected.extend("cond_stage_model." + k for k in legacy)
+            else:
+                r = embedders[idx].load_state_dict(legacy, strict=False)
+                missing.extend(f"conditioner.embedders.{idx}." + k for k in r[0])
+                unexpected.extend("cond_stage_model." + k for k in r[1])
 
         def _load(module, sub, prefix):
             r = module.load_state_dict(sub, strict=False)
@@ -96,7 +124,6 @@ class DiffusionEngine(nn.Module):
             _load(self.model.diffusion_model, parts["model.diffusion_model."], "model.diffusion_model.")
         if parts["first_stage_model."]:
             _load(self.first_stage_model, parts["first_stage_model."], "first_stage_model.")
-        embedders = list(getattr(self.conditioner, "embedders", []))
         for idx, sub in sorted(cond.items()):
             if idx >= len(embedders):
                 unexpected.extend(f"conditioner.embedders.{idx}.{k}" for k in sub)

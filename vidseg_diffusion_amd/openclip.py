@@ -202,6 +202,8 @@ def run_blocks(x, packed_blocks, B, N, heads, causal):
 
 
 class _Tower(nn.Module):
+    HOST_MASTERS = True          # engine.DiffusionEngine._apply leaves these modules alone (.to / .cuda / .half are no-ops)
+
     def __init__(self):
         super().__init__()
         self._packed = _Packed()

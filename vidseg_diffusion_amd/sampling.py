@@ -99,6 +99,7 @@ class VScalingWithEDMcNoise:
 # ----------------------------------------------------------------------------- denoiser.py
 class Denoiser(nn.Module):
     """denoiser.py:13-46.  `sigma` is a per-sample vector; it is evaluated on the host."""
+    HOST_MASTERS = True          # the sigma table stays an fp32 host table: engine.to(device) / .half() do not touch it
 
     def __init__(self, scaling_config: Dict):
         super().__init__()

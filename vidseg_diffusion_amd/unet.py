@@ -368,6 +368,7 @@ class _ConvIn(nn.Conv2d):
 
 class UNetModel(nn.Module):
     """sgm/modules/diffusionmodules/openaimodel.py:487-954 for the SD 2.1 configuration."""
+    HOST_MASTERS = True          # engine.DiffusionEngine._apply leaves these modules alone (.to / .cuda / .half are no-ops)
 
     def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, dropout=0.0,
                  channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False, num_heads=-1,

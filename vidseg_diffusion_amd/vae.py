@@ -294,6 +294,7 @@ class VideoDecoder(Decoder):
 
 class AutoencoderKL(nn.Module):
     """sgm/models/autoencoder.py:508-522 (+ :437-506) with DiagonalGaussianRegularizer(sample=True)."""
+    HOST_MASTERS = True          # engine.DiffusionEngine._apply leaves these modules alone (.to / .cuda / .half are no-ops)
 
     def __init__(self, embed_dim=4, ddconfig=None, lossconfig=None, loss_config=None, monitor=None, ckpt_path=None,
                  ckpt_engine=None, max_batch_size=None, **ignored):
