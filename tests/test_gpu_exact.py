@@ -690,3 +690,76 @@ def test_exact_video_unet_forward_vs_reference(X):
     assert worst <= 1e-4
     net.set_precision("fp16")
     assert np.array_equal(net(x, **kw).cpu().numpy(), out16)
+
+
+def _narrow_sd_exact():
+    from vidseg_diffusion_amd.unet import UNetModel
+    net = UNetModel(**synthetic.SD21_NARROW)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, 1234).items()})
+    net.pack(torch.device("cuda:0"))
+    net.set_precision("exact")
+    return net
+
+
+def _nrms(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def test_exact_mode_inversion_vs_reference(X):
+    """a3b in the parity precision (VERDICT r5 #3a): `EDMSampler.inversion` (sampling.py:264-296: sigmas ascending, sigma[0] += 1e-8, the
+    first pair skips the network, 24 CFG evaluations up to sigma = 14.6, result / sqrt(1 + sigma_last^2)) of the narrow SD UNet in the exact
+    mode against the REFERENCE's own fp32 run (tests/golden/unet_sd_narrow.npz: inv_step5, inv_final).  ABSOLUTE bars -- the 16-bit mode's
+    test (tests/test_gpu_unet.py::test_inversion_vs_reference) can only be stated relative to its storage format's 2e-2."""
+    from vidseg_diffusion_amd.pipeline import build_sd_engine
+    dev = torch.device("cuda:0")
+    z = np.load(G)
+    g = {k: z[k] for k in ("sm_c", "sm_latent", "inv_step5", "inv_final")}
+    net = _narrow_sd_exact()
+    eng = build_sd_engine(net)
+    c = {"crossattn": torch.from_numpy(g["sm_c"]).to(dev)}
+    uc = {"crossattn": torch.zeros_like(c["crossattn"])}
+    x, lats = eng.sampler.inversion(lambda inp, s, cc, **k: eng.denoiser(eng.model, inp, s, cc), torch.from_numpy(g["sm_latent"]).to(dev),
+                                    cond=c, uc=uc, num_steps=25)
+    assert len(lats) == 26 and lats[-1] is x
+    e5, ef = _nrms(lats[5].cpu().numpy(), g["inv_step5"]), _nrms(x.cpu().numpy(), g["inv_final"])
+    print(f"exact-mode inversion vs reference: x after pair 5 nrms {e5:.2e}, final (24 evaluations) nrms {ef:.2e}")
+    net.release_exact()
+    assert e5 <= 1e-4, e5
+    assert ef <= 1e-3, ef                                  # the north star's tolerance; measured value printed above
+
+
+def test_exact_mode_inversion_window_vs_reference(X):
+    """`--inversion_type inversion` through the harness in the parity precision (sd_pipeline_vspw.py:233-236, 340-345): sampler.inversion,
+    the feature pass from t_start = 0 (dumps at all 25 steps), Steps 3 / 3b -- against the window the REFERENCE itself ran that way
+    (tests/golden/sd_inversion_window_narrow.npz, tools/gen_golden_inversion_window.py): 49 network evaluations.  Absolute bars on the
+    trajectory and the step-24 Q taps, and the masks must be the reference's."""
+    from tools_metrics import matched_iou
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd.pipeline import build_sd_engine, segment_window
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(os.path.dirname(G), "sd_inversion_window_narrow.npz"))
+    g = {k: z[k] for k in z.files}
+    Fn, K = int(g["F"]), int(g["K"])
+    net = _narrow_sd_exact()
+    eng = build_sd_engine(net, num_steps=25, scale=5.0)
+    c = {"crossattn": torch.from_numpy(g["c"]).to(dev)}
+    uc = {"crossattn": torch.zeros_like(c["crossattn"])}
+    FE.FeatureStore.clear()
+    FE.MaskStore.clear()
+    labels, _ = segment_window(eng, torch.from_numpy(g["latent"]).to(dev), c, uc, num_masks=K, num_steps=25, t_start=22, seed=17,
+                               is_refine_mask=True, feature_folder="/nonexistent/xinv", exp_name="w", keep_all_steps=True,
+                               inversion_type="inversion")
+    store = FE.FeatureStore.folder("/nonexistent/xinv", "w")
+    errs = {i: _nrms(store[f"xt_time_{i}"].cpu().numpy(), g[f"x_step{i}"]) for i in (0, 12, 24)}
+    taps = {b: _nrms(store[f"output_block_{b}_spatial_self_attn_q_time_24"].float().cpu().numpy(), g[f"q{b}"].astype(np.float32)) for b in (6, 7, 8)}
+    iou, same = matched_iou(np.asarray(labels).reshape(-1), g["corrected_labels"].astype(np.int64).reshape(-1), K)
+    print("exact-mode inversion window vs reference: x nrms", {i: f"{e:.2e}" for i, e in errs.items()}, "step-24 Q taps nrms",
+          {b: f"{e:.2e}" for b, e in taps.items()}, f"masks IoU {iou:.4f} identical {same:.4f}")
+    FE.FeatureStore.clear()
+    FE.MaskStore.clear()
+    net.release_exact()
+    assert max(errs.values()) <= 1e-3, errs
+    assert max(taps.values()) <= 1e-3, taps
+    assert iou >= 0.99, (iou, same)

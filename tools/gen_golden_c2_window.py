@@ -81,10 +81,13 @@ class RestartRecorder:
 
 
 def run_window(fe, wid, state):
-    zero_gain = float(os.environ.get("C2_ZERO_GAIN", synthetic.HEADLINE["zero_gain"]))
+    spec = os.environ.get("C2_SPEC") == "1"                  # the SURVEY 8(d)-specified inputs (round 6): N(0, 0.02) weights INCLUDING the
+    # zero-init modules (zero_gain 1.0) and the 6-blob drifting clip (synthetic.latent_clip) -> tests/golden/c2_spec_w<w>.npz, labels only
+    zero_gain = 1.0 if spec else float(os.environ.get("C2_ZERO_GAIN", synthetic.HEADLINE["zero_gain"]))
     # window w > 0 of the headline clip (bench.py make_inputs: latent seed 1 + w, noise seed 100 + w, the same
     # conditioning) -> tests/golden/c2_window_w<w>.npz holding the reference's labels and the input hashes only (no taps)
-    out_path = os.environ.get("C2_OUT", os.path.join(ROOT, "tests", "golden", "c2_window.npz" if wid == 0 else f"c2_window_w{wid}.npz"))
+    out_path = os.environ.get("C2_OUT", os.path.join(ROOT, "tests", "golden", f"c2_spec_w{wid}.npz" if spec else
+                                                     ("c2_window.npz" if wid == 0 else f"c2_window_w{wid}.npz")))
     from sgm.modules.diffusionmodules.denoiser import DiscreteDenoiser
     from sgm.modules.diffusionmodules.openaimodel import UNetModel
     from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
@@ -103,10 +106,10 @@ def run_window(fe, wid, state):
     rec = dict(state_dict_signature=synthetic.state_dict_signature(shapes), weight_seed=1234, zero_gain=zero_gain,
                F=F, lat=LAT, K=K, t_start=T_START, num_steps=NUM_STEPS, seed=17)
 
-    lat = synthetic.headline_latent(F, LAT, LAT, window_id=wid)
+    lat = synthetic.latent_clip(F, LAT, LAT, seed=1 + wid) if spec else synthetic.headline_latent(F, LAT, LAT, window_id=wid)
     c, uc = synthetic.sd_conditioning(F, context_dim=cfg["context_dim"], seq=77, seed=1)
     noise = torch.randn((F, 4, LAT, LAT), generator=torch.Generator().manual_seed(100 + wid))
-    rec.update(window_id=wid)
+    rec.update(window_id=wid, clip="latent_clip(seed=1+w): 6 drifting blobs" if spec else "headline_latent: 20-region lattice clip")
     rec.update(latent_sha256=synthetic.sha256_of(lat), c_sha256=synthetic.sha256_of(c), noise_sha256=synthetic.sha256_of(noise.numpy()))
 
     # ---- batch-chunked network call (values identical to the batch-28 call, see module docstring) -------------------------
@@ -200,16 +203,17 @@ def run_window(fe, wid, state):
     finally:
         os.chdir(cwd)
         shutil.rmtree(base, ignore_errors=True)
-    if wid:                                                   # labels-only fixture
+    if wid or spec:                                           # labels-only fixture
         for k in [k for k in rec if k.startswith("q") or k.startswith("x_")]:
             del rec[k]
-    gt = synthetic.headline_partition(F, LAT, LAT, window_id=wid)
-    rec["generating_partition_agreement"] = np.float64(_agreement(rec["match_labels"], gt, K))
+    if not spec:
+        gt = synthetic.headline_partition(F, LAT, LAT, window_id=wid)
+        rec["generating_partition_agreement"] = np.float64(_agreement(rec["match_labels"], gt, K))
     import sklearn
     rec["versions"] = np.array([f"torch {torch.__version__}", f"sklearn {sklearn.__version__}", f"numpy {np.__version__}"])
     np.savez_compressed(out_path, **rec)
     print("wrote", out_path, os.path.getsize(out_path) // 1024, "KiB in", f"{time.time() - t_all:.0f} s;",
-          "labels vs generating partition:", float(rec["generating_partition_agreement"]))
+          "labels vs generating partition:", float(rec.get("generating_partition_agreement", np.nan)))
 
 
 def _agreement(labels, gt, K):
