@@ -704,13 +704,20 @@ class ExactRunner:
         out = linear_x(t if t.dtype == F16 else split3(t), e["w_out"], e["b_out"], residual=x.view(B, N, C))   # ATT:921-927
         return out.view(B, H, W, C)
 
-    def block(self, blk, x, x_skip, emb_all, ctx3, skip_resample=False, mod=None):
+    def block(self, blk, x, x_skip, emb_all, ctx3, skip_resample=False, mod=None, res_cache=None):
+        """res_cache: the fork point of a Step-4 sweep (pipeline.modulation_sweep, `shared_prefix`): a dict that receives the ResBlock's
+        output on the pass that computes it ("x" absent) and hands it back on the later ones, which skip the ResBlock."""
         U = self.U
         for layer in blk:
             if skip_resample and isinstance(layer, (U.Upsample, U.Downsample)):   # taps-only evaluation: nothing downstream reads this
                 continue
             if isinstance(layer, U.ResBlock):
-                x = self.resblock(layer, x, x_skip, emb_all)
+                if res_cache is not None and "x" in res_cache:
+                    x = res_cache["x"]
+                else:
+                    x = self.resblock(layer, x, x_skip, emb_all)
+                    if res_cache is not None:
+                        res_cache["x"] = x
                 x_skip = None
             elif isinstance(layer, U.SpatialTransformer):
                 x = self.transformer(layer, x, ctx3, layer.tap, mod)
@@ -766,20 +773,41 @@ class ExactRunner:
         ctx3 = ops.window_cached(self, "_ctx3", (context,), lambda: split3(context.float().contiguous()))
         if self.video:                                                                                # first frame's context per video, VA:400-404
             self.tctx3 = ops.window_cached(self, "_tctx3", (context,), lambda: split3(context[::self.T].float().contiguous()))
-        xn = x_nchw.float().permute(0, 2, 3, 1).contiguous()
-        B, H, W, Cin = xn.shape
-        h = torch.empty((B, H, W, mc), dtype=F32, device=dev)
-        call("vidseg_conv_in_f32", ptr(xn), ptr(self.cin_w), ptr(self.cin_b), B, H, W, Cin, mc, ptr(h), stream())
-        hs = [h]
-        for i, blk in list(enumerate(net.input_blocks))[1:]:
-            h = self.block(blk, h, None, emb_all, ctx3, mod=net._block_mod("input", i, blk, False, is_injected_step, modulate_params, dev))
-            hs.append(h)
-        h = self.block(net.middle_block, h, None, emb_all, ctx3)
+        # Step-4 sweep: the first evaluation of all 2K modulated passes of a window is the same computation up to the first modulated
+        # attention (same noised latent, same step, same injected dumps; pipeline.modulation_sweep owns `shared_prefix`): the pass that
+        # finds the prefix empty computes and leaves it -- the skip stack and the fork block's ResBlock output --, the others resume there.
+        from .util import shared_prefix
+        pre = shared_prefix(modulate_params, is_modulate_step)
+        resume = pre is not None and pre.get("state") is not None
+        if resume:
+            hs, res_cache = list(pre["state"][0]), {"x": pre["state"][1]}
+            h = None
+        else:
+            xn = x_nchw.float().permute(0, 2, 3, 1).contiguous()
+            B, H, W, Cin = xn.shape
+            h = torch.empty((B, H, W, mc), dtype=F32, device=dev)
+            call("vidseg_conv_in_f32", ptr(xn), ptr(self.cin_w), ptr(self.cin_b), B, H, W, Cin, mc, ptr(h), stream())
+            hs = [h]
+            for i, blk in list(enumerate(net.input_blocks))[1:]:
+                h = self.block(blk, h, None, emb_all, ctx3, mod=net._block_mod("input", i, blk, False, is_injected_step, modulate_params, dev))
+                hs.append(h)
+            h = self.block(net.middle_block, h, None, emb_all, ctx3)
         for i, blk in enumerate(net.output_blocks):
+            if resume and i < pre["fork"]:
+                continue
             mod = net._block_mod("output", i, blk, is_modulate_step, is_injected_step, modulate_params, dev)
             if stop_after_block is not None and i == stop_after_block:
                 self.block(blk, h, hs.pop(), emb_all, ctx3, skip_resample=True, mod=mod)
                 return None
+            if pre is not None and i == pre["fork"]:
+                if not resume:
+                    res_cache = {}
+                    skip = hs.pop()
+                    h = self.block(blk, h, skip, emb_all, ctx3, mod=mod, res_cache=res_cache)
+                    pre["state"] = (tuple(hs), res_cache["x"])
+                else:
+                    h = self.block(blk, None, None, emb_all, ctx3, mod=mod, res_cache=res_cache)
+                continue
             h = self.block(blk, h, hs.pop(), emb_all, ctx3, mod=mod)                                   # OAI:911-948
         h3 = groupnorm_split3(h, self.out_g, self.out_beta, eps=1e-5, silu=True)
         C = h.shape[-1]

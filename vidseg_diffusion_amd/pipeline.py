@@ -499,13 +499,20 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
                      modulate_block_idx=(7,), modulate_layer_type=("spatial",), modulate_attn_type=("cross_attn",),
                      modulate_timestep=None, modulate_schedule="constant", modulate_lambda_start=50.0, modulate_lambda_end=50.0,
                      is_injected_features=True, is_latent_blending=True, feature_folder="features_outputs_VSPW", exp_name="exp",
-                     frame_names=None, noise=None, seed=17):
+                     frame_names=None, noise=None, seed=17, share_prefix=True):
     """Step 4 for one window: 2*K modulated sampler passes (+lambda then -lambda, one per label in `unique_labels`), each
     with the dumped Q/K injected, lambda*mask added to the chosen attention outputs of the chosen decoder block(s) at the
     modulation timestep(s) and, if asked, the latent blended with the feature pass's x_t outside the mask.  The feature pass
     (Step 2, `segment_window(..., keep_all_steps=True)`) must have left its dumps in the FeatureStore under
     (feature_folder, exp_name) and Step 3 its label maps under `masks_folder`.
-    Returns {(sign, label): final latent fp32 [F,4,h,w]} -- what the reference hands to decode_first_stage (SDP:150-151)."""
+    Returns {(sign, label): final latent fp32 [F,4,h,w]} -- what the reference hands to decode_first_stage (SDP:150-151).
+
+    share_prefix: all 2*K passes start from the same noised latent (SDP:341 with the window's seed), so their FIRST network evaluation
+    is one and the same computation up to the first modulated attention -- encoder, middle block, the decoder blocks before
+    min(modulate_block_idx) and that block's ResBlock (with injection: the same dumps at the same step).  It is computed by the first
+    pass and resumed by the other 2*K - 1 (exact.ExactRunner.forward; bit-identical latents, tests/test_gpu_exact.py); the later
+    evaluations of a pass see that pass's own x and run in full.  Applies when the first sampled step is a modulated one (the
+    drivers' default: modulate_timestep = t_start, SDP:233-234) and the network runs in the exact precision."""
     F, _, lh, lw = latent.shape
     modulate_timestep = [t_start] if modulate_timestep is None else [int(t) for t in modulate_timestep]
     blocks = [int(b) for b in modulate_block_idx]
@@ -524,6 +531,9 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
     ops.new_window()
     seed_everything(seed)
     x0 = sampler.add_noise(latent, cond=c, uc=uc, num_steps=num_steps, noise_level=t_start, noise=noise)   # same start as Step 2
+    # (s_churn > 0 would draw fresh noise into every pass's first input, SAM:103-109: then nothing is shared)
+    shared = {"step": t_start, "fork": min(blocks), "state": None} \
+        if share_prefix and t_start in modulate_timestep and float(getattr(sampler, "s_churn", 0.0)) == 0.0 else None
     out = {}
     for sign in (1.0, -1.0):                                            # SDP:436-442
         for mask_id in [int(v) for v in np.asarray(unique_labels).reshape(-1)]:
@@ -538,6 +548,8 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
                   "injected_features_group": {}, "modulate_layer_frames": {}, "modulate_block_frames": {},
                   "modulate_timestep_frames": {}, "modulate_lambda_layers": {}, "latent_mask_start": min(modulate_timestep),
                   "latent_mask_end": num_steps if video else min(modulate_timestep) + 1}                     # SVP:467 / SDP:484
+            if shared is not None:
+                mp["shared_prefix"] = shared
             out[(int(sign), mask_id)] = sampler(denoiser, x0.clone(), cond=c, uc=uc, img_callback=None, is_modulate=True,
                                                 modulate_params=mp, uc_list=None, t_start=t_start,
                                                 is_latent_blending=is_latent_blending, feature_height=base_h * scale,

@@ -167,3 +167,15 @@ def load_checkpoint_state_dict(path, prefix="model.diffusion_model."):
     if not out:                                                  # already a bare UNet state dict
         out = dict(sd)
     return out
+
+
+def shared_prefix(modulate_params, is_modulate_step):
+    """The Step-4 sweep's shared first-evaluation prefix (pipeline.modulation_sweep): `modulate_params["shared_prefix"]` =
+    {"step": the sweep's first sampler step, "fork": the first modulated decoder block, "state": None until computed}.  Returns it when
+    THIS evaluation is that step's modulated evaluation, else None (every other evaluation runs in full)."""
+    if modulate_params is None or not is_modulate_step:
+        return None
+    sp = modulate_params.get("shared_prefix")
+    if sp is None or modulate_params.get("timestep") != sp["step"]:
+        return None
+    return sp
