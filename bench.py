@@ -33,6 +33,8 @@ beside this file (and to gpurun_out/ when present).  Objects of the full record 
                 events are recorded in, right after the timed region.
   roofline_post_unet  the post-UNet kernels alone at the headline's sizes: bytes / time against 8 TB/s (k_mean_normalize, one Lloyd
                 E-step, 4-NN, dense tracking), the float64 contractions also against the f64 MFMA peak.
+  step45        Steps 4-5 of one SD window in the parity precision (2K modulated passes + decodes + difference maps + arg-max), with
+                and without the shared first-evaluation prefix; the SVD counterpart is `secondary.step4_latent_blending`.
   full_schedule / fast_mode   the other precision / schedule modes on the same windows (see above), with their mask scores.
   secondary     N = 1: BASELINE configs[2] (SVD 14x576x1024, t_start 17, refinement) measured after the headline, fewer steps, same
                 precision mode (+ its own fast_mode).  N > 1: BASELINE configs[3] (SVD, 14 frames per GPU over the N ranks, RCCL
@@ -382,6 +384,87 @@ def post_unet_roofline(dev, F=F_WIN, fh=LAT // 2, fw=LAT // 2, C=640, K=20, reps
                     "others are float64 contractions (exactness is the point: bit-exact labels) priced against the f64 MFMA peak"}
 
 
+def step45_sd(eng, cfg, dev, k_masks, ab_labels=3):
+    """Steps 4-5 of one SD window (BASELINE configs[1] geometry) in the parity precision, outside `value`: after Steps 1-3 with every step's
+    dumps kept (sd_pipeline_vspw.py:336-405), the 2K modulated sampler passes (SDP:416-515: lambda * mask on decoder block 7's
+    cross-attention output at step 22, the feature pass's q / k dumps injected into decoder blocks 1-11, latents blended with the feature
+    pass's x_t outside the mask at steps 22-23), each final latent through the first stage's decoder (SDP:150-152), the per-label
+    difference maps and the arg-max over labels (process_output.py:8-167).  The sweep is timed twice: `ab_labels` labels with every pass
+    in full (share_prefix=False) and all K labels with the first evaluation's prefix shared (pipeline.modulation_sweep)."""
+    from vidseg_diffusion_amd import feature_extraction as FE
+    from vidseg_diffusion_amd import process_output as PO
+    from vidseg_diffusion_amd import synthetic
+    from vidseg_diffusion_amd.pipeline import modulation_sweep, segment_window
+    from vidseg_diffusion_amd.vae import AutoencoderKL, decode_first_stage
+    net = eng.model.diffusion_model
+    prec0 = net.precision
+    dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4], num_res_blocks=2,
+              attn_resolutions=[], dropout=0.0)
+    vae = AutoencoderKL(embed_dim=4, ddconfig=dd)
+    vshapes = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+    vae.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(vshapes, seed=99).items()})
+    sync = torch.cuda.synchronize
+    try:
+        net.set_precision("exact")
+        FE.FeatureStore.clear()
+        FE.MaskStore.clear()
+        lat, c, uc, noise = make_inputs(dev, 0, cfg)
+        base, exp = "/nonexistent/bench_step45", "w0"
+        skw = dict(num_masks=k_masks, num_steps=NUM_STEPS, t_start=22, seed=17, noise=noise, feature_folder=base, exp_name=exp, keep_all_steps=True)
+        segment_window(eng, lat, c, uc, **skw)
+        sync()
+        t0 = time.perf_counter()
+        lab, _ = segment_window(eng, lat, c, uc, **skw)
+        sync()
+        t_feat = time.perf_counter() - t0
+        folder = os.path.join(base, exp, "match_gt_mask", f"output_block_8_output_block_7_output_block_6_spatial_self_attn_q_masks_{k_masks}")
+        labels = [int(v) for v in np.unique(lab)]
+        kw = dict(t_start=22, num_steps=NUM_STEPS, feature_folder=base, exp_name=exp, noise=noise, seed=17)
+        modulation_sweep(eng, lat, c, uc, labels[:1], folder, **kw)                          # warm-up (allocator, first-touch)
+        decode_first_stage(vae, lat, 0.18215)
+        sync()
+        t0 = time.perf_counter()
+        plain = modulation_sweep(eng, lat, c, uc, labels[:ab_labels], folder, share_prefix=False, **kw)
+        sync()
+        t_plain = (time.perf_counter() - t0) / (2 * ab_labels)
+        t0 = time.perf_counter()
+        res = modulation_sweep(eng, lat, c, uc, labels, folder, share_prefix=True, **kw)
+        sync()
+        t_sweep = time.perf_counter() - t0
+        same = all(torch.equal(plain[k], res[k]) for k in plain)
+        t0 = time.perf_counter()
+        maps, maxima = [], []
+        for lb in labels:
+            m, mx = PO.difference_map(decode_first_stage(vae, res[(1, lb)], 0.18215), decode_first_stage(vae, res[(-1, lb)], 0.18215))
+            maps.append(m)
+            maxima.append(mx)
+        sync()
+        t_dec = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        seg = PO.seg_map(torch.stack(maps), torch.stack(maxima), labels)
+        sync()
+        t_arg = time.perf_counter() - t0
+        n = 2 * len(labels)
+        total = t_sweep + t_dec + t_arg
+        return {"config": "SD configs[1] geometry (14 x 512 x 512, K = 20), precision exact", "passes_per_window": n,
+                "sweep_ms_per_window": round(1e3 * t_sweep, 1), "ms_per_pass": round(1e3 * t_sweep / n, 2),
+                "ms_per_pass_every_pass_in_full": round(1e3 * t_plain, 2),
+                "prefix_saving_frac": round(1.0 - (t_sweep / n) / t_plain, 4), "bit_identical_to_unshared": bool(same),
+                "decode_and_difference_ms_per_window": round(1e3 * t_dec, 1), "argmax_ms_per_window": round(1e3 * t_arg, 2),
+                "steps_4_5_ms_per_window": round(1e3 * total, 1), "steps_1_3_all_dumps_ms_per_window": round(1e3 * t_feat, 1),
+                "frames_per_s_steps_1_to_5": round(F_WIN / (t_feat + total), 3), "labels_in_segmentation_map": int(len(torch.unique(seg))),
+                "note": "2K modulated passes of 3 CFG evaluations each (block 7 cross-attention, lambda 50, q / k injection into decoder blocks "
+                        "1-11, latent blending at steps 22-23) + 2K first-stage decodes (16-bit kernels) + difference maps + arg-max; the first "
+                        "evaluation's prefix (encoder, middle, decoder blocks 0-6, block 7's ResBlock) is computed once and resumed by the other "
+                        "2K - 1 passes; `ms_per_pass_every_pass_in_full` = the same passes without that (timed on %d labels); outside `value`" % ab_labels}
+    except Exception as e:
+        return {"error": repr(e)[:300]}
+    finally:
+        net.set_precision(prec0)
+        FE.FeatureStore.clear()
+        FE.MaskStore.clear()
+
+
 def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, prebuilt=None):
     """Time `steps` steps of one config; returns (out dict for rank 0 | None, sd_cpu, cfg, eng, labels)."""
     from vidseg_diffusion_amd import feature_extraction as FE
@@ -610,20 +693,32 @@ def run_config(args, svd, rank, world, dev, steps, warmup, secondary=False, preb
             kw = dict(t_start=t_start, num_steps=NUM_STEPS, modulate_block_idx=(8,), modulate_layer_type=("spatial", "temporal"),
                       modulate_attn_type=("self_attn",), is_injected_features=False, is_latent_blending=True, feature_folder=base, exp_name=exp,
                       noise=noise, seed=17)
+            two = [int(v) for v in np.unique(lab)[:2]]
             modulation_sweep(eng, lat, cw, ucw, [label], folder, **kw)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            res = modulation_sweep(eng, lat, cw, ucw, [label], folder, **kw)
+            res = modulation_sweep(eng, lat, cw, ucw, [label], folder, share_prefix=False, **kw)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            res2 = modulation_sweep(eng, lat, cw, ucw, two, folder, share_prefix=True, **kw)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            n2 = 2 * len(two)
+            resumed = (dt2 - dt / 2) / max(n2 - 1, 1)                                # a pass that resumes the shared prefix
             out["step4_latent_blending"] = {"ms_per_modulated_pass": round(1e3 * dt / 2, 2), "passes_per_window": 2 * k_masks, "precision": prec4,
-                                            "finite": bool(all(torch.isfinite(v).all().item() for v in res.values())),
-                                            "note": "one label's +lambda / -lambda modulated sampler passes (8 CFG evaluations each, lambda*mask added "
+                                            "ms_per_pass_resuming_shared_prefix": round(1e3 * resumed, 2),
+                                            "sweep_ms_per_window_extrapolated": round(1e3 * (dt / 2 + (2 * k_masks - 1) * resumed), 1),
+                                            "bit_identical_to_unshared": bool(all(torch.equal(res[k], res2[k]) for k in res)),
+                                            "finite": bool(all(torch.isfinite(v).all().item() for v in res2.values())),
+                                            "note": "the +lambda / -lambda modulated sampler passes of a label (8 CFG evaluations each, lambda*mask added "
                                                     "to the spatial and temporal self-attention rows of decoder block 8 at step 17, latents blended "
                                                     "with the feature pass's x_t outside the mask at every step): the Step 4 unit of configs[2]; "
-                                                    "outside `value` (Steps 1-3b), which the metric is quoted on; same precision mode as `value` (round 5: "
-                                                    "the exact runner carries the Step-4 hooks; tests/test_gpu_c3_window.py::test_step4_latent_blending_full_size "
-                                                    "pins these passes against the reference's own run at full size)"}
+                                                    "outside `value` (Steps 1-3b), which the metric is quoted on; same precision mode as `value`; "
+                                                    "ms_per_modulated_pass = every pass in full (one label), ms_per_pass_resuming_shared_prefix = a pass "
+                                                    "that resumes the first evaluation's shared prefix (pipeline.modulation_sweep, timed on two labels); "
+                                                    "the 2K-pass sweep extrapolated = 1 full + (2K - 1) resumed; tests/test_gpu_c3_window.py::"
+                                                    "test_step4_latent_blending_full_size pins these passes against the reference's own run"}
         except Exception as e:
             out["step4_latent_blending"] = {"error": repr(e)[:300]}
         finally:
@@ -730,7 +825,8 @@ def compact_line(full):
         if isinstance(v.get("fast_mode"), dict):
             o["fast_mode"] = _pick(v["fast_mode"], ("value", "ms_per_step"))
         if isinstance(v.get("step4_latent_blending"), dict):
-            o["step4_latent_blending"] = _pick(v["step4_latent_blending"], ("ms_per_modulated_pass", "passes_per_window", "precision", "error"))
+            o["step4_latent_blending"] = _pick(v["step4_latent_blending"], ("ms_per_modulated_pass", "ms_per_pass_resuming_shared_prefix",
+                                                                             "sweep_ms_per_window_extrapolated", "passes_per_window", "precision", "error"))
         out[key] = o
     if isinstance(full.get("step45"), dict):
         out["step45"] = {k: v for k, v in full["step45"].items() if not isinstance(v, (str, dict, list))}
@@ -1020,6 +1116,9 @@ def main():
             else:
                 out["exact_mode"] = time_mode("exact", False, x_note + "Every step in full")
                 out["parity_mode"] = time_mode("exact", True, x_note + "Last step pruned to the conditional half / decoder blocks <= 8 (masks_only)")
+        if plain and not svd and args.exact and os.environ.get("VIDSEG_BENCH_STEP45", "1") != "0":
+            stage("Steps 4-5 of one SD window (2K modulated passes + decodes + segmentation map)")
+            out["step45"] = step45_sd(eng, cfg, dev, k_masks)
         if plain and not svd:
             stage("post-UNet kernels alone")
             try:

@@ -12,7 +12,7 @@
  * caller-owned, nothing is allocated or freed; calls are asynchronous on `stream`; the return value is 0 or a
  * negative error code (VIDSEG_ERR_*), with a message available from vidseg_last_error() (thread-local);
  * no exceptions cross the boundary; no global mutable state except the opt-in GEMM profiler.
- * Layouts: activations NHWC bf16 (tokens [B][H*W][C] == images [B][H][W][C]); dumped features fp16 [2F][N][C]
+ * Layouts: activations NHWC in the 16-bit activation type "a16" (IEEE fp16 in the default build, see vidseg_act_is_fp16; tokens [B][H*W][C] == images [B][H][W][C]); dumped features fp16 [2F][N][C]
  * with the unconditional half first (sgm/modules/diffusionmodules/guiders.py:33-42); labels int32.
  */
 #ifndef VIDSEG_HIP_H
@@ -35,7 +35,7 @@ int vidseg_version(void);
 const char* vidseg_last_error(void);
 /* 16-bit storage format of every `*_a16` entry point's activation / weight arguments ("a16" = the build's 16-bit activation
  * type): 1 = IEEE fp16 (default build; the reference's CUDA autocast dtype), 0 = bfloat16 (-DVIDSEG_ACT_BF16).  Parameter names
- * and comments that say "bf16" mean that 16-bit type. */
+ * and comments that say "a16" mean that 16-bit type. */
 int vidseg_act_dtype(void);
 
 /* ------------------------------------------------------------------------------------------------------
@@ -120,7 +120,7 @@ int vidseg_trajectory_vote(const int32_t* idx, const int32_t* labels, int F, int
  * UNet operators
  * ---------------------------------------------------------------------------------------------------- */
 
-/* nn.Linear / 1x1 conv (ATT:274-280, 862, 886; OAI:317-324) as a bf16 MFMA GEMM: out = act(cat(a0,a1) @ w^T +
+/* nn.Linear / 1x1 conv (ATT:274-280, 862, 886; OAI:317-324) as a 16-bit (a16) MFMA GEMM: out = act(cat(a0,a1) @ w^T +
  * bias + rowvec[sample]) + residual.  act: 0 none, 1 SiLU (OAI:605-609 time_embed), 2 GEGLU (ATT:89-96; w/bias
  * packed in 32-row value|gate groups).  tap/tap2: fp16 copies of output columns [0,tap_cols) / [tap_cols,2*tap_cols)
  * = the q / k dumps of ATT:330-331. */
@@ -147,13 +147,13 @@ int vidseg_conv3x3_a16_tap(const void* x0, const void* x1, int C0, int C1, int B
 /* First stage (VAE encoder, model.py:487-600): row softmax of fp32 logits (the single-head dim-512 mid attention runs as
  * GEMM -> softmax -> GEMM, model.py:161-202) and DiagonalGaussianDistribution.sample * scale_factor
  * (distributions.py:24-41, sgm/models/diffusion.py:138-151); moments NHWC [B][HW][2Z] fp32, noise / out NCHW [B][Z][HW]. */
-int vidseg_softmax_rows_a16(const float* x, long long rows, int cols, float scale, void* out_bf16, vidseg_stream_t stream);
+int vidseg_softmax_rows_a16(const float* x, long long rows, int cols, float scale, void* out_a16, vidseg_stream_t stream);
 int vidseg_gaussian_sample(const float* moments_nhwc, const float* noise_nchw, int B, int HW, int Z, float scale, float* out_nchw,
                            vidseg_stream_t stream);
-/* OAI:638-644 input conv (Cin 4/8): x fp32 NHWC, w fp32 [3][3][Cin][Cout] -> bf16 NHWC. */
+/* OAI:638-644 input conv (Cin 4/8): x fp32 NHWC, w fp32 [3][3][Cin][Cout] -> a16 NHWC. */
 int vidseg_conv_in(const float* x, const float* w, const float* bias, int B, int H, int W, int Cin, int Cout,
-                   void* out_bf16_nhwc, vidseg_stream_t stream);
-/* OAI:825-829 output conv (Cout 4): x bf16 NHWC, w bf16 [4][3][3][Cin] -> fp32 NCHW. */
+                   void* out_a16_nhwc, vidseg_stream_t stream);
+/* OAI:825-829 output conv (Cout 4): x a16 NHWC, w a16 [4][3][3][Cin] -> fp32 NCHW. */
 int vidseg_conv_out4(const void* x, const void* w, const float* bias, int B, int H, int W, int Cin, float* out_f32_nchw,
                      vidseg_stream_t stream);
 /* GroupNorm32 (DU:276-278, fp32 statistics; eps 1e-5) / ATT:127 Normalize (eps 1e-6), optional SiLU.
@@ -210,7 +210,7 @@ int vidseg_add_rowvec_a16(const void* x, const void* vec, long long rows, int C,
 int vidseg_timestep_embedding(const float* t, int B, int dim, float max_period, void* out, vidseg_stream_t stream);
 int vidseg_silu_a16(const void* x, long long n, void* out, vidseg_stream_t stream);
 int vidseg_f32_to_a16(const float* x, long long n, void* out, vidseg_stream_t stream);
-int vidseg_f16_to_a16(const void* x, long long n, void* out, vidseg_stream_t stream); /* injected fp16 dumps -> bf16 operands */
+int vidseg_f16_to_a16(const void* x, long long n, void* out, vidseg_stream_t stream); /* injected fp16 dumps -> a16 operands (a copy in the fp16 build) */
 
 /* ------------------------------------------------------------------------------------------------------
  * Sampler arithmetic on fp32 latents (SURVEY.md rows a2-a6, a17 latent blending)
