@@ -495,11 +495,23 @@ def load_feature_masks(masks_path, mask_id, num_frames=14, feature_timestep="24"
     return out
 
 
+_SWEEP_STREAMS = {}
+
+
+def _sweep_lanes(device, n):
+    """The sweep's lane streams, created once per device (ops.workspace binds scratch per stream: fresh streams per call would leak it)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    got = _SWEEP_STREAMS.setdefault(key, [])
+    while len(got) < n:
+        got.append(torch.cuda.Stream(device=device))
+    return got[:n]
+
+
 def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder, *, t_start=22, num_steps=25, feature_timestep="24",
                      modulate_block_idx=(7,), modulate_layer_type=("spatial",), modulate_attn_type=("cross_attn",),
                      modulate_timestep=None, modulate_schedule="constant", modulate_lambda_start=50.0, modulate_lambda_end=50.0,
                      is_injected_features=True, is_latent_blending=True, feature_folder="features_outputs_VSPW", exp_name="exp",
-                     frame_names=None, noise=None, seed=17, share_prefix=True):
+                     frame_names=None, noise=None, seed=17, share_prefix=True, lanes=2):
     """Step 4 for one window: 2*K modulated sampler passes (+lambda then -lambda, one per label in `unique_labels`), each
     with the dumped Q/K injected, lambda*mask added to the chosen attention outputs of the chosen decoder block(s) at the
     modulation timestep(s) and, if asked, the latent blended with the feature pass's x_t outside the mask.  The feature pass
@@ -535,25 +547,48 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
     shared = {"step": t_start, "fork": min(blocks), "state": None} \
         if share_prefix and t_start in modulate_timestep and float(getattr(sampler, "s_churn", 0.0)) == 0.0 else None
     out = {}
-    for sign in (1.0, -1.0):                                            # SDP:436-442
-        for mask_id in [int(v) for v in np.asarray(unique_labels).reshape(-1)]:
-            masks = load_feature_masks(masks_folder, mask_id, num_frames=F, feature_timestep=feature_timestep,
-                                       modulate_block_idx=blocks[0], base_height=base_h, base_width=base_w,
-                                       frame_name_list=frame_names, device=latent.device)
-            mp = {"feature_masks": masks, "modulate_block_idx": blocks, "modulate_layer_type": list(modulate_layer_type),
-                  "modulate_attn_type": list(modulate_attn_type), "modulate_timestep": modulate_timestep,
-                  "modulate_schedule": modulate_schedule, "modulate_lambda_start": sign * modulate_lambda_start,
-                  "modulate_lambda_end": sign * modulate_lambda_end, "num_frames": F, "modulate_uc": True,
-                  "is_injected_features": is_injected_features, **inj, "feature_folder": feature_folder, "exp_name": exp_name,
-                  "injected_features_group": {}, "modulate_layer_frames": {}, "modulate_block_frames": {},
-                  "modulate_timestep_frames": {}, "modulate_lambda_layers": {}, "latent_mask_start": min(modulate_timestep),
-                  "latent_mask_end": num_steps if video else min(modulate_timestep) + 1}                     # SVP:467 / SDP:484
-            if shared is not None:
-                mp["shared_prefix"] = shared
-            out[(int(sign), mask_id)] = sampler(denoiser, x0.clone(), cond=c, uc=uc, img_callback=None, is_modulate=True,
-                                                modulate_params=mp, uc_list=None, t_start=t_start,
-                                                is_latent_blending=is_latent_blending, feature_height=base_h * scale,
-                                                feature_width=base_w * scale)
+
+    def run(sign, mask_id):
+        masks = load_feature_masks(masks_folder, mask_id, num_frames=F, feature_timestep=feature_timestep,
+                                   modulate_block_idx=blocks[0], base_height=base_h, base_width=base_w,
+                                   frame_name_list=frame_names, device=latent.device)
+        mp = {"feature_masks": masks, "modulate_block_idx": blocks, "modulate_layer_type": list(modulate_layer_type),
+              "modulate_attn_type": list(modulate_attn_type), "modulate_timestep": modulate_timestep,
+              "modulate_schedule": modulate_schedule, "modulate_lambda_start": sign * modulate_lambda_start,
+              "modulate_lambda_end": sign * modulate_lambda_end, "num_frames": F, "modulate_uc": True,
+              "is_injected_features": is_injected_features, **inj, "feature_folder": feature_folder, "exp_name": exp_name,
+              "injected_features_group": {}, "modulate_layer_frames": {}, "modulate_block_frames": {},
+              "modulate_timestep_frames": {}, "modulate_lambda_layers": {}, "latent_mask_start": min(modulate_timestep),
+              "latent_mask_end": num_steps if video else min(modulate_timestep) + 1}                     # SVP:467 / SDP:484
+        if shared is not None:
+            mp["shared_prefix"] = shared
+        return sampler(denoiser, x0.clone(), cond=c, uc=uc, img_callback=None, is_modulate=True, modulate_params=mp, uc_list=None,
+                       t_start=t_start, is_latent_blending=is_latent_blending, feature_height=base_h * scale, feature_width=base_w * scale)
+
+    jobs = [(sign, int(v)) for sign in (1.0, -1.0) for v in np.asarray(unique_labels).reshape(-1)]        # SDP:436-442
+    nl = max(1, int(lanes))
+    if nl == 1 or len(jobs) < 3:
+        for sign, mask_id in jobs:
+            out[(int(sign), mask_id)] = run(sign, mask_id)
+        return out
+    # lanes > 1: the passes are independent given the feature pass's dumps, so `lanes` of them are in flight at once, each on its own HIP
+    # stream with its own scratch (the same launches on the same data as the sequential sweep: bit-identical latents).  The first
+    # pass runs on the caller's stream: it leaves the shared prefix and the window's cached context projections (ops.window_cached),
+    # which the lanes read after waiting for it.
+    main = torch.cuda.current_stream()
+    out[(int(jobs[0][0]), jobs[0][1])] = run(*jobs[0])
+    streams = _sweep_lanes(latent.device, nl)
+    state = [] if shared is None or shared["state"] is None else [*shared["state"][0], shared["state"][1]]
+    for st in streams:
+        st.wait_stream(main)
+        hand_to_stream(st, x0, latent, c, uc, *state)
+    for j, (sign, mask_id) in enumerate(jobs[1:]):
+        with torch.cuda.stream(streams[j % nl]):
+            out[(int(sign), mask_id)] = run(sign, mask_id)
+    for st in streams:
+        main.wait_stream(st)
+    for v in out.values():
+        v.record_stream(main)
     return out
 
 
