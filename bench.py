@@ -390,8 +390,8 @@ def step45_sd(eng, cfg, dev, k_masks, ab_labels=3):
     cross-attention output at step 22, the feature pass's q / k dumps injected into decoder blocks 1-11, latents blended with the feature
     pass's x_t outside the mask at steps 22-23), each final latent through the first stage's decoder (SDP:150-152), the per-label
     difference maps and the arg-max over labels (process_output.py:8-167).  The sweep is timed twice: `ab_labels` labels with every pass
-    in full, one after the other (share_prefix=False, lanes=1), and all K labels as the sweep runs by default: the first evaluation's prefix
-    shared and two passes in flight on their own HIP streams (pipeline.modulation_sweep)."""
+    in full (share_prefix=False) and all K labels as the sweep runs by default: the first evaluation's prefix shared
+    (pipeline.modulation_sweep)."""
     from vidseg_diffusion_amd import feature_extraction as FE
     from vidseg_diffusion_amd import process_output as PO
     from vidseg_diffusion_amd import synthetic
@@ -457,8 +457,8 @@ def step45_sd(eng, cfg, dev, k_masks, ab_labels=3):
                 "note": "2K modulated passes of 3 CFG evaluations each (block 7 cross-attention, lambda 50, q / k injection into decoder blocks "
                         "1-11, latent blending at steps 22-23) + 2K first-stage decodes (16-bit kernels) + difference maps + arg-max; the first "
                         "evaluation's prefix (encoder, middle, decoder blocks 0-6, block 7's ResBlock) is computed once and resumed by the other "
-                        "2K - 1 passes and two passes are in flight at once (their own HIP streams); `ms_per_pass_every_pass_in_full` = the same passes "
-                        "one after the other without the shared prefix (timed on %d labels, bit-identical latents); outside `value`" % ab_labels}
+                        "2K - 1 passes; `ms_per_pass_every_pass_in_full` = the same passes without the shared prefix (timed on %d labels, "
+                        "bit-identical latents); outside `value`" % ab_labels}
     except Exception as e:
         return {"error": repr(e)[:300]}
     finally:
