@@ -1163,7 +1163,9 @@ def main():
             stage("secondary: SVD configs[2]")
             try:
                 args.inversion = False
-                sec, _sd2, _cfg2, eng2, _lab2, rs2, _t2 = run_config(args, True, rank, world, dev, steps=3, warmup=1, secondary=True)
+                # 1 warm-up + 8 timed steps: the timed steps cycle over fixture windows 1..8 -- window 6, the one the parity mode is known
+                # to miss (tests/test_gpu_c3_window.py), is among the windows `mask_iou_vs_reference` scores
+                sec, _sd2, _cfg2, eng2, _lab2, rs2, _t2 = run_config(args, True, rank, world, dev, steps=8, warmup=1, secondary=True)
                 out["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "unique_labels",
                                                        "step4_latent_blending") if k in sec}
                 out["secondary"]["roofline"] = {k: sec["roofline"][k] for k in ("achieved", "frac", "kernel", "family")}

@@ -49,7 +49,11 @@ if has final; then
   timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY -d /tmp/pm -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap --no-secondary > /tmp/pm.log 2>&1
   db=$(find /tmp/pm -name "*results.db" | head -1)
   python $GRAFT_REPO_ROOT/tools/pmc_mfma_util.py $db $GRAFT_REPO_ROOT/gpurun_out/$T/mfma_util.json | tail -24
+  rm -rf /tmp/pt; timeout 400 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum -d /tmp/pt -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap --no-secondary > /tmp/pt.log 2>&1
+  db=$(find /tmp/pt -name "*results.db" | head -1)
+  python $GRAFT_REPO_ROOT/tools/pmc_by_kernel.py $db k_gemm > $GRAFT_REPO_ROOT/gpurun_out/$T/gemm_l2_counters.md; head -12 $GRAFT_REPO_ROOT/gpurun_out/$T/gemm_l2_counters.md
   cd $GRAFT_REPO_ROOT
+  timeout 900 python tools/race_stress.py --exact --twin --iters 60 > gpurun_out/$T/race_stress_exact_twin.txt 2>&1; tail -2 gpurun_out/$T/race_stress_exact_twin.txt
   timeout 900 python tools/race_stress.py --exact --iters 100 > gpurun_out/$T/race_stress_exact.txt 2>&1; tail -4 gpurun_out/$T/race_stress_exact.txt
   timeout 600 python tools/determinism_check.py --precision exact --overlap --windows 0-5 --reps 2 > gpurun_out/$T/determinism_exact_a.txt 2>&1
   timeout 600 python tools/determinism_check.py --precision exact --overlap --windows 0-5 --reps 2 > gpurun_out/$T/determinism_exact_b.txt 2>&1
