@@ -567,10 +567,26 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
 
     jobs = [(sign, int(v)) for sign in (1.0, -1.0) for v in np.asarray(unique_labels).reshape(-1)]        # SDP:436-442
     nl = max(1, int(lanes))
-    if nl == 1 or len(jobs) < 3:
-        for sign, mask_id in jobs:
-            out[(int(sign), mask_id)] = run(sign, mask_id)
-        return out
+    # nothing reads the Q/K taps of a modulated pass (the drivers hand Step 4 no dump callback, SDP:146-149): the taps are switched off for
+    # the sweep -- no tap stores in the projection epilogues, and the cross-attention k | v of the un-injected blocks come from the window cache
+    net = engine.model.diffusion_model
+    mode0 = getattr(net, "tap_mode", None)
+    if mode0 is not None and mode0 != "none":
+        net.tap_mode = "none"
+        net._set_taps()
+    try:
+        if nl == 1 or len(jobs) < 3:
+            for sign, mask_id in jobs:
+                out[(int(sign), mask_id)] = run(sign, mask_id)
+            return out
+        return _sweep_on_lanes(jobs, run, out, shared, nl, latent, x0, c, uc)
+    finally:
+        if mode0 is not None and mode0 != "none":
+            net.tap_mode = mode0
+            net._set_taps()
+
+
+def _sweep_on_lanes(jobs, run, out, shared, nl, latent, x0, c, uc):
     # lanes > 1 (EXPERIMENTAL, not the default): the passes are independent given the feature pass's dumps, so `lanes` of them can be
     # in flight at once, each on its own HIP stream with its own scratch; the first pass runs on the caller's stream and leaves the
     # shared prefix and the window's cached context projections (ops.window_cached), which the lanes read after waiting for it.
