@@ -117,13 +117,10 @@ def test_two_ranks_equal_sequential_windows():
 
 def test_two_ranks_equal_sequential_svd_windows():
     """BASELINE configs[3]'s unit: SVD windows, one per rank, through segment_windows_sharded / ShardedPipeline with the narrow
-    VideoUNet (temporal attention / temporal convolutions / AlphaBlender inside every window, one-token context) -- in the 16-bit
-    mode and in the parity mode bench.py quotes its SVD figures on (exact precision + masks_only); the gathered label chain must be the
-    sequential window loop's bit for bit."""
-    from vidseg_diffusion_amd import ops
+    VideoUNet (temporal attention / temporal convolutions / AlphaBlender inside every window, one-token context) in the 16-bit mode,
+    one and two lanes; the gathered label chain must be the sequential window loop's bit for bit."""
     _two_ranks_vs_sequential("svd", "fp16")
-    if ops.act_dtype() == torch.float16:
-        _two_ranks_vs_sequential("svd", "exact")
+    # the parity mode (exact + masks_only) of the same unit runs at FULL size in tests/test_gpu_c3_window.py::test_two_ranks_full_size_svd_windows
 
 
 def _rccl_worker(port, q):
@@ -190,12 +187,8 @@ def test_bench_gpus_flag_starts_the_ranks():
     out = lines[0]
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["scaling"] == "weak"
     assert abs(out["value"] - 2 * 14 * 2 / (out["ms_per_step"] * 2 / 1e3)) / out["value"] < 1e-2      # frames of BOTH ranks / max-rank time
-    # the same launch for configs[3]'s unit (SVD windows, one per rank)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--narrow", "--config", "svd", "--steps", "2", "--warmup", "1",
-                        "--no-secondary", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["rccl_ranks"] == 2 and "SVD" in lines[0]["metric"], r.stdout
+    # configs[3]'s unit (SVD windows, one per rank) through the same launcher: covered at FULL size by
+    # tests/test_gpu_c3_window.py::test_two_ranks_full_size_svd_windows and, for the launcher's flags, by tests/test_parallel_gloo.py::test_bench_self_launch
 
 
 def _frames_worker(rank, world, port, q):

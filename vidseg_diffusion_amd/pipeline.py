@@ -511,7 +511,7 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
                      modulate_block_idx=(7,), modulate_layer_type=("spatial",), modulate_attn_type=("cross_attn",),
                      modulate_timestep=None, modulate_schedule="constant", modulate_lambda_start=50.0, modulate_lambda_end=50.0,
                      is_injected_features=True, is_latent_blending=True, feature_folder="features_outputs_VSPW", exp_name="exp",
-                     frame_names=None, noise=None, seed=17, share_prefix=True, lanes=1):
+                     frame_names=None, noise=None, seed=17, share_prefix=True, lanes=1, keep_taps=False):
     """Step 4 for one window: 2*K modulated sampler passes (+lambda then -lambda, one per label in `unique_labels`), each
     with the dumped Q/K injected, lambda*mask added to the chosen attention outputs of the chosen decoder block(s) at the
     modulation timestep(s) and, if asked, the latent blended with the feature pass's x_t outside the mask.  The feature pass
@@ -571,7 +571,8 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
     # the sweep -- no tap stores in the projection epilogues, and the cross-attention k | v of the un-injected blocks come from the window cache
     net = engine.model.diffusion_model
     mode0 = getattr(net, "tap_mode", None)
-    if mode0 is not None and mode0 != "none":
+    switch = mode0 is not None and mode0 != "none" and not keep_taps    # keep_taps=True: the round-5 behaviour (bench.py's A/B leg)
+    if switch:
         net.tap_mode = "none"
         net._set_taps()
     try:
@@ -581,7 +582,7 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
             return out
         return _sweep_on_lanes(jobs, run, out, shared, nl, latent, x0, c, uc)
     finally:
-        if mode0 is not None and mode0 != "none":
+        if switch:
             net.tap_mode = mode0
             net._set_taps()
 
