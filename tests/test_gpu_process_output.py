@@ -14,7 +14,7 @@ def _case(seed, K, F, H, W):
     return pos, neg
 
 
-@pytest.mark.parametrize("K,F,H,W", [(3, 2, 16, 24), (5, 3, 33, 47), (2, 1, 64, 64)])
+@pytest.mark.parametrize("K,F,H,W", [(3, 2, 16, 24), (5, 3, 33, 47), (2, 1, 64, 64), (2, 2, 3, 5), (2, 3, 70, 130)])
 def test_seg_map_vs_oracle(K, F, H, W):
     from oracle import process_output as OPO
     from vidseg_diffusion_amd import process_output as PO

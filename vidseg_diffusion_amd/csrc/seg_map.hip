@@ -4,8 +4,8 @@
 //   compute_difference        PO:8-29    uint8 frames, wrapped uint8 arithmetic, 5x5 Gaussian (sigma 3), "L" image
 //   filter_difference_map     PO:31-40   map * m + filter_s * map * (1 - m)
 //   get_seg_map_main          PO:75-167  map / (max + 1e-5), arg-max over the mask list, label lookup
-// HBM-bound byte work: one thread per output pixel, 25 neighbours x 6 loads served by L1/L2.  Built with -ffp-contract=off: the
-// blur is compared bit for bit with the oracle's separate multiplies and adds.
+// HBM-bound byte work (2 x 44 MB in, 3.7 MB out per 14 x 512 x 512 call): a 32 x 8 tile per block, halo distances staged in LDS.  Built
+// with -ffp-contract=off: the blur is compared bit for bit with the oracle's separate multiplies and adds.
 #include "common.h"
 
 // frame pixel -> uint8 exactly like SDP:152-168: clamp((x + 1) / 2, 0, 1) * 255 in fp32, truncated
@@ -15,26 +15,27 @@ __device__ __forceinline__ unsigned to_u8(float x) {
     return (unsigned)(t * 255.0f);
 }
 
-// PO:13: np.sqrt(np.sum((a - b) ** 2, axis=2)) on uint8 arrays: the subtraction and the square wrap modulo 256, the sum does not.
-// Two input forms: decoded frames fp32 NCHW (converted like the driver does before it writes the PNG) or the PNG's own uint8 HWC.
-__device__ __forceinline__ double wrapped_distance(const float* __restrict__ a, const float* __restrict__ b, long long plane, long long pix) {
+// PO:13: np.sqrt(np.sum((a - b) ** 2, axis=2)) on uint8 arrays: the subtraction and the square wrap modulo 256, the sum does not --
+// the radicand is an integer in [0, 765].  Two input forms: decoded frames fp32 NCHW (converted like the driver does before it writes
+// the PNG) or the PNG's own uint8 HWC.
+__device__ __forceinline__ unsigned wrapped_sq(const float* __restrict__ a, const float* __restrict__ b, long long plane, long long pix) {
     unsigned s = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const unsigned d = (to_u8(a[c * plane + pix]) - to_u8(b[c * plane + pix])) & 0xFFu;
         s += (d * d) & 0xFFu;
     }
-    return sqrt((double)s);
+    return s;
 }
-__device__ __forceinline__ double wrapped_distance(const unsigned char* __restrict__ a, const unsigned char* __restrict__ b, long long plane,
-                                                   long long pix) {
+__device__ __forceinline__ unsigned wrapped_sq(const unsigned char* __restrict__ a, const unsigned char* __restrict__ b, long long plane,
+                                               long long pix) {
     unsigned s = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const unsigned d = ((unsigned)a[pix * 3 + c] - (unsigned)b[pix * 3 + c]) & 0xFFu;
         s += (d * d) & 0xFFu;
     }
-    return sqrt((double)s);
+    return s;
 }
 
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -43,33 +44,55 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     return i;
 }
 
-// pos/neg: fp32 NCHW [F][3][H][W] decoded frames; out: uint8 [F][H][W] = the "L" image of the blurred difference (PIL F -> L:
-// clip to [0, 255], truncate); fmax[f] = its maximum (uint atomics).  Gaussian taps g[0..2] = centre, +-1, +-2 (normalised).
+// pos/neg: decoded frames (fp32 NCHW [F][3][H][W] or uint8 HWC [F][H][W][3]); out: uint8 [F][H][W] = the "L" image of the blurred
+// difference (PIL F -> L: clip to [0, 255], truncate); fmax[f] = its maximum.  Gaussian taps g0..g2 = centre, +-1, +-2 (normalised).
+// A block owns a 32 x 8 tile of one frame: the 36 x 12 halo of distances is formed ONCE in LDS (sqrt through a 766-entry table of the
+// same double sqrt: 3 instead of 25 float64 square roots per thread, 1.7 instead of 25 pixel reads per output), every thread filters
+// its pixel from LDS with the oracle's expressions in the oracle's order, and the tile's maximum is reduced in LDS: ONE atomicMax per
+// block (round 5's one-atomic-per-pixel form spent 41.6 ms per 14 x 512 x 512 call on 3.7 M atomics to 14 addresses; this one ~0.1 ms).
+#define SD_TW 32
+#define SD_TH 8
 template <typename T>
 __global__ void __launch_bounds__(256) k_seg_difference(const T* __restrict__ pos, const T* __restrict__ neg, int F, int H, int W,
                                                         double g0, double g1, double g2, unsigned char* __restrict__ out,
                                                         unsigned* __restrict__ fmax) {
+    __shared__ double s_sqrt[766];
+    __shared__ double s_d[SD_TH + 4][SD_TW + 4];
+    __shared__ unsigned s_max[4];
+    const int tid = threadIdx.x;
+    const int f = blockIdx.z;
+    const int x0 = blockIdx.x * SD_TW, y0 = blockIdx.y * SD_TH;
     const long long plane = (long long)H * W;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)F * plane) return;
-    const int f = (int)(idx / plane);
-    const int y = (int)((idx % plane) / W), x = (int)(idx % W);
     const T* a = pos + (long long)f * 3 * plane;
     const T* b = neg + (long long)f * 3 * plane;
-    const double gk[3] = {g0, g1, g2};
-    double rows[5];
-#pragma unroll
-    for (int dy = -2; dy <= 2; ++dy) {
-        const long long r = (long long)reflect101(y + dy, H) * W;
-        double v[5];
-#pragma unroll
-        for (int dx = -2; dx <= 2; ++dx) v[dx + 2] = wrapped_distance(a, b, plane, r + reflect101(x + dx, W));
-        rows[dy + 2] = gk[0] * v[2] + gk[1] * (v[1] + v[3]) + gk[2] * (v[0] + v[4]);       // symmetric row filter
+    for (int i = tid; i < 766; i += 256) s_sqrt[i] = sqrt((double)i);
+    __syncthreads();
+    for (int i = tid; i < (SD_TH + 4) * (SD_TW + 4); i += 256) {
+        const int hy = i / (SD_TW + 4), hx = i % (SD_TW + 4);
+        const int yy = reflect101(min(y0 + hy - 2, H + 1), H), xx = reflect101(min(x0 + hx - 2, W + 1), W);   // (rows / columns past the frame feed no output)
+        s_d[hy][hx] = s_sqrt[wrapped_sq(a, b, plane, (long long)yy * W + xx)];
     }
-    const double blur = gk[0] * rows[2] + gk[1] * (rows[1] + rows[3]) + gk[2] * (rows[0] + rows[4]);
-    const unsigned l = blur <= 0.0 ? 0u : (blur >= 255.0 ? 255u : (unsigned)blur);
-    out[idx] = (unsigned char)l;
-    atomicMax(&fmax[f], l);
+    __syncthreads();
+    const int tx = tid % SD_TW, ty = tid / SD_TW;
+    const int x = x0 + tx, y = y0 + ty;
+    unsigned l = 0;
+    if (x < W && y < H) {
+        const double gk[3] = {g0, g1, g2};
+        double rows[5];
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy) {
+            const double* v = &s_d[ty + dy][tx];
+            rows[dy] = gk[0] * v[2] + gk[1] * (v[1] + v[3]) + gk[2] * (v[0] + v[4]);            // symmetric row filter
+        }
+        const double blur = gk[0] * rows[2] + gk[1] * (rows[1] + rows[3]) + gk[2] * (rows[0] + rows[4]);
+        l = blur <= 0.0 ? 0u : (blur >= 255.0 ? 255u : (unsigned)blur);
+        out[(long long)f * plane + (long long)y * W + x] = (unsigned char)l;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) l = max(l, (unsigned)__shfl_xor((int)l, o));
+    if ((tid & 63) == 0) s_max[tid >> 6] = l;
+    __syncthreads();
+    if (tid == 0) atomicMax(&fmax[f], max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
 }
 
 // maps: uint8 [K][F][H][W]; mmax: [K][F]; weight: uint8 [K][F][H][W] (the label's mask resized to the frame, 0..255) or null;
@@ -104,9 +127,9 @@ int vidseg_seg_difference(const float* pos, const float* neg, int F, int H, int 
     // cv2.getGaussianKernel(5, 3): exp(-(i-2)^2 / (2 sigma^2)) normalised; written out so host and oracle share the same doubles
     const double g0 = 0.22254893673936782, g1 = 0.2105222740037377, g2 = 0.1782032576265784;
     (void)hipMemsetAsync(fmax_u32, 0, sizeof(unsigned) * F, st);
-    const long long n = (long long)F * H * W;
-    k_seg_difference<float><<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(pos, neg, F, H, W, g0, g1, g2, (unsigned char*)out_u8,
-                                                                                 (unsigned*)fmax_u32);
+    VS_REQUIRE(F <= 65535 && (H + SD_TH - 1) / SD_TH <= 65535, "seg_difference: F=%d H=%d exceed the grid", F, H);
+    k_seg_difference<float><<<dim3((unsigned)((W + SD_TW - 1) / SD_TW), (unsigned)((H + SD_TH - 1) / SD_TH), (unsigned)F), 256, 0, st>>>(
+        pos, neg, F, H, W, g0, g1, g2, (unsigned char*)out_u8, (unsigned*)fmax_u32);
     VS_CHECK_LAUNCH("seg_difference");
     return VS_OK;
 }
@@ -116,8 +139,8 @@ int vidseg_seg_difference_u8(const void* pos, const void* neg, int F, int H, int
     VS_REQUIRE(F > 0 && H >= 3 && W >= 3, "seg_difference_u8: F=%d H=%d W=%d", F, H, W);
     const double g0 = 0.22254893673936782, g1 = 0.2105222740037377, g2 = 0.1782032576265784;
     (void)hipMemsetAsync(fmax_u32, 0, sizeof(unsigned) * F, st);
-    const long long n = (long long)F * H * W;
-    k_seg_difference<unsigned char><<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(
+    VS_REQUIRE(F <= 65535 && (H + SD_TH - 1) / SD_TH <= 65535, "seg_difference_u8: F=%d H=%d exceed the grid", F, H);
+    k_seg_difference<unsigned char><<<dim3((unsigned)((W + SD_TW - 1) / SD_TW), (unsigned)((H + SD_TH - 1) / SD_TH), (unsigned)F), 256, 0, st>>>(
         (const unsigned char*)pos, (const unsigned char*)neg, F, H, W, g0, g1, g2, (unsigned char*)out_u8, (unsigned*)fmax_u32);
     VS_CHECK_LAUNCH("seg_difference_u8");
     return VS_OK;
