@@ -879,8 +879,8 @@ def emit(full):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)       # (5 / 2 until round 6: a single 150 ms hiccup in a 0.8 s timed region read as -18 %, profiles/r06_c)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--refine", action="store_true", help="also run Step 3b (correct_low_res_mask)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--narrow", action="store_true", help="debug: narrow-width UNet (NOT the benchmark config)")
