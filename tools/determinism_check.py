@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="through WindowPipeline (analysis on the second stream), as bench.py runs it")
     ap.add_argument("--prof", action="store_true", help="with the GEMM timing events on, as in bench.py's timed region (VIDSEG_GEMM=ext=0/1 picks the mechanism)")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--lanes", type=int, default=1, help="--overlap: feature passes in flight (bench.py's headline runs 2)")
+    ap.add_argument("--masks-only", action="store_true", help="the parity mode's pruned last step (bench.py's headline)")
     ap.add_argument("--refine", action="store_true", help="with Step 3b (dense tracking + trajectory vote)")
     ap.add_argument("--chain", action="store_true", help="windows chained as one clip (4-NN label propagation instead of K-means after window 0)")
     args = ap.parse_args()
@@ -52,13 +54,13 @@ def main():
         if args.prof:
             ops.gemm_profile_begin()
         if args.overlap:
-            pipe = WindowPipeline(eng, chain=args.chain, num_masks=K, is_aggre_attn=True, is_refine_mask=args.refine)
+            pipe = WindowPipeline(eng, chain=args.chain, lanes=args.lanes, num_masks=K, is_aggre_attn=True, is_refine_mask=args.refine)
             outs = []
             for w in wids:
                 lat = torch.from_numpy(synthetic.headline_latent(F, LAT, LAT, window_id=w)).to(dev)
                 noise = torch.randn((F, 4, LAT, LAT), generator=torch.Generator().manual_seed(100 + w)).to(dev)
                 got = pipe.push(lat, cc, ucc, keep_all_steps=False, exp_name=f"w{w}", noise=noise, num_steps=25, t_start=22, seed=17,
-                                feature_folder="/nonexistent/det")
+                                feature_folder="/nonexistent/det", masks_only=args.masks_only)
                 if got is not None:
                     outs.append(got)
             outs += pipe.drain()

@@ -45,7 +45,7 @@ def main():
     ref = [list(r) for r in trace]
     for trial in range(int(os.environ.get("TRIALS", "6"))):
         del trace[:]
-        modulation_sweep(eng, lat, c, uc, labels, folder, share_prefix=True, lanes=2, **kw)
+        modulation_sweep(eng, lat, c, uc, labels, folder, share_prefix=os.environ.get('SHARE', '1') == '1', lanes=2, **kw)
         torch.cuda.synchronize()
         msgs = []
         for j, (a, b) in enumerate(zip(trace, ref)):

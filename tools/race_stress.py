@@ -20,6 +20,10 @@ ap.add_argument("--exact", action="store_true", help="the exact mode's launches 
                                                    "split tile (k_gemm_p7x<4, true>), the split-operand attention")
 ap.add_argument("--twin", action="store_true", help="instead of the background stream: the SAME op on the SAME inputs on two HIP streams at once "
                                                   "(two window lanes / two sweep passes running in lockstep), both results compared with the first")
+ap.add_argument("--unet-bg", action="store_true", help="instead of the background stream: full-size exact-mode UNet evaluations (batch 28, 64x64 latents) on "
+                                                     "a second HIP stream while every op runs -- the aggressor mix of two window lanes")
+ap.add_argument("--cross", action="store_true", help="instead of the background stream: while an op runs, a second HIP stream runs the OTHER ops of the "
+                                                   "list (different kernels co-resident on the CUs: what two window lanes / two sweep passes do)")
 args = ap.parse_args()
 ad = ops.act_dtype()
 B = 28
@@ -104,7 +108,7 @@ def xrowvec(M, K, N, rows):
 
 def xglue():
     from vidseg_diffusion_amd import exact as X
-    for (Bx, H, C) in ((B, 32, 640), (B, 64, 320), (B, 32, 1280), (B, 16, 1280)):
+    for (Bx, H, C) in ((B, 8, 1280), (B, 16, 640), (B, 32, 640), (B, 64, 320), (B, 32, 1280), (B, 16, 1280)):
         x, gm, bt = rn(Bx, H, H, C), rn(C), rn(C)
         cases.append((f"exact GroupNorm+SiLU -> image B{Bx} H{H} C{C}", lambda x=x, gm=gm, bt=bt: X.groupnorm_split3(x, gm, bt, eps=1e-5, silu=True)))
         x1 = rn(Bx, H, H, C)
@@ -116,8 +120,42 @@ def xglue():
         cases.append((f"exact split3_cat M{Bx * H * H} C{C}+{C}", lambda x=x, x1=x1: X.split3_cat(x, x1)))
 
 
+def xcross(N, H, L=77, Bx=B):
+    from vidseg_diffusion_amd import exact as X
+    q, kv = rn(Bx, N, H * 64), rn(Bx, L, 2 * H * 64)
+    cases.append((f"exact cross-attention B{Bx} N{N} L{L} H{H}", lambda: X.attention_x(q, kv, H, Bx, N, L, split_out=True)))
+
+
+def xsmall():
+    """the shapes of the 8 x 8 / 16 x 16 levels, the step-constant projections and the embedding GEMMs (round 6: the twin-stream
+    instability of profiles/r06_e first showed in an 8 x 8 ResBlock)"""
+    from vidseg_diffusion_amd import exact as X
+    xconv(8, 2560, 1280); xconv(16, 1920, 1280); xconv(32, 1280, 640); xconv(32, 960, 640); xconv(64, 640, 320); xconv(16, 640, 1280); xconv(8, 1280, 1280, stride=1)
+    xlin(1792, 1280, 1280, res=True); xlin(1792, 1280, 3840); xlin(1792, 5120, 1280, res=True); xlin(2156, 1024, 2560); xlin(2156, 1024, 640)
+    xlin(28, 320, 1280); xlin(28, 1280, 1280); xlin(28, 1280, 21760)
+    xattn(64, 20); xattn(256, 20)
+    xcross(4096, 5); xcross(1024, 10); xcross(256, 20); xcross(64, 20)
+    x, gm, bt = rn(B, 8, 8, 1280), rn(1280), rn(1280)
+    t = x.view(B, 64, 1280)
+    cases.append(("exact LayerNorm -> image M1792 C1280", lambda: X.layernorm_split3(t, gm, bt)))
+    y = rn(1792, 10240)
+    cases.append(("exact geglu_split3 M1792", lambda: X.geglu_split3(y)))
+
+
+def xattn_raw(N, H, L=None, Bx=B):
+    from vidseg_diffusion_amd import exact as X
+    L = L or N
+    q, kv = rn(Bx, N, H * 64), rn(Bx, L, 2 * H * 64)
+    cases.append((f"exact attention, fp32 result (no split pass) B{Bx} N{N} L{L} H{H}", lambda: X.attention_x(q, kv, H, Bx, N, L, split_out=False)))
+
+
+if args.exact and os.environ.get("ONLY_SMALL_ATTN") == "1":
+    xattn_raw(64, 20); xattn_raw(64, 20, 77); xattn(64, 20); xcross(64, 20); xattn_raw(64, 20); xattn_raw(64, 20, 77)
+    xconv = xlin = xtemporal = xblend = xrowvec = xattn = lambda *a, **k: None
+    xglue = xsmall = lambda: None
 if args.exact:
     xglue()
+    xsmall()
     xtemporal(2, 2304, 5); xtemporal(2, 576, 10); xtemporal(1, 2304, 5); xblend(64512, 2560, 640); xblend(16128, 5120, 1280); xrowvec(64512, 640, 640, 2304)
     xattn(9216, 5, Bx=4)
     xconv(64, 320, 320, res=True); xconv(64, 960, 320); xconv(32, 640, 640, res=True); xconv(32, 1920, 640); xconv(16, 1280, 1280, res=True)
@@ -160,12 +198,38 @@ def live(t):
 
 bad_total = 0
 twin = torch.cuda.Stream()
-for name, fn in cases:
+keep = []
+if args.unet_bg:
+    import bench
+    torch.set_grad_enabled(False)
+    eng, cfg, _sd, _n = bench.build(False, False, dev)
+    unet = eng.model.diffusion_model
+    unet.set_precision("exact")
+    unet.tap_mode = "none"
+    unet._set_taps()
+    ux = rn(28, 4, 64, 64)
+    ut = torch.full((28,), 958.0, device=dev)
+    uctx = rn(28, 77, 1024)
+    unet(ux, timesteps=ut, context=uctx)
+    torch.cuda.synchronize()
+for ci, (name, fn) in enumerate(cases):
     ref = live(fn()).clone()
     torch.cuda.synchronize()
     bad = 0
     for it in range(args.iters):
-        if args.twin:
+        if args.unet_bg:
+            if it % 8 == 0:
+                with torch.cuda.stream(twin):
+                    keep.append(unet(ux, timesteps=ut, context=uctx))
+                    del keep[:-2]
+            out = live(fn())
+        elif args.cross:
+            with torch.cuda.stream(twin):
+                for k in range(3):
+                    keep.append(cases[(ci + 1 + (3 * it + k) % (len(cases) - 1)) % len(cases)][1]())
+                del keep[:-6]
+            out = live(fn())
+        elif args.twin:
             twin.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(twin):
                 out2 = live(fn())
@@ -183,6 +247,14 @@ for name, fn in cases:
             if bad <= 2:
                 d = (out.float() - ref.float()).abs()
                 print(f"   iter {it}: {int((d > 0).sum())} elements differ, max {float(d.max()):.4g}", flush=True)
+                if os.environ.get("ROW_DETAIL") == "1" and out.dim() == 3:
+                    idx = torch.nonzero(d > 0)
+                    b_, n_ = int(idx[0, 0]), int(idx[0, 1])
+                    c0, c1 = int(idx[:, 2].min()), int(idx[:, 2].max())
+                    g, r = out[b_, n_, c0:c1 + 1].float().cpu(), ref[b_, n_, c0:c1 + 1].float().cpu()
+                    ratio = g / r
+                    print(f"      sample {b_} query {n_} columns {c0}..{c1}; rows/samples touched: {sorted(set(idx[:, 0].tolist()))} / {sorted(set(idx[:, 1].tolist()))}; "
+                          f"got/ref ratio min {float(ratio.min()):.6f} max {float(ratio.max()):.6f}; got[:4] {g[:4].tolist()} ref[:4] {r[:4].tolist()}", flush=True)
     torch.cuda.synchronize()
     bad_total += bad
     print(f"{name:48s} {'OK' if bad == 0 else f'{bad} of {args.iters} runs DIFFER'}", flush=True)

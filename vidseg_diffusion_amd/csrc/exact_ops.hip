@@ -359,6 +359,16 @@ __global__ void __launch_bounds__(256) k_x_layernorm_split3_rows(const float* __
 // scores of a query live in the 16 lanes that share ty (consecutive lanes of one wave), row max / row sum by four xor-shuffles.
 // q, k, v: fp32, row strides ld* (column slices of wider buffers), head h at columns [64 h, 64 h + 64).  grid (ceil(Nq/64), H, B).
 typedef __attribute__((ext_vector_type(2))) float xf2;
+// Row reductions of k_x_attention_f32.  hipcc pairs the four rows' sums into packed fp32 VALU ops (v_pk_add_f32 v[n:n+1]) and issues the
+// ds_bpermute_b32 of each half right behind them.  Round 6: with another stream's kernels sharing the CUs, 1 launch in ~1000 came back
+// with ONE query row wrong -- always a row with (query & 15) == 13, i.e. lanes 48-63 of a wave and the HIGH register of a packed pair
+// (tools/race_stress.py --exact --unet-bg; profiles/r06_e_sweep_lanes_race.txt): the permute read the second register of the pair
+// before the packed op's last pass had written it.  The value is pinned in a VGPR and a few wait states pass before the permute reads
+// it; the arithmetic is unchanged (same bits).
+__device__ __forceinline__ float xa_shfl_xor(float v, int sh) {
+    asm volatile("s_nop 4" : "+v"(v));
+    return __shfl_xor(v, sh, 64);
+}
 #define XA_LD 68                                               // row stride of the LDS tiles (floats): 16-byte aligned rows, 4-bank skew
 __global__ void __launch_bounds__(256) k_x_attention_f32(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                          const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo, int Nq, int Nk,
@@ -427,7 +437,7 @@ __global__ void __launch_bounds__(256) k_x_attention_f32(const float* __restrict
                 if (k0 + 4 * tx + j >= Nk) p[i][j] = -INFINITY;
             float mt = fmaxf(fmaxf(p[i][0], p[i][1]), fmaxf(p[i][2], p[i][3]));
 #pragma unroll
-            for (int sh = 8; sh > 0; sh >>= 1) mt = fmaxf(mt, __shfl_xor(mt, sh, 64));
+            for (int sh = 8; sh > 0; sh >>= 1) mt = fmaxf(mt, xa_shfl_xor(mt, sh));
             const float mnew = fmaxf(mrun[i], mt);
             const float corr = expf(mrun[i] - mnew);           // exp(-inf) = 0 on the first tile
             float ls = 0.f;
@@ -437,7 +447,7 @@ __global__ void __launch_bounds__(256) k_x_attention_f32(const float* __restrict
                 ls += p[i][j];
             }
 #pragma unroll
-            for (int sh = 8; sh > 0; sh >>= 1) ls += __shfl_xor(ls, sh, 64);
+            for (int sh = 8; sh > 0; sh >>= 1) ls += xa_shfl_xor(ls, sh);
             lrun[i] = lrun[i] * corr + ls;
             mrun[i] = mnew;
             o[i][0] *= corr;

@@ -602,8 +602,11 @@ def _sweep_on_lanes(jobs, run, out, shared, nl, latent, x0, c, uc):
     for st in streams:
         st.wait_stream(main)
         hand_to_stream(st, x0, latent, c, uc, *state)
+    dbg = os.environ.get("VIDSEG_SWEEP_DEBUG", "")                      # lab probes of profiles/r06_e_sweep_lanes_race.txt
     for j, (sign, mask_id) in enumerate(jobs[1:]):
         with torch.cuda.stream(streams[j % nl]):
+            if "sleep" in dbg:
+                torch.cuda._sleep(200_000_000)                           # ~80 ms: this pass's first kernels start after the other lane's step 24
             out[(int(sign), mask_id)] = run(sign, mask_id)
     for st in streams:
         main.wait_stream(st)
