@@ -391,7 +391,7 @@ def step45_sd(eng, cfg, dev, k_masks, ab_labels=3):
     pass's x_t outside the mask at steps 22-23), each final latent through the first stage's decoder (SDP:150-152), the per-label
     difference maps and the arg-max over labels (process_output.py:8-167).  The sweep is timed twice: `ab_labels` labels with every pass
     in full with their Q/K taps written (share_prefix=False, keep_taps=True: the sweep as round 5 ran it) and all K labels as the sweep
-    runs now: the first evaluation's prefix shared, no tap stores (pipeline.modulation_sweep)."""
+    runs now: the first evaluation's prefix shared, no tap stores, two passes in flight (pipeline.modulation_sweep)."""
     from vidseg_diffusion_amd import feature_extraction as FE
     from vidseg_diffusion_amd import process_output as PO
     from vidseg_diffusion_amd import synthetic
@@ -425,7 +425,7 @@ def step45_sd(eng, cfg, dev, k_masks, ab_labels=3):
         decode_first_stage(vae, lat, 0.18215)
         sync()
         t0 = time.perf_counter()
-        plain = modulation_sweep(eng, lat, c, uc, labels[:ab_labels], folder, share_prefix=False, keep_taps=True, **kw)   # as round 5 ran it
+        plain = modulation_sweep(eng, lat, c, uc, labels[:ab_labels], folder, share_prefix=False, keep_taps=True, lanes=1, **kw)   # as round 5 ran it
         sync()
         t_plain = (time.perf_counter() - t0) / (2 * ab_labels)
         t0 = time.perf_counter()
@@ -457,7 +457,7 @@ def step45_sd(eng, cfg, dev, k_masks, ab_labels=3):
                 "note": "2K modulated passes of 3 CFG evaluations each (block 7 cross-attention, lambda 50, q / k injection into decoder blocks "
                         "1-11, latent blending at steps 22-23) + 2K first-stage decodes (16-bit kernels) + difference maps + arg-max; the first "
                         "evaluation's prefix (encoder, middle, decoder blocks 0-6, block 7's ResBlock) is computed once and resumed by the other "
-                        "2K - 1 passes, and no pass writes Q/K taps (nothing reads them); `ms_per_pass_every_pass_in_full` = the same passes as round 5 "
+                        "2K - 1 passes, no pass writes Q/K taps (nothing reads them) and two passes are in flight on their own HIP streams; `ms_per_pass_every_pass_in_full` = the same passes as round 5 "
                         "ran them, every evaluation in full with its taps (timed on %d labels, bit-identical latents); outside `value`" % ab_labels}
     except Exception as e:
         return {"error": repr(e)[:300]}

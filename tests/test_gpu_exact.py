@@ -809,7 +809,7 @@ def test_step4_sweep_shared_prefix_is_bit_identical(X, kind):
     for inject in (True, False):
         skw = dict(t_start=t0, feature_folder=base, exp_name=exp, noise=noise, seed=17, is_injected_features=inject, **kw)
         plain = modulation_sweep(eng, lat, c, uc, uniq, folder, share_prefix=False, lanes=1, **skw)     # every pass in full, one after the other
-        shared = modulation_sweep(eng, lat, c, uc, uniq, folder, share_prefix=True, **skw)              # the default: the shared prefix
+        shared = modulation_sweep(eng, lat, c, uc, uniq, folder, share_prefix=True, lanes=2, **skw)     # the default: shared prefix, two passes in flight
         assert set(plain) == set(shared) == {(s, int(l)) for s in (1, -1) for l in uniq}
         for k in plain:
             assert torch.isfinite(shared[k]).all() and torch.equal(plain[k], shared[k]), (kind, inject, k)

@@ -358,17 +358,14 @@ __global__ void __launch_bounds__(256) k_x_layernorm_split3_rows(const float* __
 // FMAs (Q and K are staged transposed, [d][token], P goes through LDS transposed, [key][query]).  Online softmax per tile: the 64
 // scores of a query live in the 16 lanes that share ty (consecutive lanes of one wave), row max / row sum by four xor-shuffles.
 // q, k, v: fp32, row strides ld* (column slices of wider buffers), head h at columns [64 h, 64 h + 64).  grid (ceil(Nq/64), H, B).
-typedef __attribute__((ext_vector_type(2))) float xf2;
-// Row reductions of k_x_attention_f32.  hipcc pairs the four rows' sums into packed fp32 VALU ops (v_pk_add_f32 v[n:n+1]) and issues the
-// ds_bpermute_b32 of each half right behind them.  Round 6: with another stream's kernels sharing the CUs, 1 launch in ~1000 came back
-// with ONE query row wrong -- always a row with (query & 15) == 13, i.e. lanes 48-63 of a wave and the HIGH register of a packed pair
-// (tools/race_stress.py --exact --unet-bg; profiles/r06_e_sweep_lanes_race.txt): the permute read the second register of the pair
-// before the packed op's last pass had written it.  The value is pinned in a VGPR and a few wait states pass before the permute reads
-// it; the arithmetic is unchanged (same bits).
-__device__ __forceinline__ float xa_shfl_xor(float v, int sh) {
-    asm volatile("s_nop 4" : "+v"(v));
-    return __shfl_xor(v, sh, 64);
-}
+// k_x_attention_f32 uses SCALAR fp32 FMAs on purpose.  Until round 6 its two contractions were written on float2 vectors and compiled
+// to packed fp32 VALU ops (v_pk_fma_f32 with a broadcast op_sel, v_pk_mul_f32).  Alone, or twice at once on two streams, the kernel was
+// bit-stable; with ANOTHER stream's UNet kernels sharing the CUs, about 1 launch in 3000 came back with ONE query row of one head wrong
+// (1e-2 absolute), always a row with (query & 15) == 13 -- lanes 48-63 of a wave, the HIGH register of a packed pair: 25 events in
+// 54 000 launches under tools/race_stress.py --exact --unet-bg, 0 in 30 000 with the scalar form (same products, same fma roundings,
+// same bits).  It is what made two window lanes / two sweep passes in flight not bit-stable (profiles/r06_e_sweep_lanes_race.txt).
+// Wait states before the row reductions' ds_bpermute did not help; whether the packed op's hazard is the compiler's or the chip's to
+// cover is not known.
 #define XA_LD 68                                               // row stride of the LDS tiles (floats): 16-byte aligned rows, 4-bank skew
 __global__ void __launch_bounds__(256) k_x_attention_f32(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                          const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo, int Nq, int Nk,
@@ -387,11 +384,11 @@ __global__ void __launch_bounds__(256) k_x_attention_f32(const float* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) Qt[(c4 + j) * XA_LD + r] = a[j] * scale;
     }
-    xf2 o[4][2];
+    float o[4][4];
     float mrun[4], lrun[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        o[i][0] = o[i][1] = xf2{0.f, 0.f};
+        o[i][0] = o[i][1] = o[i][2] = o[i][3] = 0.f;
         mrun[i] = -INFINITY;
         lrun[i] = 0.f;
     }
@@ -410,34 +407,31 @@ __global__ void __launch_bounds__(256) k_x_attention_f32(const float* __restrict
             *reinterpret_cast<f32x4*>(&Vs[r * XA_LD + c4]) = w;
         }
         __syncthreads();
-        xf2 s[4][2];
+        float s[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s[i][0] = s[i][1] = xf2{0.f, 0.f};
+        for (int i = 0; i < 4; ++i) s[i][0] = s[i][1] = s[i][2] = s[i][3] = 0.f;
 #pragma unroll 8
         for (int d = 0; d < 64; ++d) {
             const f32x4 qv = *reinterpret_cast<const f32x4*>(&Qt[d * XA_LD + 4 * ty]);
             const f32x4 kv = *reinterpret_cast<const f32x4*>(&Kt[d * XA_LD + 4 * tx]);
-            const xf2 k01 = {kv[0], kv[1]}, k23 = {kv[2], kv[3]};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const xf2 qq = {qv[i], qv[i]};
-                s[i][0] = qq * k01 + s[i][0];
-                s[i][1] = qq * k23 + s[i][1];
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[i][j] = fmaf(qv[i], kv[j], s[i][j]);
         }
         float p[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            p[i][0] = s[i][0][0];
-            p[i][1] = s[i][0][1];
-            p[i][2] = s[i][1][0];
-            p[i][3] = s[i][1][1];
+            p[i][0] = s[i][0];
+            p[i][1] = s[i][1];
+            p[i][2] = s[i][2];
+            p[i][3] = s[i][3];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (k0 + 4 * tx + j >= Nk) p[i][j] = -INFINITY;
             float mt = fmaxf(fmaxf(p[i][0], p[i][1]), fmaxf(p[i][2], p[i][3]));
 #pragma unroll
-            for (int sh = 8; sh > 0; sh >>= 1) mt = fmaxf(mt, xa_shfl_xor(mt, sh));
+            for (int sh = 8; sh > 0; sh >>= 1) mt = fmaxf(mt, __shfl_xor(mt, sh, 64));
             const float mnew = fmaxf(mrun[i], mt);
             const float corr = expf(mrun[i] - mnew);           // exp(-inf) = 0 on the first tile
             float ls = 0.f;
@@ -447,11 +441,11 @@ __global__ void __launch_bounds__(256) k_x_attention_f32(const float* __restrict
                 ls += p[i][j];
             }
 #pragma unroll
-            for (int sh = 8; sh > 0; sh >>= 1) ls += xa_shfl_xor(ls, sh);
+            for (int sh = 8; sh > 0; sh >>= 1) ls += __shfl_xor(ls, sh, 64);
             lrun[i] = lrun[i] * corr + ls;
             mrun[i] = mnew;
-            o[i][0] *= corr;
-            o[i][1] *= corr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[i][j] *= corr;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -461,13 +455,10 @@ __global__ void __launch_bounds__(256) k_x_attention_f32(const float* __restrict
         for (int kk = 0; kk < 64; ++kk) {
             const f32x4 pq = *reinterpret_cast<const f32x4*>(&Pt[kk * XA_LD + 4 * ty]);
             const f32x4 vv = *reinterpret_cast<const f32x4*>(&Vs[kk * XA_LD + 4 * tx]);
-            const xf2 v01 = {vv[0], vv[1]}, v23 = {vv[2], vv[3]};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const xf2 pp = {pq[i], pq[i]};
-                o[i][0] = pp * v01 + o[i][0];
-                o[i][1] = pp * v23 + o[i][1];
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[i][j] = fmaf(pq[i], vv[j], o[i][j]);
         }
     }
 #pragma unroll
@@ -476,7 +467,7 @@ __global__ void __launch_bounds__(256) k_x_attention_f32(const float* __restrict
         if (qi < Nq) {
             const float inv = 1.0f / lrun[i];
             *reinterpret_cast<f32x4*>(out + ((long long)b * Nq + qi) * ldo + h * 64 + 4 * tx) =
-                f32x4{o[i][0][0] * inv, o[i][0][1] * inv, o[i][1][0] * inv, o[i][1][1] * inv};
+                f32x4{o[i][0] * inv, o[i][1] * inv, o[i][2] * inv, o[i][3] * inv};
         }
     }
 }

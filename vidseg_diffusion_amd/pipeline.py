@@ -511,7 +511,7 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
                      modulate_block_idx=(7,), modulate_layer_type=("spatial",), modulate_attn_type=("cross_attn",),
                      modulate_timestep=None, modulate_schedule="constant", modulate_lambda_start=50.0, modulate_lambda_end=50.0,
                      is_injected_features=True, is_latent_blending=True, feature_folder="features_outputs_VSPW", exp_name="exp",
-                     frame_names=None, noise=None, seed=17, share_prefix=True, lanes=1, keep_taps=False):
+                     frame_names=None, noise=None, seed=17, share_prefix=True, lanes=2, keep_taps=False):
     """Step 4 for one window: 2*K modulated sampler passes (+lambda then -lambda, one per label in `unique_labels`), each
     with the dumped Q/K injected, lambda*mask added to the chosen attention outputs of the chosen decoder block(s) at the
     modulation timestep(s) and, if asked, the latent blended with the feature pass's x_t outside the mask.  The feature pass
@@ -588,13 +588,11 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
 
 
 def _sweep_on_lanes(jobs, run, out, shared, nl, latent, x0, c, uc):
-    # lanes > 1 (EXPERIMENTAL, not the default): the passes are independent given the feature pass's dumps, so `lanes` of them can be
-    # in flight at once, each on its own HIP stream with its own scratch; the first pass runs on the caller's stream and leaves the
-    # shared prefix and the window's cached context projections (ops.window_cached), which the lanes read after waiting for it.
-    # Measured in round 6 at full size (profiles/r06_e_sweep_lanes_race.txt): -3.8 % per pass, but with the shared prefix 1-3 of 40
-    # passes come out <= 4e-5 away from the sequential sweep's latents, run to run, at step 24 -- every kernel is bit-stable when run
-    # twice at once on two streams (tools/race_stress.py --twin) and the effect disappears with VIDSEG_WINDOW_CACHE=0; not root-caused,
-    # so the sweep runs its passes one after the other.
+    # lanes > 1: the passes are independent given the feature pass's dumps, so `lanes` of them are in flight at once, each on its own HIP
+    # stream with its own scratch (the same launches on the same data as the sequential sweep: bit-identical latents, -3.8 % per pass).
+    # The first pass runs on the caller's stream: it leaves the shared prefix and the window's cached context projections
+    # (ops.window_cached), which the lanes read after waiting for it.  (Round 6 found 1-3 of 40 passes NOT bit-stable in this form and
+    # traced it to k_x_attention_f32's packed-fp32 VALU ops under CU sharing -- fixed there, profiles/r06_e_sweep_lanes_race.txt.)
     main = torch.cuda.current_stream()
     out[(int(jobs[0][0]), jobs[0][1])] = run(*jobs[0])
     streams = _sweep_lanes(latent.device, nl)
@@ -602,11 +600,8 @@ def _sweep_on_lanes(jobs, run, out, shared, nl, latent, x0, c, uc):
     for st in streams:
         st.wait_stream(main)
         hand_to_stream(st, x0, latent, c, uc, *state)
-    dbg = os.environ.get("VIDSEG_SWEEP_DEBUG", "")                      # lab probes of profiles/r06_e_sweep_lanes_race.txt
     for j, (sign, mask_id) in enumerate(jobs[1:]):
         with torch.cuda.stream(streams[j % nl]):
-            if "sleep" in dbg:
-                torch.cuda._sleep(200_000_000)                           # ~80 ms: this pass's first kernels start after the other lane's step 24
             out[(int(sign), mask_id)] = run(sign, mask_id)
     for st in streams:
         main.wait_stream(st)
