@@ -54,9 +54,11 @@ if has final; then
   python $GRAFT_REPO_ROOT/tools/pmc_by_kernel.py $db k_gemm > $GRAFT_REPO_ROOT/gpurun_out/$T/gemm_l2_counters.md; head -12 $GRAFT_REPO_ROOT/gpurun_out/$T/gemm_l2_counters.md
   cd $GRAFT_REPO_ROOT
   timeout 900 python tools/race_stress.py --exact --twin --iters 60 > gpurun_out/$T/race_stress_exact_twin.txt 2>&1; tail -2 gpurun_out/$T/race_stress_exact_twin.txt
+  timeout 1200 python tools/race_stress.py --exact --unet-bg --iters 150 > gpurun_out/$T/race_stress_exact_unet_bg.txt 2>&1; tail -2 gpurun_out/$T/race_stress_exact_unet_bg.txt
+  bash tools/lanes_determinism.sh > gpurun_out/$T/lanes_determinism.txt 2>&1; tail -3 gpurun_out/$T/lanes_determinism.txt
   timeout 900 python tools/race_stress.py --exact --iters 100 > gpurun_out/$T/race_stress_exact.txt 2>&1; tail -4 gpurun_out/$T/race_stress_exact.txt
-  timeout 600 python tools/determinism_check.py --precision exact --overlap --windows 0-5 --reps 2 > gpurun_out/$T/determinism_exact_a.txt 2>&1
-  timeout 600 python tools/determinism_check.py --precision exact --overlap --windows 0-5 --reps 2 > gpurun_out/$T/determinism_exact_b.txt 2>&1
+  timeout 600 python tools/determinism_check.py --precision exact --overlap --lanes 2 --masks-only --windows 0-5 --reps 2 > gpurun_out/$T/determinism_exact_a.txt 2>&1
+  timeout 600 python tools/determinism_check.py --precision exact --overlap --lanes 2 --masks-only --windows 0-5 --reps 2 > gpurun_out/$T/determinism_exact_b.txt 2>&1
   diff <(grep -v "^\[" gpurun_out/$T/determinism_exact_a.txt) <(grep -v "^\[" gpurun_out/$T/determinism_exact_b.txt) > gpurun_out/$T/determinism_exact_diff.txt && echo "determinism: two processes identical" || (echo "determinism: DIFF"; head -5 gpurun_out/$T/determinism_exact_diff.txt)
   tail -3 gpurun_out/$T/determinism_exact_a.txt
 fi
