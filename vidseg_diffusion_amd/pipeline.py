@@ -511,7 +511,7 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
                      modulate_block_idx=(7,), modulate_layer_type=("spatial",), modulate_attn_type=("cross_attn",),
                      modulate_timestep=None, modulate_schedule="constant", modulate_lambda_start=50.0, modulate_lambda_end=50.0,
                      is_injected_features=True, is_latent_blending=True, feature_folder="features_outputs_VSPW", exp_name="exp",
-                     frame_names=None, noise=None, seed=17, share_prefix=True, lanes=2, keep_taps=False):
+                     frame_names=None, noise=None, seed=17, share_prefix=True, lanes=None, keep_taps=False):
     """Step 4 for one window: 2*K modulated sampler passes (+lambda then -lambda, one per label in `unique_labels`), each
     with the dumped Q/K injected, lambda*mask added to the chosen attention outputs of the chosen decoder block(s) at the
     modulation timestep(s) and, if asked, the latent blended with the feature pass's x_t outside the mask.  The feature pass
@@ -566,7 +566,7 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
                        t_start=t_start, is_latent_blending=is_latent_blending, feature_height=base_h * scale, feature_width=base_w * scale)
 
     jobs = [(sign, int(v)) for sign in (1.0, -1.0) for v in np.asarray(unique_labels).reshape(-1)]        # SDP:436-442
-    nl = max(1, int(lanes))
+    nl = max(1, int(lanes)) if lanes is not None else (1 if video else 2)   # SVD's launches fill the chip: two in flight measured slower (feature passes: -7 %)
     # nothing reads the Q/K taps of a modulated pass (the drivers hand Step 4 no dump callback, SDP:146-149): the taps are switched off for
     # the sweep -- no tap stores in the projection epilogues, and the cross-attention k | v of the un-injected blocks come from the window cache
     net = engine.model.diffusion_model
