@@ -99,9 +99,6 @@ class VScalingWithEDMcNoise:
 
 
 # ----------------------------------------------------------------------------- denoiser.py
-_TDEV_BLOCKING = os.environ.get("VIDSEG_TDEV_BLOCKING") == "1"
-
-
 class Denoiser(nn.Module):
     """denoiser.py:13-46.  `sigma` is a per-sample vector; it is evaluated on the host."""
     HOST_MASTERS = True          # the sigma table stays an fp32 host table: engine.to(device) / .half() do not touch it
@@ -122,10 +119,7 @@ class Denoiser(nn.Module):
         c_skip, c_out, c_in, c_noise = self.scaling(sigma)
         c_noise = self.possibly_quantize_c_noise(c_noise.reshape(sigma.shape))
         t_host = c_noise.float()
-        # non_blocking: a small pageable host tensor is staged at call time (tools/lab/h2d_async_probe.py), so the copy is safe without the
-        # stream synchronize a blocking .to() appends -- that synchronize paced the host to the GPU once per evaluation and kept two
-        # window lanes from overlapping anywhere but at window boundaries (VIDSEG_TDEV_BLOCKING=1: the old behaviour, for A/Bs)
-        t_dev = t_host.to(input.device, non_blocking=not _TDEV_BLOCKING)
+        t_dev = t_host.to(input.device)      # (non_blocking measured in round 6: no gain -- 86.9 / 86.3 against 86.8 / 86.7 frames/s)
         t_dev._vidseg_host = t_host                                           # exact.ExactRunner embeds the timesteps on the host: no read-back
         net = network(ops.rows_axpby(input, c_in), t_dev, cond, is_modulate_step=is_modulate_step,
                       is_injected_step=is_injected_step, modulate_params=modulate_params, **additional_model_inputs)
