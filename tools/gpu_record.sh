@@ -43,6 +43,8 @@ if has svdprof; then
 fi
 if has final; then
   cd $GRAFT_REPO_ROOT
+  ( time VIDSEG_DIST_BACKEND=gloo VIDSEG_ONE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 3 --warmup 1 > gpurun_out/$T/bench_2ranks_one_gpu.json 2> gpurun_out/$T/bench_2ranks_one_gpu.err ) 2>> gpurun_out/$T/pytest_time.txt
+  cp bench_full.json gpurun_out/$T/bench_2ranks_one_gpu_full.json; wc -c gpurun_out/$T/bench_2ranks_one_gpu.json
   ( time VIDSEG_ACT=bf16 timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/$T/pytest_gpu_bf16.log 2>&1 ) 2>> gpurun_out/$T/pytest_time.txt
   tail -2 gpurun_out/$T/pytest_gpu_bf16.log
   cd /tmp
