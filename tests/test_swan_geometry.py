@@ -7,7 +7,8 @@ SD 2.1, K = 20, t_start 22, Steps 3 + 3b).
 
 CPU: the oracle against it (one forward always; the whole window behind VIDSEG_SLOW_TESTS).
 GPU: the HIP path against it -- narrow width in both precisions, masks = the reference's in the exact mode -- and the FULL-width UNet at
-that geometry as a property test (finite, tap shapes, the analysis of the device's own taps = the oracle's, bit for bit)."""
+that geometry as a property test (finite, tap shapes, the analysis of the device's own taps = the oracle's, bit for bit:
+tests/test_gpu_c2_window.py::test_full_width_window_at_the_swan_geometry, which shares that module's full-width network)."""
 import os
 
 import numpy as np
@@ -109,7 +110,8 @@ def _window_on_device(net, g, precision, refine=True, width_c=None):
     lat, c, noise = swan_inputs(g)
     if width_c is not None:                                             # the full-width network reads a 1024-wide context
         c = np.random.Generator(np.random.PCG64(12)).standard_normal((F, 77, width_c)).astype(np.float32)
-    net.pack(dev)
+    if getattr(net, "_packed_on", None) is None:
+        net.pack(dev)
     net.set_precision(precision)
     eng = build_sd_engine(net, num_steps=25, scale=5.0)
     cc = {"crossattn": torch.from_numpy(c).to(dev)}
@@ -150,33 +152,4 @@ def test_narrow_window_at_the_swan_geometry_vs_reference(gold):
             assert iou >= 0.99, (iou, same)
         else:
             assert ex <= act_mode()[1] and max(et.values()) <= act_mode()[1], (ex, et)
-    net.release_exact()
-
-
-@pytest.mark.gpu
-def test_full_width_window_at_the_swan_geometry():
-    """The FULL-width SD 2.1 UNet (865.9 M parameters) on a 14-frame window at latent 56x104, parity precision: every tap finite and of the
-    reference's shape ([28, 1456, 640] at decoder blocks 6-8), and the analysis stage (3-block mean, K-means K = 20 / n_init 10, 4-NN, dense
-    tracking + vote over 20 384 tokens -- not a multiple of any tile) of the device's own taps equal to the oracle's, bit for bit."""
-    from conftest import act_mode
-    from oracle import analysis as OA
-    from vidseg_diffusion_amd.unet import UNetModel
-    z = np.load(G)
-    g = {k: z[k] for k in z.files}
-    net = UNetModel(**synthetic.SD21_FULL)
-    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in
-                         synthetic.fill_state_dict(shapes, seed=1234, zero_gain=synthetic.HEADLINE["zero_gain"]).items()})
-    prec = "exact" if act_mode()[0] == "f16" else "fp16"
-    labels, taps, x, _ = _window_on_device(net, g, prec, width_c=synthetic.SD21_FULL["context_dim"])
-    assert x.shape == (F, 4, LH, LW) and np.isfinite(x).all()
-    for b in (6, 7, 8):
-        assert taps[b].shape == (2 * F, N, 640) and taps[b].dtype == np.float16 and np.isfinite(taps[b].astype(np.float32)).all()
-    np.random.seed(17)
-    _, lab, _ = OA.match_gt_mask(OA.aggregate_blocks([taps[8], taps[7], taps[6]]), K, np.random.mtrand._rand)
-    th, tw = OA.dense_tracking(taps[7], F, LH // 2, LW // 2)
-    corr, _ = OA.correct_low_res_mask(lab.reshape(F, LH // 2, LW // 2), th, tw)
-    same = float(np.mean(labels.reshape(-1) == corr))
-    print(f"swan geometry, full width, {prec}: {len(np.unique(labels))} labels, device masks == oracle analysis of the device's taps on {same:.6f} of the tokens")
-    assert np.array_equal(labels.reshape(-1), corr)
     net.release_exact()
