@@ -51,6 +51,10 @@ if has final; then
   timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY -d /tmp/pm -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap --no-secondary > /tmp/pm.log 2>&1
   db=$(find /tmp/pm -name "*results.db" | head -1)
   python $GRAFT_REPO_ROOT/tools/pmc_mfma_util.py $db $GRAFT_REPO_ROOT/gpurun_out/$T/mfma_util.json | tail -24
+  rm -rf /tmp/prof_s45; timeout 800 rocprofv3 --kernel-trace --stats -d /tmp/prof_s45 -o r -- python $GRAFT_REPO_ROOT/tools/step45_timing.py > $GRAFT_REPO_ROOT/gpurun_out/$T/step45_under_rocprof.json 2>/tmp/prof_s45.err
+  db=$(find /tmp/prof_s45 -name "*results.db" | head -1)
+  python $GRAFT_REPO_ROOT/tools/prof_summary.py $db "$T: python tools/step45_timing.py (Steps 1-3 twice, warm-up, 6 passes as round 5 ran them, 40 passes of the sweep, 40 decodes + difference maps + arg-max) under rocprofv3 --kernel-trace --stats" > $GRAFT_REPO_ROOT/gpurun_out/$T/step45_kernel_stats.md
+  head -14 $GRAFT_REPO_ROOT/gpurun_out/$T/step45_kernel_stats.md | cut -c1-160
   rm -rf /tmp/pt; timeout 400 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum -d /tmp/pt -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap --no-secondary > /tmp/pt.log 2>&1
   db=$(find /tmp/pt -name "*results.db" | head -1)
   python $GRAFT_REPO_ROOT/tools/pmc_by_kernel.py $db k_gemm > $GRAFT_REPO_ROOT/gpurun_out/$T/gemm_l2_counters.md; head -12 $GRAFT_REPO_ROOT/gpurun_out/$T/gemm_l2_counters.md
