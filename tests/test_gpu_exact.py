@@ -765,8 +765,9 @@ def test_exact_mode_inversion_window_vs_reference(X):
     assert iou >= 0.99 and same >= 0.995, (iou, same)      # measured: identical to the reference's masks on every token
 
 
+@pytest.mark.parametrize("precision", ["exact", "fp16"])
 @pytest.mark.parametrize("kind", ["sd", "svd"])
-def test_step4_sweep_shared_prefix_is_bit_identical(X, kind):
+def test_step4_sweep_shared_prefix_is_bit_identical(X, kind, precision):
     """pipeline.modulation_sweep(share_prefix=True): the first evaluation of the 2K modulated passes shares the encoder / middle / decoder
     blocks before the first modulated one (+ that block's ResBlock).  Same launches on the same data, so every final latent must equal the
     unshared sweep's bit for bit -- narrow SD (block 7 cross-attention, injected spatial q / k, blending at steps 22-23: the SD driver's
@@ -798,11 +799,11 @@ def test_step4_sweep_shared_prefix_is_bit_identical(X, kind):
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, 1234).items()})
     net.pack(dev)
-    net.set_precision("exact")
+    net.set_precision(precision)                                         # the exact runner and the 16-bit forward both carry the fork
     eng = build_svd_engine(net, num_frames=Fn) if kind == "svd" else build_sd_engine(net)
     FE.FeatureStore.clear()
     FE.MaskStore.clear()
-    base, exp = f"/nonexistent/x_share_{kind}", "exp"
+    base, exp = f"/nonexistent/x_share_{kind}_{precision}", "exp"
     labels, _ = segment_window(eng, lat, c, uc, num_masks=3, t_start=t0, seed=17, noise=noise, feature_folder=base, exp_name=exp, keep_all_steps=True)
     folder = os.path.join(base, exp, "match_gt_mask", "output_block_8_output_block_7_output_block_6_spatial_self_attn_q_masks_3")
     uniq = np.unique(labels)
@@ -816,4 +817,5 @@ def test_step4_sweep_shared_prefix_is_bit_identical(X, kind):
         assert (shared[(1, int(uniq[0]))] - shared[(-1, int(uniq[0]))]).abs().max() > 0
     FE.FeatureStore.clear()
     FE.MaskStore.clear()
-    net.release_exact()
+    if precision == "exact":
+        net.release_exact()

@@ -524,7 +524,7 @@ def modulation_sweep(engine: Engine, latent, c, uc, unique_labels, masks_folder,
     min(modulate_block_idx) and that block's ResBlock (with injection: the same dumps at the same step).  It is computed by the first
     pass and resumed by the other 2*K - 1 (exact.ExactRunner.forward; bit-identical latents, tests/test_gpu_exact.py); the later
     evaluations of a pass see that pass's own x and run in full.  Applies when the first sampled step is a modulated one (the
-    drivers' default: modulate_timestep = t_start, SDP:233-234) and the network runs in the exact precision.
+    drivers' default: modulate_timestep = t_start, SDP:233-234); both the exact runner and the 16-bit forward carry the fork.
     lanes: passes in flight at once, each on its own HIP stream (default: 2 for the SD network, 1 for SVD, whose launches fill the chip);
     same launches on the same data, bit-identical latents.  keep_taps: write the Q/K taps in every evaluation as a feature pass does
     (nothing reads them in Step 4; round 5's behaviour, kept for bench.py's A/B)."""

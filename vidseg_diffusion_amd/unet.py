@@ -346,10 +346,17 @@ def get_modulate_lambda(modulate_lambda_start, modulate_lambda_end, modulate_sch
 class TimestepEmbedSequential(nn.Sequential):
     """openaimodel.py:67-114: children dispatched by type."""
 
-    def run(self, x, x_skip, emb_all, context, mod=None, skip_resample=False):
+    def run(self, x, x_skip, emb_all, context, mod=None, skip_resample=False, res_cache=None):
+        """res_cache: the fork point of a Step-4 sweep (pipeline.modulation_sweep, `shared_prefix`): receives the ResBlock's output on the
+        pass that computes it and hands it back on the later ones, which skip the ResBlock."""
         for layer in self:
             if isinstance(layer, ResBlock):
-                x = layer.run(x, x_skip, emb_all)
+                if res_cache is not None and "x" in res_cache:
+                    x = res_cache["x"]
+                else:
+                    x = layer.run(x, x_skip, emb_all)
+                    if res_cache is not None:
+                        res_cache["x"] = x
                 x_skip = None
             elif isinstance(layer, SpatialTransformer):
                 x = layer.run(x, context, mod)
@@ -552,17 +559,33 @@ class UNetModel(nn.Module):
         dev = x_nhwc_f32.device
         emb = self.embed(timesteps, y)
         emb_all = ops.linear(ops.silu(emb), self.emb_w, self.emb_b, out_f32=True)                       # every ResBlock's emb_layers
-        h = ops.conv_in(x_nhwc_f32, self.cin_w, self.cin_b)
-        hs = [h]
-        for i, blk in list(enumerate(self.input_blocks))[1:]:
-            h = blk.run(h, None, emb_all, context_bf16, self._block_mod("input", i, blk, False, is_injected_step, modulate_params, dev))
-            hs.append(h)
-        h = self.middle_block.run(h, None, emb_all, context_bf16)
+        from .util import shared_prefix
+        pre = shared_prefix(modulate_params, is_modulate_step)      # Step-4 sweep: the first evaluation's shared prefix (see exact.ExactRunner.forward)
+        resume = pre is not None and pre.get("state") is not None
+        if resume:
+            hs, h = list(pre["state"][0]), None
+        else:
+            h = ops.conv_in(x_nhwc_f32, self.cin_w, self.cin_b)
+            hs = [h]
+            for i, blk in list(enumerate(self.input_blocks))[1:]:
+                h = blk.run(h, None, emb_all, context_bf16, self._block_mod("input", i, blk, False, is_injected_step, modulate_params, dev))
+                hs.append(h)
+            h = self.middle_block.run(h, None, emb_all, context_bf16)
         for i, blk in enumerate(self.output_blocks):
+            if resume and i < pre["fork"]:
+                continue
             mod = self._block_mod("output", i, blk, is_modulate_step, is_injected_step, modulate_params, dev)
             if stop_after_block is not None and i == stop_after_block:
                 blk.run(h, hs.pop(), emb_all, context_bf16, mod, skip_resample=True)
                 return None
+            if pre is not None and i == pre["fork"]:
+                if resume:
+                    h = blk.run(None, None, emb_all, context_bf16, mod, res_cache={"x": pre["state"][1]})
+                else:
+                    rc = {}
+                    h = blk.run(h, hs.pop(), emb_all, context_bf16, mod, res_cache=rc)
+                    pre["state"] = (tuple(hs), rc["x"])
+                continue
             h = blk.run(h, hs.pop(), emb_all, context_bf16, mod)                                         # OAI:911-948
         h = ops.groupnorm(h, self.out_g, self.out_beta, eps=1e-5, silu=True)
         return ops.conv_out4(h, self.out_w, self.out_b)

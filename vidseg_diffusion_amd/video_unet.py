@@ -223,10 +223,15 @@ class SpatialVideoTransformer(SpatialTransformer):
 
 
 class VideoTimestepEmbedSequential(TimestepEmbedSequential):
-    def run(self, x, x_skip, emb_all, context, T=None, mod=None, skip_resample=False):
+    def run(self, x, x_skip, emb_all, context, T=None, mod=None, skip_resample=False, res_cache=None):
         for layer in self:
             if isinstance(layer, VideoResBlock):
-                x = layer.run(x, x_skip, emb_all, T)
+                if res_cache is not None and "x" in res_cache:                  # Step-4 sweep fork point (unet.TimestepEmbedSequential.run)
+                    x = res_cache["x"]
+                else:
+                    x = layer.run(x, x_skip, emb_all, T)
+                    if res_cache is not None:
+                        res_cache["x"] = x
                 x_skip = None
             elif isinstance(layer, SpatialVideoTransformer):
                 x = layer.run(x, context, T, mod)
@@ -348,19 +353,35 @@ class VideoUNet(UNetModel):
             self.pack(x_nhwc_f32.device)
         emb = self.embed(timesteps, y)
         emb_all = ops.linear(ops.silu(emb), self.emb_w, self.emb_b, out_f32=True)
-        h = ops.conv_in(x_nhwc_f32, self.cin_w, self.cin_b)
-        hs = [h]
         dev = x_nhwc_f32.device
-        for i, blk in list(enumerate(self.input_blocks))[1:]:
-            h = blk.run(h, None, emb_all, context_bf16, T,
-                        self._block_mod("input", i, blk, False, is_injected_step, modulate_params, dev))   # VM:480-510
-            hs.append(h)
-        h = self.middle_block.run(h, None, emb_all, context_bf16, T)
+        from .util import shared_prefix
+        pre = shared_prefix(modulate_params, is_modulate_step)      # Step-4 sweep: the first evaluation's shared prefix (see exact.ExactRunner.forward)
+        resume = pre is not None and pre.get("state") is not None
+        if resume:
+            hs, h = list(pre["state"][0]), None
+        else:
+            h = ops.conv_in(x_nhwc_f32, self.cin_w, self.cin_b)
+            hs = [h]
+            for i, blk in list(enumerate(self.input_blocks))[1:]:
+                h = blk.run(h, None, emb_all, context_bf16, T,
+                            self._block_mod("input", i, blk, False, is_injected_step, modulate_params, dev))   # VM:480-510
+                hs.append(h)
+            h = self.middle_block.run(h, None, emb_all, context_bf16, T)
         for i, blk in enumerate(self.output_blocks):
+            if resume and i < pre["fork"]:
+                continue
             mod = self._block_mod("output", i, blk, is_modulate_step, is_injected_step, modulate_params, dev)
             if stop_after_block is not None and i == stop_after_block:                                    # taps-only evaluation
                 blk.run(h, hs.pop(), emb_all, context_bf16, T, mod, skip_resample=True)
                 return None
+            if pre is not None and i == pre["fork"]:
+                if resume:
+                    h = blk.run(None, None, emb_all, context_bf16, T, mod, res_cache={"x": pre["state"][1]})
+                else:
+                    rc = {}
+                    h = blk.run(h, hs.pop(), emb_all, context_bf16, T, mod, res_cache=rc)
+                    pre["state"] = (tuple(hs), rc["x"])
+                continue
             h = blk.run(h, hs.pop(), emb_all, context_bf16, T, mod)                                       # VM:521-562
         h = ops.groupnorm(h, self.out_g, self.out_beta, eps=1e-5, silu=True)
         return ops.conv_out4(h, self.out_w, self.out_b)
